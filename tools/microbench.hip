@@ -1,0 +1,112 @@
+// Integer / fp64 issue-rate microbenchmark for gfx950 (k_fq_mac_bench).
+// Establishes the arithmetic ceiling that the big-integer kernels are priced against, beside the
+// HBM roofline that BASELINE.json prescribes.  Build: hipcc --offload-arch=gfx950 -O3 microbench.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+constexpr int ITERS = 4096;
+constexpr int CHAINS = 8;
+
+template <int OP>
+__global__ __launch_bounds__(256) void k_rate(uint32_t* out, uint32_t seed) {
+    uint32_t a = threadIdx.x * 2654435761u + seed, b = a ^ 0x9e3779b9u;
+    uint64_t acc[CHAINS];
+    double d[CHAINS];
+#pragma unroll
+    for (int c = 0; c < CHAINS; ++c) { acc[c] = a + c; d[c] = (double)(a + c) * 1e-9; }
+    double da = 1.0000001, db = 1e-7;
+    for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+        for (int c = 0; c < CHAINS; ++c) {
+            if constexpr (OP == 0) {  // v_mad_u64_u32
+                asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[c]) : "v"(a), "v"(b) : "vcc");
+            } else if constexpr (OP == 1) {  // v_mul_lo_u32
+                uint32_t lo = (uint32_t)acc[c];
+                asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(lo) : "v"(b));
+                acc[c] = lo;
+            } else if constexpr (OP == 2) {  // v_mul_hi_u32
+                uint32_t lo = (uint32_t)acc[c];
+                asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(lo) : "v"(b));
+                acc[c] = lo;
+            } else if constexpr (OP == 3) {  // v_mad_u32_u24
+                uint32_t lo = (uint32_t)acc[c];
+                asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(lo) : "v"(b), "v"(a));
+                acc[c] = lo;
+            } else if constexpr (OP == 4) {  // v_fma_f64
+                asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(d[c]) : "v"(da), "v"(db));
+            } else if constexpr (OP == 5) {  // v_add_co_u32 + v_addc_co_u32 (64-bit add)
+                uint32_t lo = (uint32_t)acc[c], hi = (uint32_t)(acc[c] >> 32);
+                asm volatile("v_add_co_u32 %0, vcc, %0, %2\n\tv_addc_co_u32 %1, vcc, %1, %3, vcc" : "+v"(lo), "+v"(hi) : "v"(a), "v"(b) : "vcc");
+                acc[c] = ((uint64_t)hi << 32) | lo;
+            } else if constexpr (OP == 6) {  // v_add_u32 (full-rate reference)
+                uint32_t lo = (uint32_t)acc[c];
+                asm volatile("v_add_u32 %0, %0, %1" : "+v"(lo) : "v"(b));
+                acc[c] = lo;
+            } else if constexpr (OP == 7) {  // v_mad_u64_u32 + v_addc (product scanning step)
+                uint32_t top = (uint32_t)d[c];
+                asm volatile("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(acc[c]), "+v"(top) : "v"(a), "v"(b) : "vcc");
+                d[c] = top;
+            } else if constexpr (OP == 8) {  // v_mul_u32_u24 + v_mul_hi_u32_u24
+                uint32_t lo = (uint32_t)acc[c], hi;
+                asm volatile("v_mul_hi_u32_u24 %1, %0, %2\n\tv_mul_u32_u24 %0, %0, %2" : "+v"(lo), "=&v"(hi) : "v"(b));
+                acc[c] = lo ^ hi;
+            } else if constexpr (OP == 9) {  // v_mad_i32_i24 pure
+                uint32_t lo = (uint32_t)acc[c];
+                asm volatile("v_mad_i32_i24 %0, %0, %1, %2" : "+v"(lo) : "v"(b), "v"(a));
+                acc[c] = lo;
+            }
+        }
+    }
+    uint64_t s = 0;
+    double ds = 0;
+#pragma unroll
+    for (int c = 0; c < CHAINS; ++c) { s += acc[c]; ds += d[c]; }
+    if (s == 0x1234567 && ds == 1.5) out[0] = 1;  // keep alive
+    if (threadIdx.x == 0 && blockIdx.x == 0) out[1] = (uint32_t)s;
+}
+
+template <int OP>
+int run(const char* name, int ops_per_step, uint32_t* d_out) {
+    int blocks = 256 * 8;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(k_rate<OP>, dim3(blocks), dim3(256), 0, 0, d_out, 1u);
+    CK(hipDeviceSynchronize());
+    float best = 1e30f;
+    for (int r = 0; r < 5; ++r) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k_rate<OP>, dim3(blocks), dim3(256), 0, 0, d_out, (uint32_t)r);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) best = ms;
+    }
+    double n = (double)blocks * 256 * ITERS * CHAINS * ops_per_step;
+    double per_s = n / (best * 1e-3);
+    // lanes per clock per SIMD at 2.4 GHz, 256 CU x 4 SIMD
+    double lanes_clk_simd = per_s / (256.0 * 4 * 2.4e9);
+    printf("%-34s %8.3f ms  %10.3e lane-ops/s  %6.2f lanes/clk/SIMD (@2.4GHz)\n", name, best, per_s, lanes_clk_simd);
+    return 0;
+}
+
+int main() {
+    uint32_t* d_out;
+    CK(hipMalloc(&d_out, 64));
+    hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, 0));
+    printf("device: %s  CUs=%d  clock=%d kHz\n", p.name, p.multiProcessorCount, p.clockRate);
+    run<6>("v_add_u32", 1, d_out);
+    run<0>("v_mad_u64_u32", 1, d_out);
+    run<7>("v_mad_u64_u32+v_addc (per pair)", 1, d_out);
+    run<1>("v_mul_lo_u32", 1, d_out);
+    run<2>("v_mul_hi_u32", 1, d_out);
+    run<3>("v_mad_u32_u24", 1, d_out);
+    run<9>("v_mad_i32_i24", 1, d_out);
+    run<8>("v_mul_u32_u24+v_mul_hi_u32_u24 (pair)", 1, d_out);
+    run<4>("v_fma_f64", 1, d_out);
+    run<5>("v_add_co+v_addc (per pair)", 1, d_out);
+    return 0;
+}
