@@ -1,0 +1,111 @@
+// Shared host-side plumbing of libblaze_hip: error convention, HIP checks, device arena.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/blaze_hip.h"
+
+namespace blz {
+
+void set_last_error(const char* fmt, ...);
+int log_level();  // BLAZE_LOG=0..3 (env), the RUST_LOG analogue of README.md:150
+
+#define BLZ_LOG(lvl, ...)                                  \
+    do {                                                   \
+        if (::blz::log_level() >= (lvl)) {                 \
+            fprintf(stderr, "[blaze_hip] " __VA_ARGS__);   \
+            fputc('\n', stderr);                           \
+        }                                                  \
+    } while (0)
+
+// HIP call -> error code of the given class on failure
+#define BLZ_HIP(call, errcode)                                                                     \
+    do {                                                                                           \
+        hipError_t e__ = (call);                                                                   \
+        if (e__ != hipSuccess) {                                                                   \
+            ::blz::set_last_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, \
+                                  __LINE__);                                                       \
+            return (errcode);                                                                      \
+        }                                                                                          \
+    } while (0)
+
+#define BLZ_TRY(expr)              \
+    do {                           \
+        int rc__ = (expr);         \
+        if (rc__ != BLZ_OK) return rc__; \
+    } while (0)
+
+inline int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    set_last_error("%s", buf);
+    return code;
+}
+
+// number of usable devices, 0 if the runtime cannot see any
+int device_count();
+// make `device_id` current; BLZ_ERR_FILE if it does not exist (the reference unwraps the open()
+// of /dev/xdma{id}_*: src/utils.rs:74)
+int use_device(int device_id);
+
+// growable device buffer
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return BLZ_OK;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8;  // slack so slightly larger tasks do not reallocate
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            e = hipMalloc(&p, bytes);
+            want = bytes;
+        }
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(BLZ_ERR_UNKNOWN, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        }
+        cap = want;
+        return BLZ_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T>
+    T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// Per-device, process-global byte-addressed arena: the "HBM" of load_data_to_hbm / hbm_point_addr
+// (src/ingo_msm/msm_api.rs:299-322).  An extent is one contiguous load; reads and MSM tasks must
+// fall inside a single extent.  Each extent may carry a Montgomery-form shadow of its points for a
+// given curve, built lazily by the MSM engine.
+struct ArenaExtent {
+    uint64_t start = 0;
+    size_t len = 0;
+    void* raw = nullptr;
+    void* mont = nullptr;  // shadow, same size, valid for mont_curve
+    int mont_curve = -1;
+};
+struct Arena {
+    std::mutex mu;
+    std::vector<ArenaExtent> ext;
+};
+Arena& arena_for(int device_id);
+// find extent containing [pos, pos+len); nullptr if none
+ArenaExtent* arena_find(Arena& a, uint64_t pos, size_t len);
+// write bytes (host or device source) at pos; creates / replaces extents as needed
+int arena_write(int device_id, uint64_t pos, const void* src, size_t len, bool src_is_device, hipStream_t st);
+
+}  // namespace blz

@@ -1,0 +1,370 @@
+// Pippenger windowed-bucket G1 MSM for gfx950 (the device task of SURVEY.md a7: what the FPGA
+// bitstream behind src/ingo_msm/msm_hw_code.rs:6-54 computes; kernels are new design).
+//
+// Pipeline (one stream):
+//   k_count        signed c-bit digits of every scalar -> per-(window,bucket) histogram
+//   k_scan_*       exclusive scan: bucket offsets + accumulate-unit offsets (runs split at L)
+//   k_scatter      (point index | sign) written to its bucket's slice of `entries`
+//   k_fill_units   unit -> bucket map
+//   k_accumulate   one lane per unit: gathers its run of points, XYZZ mixed adds   [phase 1]
+//   k_combine_units   only when a bucket needed more than one unit
+//   k_reduce_level Sum_b b*S_b per window by segmented running sums, a few levels  [phase 2]
+//   k_finish       Horner over windows, single inversion, canonical Z=1|y|x        [phase 3]
+//
+// HBM layout: points AoS Montgomery (2N dwords each, 16-B aligned), scalars raw 32 B LE, entries
+// u32, bucket partials AoS XYZZ (4N dwords).  The gathers are 96-B (64-B) contiguous per lane;
+// the arithmetic (v_mad_u64_u32) bounds every kernel here, not HBM.
+#include "msm_engine.hpp"
+#include "field.cuh"
+
+namespace blz {
+
+size_t fq_bytes(int curve) { return curve == BLZ_BN254 ? 32 : 48; }
+
+// ------------------------------------------------------------------------------------------------
+// plan
+// ------------------------------------------------------------------------------------------------
+MsmPlan make_plan(uint32_t npts, int sbits, int force_c) {
+    MsmPlan best;
+    double best_cost = 1e300;
+    const double madd = 10.0, padd = 14.0, sort_cost = 1.5;
+    for (int c = 3; c <= 23; ++c) {
+        if (force_c > 0 && c != force_c) continue;
+        int W = (sbits + 1 + c - 1) / c;
+        uint64_t Bw = 1ull << (c - 1);
+        uint64_t G = (uint64_t)W * Bw;
+        if (G > (1ull << 26)) continue;                       // workspace bound (partials: 192 B each)
+        if ((uint64_t)npts * W >= (1ull << 32)) continue;      // entries are indexed with u32
+        double cost = (double)W * ((double)npts * (madd + sort_cost) + (double)Bw * 2.0 * padd);
+        if (cost < best_cost) {
+            best_cost = cost;
+            best.npts = npts; best.sbits = sbits; best.c = c; best.W = W; best.Bw = (uint32_t)Bw; best.G = G;
+        }
+    }
+    best.L = 256;
+    return best;
+}
+
+// ------------------------------------------------------------------------------------------------
+// scalar -> signed digits
+// ------------------------------------------------------------------------------------------------
+template <int SW>
+struct ScalarWords {
+    uint32_t s[SW];
+    __device__ __forceinline__ void load(const uint32_t* scalars, uint32_t p) {
+        if constexpr (SW == 8) {
+            const uint4* q = reinterpret_cast<const uint4*>(scalars) + 2 * (size_t)p;
+            uint4 a = q[0], b = q[1];
+            s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
+        } else {
+            s[0] = scalars[p];
+        }
+    }
+    // pops the next c-bit window as a signed digit in (-2^(c-1), 2^(c-1)]
+    __device__ __forceinline__ int next(int c, uint32_t mask, uint32_t half, uint32_t& carry) {
+        uint32_t v = (s[0] & mask) + carry;
+#pragma unroll
+        for (int i = 0; i + 1 < SW; ++i) s[i] = __builtin_amdgcn_alignbit(s[i + 1], s[i], c);
+        s[SW - 1] >>= c;
+        if (v > half) { carry = 1; return (int)v - (int)(half << 1); }
+        carry = 0;
+        return (int)v;
+    }
+};
+
+template <int SW>
+__global__ __launch_bounds__(256) void k_count(const uint32_t* __restrict__ scalars, uint32_t npts, int c, int W,
+                                               uint32_t Bw, uint32_t* __restrict__ count) {
+    uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= npts) return;
+    ScalarWords<SW> sw;
+    sw.load(scalars, p);
+    const uint32_t mask = (1u << c) - 1u, half = 1u << (c - 1);
+    uint32_t carry = 0;
+    for (int w = 0; w < W; ++w) {
+        int d = sw.next(c, mask, half, carry);
+        if (d != 0) {
+            uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1u;
+            atomicAdd(&count[(size_t)w * Bw + b], 1u);
+        }
+    }
+}
+
+template <int SW>
+__global__ __launch_bounds__(256) void k_scatter(const uint32_t* __restrict__ scalars, uint32_t npts, int c, int W,
+                                                 uint32_t Bw, uint32_t* __restrict__ cursor,
+                                                 uint32_t* __restrict__ entries) {
+    uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= npts) return;
+    ScalarWords<SW> sw;
+    sw.load(scalars, p);
+    const uint32_t mask = (1u << c) - 1u, half = 1u << (c - 1);
+    uint32_t carry = 0;
+    for (int w = 0; w < W; ++w) {
+        int d = sw.next(c, mask, half, carry);
+        if (d != 0) {
+            uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1u;
+            uint32_t pos = atomicAdd(&cursor[(size_t)w * Bw + b], 1u);
+            entries[pos] = p | (d < 0 ? 0x80000000u : 0u);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// exclusive scan of (count, units(count)) packed in one u64: low = entries, high = units
+// ------------------------------------------------------------------------------------------------
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = 256 * SCAN_ITEMS;
+
+__device__ __forceinline__ uint64_t pack_cu(uint32_t cnt, uint32_t L) {
+    return (uint64_t)cnt | ((uint64_t)((cnt + L - 1) / L) << 32);
+}
+__device__ __forceinline__ uint64_t block_sum_u64(uint64_t v, uint64_t* sh) {
+    // wave reduce then across 4 waves
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) sh[wv] = v;
+    __syncthreads();
+    uint64_t t = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    return t;
+}
+
+__global__ __launch_bounds__(256) void k_scan_reduce(const uint32_t* __restrict__ count, uint64_t G, uint32_t L,
+                                                     uint64_t* __restrict__ blocksums, uint32_t* __restrict__ stats) {
+    __shared__ uint64_t sh[4];
+    uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE;
+    uint64_t acc = 0;
+    uint32_t mx = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        uint64_t i = base + (uint64_t)k * 256 + threadIdx.x;
+        if (i < G) {
+            uint32_t cn = count[i];
+            acc += pack_cu(cn, L);
+            mx = cn > mx ? cn : mx;
+        }
+    }
+    uint64_t tot = block_sum_u64(acc, sh);
+    for (int o = 32; o > 0; o >>= 1) { uint32_t t = __shfl_down(mx, o, 64); mx = t > mx ? t : mx; }
+    if ((threadIdx.x & 63) == 0 && mx) atomicMax(&stats[1], mx);
+    if (threadIdx.x == 0) blocksums[blockIdx.x] = tot;
+}
+
+// single block: exclusive scan of blocksums in place; totals -> stats[0] (units), stats[2] (entries)
+__global__ __launch_bounds__(1024) void k_scan_sums(uint64_t* __restrict__ blocksums, uint32_t nblocks,
+                                                    uint32_t* __restrict__ stats) {
+    __shared__ uint64_t sh[1024];
+    __shared__ uint64_t carry_sh;
+    if (threadIdx.x == 0) carry_sh = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nblocks; base += 1024) {
+        uint32_t i = base + threadIdx.x;
+        uint64_t v = i < nblocks ? blocksums[i] : 0;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            uint64_t t = threadIdx.x >= (uint32_t)o ? sh[threadIdx.x - o] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += t;
+            __syncthreads();
+        }
+        uint64_t incl = sh[threadIdx.x];
+        uint64_t carry = carry_sh;
+        if (i < nblocks) blocksums[i] = carry + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_sh = carry + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        stats[0] = (uint32_t)(carry_sh >> 32);
+        stats[2] = (uint32_t)(carry_sh & 0xffffffffu);
+    }
+}
+
+// per-block exclusive scan with the block's base; writes off[], unit_off[] and turns count[] into
+// the scatter cursor (count[g] = off[g]).  Element G (one past the end) receives the totals.
+__global__ __launch_bounds__(256) void k_scan_final(uint32_t* __restrict__ count, uint64_t G, uint32_t L,
+                                                    const uint64_t* __restrict__ blocksums,
+                                                    uint32_t* __restrict__ off, uint32_t* __restrict__ unit_off) {
+    __shared__ uint64_t sh[256];
+    uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+    uint64_t v[SCAN_ITEMS];
+    uint64_t tsum = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        uint64_t i = base + k;
+        v[k] = i < G ? pack_cu(count[i], L) : 0;
+        tsum += v[k];
+    }
+    sh[threadIdx.x] = tsum;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        uint64_t t = threadIdx.x >= (uint32_t)o ? sh[threadIdx.x - o] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += t;
+        __syncthreads();
+    }
+    uint64_t run = blocksums[blockIdx.x] + sh[threadIdx.x] - tsum;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        uint64_t i = base + k;
+        if (i <= G) {
+            off[i] = (uint32_t)(run & 0xffffffffu);
+            unit_off[i] = (uint32_t)(run >> 32);
+            if (i < G) count[i] = (uint32_t)(run & 0xffffffffu);
+        }
+        run += v[k];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fill_units(const uint32_t* __restrict__ unit_off, uint64_t G,
+                                                    uint32_t* __restrict__ unit_bucket) {
+    uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= G) return;
+    uint32_t u0 = unit_off[g], u1 = unit_off[g + 1];
+    for (uint32_t u = u0; u < u1; ++u) unit_bucket[u] = (uint32_t)g;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+int msm_env_int(const char* name, int dflt) {
+    const char* s = getenv(name);
+    return s && *s ? atoi(s) : dflt;
+}
+
+static const MsmCurveOps* ops_for(int curve) {
+    switch (curve) {
+        case BLZ_BLS377: return &msm_ops_bls377();
+        case BLZ_BLS381: return &msm_ops_bls381();
+        case BLZ_BN254: return &msm_ops_bn254();
+    }
+    return nullptr;
+}
+
+void launch_fill_units(MsmEngine& E) {
+    const uint64_t G = E.last_plan.G;
+    hipLaunchKernelGGL(k_fill_units, dim3((uint32_t)((G + 255) / 256)), dim3(256), 0, E.stream, E.unit_off.as<uint32_t>(), G,
+                       E.unit_bucket.as<uint32_t>());
+}
+
+int MsmEngine::init(int device_id, int curve_id) {
+    device = device_id;
+    curve = curve_id;
+    if (!ops_for(curve)) return fail(BLZ_ERR_INVALID_PARAM, "unknown curve %d", curve);
+    BLZ_TRY(use_device(device));
+    BLZ_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), BLZ_ERR_UNKNOWN);
+    for (auto& e : ev) BLZ_HIP(hipEventCreate(&e), BLZ_ERR_UNKNOWN);
+    BLZ_HIP(hipHostMalloc((void**)&stats_h, 64), BLZ_ERR_UNKNOWN);
+    BLZ_HIP(hipHostMalloc((void**)&result_h, 256), BLZ_ERR_UNKNOWN);
+    BLZ_TRY(stats.reserve(64));
+    BLZ_TRY(result.reserve(256 * 64));
+    return BLZ_OK;
+}
+
+void MsmEngine::destroy() {
+    if (!stream) return;
+    (void)hipSetDevice(device);
+    (void)hipStreamSynchronize(stream);
+    for (DevBuf* b : {&count, &off, &unit_off, &unit_bucket, &entries, &partial, &lvlA[0], &lvlA[1], &lvlC[0],
+                      &lvlC[1], &blocksums, &stats, &result})
+        b->release();
+    for (auto& e : ev)
+        if (e) (void)hipEventDestroy(e);
+    if (stats_h) (void)hipHostFree(stats_h);
+    if (result_h) (void)hipHostFree(result_h);
+    (void)hipStreamDestroy(stream);
+    stream = nullptr;
+}
+
+int MsmEngine::points_to_mont(const void* d_raw, void* d_mont, uint32_t npts) {
+    BLZ_TRY(use_device(device));
+    return ops_for(curve)->points_to_mont(*this, d_raw, d_mont, npts);
+}
+
+int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int sbits) {
+    BLZ_TRY(use_device(device));
+    const MsmCurveOps* ops = ops_for(curve);
+    MsmEngine& E = *this;
+    hipStream_t st = stream;
+    BLZ_HIP(hipEventRecord(ev[0], st), BLZ_ERR_UNKNOWN);
+    if (npts == 0) {
+        BLZ_TRY(ops->emit_infinity(E));
+        for (int i = 1; i <= 4; ++i) BLZ_HIP(hipEventRecord(ev[i], st), BLZ_ERR_UNKNOWN);
+        last_plan = MsmPlan();
+        timings_pending = true;
+        return BLZ_OK;
+    }
+    MsmPlan P = make_plan(npts, sbits, msm_env_int("BLAZE_MSM_C", 0));
+    if (P.c == 0) return fail(BLZ_ERR_INVALID_PARAM, "no window plan for npts=%u sbits=%d", npts, sbits);
+    P.L = (uint32_t)msm_env_int("BLAZE_MSM_L", (int)P.L);
+    last_plan = P;
+    const uint64_t G = P.G;
+    const uint64_t max_entries = (uint64_t)npts * P.W;
+    const uint64_t max_units = G + max_entries / P.L + 1;
+    const uint32_t nscan = (uint32_t)((G + 1 + SCAN_TILE - 1) / SCAN_TILE);
+    BLZ_TRY(count.reserve((G + 1) * 4));
+    BLZ_TRY(off.reserve((G + 2) * 4));
+    BLZ_TRY(unit_off.reserve((G + 2) * 4));
+    BLZ_TRY(blocksums.reserve((size_t)nscan * 8));
+    BLZ_TRY(entries.reserve(max_entries * 4));
+    BLZ_LOG(2, "msm plan: npts=%u sbits=%d c=%d W=%d Bw=%u G=%llu L=%u", npts, sbits, P.c, P.W, P.Bw,
+            (unsigned long long)G, P.L);
+
+    BLZ_HIP(hipMemsetAsync(count.p, 0, (G + 1) * 4, st), BLZ_ERR_UNKNOWN);
+    BLZ_HIP(hipMemsetAsync(stats.p, 0, 64, st), BLZ_ERR_UNKNOWN);
+    const uint32_t* sc = (const uint32_t*)d_scalars;
+    dim3 gp((npts + 255) / 256), b256(256);
+    if (sbits == 256) hipLaunchKernelGGL(k_count<8>, gp, b256, 0, st, sc, npts, P.c, P.W, P.Bw, count.as<uint32_t>());
+    else hipLaunchKernelGGL(k_count<1>, gp, b256, 0, st, sc, npts, P.c, P.W, P.Bw, count.as<uint32_t>());
+    hipLaunchKernelGGL(k_scan_reduce, dim3(nscan), b256, 0, st, count.as<uint32_t>(), G, P.L, blocksums.as<uint64_t>(),
+                       stats.as<uint32_t>());
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, blocksums.as<uint64_t>(), nscan, stats.as<uint32_t>());
+    hipLaunchKernelGGL(k_scan_final, dim3(nscan), b256, 0, st, count.as<uint32_t>(), G, P.L, blocksums.as<uint64_t>(),
+                       off.as<uint32_t>(), unit_off.as<uint32_t>());
+    if (sbits == 256)
+        hipLaunchKernelGGL(k_scatter<8>, gp, b256, 0, st, sc, npts, P.c, P.W, P.Bw, count.as<uint32_t>(), entries.as<uint32_t>());
+    else
+        hipLaunchKernelGGL(k_scatter<1>, gp, b256, 0, st, sc, npts, P.c, P.W, P.Bw, count.as<uint32_t>(), entries.as<uint32_t>());
+    BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
+    // unit totals are needed on the host to size the accumulate launch
+    BLZ_HIP(hipMemcpyAsync(stats_h, stats.p, 16, hipMemcpyDeviceToHost, st), BLZ_ERR_READ);
+    BLZ_HIP(hipStreamSynchronize(st), BLZ_ERR_UNKNOWN);
+    const uint32_t U = stats_h[0], maxcount = stats_h[1];
+    if ((uint64_t)U > max_units) return fail(BLZ_ERR_UNKNOWN, "unit count %u exceeds bound", U);
+    BLZ_LOG(2, "msm: units=%u max_bucket=%u entries=%u", U, maxcount, stats_h[2]);
+    BLZ_TRY(ops->run_tail(E, d_pts, U, maxcount));
+    timings_pending = true;
+    return BLZ_OK;
+}
+
+int MsmEngine::finish(uint8_t* out) {
+    BLZ_TRY(use_device(device));
+    size_t rs = 3 * fq_bytes(curve);
+    BLZ_HIP(hipMemcpyAsync(result_h, result.p, rs, hipMemcpyDeviceToHost, stream), BLZ_ERR_READ);
+    BLZ_HIP(hipStreamSynchronize(stream), BLZ_ERR_UNKNOWN);
+    memcpy(out, result_h, rs);
+    if (timings_pending) {
+        float t = 0;
+        // ev0 start, ev1 sort done, ev2 accumulate done, ev3 reduce done, ev4 finish done
+        (void)hipEventElapsedTime(&t, ev[0], ev[4]); last_ms[0] = t;
+        last_ms[1] = 0;
+        (void)hipEventElapsedTime(&t, ev[0], ev[1]); last_ms[2] = t;
+        (void)hipEventElapsedTime(&t, ev[1], ev[2]); last_ms[3] = t;
+        (void)hipEventElapsedTime(&t, ev[2], ev[3]); last_ms[4] = t;
+        (void)hipEventElapsedTime(&t, ev[3], ev[4]); last_ms[5] = t;
+        last_ms[6] = (float)last_plan.c;
+        last_ms[7] = (float)last_plan.W;
+        timings_pending = false;
+    }
+    return BLZ_OK;
+}
+
+int MsmEngine::combine_partials(const uint8_t* partials, size_t cnt, uint8_t* out) {
+    BLZ_TRY(use_device(device));
+    return ops_for(curve)->combine(*this, partials, cnt, out);
+}
+
+}  // namespace blz

@@ -1,0 +1,57 @@
+// Host-side interface of the MSM device pipeline (implemented in msm.hip).
+#pragma once
+#include "common.hpp"
+
+namespace blz {
+
+struct MsmPlan {
+    uint32_t npts = 0;   // points in the sum (n * precompute_factor)
+    int sbits = 256;     // scalar width per point: 256 (pf=1) or 32 (pf=8 chunk)
+    int c = 0;           // window bits
+    int W = 0;           // windows, W*c >= sbits+1
+    uint32_t Bw = 0;     // buckets per window = 2^(c-1) (signed digits)
+    uint64_t G = 0;      // W * Bw
+    uint32_t L = 0;      // max run length handled by one accumulate unit
+};
+MsmPlan make_plan(uint32_t npts, int sbits, int force_c);
+
+struct MsmEngine {
+    int device = 0;
+    int curve = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[8] = {};
+    DevBuf count, off, unit_off, unit_bucket, entries, partial, lvlA[2], lvlC[2], blocksums, stats, result;
+    uint32_t* stats_h = nullptr;   // pinned: [0] total units, [1] max bucket count, [2] total entries
+    uint8_t* result_h = nullptr;   // pinned result bytes
+    MsmPlan last_plan;
+    float last_ms[8] = {};
+    bool timings_pending = false;
+
+    int init(int device_id, int curve_id);
+    void destroy();
+    // raw wire-format points (x||y canonical LE) -> Montgomery AoS, npts points
+    int points_to_mont(const void* d_raw, void* d_mont, uint32_t npts);
+    // enqueue the whole pipeline on `stream`; result bytes land in result.p (device) when done
+    int run(const void* d_points_mont, const void* d_scalars, uint32_t npts, int sbits);
+    // wait for the stream, copy the result out (result_size bytes), collect phase timings
+    int finish(uint8_t* out);
+    // add `count` partial results (host bytes) on the device, normalised output
+    int combine_partials(const uint8_t* partials, size_t count, uint8_t* out);
+};
+
+size_t fq_bytes(int curve);
+int msm_env_int(const char* name, int dflt);
+void launch_fill_units(MsmEngine& E);
+
+// per-curve entry points (one translation unit per curve: msm_<curve>.hip)
+struct MsmCurveOps {
+    int (*points_to_mont)(MsmEngine&, const void* d_raw, void* d_mont, uint32_t npts);
+    int (*emit_infinity)(MsmEngine&);
+    int (*run_tail)(MsmEngine&, const void* d_pts, uint32_t units, uint32_t maxcount);
+    int (*combine)(MsmEngine&, const uint8_t* partials, size_t count, uint8_t* out);
+};
+const MsmCurveOps& msm_ops_bls377();
+const MsmCurveOps& msm_ops_bls381();
+const MsmCurveOps& msm_ops_bn254();
+
+}  // namespace blz

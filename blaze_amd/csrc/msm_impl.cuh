@@ -1,0 +1,328 @@
+// Curve-templated kernels and host launchers of the MSM pipeline (phases 1-3).  Included by one
+// translation unit per curve (msm_bls377.hip, msm_bls381.hip, msm_bn254.hip) so the three
+// instantiations compile in parallel.  See msm.hip for the pipeline overview.
+#pragma once
+#include "msm_engine.hpp"
+#include "ec.cuh"
+
+namespace blz {
+
+// ------------------------------------------------------------------------------------------------
+// points: wire format -> Montgomery AoS
+// ------------------------------------------------------------------------------------------------
+template <class F>
+__global__ __launch_bounds__(256) void k_points_to_mont(const uint32_t* raw, uint32_t* mont,  // may alias (in place)
+                                                        uint32_t npts) {
+    uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= npts) return;
+    Fp<F> x, y;
+    fp_load(x, raw + (size_t)p * 2 * F::N);
+    fp_load(y, raw + (size_t)p * 2 * F::N + F::N);
+    fp_to_mont(x, x);
+    fp_to_mont(y, y);
+    fp_store(mont + (size_t)p * 2 * F::N, x);
+    fp_store(mont + (size_t)p * 2 * F::N + F::N, y);
+}
+
+template <class F>
+BLZ_DEV void load_affine(Affine<F>& a, const uint32_t* pts, uint32_t idx) {
+    const uint32_t* q = pts + (size_t)idx * 2 * F::N;
+    fp_load(a.x, q);
+    fp_load(a.y, q + F::N);
+}
+template <class F>
+BLZ_DEV void load_xyzz(XYZZ<F>& a, const uint32_t* base, size_t idx) {
+    const uint32_t* q = base + idx * 4 * F::N;
+    fp_load(a.x, q);
+    fp_load(a.y, q + F::N);
+    fp_load(a.zz, q + 2 * F::N);
+    fp_load(a.zzz, q + 3 * F::N);
+}
+template <class F>
+BLZ_DEV void store_xyzz(uint32_t* base, size_t idx, const XYZZ<F>& a) {
+    uint32_t* q = base + idx * 4 * F::N;
+    fp_store(q, a.x);
+    fp_store(q + F::N, a.y);
+    fp_store(q + 2 * F::N, a.zz);
+    fp_store(q + 3 * F::N, a.zzz);
+}
+
+// ------------------------------------------------------------------------------------------------
+// phase 1: bucket accumulation.  One lane per unit (a run of <= L entries of one bucket).
+// ------------------------------------------------------------------------------------------------
+template <class F>
+__global__ __launch_bounds__(128) void k_accumulate(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ entries,
+                                                    const uint32_t* __restrict__ off, const uint32_t* __restrict__ unit_off,
+                                                    const uint32_t* __restrict__ unit_bucket, uint32_t U, uint32_t L,
+                                                    uint32_t* __restrict__ partial) {
+    uint32_t u = blockIdx.x * 128u + threadIdx.x;
+    if (u >= U) return;
+    uint32_t g = unit_bucket[u];
+    uint32_t k = u - unit_off[g];
+    uint32_t start = off[g] + k * L;
+    uint32_t end = off[g + 1];
+    if (end - start > L) end = start + L;
+    XYZZ<F> acc;
+    pt_set_inf(acc);
+    Affine<F> nxt;
+    uint32_t e = entries[start];
+    load_affine(nxt, pts, e & 0x7fffffffu);
+    for (uint32_t j = start; j < end; ++j) {
+        Affine<F> cur = nxt;
+        uint32_t ecur = e;
+        if (j + 1 < end) {  // prefetch the next point under the current add
+            e = entries[j + 1];
+            load_affine(nxt, pts, e & 0x7fffffffu);
+        }
+        if (ecur & 0x80000000u) fp_neg(cur.y, cur.y);
+        pt_madd(acc, cur);
+    }
+    store_xyzz(partial, u, acc);
+}
+
+// buckets that needed several units: fold partial[u0 + k*stride] for k in the same 16-group
+template <class F>
+__global__ __launch_bounds__(128) void k_combine_units(const uint32_t* __restrict__ unit_off,
+                                                       const uint32_t* __restrict__ unit_bucket, uint32_t U,
+                                                       uint32_t stride, uint32_t* __restrict__ partial) {
+    uint32_t u = blockIdx.x * 128u + threadIdx.x;
+    if (u >= U) return;
+    uint32_t g = unit_bucket[u];
+    uint32_t u0 = unit_off[g], u1 = unit_off[g + 1];
+    uint32_t k = u - u0;
+    if (u1 - u0 <= stride) return;
+    if (k % (16u * stride) != 0) return;
+    XYZZ<F> acc;
+    load_xyzz(acc, partial, u);
+    for (uint32_t j = 1; j < 16; ++j) {
+        uint32_t v = u + j * stride;
+        if (v >= u1) break;
+        XYZZ<F> t;
+        load_xyzz(t, partial, v);
+        pt_add(acc, t);
+    }
+    store_xyzz(partial, u, acc);
+}
+
+// ------------------------------------------------------------------------------------------------
+// phase 2: per window Sum_i (i + woff) * A_i by segments.  See DESIGN.md for the recurrence:
+//   F = Sum_t s_t + SEG * Sum_t t * r_t,  r_t = Sum_j A_(t SEG + j),  s_t = Sum_j (j + woff) A_(t SEG + j)
+// outA[t] = r_t (weights t at the next level, woff = 0), outC[t] = Sum C_in + 2^shift * s_t.
+// ------------------------------------------------------------------------------------------------
+template <class F, bool FIRST>
+__global__ __launch_bounds__(64) void k_reduce_level(const uint32_t* __restrict__ inA, const uint32_t* __restrict__ inC,
+                                                     const uint32_t* __restrict__ unit_off, uint32_t M, uint32_t SEG,
+                                                     uint32_t T, int W, int shift, uint32_t* __restrict__ outA,
+                                                     uint32_t* __restrict__ outC) {
+    uint32_t tid = blockIdx.x * 64u + threadIdx.x;
+    if (tid >= T * (uint32_t)W) return;
+    uint32_t w = tid / T, t = tid - w * T;
+    uint32_t lo = t * SEG;
+    uint32_t hi = lo + SEG;
+    if (hi > M) hi = M;
+    XYZZ<F> run, s, cs;
+    pt_set_inf(run);
+    pt_set_inf(s);
+    pt_set_inf(cs);
+    for (uint32_t i = hi; i-- > lo;) {
+        XYZZ<F> a;
+        size_t idx = (size_t)w * M + i;
+        if constexpr (FIRST) {
+            uint32_t u0 = unit_off[idx], u1 = unit_off[idx + 1];
+            if (u1 > u0) load_xyzz(a, inA, u0);
+            else pt_set_inf(a);
+        } else {
+            load_xyzz(a, inA, idx);
+            XYZZ<F> cc;
+            load_xyzz(cc, inC, idx);
+            pt_add(cs, cc);
+        }
+        pt_add(run, a);
+        if (FIRST || i != lo) pt_add(s, run);  // woff = 1 at the first level, 0 afterwards
+    }
+    for (int d = 0; d < shift; ++d) { XYZZ<F> t2; pt_dbl(t2, s); s = t2; }
+    pt_add(cs, s);
+    store_xyzz(outA, (size_t)w * T + t, run);
+    store_xyzz(outC, (size_t)w * T + t, cs);
+}
+
+// ------------------------------------------------------------------------------------------------
+// phase 3: Horner over the window sums, normalise, emit Z | Y | X canonical little-endian
+// (layout read back by tests/msm/mod.rs:397-399).  Infinity: Z = 0, Y = 1, X = 0.
+// ------------------------------------------------------------------------------------------------
+template <class F>
+__device__ void emit_result(uint32_t* out, const XYZZ<F>& p) {
+    Affine<F> a;
+    bool fin = pt_to_affine(a, p);
+    Fp<F> x, y, z;
+    fp_zero(z);
+    if (fin) {
+        fp_from_mont(x, a.x);
+        fp_from_mont(y, a.y);
+        z.v[0] = 1;
+    } else {
+        fp_zero(x);
+        fp_zero(y);
+        y.v[0] = 1;
+    }
+    fp_store(out, z);
+    fp_store(out + F::N, y);
+    fp_store(out + 2 * F::N, x);
+}
+
+template <class F>
+__global__ void k_finish(const uint32_t* __restrict__ winsum, int W, int c, uint32_t* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    XYZZ<F> acc;
+    pt_set_inf(acc);
+    for (int w = W - 1; w >= 0; --w) {
+        for (int d = 0; d < c; ++d) { XYZZ<F> t; pt_dbl(t, acc); acc = t; }
+        XYZZ<F> tw;
+        load_xyzz(tw, winsum, (size_t)w);
+        pt_add(acc, tw);
+    }
+    emit_result(out, acc);
+}
+
+template <class F>
+__global__ void k_emit_infinity(uint32_t* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    XYZZ<F> acc;
+    pt_set_inf(acc);
+    emit_result(out, acc);
+}
+
+// partials: count x (Z | Y | X) canonical, homogeneous projective x = X/Z, y = Y/Z
+template <class F>
+__global__ void k_combine_partials(const uint32_t* __restrict__ partials, uint32_t count, uint32_t* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    XYZZ<F> acc;
+    pt_set_inf(acc);
+    for (uint32_t i = 0; i < count; ++i) {
+        const uint32_t* q = partials + (size_t)i * 3 * F::N;
+        Fp<F> Z, Y, X;
+        fp_load(Z, q);
+        fp_load(Y, q + F::N);
+        fp_load(X, q + 2 * F::N);
+        fp_to_mont(Z, Z);
+        if (fp_is_zero(Z)) continue;
+        fp_to_mont(Y, Y);
+        fp_to_mont(X, X);
+        Fp<F> zi;
+        fp_inv(zi, Z);
+        Affine<F> a;
+        fp_mul(a.x, X, zi);
+        fp_mul(a.y, Y, zi);
+        pt_madd(acc, a);
+    }
+    emit_result(out, acc);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// host launchers
+// ------------------------------------------------------------------------------------------------
+template <class F>
+int points_to_mont_t(MsmEngine& E, const void* d_raw, void* d_mont, uint32_t npts) {
+    if (npts == 0) return BLZ_OK;
+    hipLaunchKernelGGL(k_points_to_mont<F>, dim3((npts + 255) / 256), dim3(256), 0, E.stream, (const uint32_t*)d_raw,
+                       (uint32_t*)d_mont, npts);
+    BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
+    return BLZ_OK;
+}
+
+template <class F>
+int emit_infinity_t(MsmEngine& E) {
+    hipLaunchKernelGGL(k_emit_infinity<F>, dim3(1), dim3(64), 0, E.stream, E.result.as<uint32_t>());
+    BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
+    return BLZ_OK;
+}
+
+// phases 1-3 after the digit sort: U units, longest bucket run `maxcount`
+template <class F>
+int run_tail_t(MsmEngine& E, const void* d_pts, uint32_t U, uint32_t maxcount) {
+    hipStream_t st = E.stream;
+    const MsmPlan& P = E.last_plan;
+    const uint64_t G = P.G;
+    BLZ_TRY(E.unit_bucket.reserve(((size_t)U + 1) * 4));
+    BLZ_TRY(E.partial.reserve(((size_t)U + 1) * 16 * F::N));
+    BLZ_HIP(hipEventRecord(E.ev[1], st), BLZ_ERR_UNKNOWN);
+
+    // ---- phase 1
+    if (U) {
+        launch_fill_units(E);
+        hipLaunchKernelGGL(k_accumulate<F>, dim3((U + 127) / 128), dim3(128), 0, st, (const uint32_t*)d_pts,
+                           E.entries.as<uint32_t>(), E.off.as<uint32_t>(), E.unit_off.as<uint32_t>(),
+                           E.unit_bucket.as<uint32_t>(), U, P.L, E.partial.as<uint32_t>());
+        uint32_t maxunits = (maxcount + P.L - 1) / P.L;
+        for (uint32_t stride = 1; stride < maxunits; stride *= 16)
+            hipLaunchKernelGGL(k_combine_units<F>, dim3((U + 127) / 128), dim3(128), 0, st, E.unit_off.as<uint32_t>(),
+                               E.unit_bucket.as<uint32_t>(), U, stride, E.partial.as<uint32_t>());
+        BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
+    }
+    BLZ_HIP(hipEventRecord(E.ev[2], st), BLZ_ERR_UNKNOWN);
+
+    // ---- phase 2
+    const uint32_t SEG = (uint32_t)msm_env_int("BLAZE_MSM_SEG", 32);
+    uint32_t M = P.Bw;
+    int level = 0, shift = 0, seglog = 0;
+    while ((1u << seglog) < SEG) ++seglog;
+    const uint32_t* curA = E.partial.as<uint32_t>();
+    const uint32_t* curC = nullptr;
+    for (;;) {
+        uint32_t T = (M + SEG - 1) / SEG;
+        DevBuf& oA = E.lvlA[level & 1];
+        DevBuf& oC = E.lvlC[level & 1];
+        BLZ_TRY(oA.reserve((size_t)T * P.W * 16 * F::N));
+        BLZ_TRY(oC.reserve((size_t)T * P.W * 16 * F::N));
+        uint32_t nthreads = T * (uint32_t)P.W;
+        if (level == 0)
+            hipLaunchKernelGGL((k_reduce_level<F, true>), dim3((nthreads + 63) / 64), dim3(64), 0, st, curA, curC,
+                               E.unit_off.as<uint32_t>(), M, SEG, T, P.W, shift, oA.as<uint32_t>(), oC.as<uint32_t>());
+        else
+            hipLaunchKernelGGL((k_reduce_level<F, false>), dim3((nthreads + 63) / 64), dim3(64), 0, st, curA, curC,
+                               E.unit_off.as<uint32_t>(), M, SEG, T, P.W, shift, oA.as<uint32_t>(), oC.as<uint32_t>());
+        curA = oA.as<uint32_t>();
+        curC = oC.as<uint32_t>();
+        shift += seglog;
+        M = T;
+        ++level;
+        if (T == 1) break;
+    }
+    BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
+    BLZ_HIP(hipEventRecord(E.ev[3], st), BLZ_ERR_UNKNOWN);
+
+    // ---- phase 3
+    hipLaunchKernelGGL(k_finish<F>, dim3(1), dim3(64), 0, st, curC, P.W, P.c, E.result.as<uint32_t>());
+    BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
+    BLZ_HIP(hipEventRecord(E.ev[4], st), BLZ_ERR_UNKNOWN);
+    return BLZ_OK;
+}
+
+template <class F>
+int combine_t(MsmEngine& E, const uint8_t* partials, size_t count, uint8_t* out) {
+    size_t rs = 3 * F::N * 4;
+    DevBuf tmp;
+    BLZ_TRY(tmp.reserve(rs * (count ? count : 1)));
+    if (count) BLZ_HIP(hipMemcpyAsync(tmp.p, partials, rs * count, hipMemcpyHostToDevice, E.stream), BLZ_ERR_WRITE);
+    hipLaunchKernelGGL(k_combine_partials<F>, dim3(1), dim3(64), 0, E.stream, tmp.as<uint32_t>(), (uint32_t)count,
+                       E.result.as<uint32_t>() + 64);
+    BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
+    BLZ_HIP(hipMemcpyAsync(E.result_h, E.result.as<uint32_t>() + 64, rs, hipMemcpyDeviceToHost, E.stream), BLZ_ERR_READ);
+    BLZ_HIP(hipStreamSynchronize(E.stream), BLZ_ERR_UNKNOWN);
+    memcpy(out, E.result_h, rs);
+    tmp.release();
+    return BLZ_OK;
+}
+
+template <class F>
+MsmCurveOps make_ops() {
+    MsmCurveOps o;
+    o.points_to_mont = &points_to_mont_t<F>;
+    o.emit_infinity = &emit_infinity_t<F>;
+    o.run_tail = &run_tail_t<F>;
+    o.combine = &combine_t<F>;
+    return o;
+}
+
+}  // namespace blz

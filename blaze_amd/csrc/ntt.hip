@@ -1,0 +1,380 @@
+// Radix-2^k NTT over the BLS12-381 scalar field for gfx950 (device task of SURVEY.md a16: what the
+// bitstream behind src/ingo_ntt/ntt_hw_code.rs:6-83 computes on one 2^27 x 32 B buffer).
+//
+//   X[k] = sum_i x[i] w^(ik),  natural order in and out,  w = 7^((r-1)/2^log_size)
+//
+// n = A*B*C (each <= 512).  With i = i0 + A i1 + AB i2 and k = k2 + C k1 + CB k0:
+//   pass 1: C-point NTTs over i2 (stride AB), then * w^(A i1 k2)
+//   pass 2: B-point NTTs over i1 (stride A),  then * w^(i0 (k2 + C k1))
+//   pass 3: A-point NTTs over i0 (contiguous), written to the natural address k2 + C k1 + CB k0
+// A pass stages a tile of COLS adjacent columns x radix rows in LDS (COLS*32 B contiguous per row
+// access), runs the radix-2 stages there and applies the inter-pass twiddle on the way out.
+// Data stay in plain canonical form; only twiddles are in Montgomery form (mont_mul(x, tR) = x t),
+// so there is no conversion pass.  Algorithmic traffic 2 x 4 GiB; this 3-pass form moves 3x that.
+#include "common.hpp"
+#include "field.cuh"
+
+namespace blz {
+
+using Fr = Fr_BLS381;
+using E = Fp<Fr>;
+
+struct NttTables {  // all Montgomery form, device memory
+    uint32_t* wpass[3];  // wpass[p][j] = root_p^j, j < radix_p/2   (root_p = primitive radix_p-th root)
+    uint32_t* t0;        // w^j            j < 512
+    uint32_t* t1;        // w^(512 j)      j < 512
+    uint32_t* t2;        // w^(2^18 j)     j < 512
+};
+
+// out[j] = base^(j * mult) where base = ROOT^(2^(TWO_ADICITY - logn))
+__global__ void k_ntt_table(uint32_t* out, int count, int logn, uint64_t mult) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    E w;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w.v[i] = Fr::ROOT[i];
+    for (int i = 0; i < Fr::TWO_ADICITY - logn; ++i) fp_sqr(w, w);
+    uint64_t e = (uint64_t)j * mult;
+    E acc;
+    fp_one(acc);
+    for (int b = 63; b >= 0; --b) {
+        fp_sqr(acc, acc);
+        if ((e >> b) & 1) fp_mul(acc, acc, w);
+    }
+    fp_store(out + (size_t)j * 8, acc);
+}
+
+BLZ_DEV void lds_load(E& r, const uint32_t* lds, uint32_t idx) {
+    const uint4* q = reinterpret_cast<const uint4*>(lds) + 2 * (size_t)idx;
+    uint4 a = q[0], b = q[1];
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+}
+BLZ_DEV void lds_store(uint32_t* lds, uint32_t idx, const E& r) {
+    uint4* q = reinterpret_cast<uint4*>(lds) + 2 * (size_t)idx;
+    q[0] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
+    q[1] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
+}
+
+// w^e for e < 2^27 from the three 512-entry tables
+BLZ_DEV void tw_pow(E& r, const NttTables& T, uint32_t e) {
+    E a, b;
+    fp_load(r, T.t0 + (size_t)(e & 511u) * 8);
+    uint32_t e1 = (e >> 9) & 511u, e2 = e >> 18;
+    if (e1) { fp_load(a, T.t1 + (size_t)e1 * 8); fp_mul(r, r, a); }
+    if (e2) { fp_load(b, T.t2 + (size_t)e2 * 8); fp_mul(r, r, b); }
+}
+
+struct NttGeom {
+    int logA, logB, logC, logn;
+};
+
+// PASS 1..3 as in the header comment.  Tile = COLS columns x (1 << lr) rows, 256 threads.
+template <int PASS>
+__global__ __launch_bounds__(256) void k_ntt_pass(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, NttGeom g,
+                                                  NttTables T, int cols_log) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int lr = PASS == 1 ? g.logC : PASS == 2 ? g.logB : g.logA;  // log radix of this pass
+    const uint32_t radix = 1u << lr;
+    const uint32_t COLS = 1u << cols_log;
+    const uint32_t A = 1u << g.logA, B = 1u << g.logB, C = 1u << g.logC;
+    // tile coordinates
+    uint64_t col_base;    // first column (the "other" index that is contiguous in the tile)
+    uint64_t fixed;       // the remaining fixed index
+    uint64_t in_base, in_rstride, in_cstride;
+    const uint64_t tile = blockIdx.x;
+    if (PASS == 1) {  // rows i2 (stride AB), cols i0 (stride 1), fixed i1
+        uint64_t tiles_per = A >> cols_log;
+        fixed = tile / tiles_per;  // i1
+        col_base = (tile % tiles_per) << cols_log;
+        in_base = col_base + (uint64_t)A * fixed;
+        in_rstride = (uint64_t)A * B;
+        in_cstride = 1;
+    } else if (PASS == 2) {  // rows i1 (stride A), cols i0, fixed k2
+        uint64_t tiles_per = A >> cols_log;
+        fixed = tile / tiles_per;  // k2
+        col_base = (tile % tiles_per) << cols_log;
+        in_base = col_base + (uint64_t)A * B * fixed;
+        in_rstride = A;
+        in_cstride = 1;
+    } else {  // rows i0 (stride 1), cols k2 (stride AB), fixed k1
+        uint64_t tiles_per = C >> cols_log;
+        fixed = tile / tiles_per;  // k1
+        col_base = (tile % tiles_per) << cols_log;
+        in_base = (uint64_t)A * fixed + (uint64_t)A * B * col_base;
+        in_rstride = 1;
+        in_cstride = (uint64_t)A * B;
+    }
+    const uint32_t total = radix << cols_log;
+    // ---- load, rows bit-reversed (decimation in time)
+    for (uint32_t e = threadIdx.x; e < total; e += 256) {
+        uint32_t row, col;
+        if (PASS == 3) { row = e & (radix - 1); col = e >> lr; }   // contiguous along rows
+        else { col = e & (COLS - 1); row = e >> cols_log; }         // contiguous along cols
+        E x;
+        fp_load(x, in + (in_base + row * in_rstride + col * in_cstride) * 8);
+        uint32_t rrow = lr ? (__brev(row) >> (32 - lr)) : 0;
+        lds_store(lds, rrow * COLS + col, x);
+    }
+    __syncthreads();
+    // ---- radix-2 stages
+    const uint32_t* wp = T.wpass[PASS - 1];
+    const uint32_t nbf = (radix >> 1) << cols_log;
+    for (int s = 1; s <= lr; ++s) {
+        const uint32_t half = 1u << (s - 1);
+        for (uint32_t e = threadIdx.x; e < nbf; e += 256) {
+            uint32_t col = e & (COLS - 1), b = e >> cols_log;
+            uint32_t blk = b >> (s - 1), k = b & (half - 1);
+            uint32_t u = (blk << s) + k, v = u + half;
+            E xu, xv;
+            lds_load(xu, lds, u * COLS + col);
+            lds_load(xv, lds, v * COLS + col);
+            uint32_t tw = k << (lr - s);
+            if (tw) {
+                E w;
+                fp_load(w, wp + (size_t)tw * 8);
+                fp_mul(xv, xv, w);
+            }
+            E sum, dif;
+            fp_add(sum, xu, xv);
+            fp_sub(dif, xu, xv);
+            lds_store(lds, u * COLS + col, sum);
+            lds_store(lds, v * COLS + col, dif);
+        }
+        __syncthreads();
+    }
+    // ---- inter-pass twiddle + store
+    for (uint32_t e = threadIdx.x; e < total; e += 256) {
+        uint32_t row, col;
+        if (PASS == 3) { col = e & (COLS - 1); row = e >> cols_log; }  // output contiguous along k2 (cols)
+        else { col = e & (COLS - 1); row = e >> cols_log; }
+        E x;
+        lds_load(x, lds, row * COLS + col);
+        uint64_t oaddr;
+        if (PASS == 1) {
+            // element (i0 = col_base+col, i1 = fixed, k2 = row): * w^(A i1 k2)
+            uint32_t ex = (uint32_t)(((uint64_t)fixed * row) << g.logA);
+            if (ex) { E w; tw_pow(w, T, ex); fp_mul(x, x, w); }
+            oaddr = in_base + row * in_rstride + col;
+        } else if (PASS == 2) {
+            // element (i0, k1 = row, k2 = fixed): * w^(i0 (k2 + C k1))
+            uint64_t i0 = col_base + col;
+            uint32_t ex = (uint32_t)(i0 * (fixed + ((uint64_t)row << g.logC)));
+            if (ex) { E w; tw_pow(w, T, ex); fp_mul(x, x, w); }
+            oaddr = in_base + row * in_rstride + col;
+        } else {
+            // element (k0 = row, k1 = fixed, k2 = col_base+col) -> natural address k2 + C k1 + CB k0
+            oaddr = (col_base + col) + (uint64_t)C * fixed + (uint64_t)C * B * row;
+        }
+        fp_store(out + oaddr * 8, x);
+    }
+}
+
+}  // namespace blz
+
+using namespace blz;
+
+struct blz_ntt {
+    int device = 0;
+    int logn = 27;
+    NttGeom geom{};
+    int cols_log[3] = {0, 0, 0};
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    DevBuf buf[2], scratch, tables;
+    NttTables T{};
+    bool in_flight = false;
+    bool has_data[2] = {false, false};
+    float last_ms = 0.f;
+};
+
+namespace {
+
+size_t ntt_bytes(const blz_ntt* h) { return (size_t)32 << h->logn; }
+
+int ntt_setup(blz_ntt* h) {
+    // split logn into three radices, largest last-pass first so the contiguous pass is wide
+    int l = h->logn;
+    int la = l > 9 ? 9 : l;
+    int lb = (l - la) > 9 ? 9 : (l - la);
+    int lc = l - la - lb;
+    if (lc > 9) return fail(BLZ_ERR_INVALID_PARAM, "log_size %d not supported (max 27)", l);
+    h->geom = NttGeom{la, lb, lc, l};
+    // columns per tile: LDS = radix * COLS * 32 B <= 128 KiB, and COLS <= extent of the column index
+    auto pick = [](int lr, int lcols_avail) {
+        int c = 17 - 5 - lr;  // log2(128 KiB / 32 B / radix)
+        if (c > 3) c = 3;
+        if (c > lcols_avail) c = lcols_avail;
+        if (c < 0) c = 0;
+        return c;
+    };
+    h->cols_log[0] = pick(lc, la);  // pass 1: cols i0 (< A)
+    h->cols_log[1] = pick(lb, la);  // pass 2: cols i0 (< A)
+    h->cols_log[2] = pick(la, lc);  // pass 3: cols k2 (< C)
+    size_t tb = (size_t)(3 * 256 + 3 * 512) * 32;
+    BLZ_TRY(h->tables.reserve(tb));
+    uint32_t* p = h->tables.as<uint32_t>();
+    for (int i = 0; i < 3; ++i) { h->T.wpass[i] = p; p += 256 * 8; }
+    h->T.t0 = p; p += 512 * 8;
+    h->T.t1 = p; p += 512 * 8;
+    h->T.t2 = p; p += 512 * 8;
+    const uint64_t n = 1ull << l;
+    int lrs[3] = {lc, lb, la};
+    for (int i = 0; i < 3; ++i) {
+        int cnt = lrs[i] ? (1 << (lrs[i] - 1)) : 1;
+        hipLaunchKernelGGL(k_ntt_table, dim3(1), dim3(256), 0, h->stream, h->T.wpass[i], cnt, l, n >> lrs[i]);
+    }
+    hipLaunchKernelGGL(k_ntt_table, dim3(2), dim3(256), 0, h->stream, h->T.t0, 512, l, (uint64_t)1);
+    hipLaunchKernelGGL(k_ntt_table, dim3(2), dim3(256), 0, h->stream, h->T.t1, 512, l, (uint64_t)512);
+    hipLaunchKernelGGL(k_ntt_table, dim3(2), dim3(256), 0, h->stream, h->T.t2, 512, l, (uint64_t)1 << 18);
+    BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
+    BLZ_HIP(hipStreamSynchronize(h->stream), BLZ_ERR_UNKNOWN);
+    return BLZ_OK;
+}
+
+template <int PASS>
+int launch_pass(blz_ntt* h, const void* in, void* out) {
+    const NttGeom& g = h->geom;
+    int lr = PASS == 1 ? g.logC : PASS == 2 ? g.logB : g.logA;
+    int cl = h->cols_log[PASS - 1];
+    size_t lds = ((size_t)32 << lr) << cl;
+    uint64_t tiles = (1ull << g.logn) >> (lr + cl);
+    static bool attr_set = false;
+    if (!attr_set) {
+        BLZ_HIP(hipFuncSetAttribute((const void*)k_ntt_pass<PASS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                BLZ_ERR_UNKNOWN);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_ntt_pass<PASS>, dim3((unsigned)tiles), dim3(256), lds, h->stream, (const uint32_t*)in,
+                       (uint32_t*)out, g, h->T, cl);
+    BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
+    return BLZ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int blz_ntt_new(int device_id, int log_size, blz_ntt** out) {
+    if (!out) return fail(BLZ_ERR_INVALID_PARAM, "null out");
+    *out = nullptr;
+    if (log_size < 1 || log_size > 27) return fail(BLZ_ERR_INVALID_PARAM, "log_size %d out of range [1,27]", log_size);
+    BLZ_TRY(use_device(device_id));
+    blz_ntt* h = new blz_ntt();
+    h->device = device_id;
+    h->logn = log_size;
+    hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev1);
+    int rc = e == hipSuccess ? ntt_setup(h) : fail(BLZ_ERR_UNKNOWN, "stream/event creation failed: %s", hipGetErrorString(e));
+    if (rc != BLZ_OK) {
+        blz_ntt_free(h);
+        return rc;
+    }
+    *out = h;
+    return BLZ_OK;
+}
+
+void blz_ntt_free(blz_ntt* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    h->buf[0].release(); h->buf[1].release(); h->scratch.release(); h->tables.release();
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int blz_ntt_initialize(blz_ntt* h) {
+    if (!h) return fail(BLZ_ERR_INVALID_PARAM, "null handle");
+    return BLZ_OK;  // ntt_api.rs:37-56 writes debug-program registers; nothing to program here
+}
+
+static int ntt_set_data_common(blz_ntt* h, size_t buf_host, const void* data, size_t len, bool on_device) {
+    if (!h || !data) return fail(BLZ_ERR_INVALID_PARAM, "null argument");
+    if (buf_host > 1) return fail(BLZ_ERR_INVALID_PARAM, "buf_host must be 0 or 1");
+    if (len != ntt_bytes(h)) return fail(BLZ_ERR_INVALID_PARAM, "data length %zu != %zu", len, ntt_bytes(h));
+    BLZ_TRY(use_device(h->device));
+    BLZ_TRY(h->buf[buf_host].reserve(len));
+    // a dedicated (blocking) copy: the compute stream may be busy on the other buffer
+    // (double-buffer contract, tests/integration_ntt.rs:102-136)
+    BLZ_HIP(hipMemcpy(h->buf[buf_host].p, data, len, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice), BLZ_ERR_WRITE);
+    h->has_data[buf_host] = true;
+    return BLZ_OK;
+}
+
+int blz_ntt_set_data(blz_ntt* h, size_t buf_host, const uint8_t* data, size_t len) {
+    return ntt_set_data_common(h, buf_host, data, len, false);
+}
+int blz_ntt_set_data_device(blz_ntt* h, size_t buf_host, const void* d_data, size_t len) {
+    return ntt_set_data_common(h, buf_host, d_data, len, true);
+}
+
+int blz_ntt_start_process(blz_ntt* h, size_t buf_kernel) {
+    if (!h) return fail(BLZ_ERR_INVALID_PARAM, "null handle");
+    if (buf_kernel > 1) return fail(BLZ_ERR_INVALID_PARAM, "buf_kernel must be 0 or 1");
+    if (!h->has_data[buf_kernel]) return fail(BLZ_ERR_INVALID_PARAM, "buffer %zu holds no data", buf_kernel);
+    if (h->in_flight) return fail(BLZ_ERR_INVALID_PARAM, "a transform is already running; call wait_result first");
+    BLZ_TRY(use_device(h->device));
+    BLZ_TRY(h->scratch.reserve(ntt_bytes(h)));
+    void* b = h->buf[buf_kernel].p;
+    void* s = h->scratch.p;
+    BLZ_HIP(hipEventRecord(h->ev0, h->stream), BLZ_ERR_UNKNOWN);
+    const void* cur = b;
+    if (h->geom.logC) { BLZ_TRY(launch_pass<1>(h, cur, s)); cur = s; }
+    if (h->geom.logB) { BLZ_TRY(launch_pass<2>(h, cur, s)); cur = s; }
+    if (cur == b) {  // single pass: keep it out of place through the scratch
+        BLZ_HIP(hipMemcpyAsync(s, b, ntt_bytes(h), hipMemcpyDeviceToDevice, h->stream), BLZ_ERR_UNKNOWN);
+        cur = s;
+    }
+    BLZ_TRY(launch_pass<3>(h, cur, b));
+    BLZ_HIP(hipEventRecord(h->ev1, h->stream), BLZ_ERR_UNKNOWN);
+    h->in_flight = true;
+    return BLZ_OK;
+}
+
+int blz_ntt_wait_result(blz_ntt* h) {
+    if (!h) return fail(BLZ_ERR_INVALID_PARAM, "null handle");
+    if (!h->in_flight) return fail(BLZ_ERR_INVALID_PARAM, "wait_result with no transform in flight");
+    BLZ_TRY(use_device(h->device));
+    BLZ_HIP(hipStreamSynchronize(h->stream), BLZ_ERR_UNKNOWN);
+    (void)hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1);
+    h->in_flight = false;
+    return BLZ_OK;
+}
+
+static int ntt_result_common(blz_ntt* h, size_t buf, void* out, size_t out_cap, bool on_device) {
+    if (!h || !out) return fail(BLZ_ERR_INVALID_PARAM, "null argument");
+    if (buf > 1 || !h->has_data[buf]) return fail(BLZ_ERR_INVALID_PARAM, "buffer %zu holds no data", buf);
+    if (out_cap < ntt_bytes(h)) return fail(BLZ_ERR_INVALID_PARAM, "output buffer too small");
+    BLZ_TRY(use_device(h->device));
+    BLZ_HIP(hipMemcpy(out, h->buf[buf].p, ntt_bytes(h), on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost), BLZ_ERR_READ);
+    return BLZ_OK;
+}
+int blz_ntt_result(blz_ntt* h, size_t buf, uint8_t* out, size_t out_cap) { return ntt_result_common(h, buf, out, out_cap, false); }
+int blz_ntt_result_device(blz_ntt* h, size_t buf, void* d_out, size_t out_cap) { return ntt_result_common(h, buf, d_out, out_cap, true); }
+
+int blz_ntt_reset(blz_ntt* h) {
+    if (!h) return fail(BLZ_ERR_INVALID_PARAM, "null handle");
+    BLZ_TRY(use_device(h->device));
+    BLZ_HIP(hipStreamSynchronize(h->stream), BLZ_ERR_UNKNOWN);
+    h->in_flight = false;
+    return BLZ_OK;
+}
+
+int blz_ntt_last_kernel_ms(blz_ntt* h, float* out) {
+    if (!h || !out) return fail(BLZ_ERR_INVALID_PARAM, "null argument");
+    *out = h->last_ms;
+    return BLZ_OK;
+}
+
+int blz_ntt_banks_preprocess_device(blz_ntt* h, const void* d_in, void* d_banks) {
+    (void)h; (void)d_in; (void)d_banks;
+    return fail(BLZ_ERR_INVALID_PARAM, "bank permutation kernels are not built yet (SURVEY.md 8(f) rank 3)");
+}
+int blz_ntt_banks_postprocess_device(blz_ntt* h, const void* d_banks, void* d_out) {
+    (void)h; (void)d_banks; (void)d_out;
+    return fail(BLZ_ERR_INVALID_PARAM, "bank permutation kernels are not built yet (SURVEY.md 8(f) rank 3)");
+}
+
+}  // extern "C"

@@ -1,0 +1,155 @@
+// Element-wise kernels over the device field / group primitives, so tests can compare each of them
+// with the CPU oracle (include/blaze_hip.h "test hooks").  Not on the MSM/NTT product path.
+#include "common.hpp"
+#include "ec.cuh"
+
+namespace blz {
+
+template <class P>
+__global__ __launch_bounds__(64) void k_test_field(int op, const uint32_t* a, const uint32_t* b, uint32_t* out, uint32_t n) {
+    uint32_t i = blockIdx.x * 64u + threadIdx.x;
+    if (i >= n) return;
+    Fp<P> x, y, r;
+    fp_load(x, a + (size_t)i * P::N);
+    fp_load(y, b + (size_t)i * P::N);
+    fp_to_mont(x, x);
+    fp_to_mont(y, y);
+    switch (op) {
+        case 0: fp_mul(r, x, y); break;
+        case 1: fp_add(r, x, y); break;
+        case 2: fp_sub(r, x, y); break;
+        case 3: fp_inv(r, x); break;
+        default: fp_sqr(r, x); break;
+    }
+    fp_from_mont(r, r);
+    fp_store(out + (size_t)i * P::N, r);
+}
+
+template <class F>
+__global__ __launch_bounds__(64) void k_test_ec(int op, const uint32_t* p, const uint32_t* q, const uint8_t* inf_flags,
+                                                uint32_t* out, uint8_t* out_inf, uint32_t n) {
+    uint32_t i = blockIdx.x * 64u + threadIdx.x;
+    if (i >= n) return;
+    Affine<F> P, Q;
+    fp_load(P.x, p + (size_t)i * 2 * F::N);
+    fp_load(P.y, p + (size_t)i * 2 * F::N + F::N);
+    fp_load(Q.x, q + (size_t)i * 2 * F::N);
+    fp_load(Q.y, q + (size_t)i * 2 * F::N + F::N);
+    fp_to_mont(P.x, P.x); fp_to_mont(P.y, P.y); fp_to_mont(Q.x, Q.x); fp_to_mont(Q.y, Q.y);
+    uint8_t fl = inf_flags[i];
+    XYZZ<F> acc, qq;
+    if (fl & 1) pt_set_inf(acc); else pt_from_affine(acc, P);
+    if (fl & 2) pt_set_inf(qq); else pt_from_affine(qq, Q);
+    // de-normalise the accumulator (scale by a non-trivial z) so the projective paths are exercised
+    if (!(fl & 1)) {
+        Fp<F> z, z2, z3;
+        z = P.x; fp_add(z, z, Q.y);
+        if (fp_is_zero(z)) fp_one(z);
+        fp_sqr(z2, z); fp_mul(z3, z2, z);
+        fp_mul(acc.x, acc.x, z2); fp_mul(acc.y, acc.y, z3); acc.zz = z2; acc.zzz = z3;
+    }
+    switch (op) {
+        case 0: if (!(fl & 2)) pt_madd(acc, Q); break;
+        case 1: { XYZZ<F> d; pt_dbl(d, acc); acc = d; } break;
+        case 2: {
+            if (!(fl & 2)) {  // de-normalise q too
+                Fp<F> z, z2, z3;
+                z = Q.x; fp_add(z, z, P.y);
+                if (fp_is_zero(z)) fp_one(z);
+                fp_sqr(z2, z); fp_mul(z3, z2, z);
+                fp_mul(qq.x, qq.x, z2); fp_mul(qq.y, qq.y, z3); qq.zz = z2; qq.zzz = z3;
+            }
+            pt_add(acc, qq);
+        } break;
+        default: if (!(fl & 2)) { fp_neg(Q.y, Q.y); pt_madd(acc, Q); } break;
+    }
+    Affine<F> r;
+    bool fin = pt_to_affine(r, acc);
+    Fp<F> x, y;
+    if (fin) { fp_from_mont(x, r.x); fp_from_mont(y, r.y); } else { fp_zero(x); fp_zero(y); }
+    fp_store(out + (size_t)i * 2 * F::N, x);
+    fp_store(out + (size_t)i * 2 * F::N + F::N, y);
+    out_inf[i] = fin ? 0 : 1;
+}
+
+struct Tmp {
+    std::vector<void*> ptrs;
+    ~Tmp() { for (void* p : ptrs) (void)hipFree(p); }
+    int alloc(void** p, size_t n) {
+        BLZ_HIP(hipMalloc(p, n ? n : 16), BLZ_ERR_UNKNOWN);
+        ptrs.push_back(*p);
+        return BLZ_OK;
+    }
+};
+
+template <class P>
+int test_field_t(int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n) {
+    Tmp tmp;
+    size_t bytes = n * P::N * 4;
+    void *da, *db, *dout;
+    BLZ_TRY(tmp.alloc(&da, bytes)); BLZ_TRY(tmp.alloc(&db, bytes)); BLZ_TRY(tmp.alloc(&dout, bytes));
+    BLZ_HIP(hipMemcpy(da, a, bytes, hipMemcpyHostToDevice), BLZ_ERR_WRITE);
+    BLZ_HIP(hipMemcpy(db, b, bytes, hipMemcpyHostToDevice), BLZ_ERR_WRITE);
+    hipLaunchKernelGGL(k_test_field<P>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, op, (const uint32_t*)da,
+                       (const uint32_t*)db, (uint32_t*)dout, (uint32_t)n);
+    BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
+    BLZ_HIP(hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost), BLZ_ERR_READ);
+    return BLZ_OK;
+}
+
+template <class F>
+int test_ec_t(int op, const uint8_t* p, const uint8_t* q, const uint8_t* fl, uint8_t* out, uint8_t* out_inf, size_t n) {
+    Tmp tmp;
+    size_t bytes = n * 2 * F::N * 4;
+    void *dp, *dq, *dfl, *dout, *dinf;
+    BLZ_TRY(tmp.alloc(&dp, bytes)); BLZ_TRY(tmp.alloc(&dq, bytes)); BLZ_TRY(tmp.alloc(&dfl, n));
+    BLZ_TRY(tmp.alloc(&dout, bytes)); BLZ_TRY(tmp.alloc(&dinf, n));
+    BLZ_HIP(hipMemcpy(dp, p, bytes, hipMemcpyHostToDevice), BLZ_ERR_WRITE);
+    BLZ_HIP(hipMemcpy(dq, q, bytes, hipMemcpyHostToDevice), BLZ_ERR_WRITE);
+    BLZ_HIP(hipMemcpy(dfl, fl, n, hipMemcpyHostToDevice), BLZ_ERR_WRITE);
+    hipLaunchKernelGGL(k_test_ec<F>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, op, (const uint32_t*)dp,
+                       (const uint32_t*)dq, (const uint8_t*)dfl, (uint32_t*)dout, (uint8_t*)dinf, (uint32_t)n);
+    BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
+    BLZ_HIP(hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost), BLZ_ERR_READ);
+    BLZ_HIP(hipMemcpy(out_inf, dinf, n, hipMemcpyDeviceToHost), BLZ_ERR_READ);
+    return BLZ_OK;
+}
+
+}  // namespace blz
+
+using namespace blz;
+
+extern "C" {
+
+int blz_test_field_op(int device_id, int curve, int field, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n) {
+    BLZ_TRY(use_device(device_id));
+    if (n == 0) return BLZ_OK;
+    if (field == 0) {
+        switch (curve) {
+            case BLZ_BLS377: return test_field_t<Fq_BLS377>(op, a, b, out, n);
+            case BLZ_BLS381: return test_field_t<Fq_BLS381>(op, a, b, out, n);
+            case BLZ_BN254: return test_field_t<Fq_BN254>(op, a, b, out, n);
+        }
+    } else {
+        switch (curve) {
+            case BLZ_BLS377: return test_field_t<Fr_BLS377>(op, a, b, out, n);
+            case BLZ_BLS381: return test_field_t<Fr_BLS381>(op, a, b, out, n);
+            case BLZ_BN254: return test_field_t<Fr_BN254>(op, a, b, out, n);
+        }
+    }
+    return fail(BLZ_ERR_INVALID_PARAM, "unknown curve %d", curve);
+}
+
+int blz_test_ec_op(int device_id, int curve, int op, const uint8_t* p, const uint8_t* q, const uint8_t* inf_flags,
+                   uint8_t* out, uint8_t* out_inf, size_t n) {
+    BLZ_TRY(use_device(device_id));
+    if (n == 0) return BLZ_OK;
+    switch (curve) {
+        case BLZ_BLS377: return test_ec_t<Fq_BLS377>(op, p, q, inf_flags, out, out_inf, n);
+        case BLZ_BLS381: return test_ec_t<Fq_BLS381>(op, p, q, inf_flags, out, out_inf, n);
+        case BLZ_BN254: return test_ec_t<Fq_BN254>(op, p, q, inf_flags, out, out_inf, n);
+    }
+    return fail(BLZ_ERR_INVALID_PARAM, "unknown curve %d", curve);
+}
+
+}  // extern "C"

@@ -1,0 +1,176 @@
+"""Host-side mirror of src/ingo_msm (msm_api.rs, msm_cfg.rs): same type names, fields and call
+sequence; every method forwards 1:1 to the C ABI (include/blaze_hip.h)."""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+from ._lib import DeviceBuffer, buf_ptr, check, lib
+from .driver_client import DriverClient, DriverPrimitive
+
+PRECOMPUTE_FACTOR_BASE = 1  # msm_api.rs:39
+PRECOMPUTE_FACTOR = 8  # msm_api.rs:40
+
+
+class Curve(enum.IntEnum):  # msm_cfg.rs:4-8 (declaration order)
+    BLS377 = 0
+    BLS381 = 1
+    BN254 = 2
+
+
+class PointMemoryType(enum.IntEnum):  # msm_cfg.rs:11-14
+    HBM = 0
+    DMA = 1
+
+
+@dataclass
+class MSMInit:  # msm_api.rs:16-20
+    mem_type: PointMemoryType
+    is_precompute: bool
+    curve: Curve
+
+
+@dataclass
+class MSMParams:  # msm_api.rs:23-26
+    nof_elements: int
+    hbm_point_addr: Optional[Tuple[int, int]] = None
+
+
+@dataclass
+class MSMInput:  # msm_api.rs:28-32
+    points: Optional[object]  # bytes-like, or DeviceBuffer for HBM-resident data
+    scalars: object
+    params: MSMParams
+
+
+@dataclass
+class MSMResult:  # msm_api.rs:33-37
+    result: bytes
+    result_label: int
+
+
+@dataclass(frozen=True)
+class MSMConfig:  # msm_cfg.rs:17-30 (sizes only: the DMA FIFO addresses have no GPU meaning)
+    result_point_size: int
+    point_size: int
+    scalar_size: int
+
+    @staticmethod
+    def msm_cfg(curve: Curve, _mem: PointMemoryType) -> "MSMConfig":  # msm_cfg.rs:32-41
+        return MSMConfig(int(lib().blz_result_size(int(curve))), int(lib().blz_point_size(int(curve))), 32)
+
+
+def _hbm(params: MSMParams):
+    if params.hbm_point_addr is None:
+        return 0, 0, 0
+    return 1, int(params.hbm_point_addr[0]), int(params.hbm_point_addr[1])
+
+
+class MSMClient(DriverPrimitive[MSMInit, MSMParams, MSMInput, MSMResult]):
+    """msm_api.rs:8-14, 42-331."""
+
+    def __init__(self, init: MSMInit, dclient: DriverClient):
+        self.mem_type = init.mem_type
+        self.precompute_factor = PRECOMPUTE_FACTOR if init.is_precompute else PRECOMPUTE_FACTOR_BASE
+        self.curve = Curve(init.curve)
+        self.msm_cfg = MSMConfig.msm_cfg(self.curve, init.mem_type)
+        self.driver_client = dclient
+        h = C.c_void_p()
+        check(lib().blz_msm_new(dclient.id, int(init.mem_type), int(bool(init.is_precompute)), int(init.curve), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().blz_msm_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- DriverPrimitive
+    def loaded_binary_parameters(self) -> list[int]:  # msm_api.rs:57-70
+        out = (C.c_uint32 * 2)()
+        check(lib().blz_msm_loaded_binary_parameters(self._h, out))
+        return [int(out[0]), int(out[1])]
+
+    def initialize(self, params: MSMParams) -> None:  # msm_api.rs:72-111
+        has, addr, off = _hbm(params)
+        check(lib().blz_msm_initialize(self._h, params.nof_elements, has, addr, off))
+
+    def start_process(self, _param: Optional[int] = None) -> None:  # msm_api.rs:113-120
+        check(lib().blz_msm_start_process(self._h))
+
+    def set_data(self, data: MSMInput) -> None:  # msm_api.rs:155-220
+        has, addr, off = _hbm(data.params)
+        on_dev = isinstance(data.scalars, DeviceBuffer)
+        if on_dev:
+            pp = data.points.ptr if data.points is not None else None
+            pn = data.points.nbytes if data.points is not None else 0
+            check(lib().blz_msm_set_data_device(self._h, pp, pn, data.scalars.ptr, data.scalars.nbytes,
+                                                data.params.nof_elements, has, addr, off))
+            return
+        pp, pn, _k1 = buf_ptr(data.points)
+        sp, sn, _k2 = buf_ptr(data.scalars)
+        check(lib().blz_msm_set_data(self._h, pp, pn, sp, sn, data.params.nof_elements, has, addr, off))
+
+    def wait_result(self) -> None:  # msm_api.rs:222-238
+        check(lib().blz_msm_wait_result(self._h))
+
+    def result(self, _param: Optional[int] = None) -> Optional[MSMResult]:  # msm_api.rs:240-274
+        out = C.create_string_buffer(self.msm_cfg.result_point_size)
+        n = C.c_size_t()
+        label = C.c_uint32()
+        check(lib().blz_msm_result(self._h, C.cast(out, C.c_void_p), len(out), C.byref(n), C.byref(label)))
+        return MSMResult(out.raw[: n.value], int(label.value))
+
+    # ---- extras (msm_api.rs:277-331)
+    def task_label(self) -> int:
+        v = C.c_uint32()
+        check(lib().blz_msm_task_label(self._h, C.byref(v)))
+        return int(v.value)
+
+    def nof_elements(self) -> int:
+        v = C.c_uint32()
+        check(lib().blz_msm_nof_elements(self._h, C.byref(v)))
+        return int(v.value)
+
+    def is_msm_engine_ready(self) -> int:
+        v = C.c_uint32()
+        check(lib().blz_msm_is_engine_ready(self._h, C.byref(v)))
+        return int(v.value)
+
+    def load_data_to_hbm(self, points, addr: int, offset: int) -> None:
+        if isinstance(points, DeviceBuffer):
+            check(lib().blz_msm_load_data_to_hbm_device(self._h, points.ptr, points.nbytes, addr, offset))
+            return
+        p, n, _k = buf_ptr(points)
+        check(lib().blz_msm_load_data_to_hbm(self._h, p, n, addr, offset))
+
+    def get_data_from_hbm(self, data_len: int, addr: int, offset: int) -> bytes:
+        out = bytearray(data_len)
+        p, _, _k = buf_ptr(out)
+        check(lib().blz_msm_get_data_from_hbm(self._h, p, data_len, addr, offset))
+        return bytes(out)
+
+    def get_api(self) -> dict:
+        """msm_api.rs:324-330 dumps every register; here: the phase timers of the last task."""
+        t = (C.c_float * 8)()
+        check(lib().blz_msm_last_timings(self._h, t))
+        keys = ["total_ms", "convert_ms", "sort_ms", "phase1_accumulate_ms", "phase2_reduce_ms", "phase3_final_ms",
+                "window_bits", "windows"]
+        return dict(zip(keys, [float(x) for x in t]))
+
+    def reset(self) -> None:
+        check(lib().blz_msm_reset(self._h))
+
+    def combine_partials(self, partials: bytes, count: int) -> bytes:
+        """Multi-GPU: rank-ordered sum of `count` partial results."""
+        out = C.create_string_buffer(self.msm_cfg.result_point_size)
+        p, _n, _k = buf_ptr(partials)
+        check(lib().blz_msm_combine_partials(self._h, p, count, C.cast(out, C.c_void_p), len(out)))
+        return out.raw

@@ -1,0 +1,92 @@
+"""Host-side mirror of src/ingo_ntt (ntt_api.rs): same names and call sequence over the C ABI."""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+from dataclasses import dataclass
+from typing import Optional
+
+from ._lib import DeviceBuffer, buf_ptr, check, lib
+from .driver_client import DriverClient, DriverPrimitive
+
+NTT_LOG_SIZE = 27  # ntt_data.rs:65: NTT_SIZE = 2^27
+NTT_WORD_SIZE = 32  # ntt_data.rs:66
+
+
+class NTT(enum.Enum):  # ntt_api.rs:8-10
+    Ntt = 0
+
+
+@dataclass
+class NttInit:  # ntt_api.rs:17
+    pass
+
+
+@dataclass
+class NTTInput:  # ntt_api.rs:19-23
+    buf_host: int
+    data: object  # bytes-like of 2^log_size * 32 bytes, or a DeviceBuffer
+
+
+class NTTClient(DriverPrimitive[NTT, NttInit, NTTInput, bytes]):
+    """ntt_api.rs:12-15, 25-125.  `log_size` defaults to the reference's fixed 2^27; smaller
+    transforms exist for tests (the reference has no such knob)."""
+
+    def __init__(self, _ptype: NTT, dclient: DriverClient, log_size: int = NTT_LOG_SIZE):
+        self.driver_client = dclient
+        self.log_size = log_size
+        self.nbytes = NTT_WORD_SIZE << log_size
+        h = C.c_void_p()
+        check(lib().blz_ntt_new(dclient.id, log_size, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().blz_ntt_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def loaded_binary_parameters(self) -> list[int]:
+        raise NotImplementedError("todo!() in the reference too (ntt_api.rs:33-35)")
+
+    def initialize(self, _param: NttInit = NttInit()) -> None:  # ntt_api.rs:37-56
+        check(lib().blz_ntt_initialize(self._h))
+
+    def start_process(self, buf_kernel: Optional[int] = None) -> None:  # ntt_api.rs:58-70
+        if buf_kernel is None:
+            raise TypeError("buf_kernel is required (the reference unwraps it: ntt_api.rs:62)")
+        check(lib().blz_ntt_start_process(self._h, buf_kernel))
+
+    def set_data(self, input: NTTInput) -> None:  # ntt_api.rs:72-87
+        if isinstance(input.data, DeviceBuffer):
+            check(lib().blz_ntt_set_data_device(self._h, input.buf_host, input.data.ptr, input.data.nbytes))
+            return
+        p, n, _k = buf_ptr(input.data)
+        check(lib().blz_ntt_set_data(self._h, input.buf_host, p, n))
+
+    def wait_result(self) -> None:  # ntt_api.rs:89-108
+        check(lib().blz_ntt_wait_result(self._h))
+
+    def result(self, buf_num: Optional[int] = None) -> Optional[bytes]:  # ntt_api.rs:110-124
+        if buf_num is None:
+            raise TypeError("buf_num is required (the reference unwraps it: ntt_api.rs:113)")
+        out = bytearray(self.nbytes)
+        p, _, _k = buf_ptr(out)
+        check(lib().blz_ntt_result(self._h, buf_num, p, self.nbytes))
+        return out
+
+    def result_device(self, buf_num: int, dst: DeviceBuffer) -> None:
+        check(lib().blz_ntt_result_device(self._h, buf_num, dst.ptr, dst.nbytes))
+
+    def reset(self) -> None:
+        check(lib().blz_ntt_reset(self._h))
+
+    def last_kernel_ms(self) -> float:
+        v = C.c_float()
+        check(lib().blz_ntt_last_kernel_ms(self._h, C.byref(v)))
+        return float(v.value)

@@ -1,0 +1,187 @@
+/* libblaze_hip - MI355X (gfx950) device path for blaze's MSM / NTT primitives.
+ *
+ * C ABI cut at the DriverPrimitive method level: one function per trait method per primitive
+ * (reference trait: src/driver_client/dclient.rs:28-46).  Each entry cites the reference
+ * interface it replaces.  Plain pointers and sizes only; the callee borrows host pointers for the
+ * duration of the call; the caller provides output buffers.  A handle is not thread-safe; distinct
+ * handles are independent (own stream and workspace).  Nothing here ever falls back to a CPU path:
+ * if no HIP device is usable every constructor fails with BLZ_ERR_FILE.
+ *
+ * Return value of every int function: 0 = Ok, otherwise a DriverClientError code in the order of
+ * the reference enum (src/error.rs:6-32); blz_last_error_message() gives the detail string
+ * (the `offset` / `path` payload of the reference variants).
+ */
+#ifndef BLAZE_HIP_H
+#define BLAZE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* src/error.rs:6-32, same order */
+enum blz_error {
+    BLZ_OK = 0,
+    BLZ_ERR_WRITE = 1,               /* WriteError{offset,source}: host->device transfer failed      */
+    BLZ_ERR_READ = 2,                /* ReadError{offset,source}: device->host transfer failed       */
+    BLZ_ERR_HBICAP_NOT_READY = 3,    /* HBICAPNotReady: never produced (no bitstream to load)        */
+    BLZ_ERR_INVALID_PARAM = 4,       /* InvalidPrimitiveParam: bad mode combination / sizes / state  */
+    BLZ_ERR_CSV = 5,                 /* CsvError: never produced                                     */
+    BLZ_ERR_LOAD_FAILED = 6,         /* LoadFailed{path}: never produced                             */
+    BLZ_ERR_FILE = 7,                /* FileError: device could not be opened (no GPU / bad ordinal) */
+    BLZ_ERR_UNKNOWN = 8              /* Unknown: kernel launch / runtime failure                     */
+};
+
+/* src/ingo_msm/msm_cfg.rs:4-8 and :11-14, declaration order */
+enum blz_curve { BLZ_BLS377 = 0, BLZ_BLS381 = 1, BLZ_BN254 = 2 };
+enum blz_mem { BLZ_HBM = 0, BLZ_DMA = 1 };
+
+#define BLZ_PRECOMPUTE_FACTOR_BASE 1u /* src/ingo_msm/msm_api.rs:39 */
+#define BLZ_PRECOMPUTE_FACTOR 8u      /* src/ingo_msm/msm_api.rs:40 */
+#define BLZ_SCALAR_SIZE 32u           /* src/ingo_msm/msm_cfg.rs:48 */
+
+typedef struct blz_msm blz_msm;
+typedef struct blz_ntt blz_ntt;
+
+const char* blz_last_error_message(void);
+/* number of usable HIP devices (0 when there is none); never fails */
+int blz_device_count(void);
+/* sizes per curve: src/ingo_msm/msm_cfg.rs:44-92 (point 96/64, result 144/96) */
+size_t blz_point_size(int curve);
+size_t blz_result_size(int curve);
+
+/* ------------------------------------------------------------------ MSM (src/ingo_msm/msm_api.rs) */
+
+/* DriverClient::new(id, cfg) (dclient.rs:79-86) + MSMClient::new(MSMInit{mem_type,is_precompute,curve})
+ * (msm_api.rs:44-55).  (BN254, HBM) is todo!() in the reference (msm_cfg.rs:38); here it is defined
+ * by analogy (point 64 B, result 96 B). */
+int blz_msm_new(int device_id, int mem_type, int is_precompute, int curve, blz_msm** out);
+void blz_msm_free(blz_msm* h);
+
+/* MSMClient::loaded_binary_parameters (msm_api.rs:57-70): [image_id, image_parameters].
+ * image_parameters packs the fields of MSMImageParametrs (msm_api.rs:333-347). */
+int blz_msm_loaded_binary_parameters(blz_msm* h, uint32_t out[2]);
+
+/* MSMClient::initialize(MSMParams{nof_elements, hbm_point_addr}) (msm_api.rs:72-111).
+ * has_hbm=0 <=> hbm_point_addr == None.  mem_type==HBM with has_hbm==0 panics in the reference
+ * (unwrap at msm_api.rs:84) -> BLZ_ERR_INVALID_PARAM here. */
+int blz_msm_initialize(blz_msm* h, uint32_t nof_elements, int has_hbm, uint64_t hbm_addr, uint64_t hbm_off);
+
+/* MSMClient::start_process (msm_api.rs:113-120): push the configured task to the task queue. */
+int blz_msm_start_process(blz_msm* h);
+
+/* MSMClient::set_data(MSMInput{points, scalars, params}) (msm_api.rs:155-220).
+ *   points == NULL, has_hbm      : scalars only, bases read from the device arena (:163-174)
+ *   points != NULL, !has_hbm     : scalars + points streamed (:175-202)
+ *   points != NULL, has_hbm      : load_data_to_hbm(points) then scalars (:203-216)
+ *   points == NULL, !has_hbm     : silent no-op in the reference (falls through) -> no-op here
+ * points_len must be nof_elements * precompute_factor * point_size, scalars_len nof_elements*32.
+ * Blocking: host buffers may be dropped when it returns (pwrite with O_SYNC, utils.rs:71). */
+int blz_msm_set_data(blz_msm* h, const uint8_t* points, size_t points_len, const uint8_t* scalars,
+                     size_t scalars_len, uint32_t nof_elements, int has_hbm, uint64_t hbm_addr,
+                     uint64_t hbm_off);
+
+/* Same semantics with inputs already resident in this device's HBM (device pointers, borrowed until
+ * wait_result returns).  No reference counterpart: the FPGA path has no device-pointer notion; this
+ * is what a multi-GPU host or a pipeline that produced scalars on the GPU calls. */
+int blz_msm_set_data_device(blz_msm* h, const void* d_points, size_t points_len, const void* d_scalars,
+                            size_t scalars_len, uint32_t nof_elements, int has_hbm, uint64_t hbm_addr,
+                            uint64_t hbm_off);
+
+/* MSMClient::wait_result (msm_api.rs:222-238): block until the armed task's result is valid.
+ * The reference spins forever when nothing is armed; here that is BLZ_ERR_INVALID_PARAM. */
+int blz_msm_wait_result(blz_msm* h);
+
+/* MSMClient::result (msm_api.rs:240-274): read result_point_size bytes + RESULT_LABEL, pop.
+ * Layout Z | Y | X, canonical little-endian, homogeneous projective (tests/msm/mod.rs:397-403);
+ * this build always emits the normalised point Z=1 (infinity: Z=0, Y=1, X=0). */
+int blz_msm_result(blz_msm* h, uint8_t* out, size_t out_cap, size_t* out_len, uint32_t* label);
+
+/* MSMClient::load_data_to_hbm / get_data_from_hbm (msm_api.rs:299-322): raw bytes at arena byte
+ * offset addr+off.  The arena is per device and process-global (points persist across handles, as
+ * they persist across clients on the card: tests/integration_msm_hbm.rs:51-56). */
+int blz_msm_load_data_to_hbm(blz_msm* h, const uint8_t* points, size_t len, uint64_t addr, uint64_t off);
+int blz_msm_load_data_to_hbm_device(blz_msm* h, const void* d_points, size_t len, uint64_t addr, uint64_t off);
+int blz_msm_get_data_from_hbm(blz_msm* h, uint8_t* out, size_t len, uint64_t addr, uint64_t off);
+/* drop every arena extent of a device (no reference counterpart; the card keeps HBM until reset) */
+int blz_arena_release(int device_id);
+
+/* MSMClient::task_label / nof_elements / is_msm_engine_ready (msm_api.rs:278-297) */
+int blz_msm_task_label(blz_msm* h, uint32_t* out);
+int blz_msm_nof_elements(blz_msm* h, uint32_t* out);
+int blz_msm_is_engine_ready(blz_msm* h, uint32_t* out);
+/* DriverClient::reset (dclient.rs:88-93): drop armed task, queued results and staged data. */
+int blz_msm_reset(blz_msm* h);
+
+/* Phase timers of the last completed task, milliseconds (the device clock counters of
+ * msm_hw_code.rs:35-46 LAST_TASK_PHASE{1,2,3}_TOTAL_CLOCKS read through get_api, msm_api.rs:324-330):
+ * [0] whole device pipeline  [1] point conversion  [2] digit sort (count+scan+scatter)
+ * [3] bucket accumulation (phase 1)  [4] bucket reduce (phase 2)  [5] window combine + affine (phase 3)
+ * [6] window bits c  [7] number of windows */
+int blz_msm_last_timings(blz_msm* h, float out[8]);
+
+/* Multi-GPU: add G partial results (each result_size bytes, as returned by blz_msm_result on each
+ * rank, in rank order) on this handle's device and emit the normalised sum.  The exchange itself
+ * (RCCL all-gather of the 144-byte partials) is the host's: SURVEY.md 8(e). */
+int blz_msm_combine_partials(blz_msm* h, const uint8_t* partials, size_t count, uint8_t* out, size_t out_cap);
+
+/* ------------------------------------------------------------------ NTT (src/ingo_ntt/ntt_api.rs) */
+
+/* DriverClient::new + NTTClient::new(NTT::Ntt, dclient) (ntt_api.rs:26-31).  log_size = 27 is the
+ * reference shape (ntt_data.rs:65); smaller sizes exist for tests.  Field: BLS12-381 Fr
+ * (BASELINE.json), forward transform, natural order in/out, omega = 2^log_size-th root derived from
+ * the multiplicative generator 7. */
+int blz_ntt_new(int device_id, int log_size, blz_ntt** out);
+void blz_ntt_free(blz_ntt* h);
+/* NTTClient::initialize(NttInit{}) (ntt_api.rs:37-56) */
+int blz_ntt_initialize(blz_ntt* h);
+/* NTTClient::set_data(NTTInput{buf_host, data}) (ntt_api.rs:72-87): data = 2^log_size x 32 B LE */
+int blz_ntt_set_data(blz_ntt* h, size_t buf_host, const uint8_t* data, size_t len);
+int blz_ntt_set_data_device(blz_ntt* h, size_t buf_host, const void* d_data, size_t len);
+/* NTTClient::start_process(Some(buf_kernel)) (ntt_api.rs:58-70): in-place transform of that buffer */
+int blz_ntt_start_process(blz_ntt* h, size_t buf_kernel);
+/* NTTClient::wait_result (ntt_api.rs:89-108) */
+int blz_ntt_wait_result(blz_ntt* h);
+/* NTTClient::result(Some(buf)) (ntt_api.rs:110-124) */
+int blz_ntt_result(blz_ntt* h, size_t buf, uint8_t* out, size_t out_cap);
+int blz_ntt_result_device(blz_ntt* h, size_t buf, void* d_out, size_t out_cap);
+/* DriverClient::reset (dclient.rs:88-93) without the 100 ms sleep */
+int blz_ntt_reset(blz_ntt* h);
+/* kernel time of the last transform in ms (what benches/ntt_bench.rs:34-39 times, minus reset()) */
+int blz_ntt_last_kernel_ms(blz_ntt* h, float* out);
+/* NTTBanks::preprocess / postprocess (ntt_data.rs:80-156) as device permutations, for byte
+ * compatibility with bank files of the FPGA flow; n = 2^log_size elements, 16 banks contiguous. */
+int blz_ntt_banks_preprocess_device(blz_ntt* h, const void* d_in, void* d_banks);
+int blz_ntt_banks_postprocess_device(blz_ntt* h, const void* d_banks, void* d_out);
+
+/* ------------------------------------------------------------------ synthetic inputs (bench/tests) */
+
+/* Device memory owned by the library (bench/tests use these instead of a tensor library). */
+int blz_device_malloc(int device_id, size_t bytes, void** out);
+int blz_device_free(int device_id, void* p);
+int blz_memcpy_h2d(int device_id, void* d_dst, const void* src, size_t bytes);
+int blz_memcpy_d2h(int device_id, void* dst, const void* d_src, size_t bytes);
+/* scalars: n x 32 B, uniform-ish in [0, r) from a counter-based generator */
+int blz_synth_scalars(int device_id, int curve, void* d_out, uint64_t n, uint64_t seed);
+/* points: element i gets pf bases B_{i,j} = 2^(32 j) * (start+i+1) * G, wire format x||y canonical */
+int blz_synth_points(int device_id, int curve, void* d_out, uint64_t n, int pf, uint64_t start);
+/* NTT input: n x 32 B uniform-ish in [0, r) of BLS12-381 Fr */
+int blz_synth_field_elements(int device_id, void* d_out, uint64_t n, uint64_t seed);
+
+/* ------------------------------------------------------------------ test hooks (element-wise kernels)
+ * Run the device field / group primitives on arrays so tests can compare them one by one with the
+ * CPU oracle.  Host pointers; canonical little-endian encodings.
+ *   fq ops (field = 0: Fq, 1: Fr): 0 mul, 1 add, 2 sub, 3 inverse(a), 4 sqr(a)
+ *   ec ops: 0 P+Q (mixed, P as accumulator), 1 2P, 2 P+Q (full XYZZ add), 3 P-Q (mixed, negated)
+ *     points x||y; inf_flags[i] bit0: P is infinity, bit1: Q is infinity; out_inf[i]=1 if result inf */
+int blz_test_field_op(int device_id, int curve, int field, int op, const uint8_t* a, const uint8_t* b,
+                      uint8_t* out, size_t n);
+int blz_test_ec_op(int device_id, int curve, int op, const uint8_t* p, const uint8_t* q,
+                   const uint8_t* inf_flags, uint8_t* out, uint8_t* out_inf, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BLAZE_HIP_H */

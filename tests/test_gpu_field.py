@@ -1,0 +1,87 @@
+"""Element-wise parity of the device field / group primitives against the CPU oracle
+(bit-exact: integer arithmetic)."""
+import ctypes as C
+import random
+
+import pytest
+
+from oracle import pyref
+
+pytestmark = pytest.mark.gpu
+
+CURVES = ["BLS377", "BLS381", "BN254"]
+
+
+def _edge_values(m):
+    return [0, 1, 2, m - 1, m - 2, (m - 1) // 2, (m + 1) // 2, (1 << (m.bit_length() - 1)), m // 3]
+
+
+@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("field", [0, 1])
+def test_field_ops(gpu, curve, field):
+    c = pyref.CURVES[curve]
+    m = c["q"] if field == 0 else c["r"]
+    nb = c["fq_bytes"] if field == 0 else 32
+    rng = random.Random(1234 + field)
+    edge = _edge_values(m)
+    a = [x for x in edge for _ in edge] + [rng.randrange(m) for _ in range(4096)]
+    b = [y for _ in edge for y in edge] + [rng.randrange(m) for _ in range(4096)]
+    n = len(a)
+    ab = b"".join(x.to_bytes(nb, "little") for x in a)
+    bb = b"".join(x.to_bytes(nb, "little") for x in b)
+    ops = {0: lambda x, y: x * y % m, 1: lambda x, y: (x + y) % m, 2: lambda x, y: (x - y) % m,
+           3: lambda x, y: pow(x, -1, m) if x else 0, 4: lambda x, y: x * x % m}
+    for op, fn in ops.items():
+        cnt = n if op != 3 else 200  # inversion is slow on one lane; sample
+        out = C.create_string_buffer(cnt * nb)
+        rc = gpu.blz_test_field_op(0, pyref.CURVES[curve]["id"], field, op, ab, bb, C.cast(out, C.c_void_p), cnt)
+        assert rc == 0, gpu.blz_last_error_message()
+        got = [int.from_bytes(out.raw[i * nb:(i + 1) * nb], "little") for i in range(cnt)]
+        exp = [fn(a[i], b[i]) for i in range(cnt)]
+        bad = [i for i in range(cnt) if got[i] != exp[i]]
+        assert not bad, f"{curve} field={field} op={op}: {len(bad)} mismatches, first at {bad[0]}: a={a[bad[0]]:#x} b={b[bad[0]]:#x}"
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_ec_ops(gpu, curve):
+    c = pyref.CURVES[curve]
+    cid = c["id"]
+    rng = random.Random(99)
+    G = pyref.generator(curve)
+    base = [pyref.mul(curve, G, rng.randrange(1, c["r"])) for _ in range(24)]
+    P, Q, fl = [], [], []
+    for i in range(24):
+        for j in range(24):
+            P.append(base[i]); Q.append(base[j]); fl.append(0)   # includes P == Q (doubling)
+    for i in range(24):
+        P.append(base[i]); Q.append(pyref.neg(curve, base[i])); fl.append(0)  # P + (-P)
+        P.append(base[i]); Q.append(base[(i + 1) % 24]); fl.append(1)        # inf + Q
+        P.append(base[i]); Q.append(base[(i + 1) % 24]); fl.append(2)        # P + inf
+        P.append(base[i]); Q.append(base[i]); fl.append(3)                   # inf + inf
+    n = len(P)
+    pb = b"".join(pyref.enc_point(curve, p) for p in P)
+    qb = b"".join(pyref.enc_point(curve, q) for q in Q)
+    flb = bytes(fl)
+    sz = 2 * c["fq_bytes"]
+
+    def expect(op, p, q, f):
+        p = None if f & 1 else p
+        q = None if f & 2 else q
+        if op == 0 or op == 2:
+            return pyref.add(curve, p, q)
+        if op == 1:
+            return pyref.add(curve, p, p)
+        return pyref.add(curve, p, pyref.neg(curve, q))
+
+    for op in (0, 1, 2, 3):
+        out = C.create_string_buffer(n * sz)
+        oinf = C.create_string_buffer(n)
+        rc = gpu.blz_test_ec_op(0, cid, op, pb, qb, flb, C.cast(out, C.c_void_p), C.cast(oinf, C.c_void_p), n)
+        assert rc == 0, gpu.blz_last_error_message()
+        for i in range(n):
+            e = expect(op, P[i], Q[i], fl[i])
+            if e is None:
+                assert oinf.raw[i] == 1, f"{curve} op={op} case {i}: expected infinity"
+            else:
+                assert oinf.raw[i] == 0, f"{curve} op={op} case {i}: unexpected infinity"
+                assert out.raw[i * sz:(i + 1) * sz] == pyref.enc_point(curve, e), f"{curve} op={op} case {i} fl={fl[i]}"
