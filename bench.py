@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""Headline benchmark: BLS12-381 G1 MSM at n = 2^26 (pf = 1) on MI355X, plus the 2^27 NTT latency.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one complete MSM over the 2^26 synthetic (scalar, point) pairs, inputs already resident
+in HBM, through the reference's call sequence (initialize -> start_process -> set_data ->
+wait_result -> result) on the C ABI.  With N > 1 the SAME 2^26 job is sharded by contiguous element
+chunk over the N GPUs of one node (strong scaling): each rank runs its shard, one all-gather of the
+144-byte partials (RCCL), every rank adds them in rank order.  value = MSMs per second, whole job.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` for the dominant
+kernel (k_accumulate) and `cpu_baseline` (the CPU oracle's Pippenger on a bounded sample)."""
+import argparse
+import ctypes as C
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+LOG_N = int(os.environ.get("BLAZE_BENCH_LOGN", "26"))
+CURVE = "BLS381"
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MSM_BYTES_PER_ELEM = 128  # 32 B scalar + 96 B point
+NTT_LOG = int(os.environ.get("BLAZE_BENCH_NTT_LOGN", "27"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-ntt", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    dev = local_rank
+    tdev = torch.device("cuda", dev)
+
+    import blaze_amd
+    from blaze_amd import DeviceBuffer
+    from blaze_amd._lib import check
+    from blaze_amd.driver_client import DriverClient
+    from blaze_amd.ingo_msm import Curve, MSMClient, MSMInit, MSMInput, MSMParams, PointMemoryType
+    from blaze_amd.multi_gpu import shard_range, sharded_msm
+
+    L = blaze_amd.lib()
+    n = 1 << LOG_N
+    lo, hi = shard_range(n, rank, world)
+    n_loc = hi - lo
+    cid = int(Curve[CURVE])
+
+    # ---- synthetic inputs, generated on the device: P_i = (i+1) G, scalars uniform-ish in [0, r)
+    d_pts = DeviceBuffer(dev, n_loc * 96)
+    d_sc = DeviceBuffer(dev, n_loc * 32)
+    check(L.blz_synth_points(dev, cid, d_pts.ptr, n_loc, 1, lo))
+    check(L.blz_synth_scalars(dev, cid, d_sc.ptr, n_loc, 0xB1A2E + rank))
+
+    client = MSMClient(MSMInit(PointMemoryType.DMA, False, Curve[CURVE]), DriverClient(dev))
+    params = MSMParams(n_loc, None)
+
+    def step():
+        client.initialize(params)
+        client.start_process()
+        client.set_data(MSMInput(d_pts, d_sc, params))
+        client.wait_result()
+        part = client.result().result
+        if world > 1:
+            return sharded_msm(part, client.combine_partials, dist, tdev)
+        return part
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(tdev)
+
+    for _ in range(args.warmup):
+        step()
+    accum_ms, total_ms = [], []
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+        api = client.get_api()  # HIP-event timers recorded on the stream the kernels run on
+        accum_ms.append(api["accumulate_kernel_ms"])
+        total_ms.append(api["total_ms"])
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=tdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = args.steps / dt
+
+    # ---- roofline of the dominant kernel (k_accumulate: one launch covers this rank's whole shard)
+    acc_avg_ms = statistics.mean(accum_ms)
+    algo_bytes = n_loc * MSM_BYTES_PER_ELEM
+    achieved = algo_bytes / (acc_avg_ms * 1e-3) / 1e9
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tf):
+        try:
+            rec = json.load(open(tf)).get(f"k_accumulate_2e{LOG_N}_{CURVE}")
+            if rec and world == 1:
+                traffic = rec["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": "k_accumulate", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": round(acc_avg_ms, 3),
+                "pipeline_ms": round(statistics.mean(total_ms), 3)}
+
+    # ---- NTT 2^27 latency (replica per rank; rank 0 reports), timed like benches/ntt_bench.rs:34-39
+    # minus the 100 ms sleep of reset(): initialize + start_process + wait_result on a resident buffer
+    ntt = None
+    if not args.no_ntt:
+        from blaze_amd.ingo_ntt import NTT, NTTClient, NTTInput, NttInit
+
+        client.close()
+        nn = 1 << NTT_LOG
+        d_in = DeviceBuffer(dev, 32 * nn)
+        check(L.blz_synth_field_elements(dev, d_in.ptr, nn, 5))
+        nc = NTTClient(NTT.Ntt, DriverClient(dev), log_size=NTT_LOG)
+        nc.set_data(NTTInput(0, d_in))
+        d_in.free()
+        kms, wall = [], []
+        for i in range(2 + 10):
+            t1 = time.perf_counter()
+            nc.initialize(NttInit())
+            nc.start_process(0)
+            nc.wait_result()
+            w = (time.perf_counter() - t1) * 1e3
+            if i >= 2:
+                kms.append(nc.last_kernel_ms())
+                wall.append(w)
+        nb = 2 * 32 * nn
+        k = statistics.median(kms)
+        ntt = {"log_size": NTT_LOG, "ms": round(statistics.median(wall), 3), "kernel_ms": round(k, 3), "samples": 10,
+               "roofline": {"bound": "hbm", "achieved": round(nb / (k * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": round(nb / (k * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                            "algorithmic_bytes": nb}}
+        nc.close()
+
+    # ---- CPU baseline: the oracle's multithreaded Pippenger on a bounded sample of the same workload
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle  # test infrastructure, used here only as the timed CPU baseline
+
+        ls = int(os.environ.get("BLAZE_BENCH_CPU_LOGN", "20"))
+        ns = min(1 << ls, n_loc)
+        pts = d_pts.download(ns * 96)
+        sc = d_sc.download(ns * 32)
+        cores = os.cpu_count() or 1
+        cbits = 13
+        threads = min(cores, (257 + cbits - 1) // cbits)  # the oracle parallelises over windows
+        t1 = time.perf_counter()
+        oracle.msm_pippenger(CURVE, pts, sc, ns, 1, threads=threads, cbits=cbits)
+        tc = time.perf_counter() - t1
+        cpu = {"value": round((ns / n) / tc, 6), "unit": "MSM/s", "cores": threads, "kind": "port",
+               "sample": f"first 2^{ls} of the 2^{LOG_N} elements: {tc:.2f} s wall on {threads} threads "
+                         f"(host has {cores}); value scaled linearly to 2^{LOG_N}"}
+
+    if rank == 0:
+        line = {
+            "metric": f"BLS12-381 MSM/s at 2^{LOG_N}", "value": round(value, 4), "unit": "MSM/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "u32 limbs (381-bit Fq Montgomery)", "data": "synthetic",
+            "config": {"workload": f"2^{LOG_N} BLS12-381 G1 MSM, pf=1, scalars+points resident in HBM",
+                       "elements": n, "elements_per_gpu": n_loc, "parallelism": f"shard{world}" if world > 1 else "single",
+                       "window_bits": int(api["window_bits"]), "windows": int(api["windows"])},
+            "roofline": roofline, "cpu_baseline": cpu, "ntt_2e27": ntt,
+            "phases_ms": {k: round(v, 3) for k, v in api.items() if k.endswith("_ms")},
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -351,6 +351,7 @@ int MsmEngine::finish(uint8_t* out) {
         // ev0 start, ev1 sort done, ev2 accumulate done, ev3 reduce done, ev4 finish done
         (void)hipEventElapsedTime(&t, ev[0], ev[4]); last_ms[0] = t;
         last_ms[1] = 0;
+        if (accum_timed && last_plan.c) { (void)hipEventElapsedTime(&t, ev[5], ev[6]); last_ms[1] = t; }
         (void)hipEventElapsedTime(&t, ev[0], ev[1]); last_ms[2] = t;
         (void)hipEventElapsedTime(&t, ev[1], ev[2]); last_ms[3] = t;
         (void)hipEventElapsedTime(&t, ev[2], ev[3]); last_ms[4] = t;

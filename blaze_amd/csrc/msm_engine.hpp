@@ -26,6 +26,7 @@ struct MsmEngine {
     MsmPlan last_plan;
     float last_ms[8] = {};
     bool timings_pending = false;
+    bool accum_timed = false;
 
     int init(int device_id, int curve_id);
     void destroy();

@@ -249,11 +249,14 @@ int run_tail_t(MsmEngine& E, const void* d_pts, uint32_t U, uint32_t maxcount) {
     BLZ_HIP(hipEventRecord(E.ev[1], st), BLZ_ERR_UNKNOWN);
 
     // ---- phase 1
+    E.accum_timed = U != 0;
     if (U) {
         launch_fill_units(E);
+        BLZ_HIP(hipEventRecord(E.ev[5], st), BLZ_ERR_UNKNOWN);  // ev5..ev6 bracket the dominant kernel alone
         hipLaunchKernelGGL(k_accumulate<F>, dim3((U + 127) / 128), dim3(128), 0, st, (const uint32_t*)d_pts,
                            E.entries.as<uint32_t>(), E.off.as<uint32_t>(), E.unit_off.as<uint32_t>(),
                            E.unit_bucket.as<uint32_t>(), U, P.L, E.partial.as<uint32_t>());
+        BLZ_HIP(hipEventRecord(E.ev[6], st), BLZ_ERR_UNKNOWN);
         uint32_t maxunits = (maxcount + P.L - 1) / P.L;
         for (uint32_t stride = 1; stride < maxunits; stride *= 16)
             hipLaunchKernelGGL(k_combine_units<F>, dim3((U + 127) / 128), dim3(128), 0, st, E.unit_off.as<uint32_t>(),

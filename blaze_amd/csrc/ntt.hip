@@ -179,6 +179,7 @@ struct blz_ntt {
     NttGeom geom{};
     int cols_log[3] = {0, 0, 0};
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;  // host<->buffer traffic, concurrent with the compute stream
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     DevBuf buf[2], scratch, tables;
     NttTables T{};
@@ -263,6 +264,7 @@ int blz_ntt_new(int device_id, int log_size, blz_ntt** out) {
     h->device = device_id;
     h->logn = log_size;
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&h->ev0);
     if (e == hipSuccess) e = hipEventCreate(&h->ev1);
     int rc = e == hipSuccess ? ntt_setup(h) : fail(BLZ_ERR_UNKNOWN, "stream/event creation failed: %s", hipGetErrorString(e));
@@ -282,6 +284,7 @@ void blz_ntt_free(blz_ntt* h) {
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     delete h;
 }
 
@@ -296,9 +299,12 @@ static int ntt_set_data_common(blz_ntt* h, size_t buf_host, const void* data, si
     if (len != ntt_bytes(h)) return fail(BLZ_ERR_INVALID_PARAM, "data length %zu != %zu", len, ntt_bytes(h));
     BLZ_TRY(use_device(h->device));
     BLZ_TRY(h->buf[buf_host].reserve(len));
-    // a dedicated (blocking) copy: the compute stream may be busy on the other buffer
-    // (double-buffer contract, tests/integration_ntt.rs:102-136)
-    BLZ_HIP(hipMemcpy(h->buf[buf_host].p, data, len, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice), BLZ_ERR_WRITE);
+    // a dedicated copy stream: the compute stream may be busy on the other buffer (double-buffer
+    // contract, tests/integration_ntt.rs:102-136).  Synchronised before returning: set_data is
+    // blocking, and a device-to-device hipMemcpy alone is not ordered against other streams.
+    BLZ_HIP(hipMemcpyAsync(h->buf[buf_host].p, data, len, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                           h->copy_stream), BLZ_ERR_WRITE);
+    BLZ_HIP(hipStreamSynchronize(h->copy_stream), BLZ_ERR_WRITE);
     h->has_data[buf_host] = true;
     return BLZ_OK;
 }
@@ -348,7 +354,9 @@ static int ntt_result_common(blz_ntt* h, size_t buf, void* out, size_t out_cap, 
     if (buf > 1 || !h->has_data[buf]) return fail(BLZ_ERR_INVALID_PARAM, "buffer %zu holds no data", buf);
     if (out_cap < ntt_bytes(h)) return fail(BLZ_ERR_INVALID_PARAM, "output buffer too small");
     BLZ_TRY(use_device(h->device));
-    BLZ_HIP(hipMemcpy(out, h->buf[buf].p, ntt_bytes(h), on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost), BLZ_ERR_READ);
+    BLZ_HIP(hipMemcpyAsync(out, h->buf[buf].p, ntt_bytes(h), on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
+                           h->copy_stream), BLZ_ERR_READ);
+    BLZ_HIP(hipStreamSynchronize(h->copy_stream), BLZ_ERR_READ);
     return BLZ_OK;
 }
 int blz_ntt_result(blz_ntt* h, size_t buf, uint8_t* out, size_t out_cap) { return ntt_result_common(h, buf, out, out_cap, false); }

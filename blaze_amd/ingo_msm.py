@@ -161,7 +161,7 @@ class MSMClient(DriverPrimitive[MSMInit, MSMParams, MSMInput, MSMResult]):
         """msm_api.rs:324-330 dumps every register; here: the phase timers of the last task."""
         t = (C.c_float * 8)()
         check(lib().blz_msm_last_timings(self._h, t))
-        keys = ["total_ms", "convert_ms", "sort_ms", "phase1_accumulate_ms", "phase2_reduce_ms", "phase3_final_ms",
+        keys = ["total_ms", "accumulate_kernel_ms", "sort_ms", "phase1_accumulate_ms", "phase2_reduce_ms", "phase3_final_ms",
                 "window_bits", "windows"]
         return dict(zip(keys, [float(x) for x in t]))
 

@@ -1,0 +1,41 @@
+"""Multi-GPU MSM: shard by contiguous element chunk, one process per GPU, one tiny exchange.
+
+MSM is a sum, so rank g of G takes elements [g n/G, (g+1) n/G) - its slice of the scalars and of
+the points.  Each rank runs the full single-GPU pipeline through its own
+MSMClient; the G partial results (144 / 96 bytes each) are exchanged with ONE all-gather (RCCL over
+xGMI when the process group backend is "nccl"; gloo in the CPU tests) and every rank adds them in
+rank order on its device (`MSMClient.combine_partials`), so every rank returns identical, normalised
+bytes.  RCCL's reduce ops are arithmetic, not a group law, hence all-gather + local add instead of
+all-reduce.  The reference has no multi-device layer (README.md:20-22 leaves it to a "management
+layer"); this module is that layer for the MSM path only."""
+from __future__ import annotations
+
+from typing import Tuple
+
+
+def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous, balanced partition of [0, n): first n % world ranks get one extra element."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def all_gather_partials(partial: bytes, dist, device=None) -> bytes:
+    """One all-gather of the fixed-size partial results, returned concatenated in rank order."""
+    import torch
+
+    world = dist.get_world_size()
+    t = torch.frombuffer(bytearray(partial), dtype=torch.uint8)
+    if device is not None:
+        t = t.to(device)
+    out = torch.empty(world * t.numel(), dtype=torch.uint8, device=t.device)
+    dist.all_gather_into_tensor(out, t)
+    return out.cpu().numpy().tobytes()
+
+
+def sharded_msm(local_partial: bytes, combine, dist, device=None) -> bytes:
+    """`local_partial`: this rank's MSM result bytes over its shard; `combine(partials, count)`:
+    rank-ordered group sum (MSMClient.combine_partials on the GPU).  Returns the full result."""
+    world = dist.get_world_size()
+    gathered = all_gather_partials(local_partial, dist, device)
+    return combine(gathered, world)

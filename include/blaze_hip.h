@@ -117,7 +117,7 @@ int blz_msm_reset(blz_msm* h);
 
 /* Phase timers of the last completed task, milliseconds (the device clock counters of
  * msm_hw_code.rs:35-46 LAST_TASK_PHASE{1,2,3}_TOTAL_CLOCKS read through get_api, msm_api.rs:324-330):
- * [0] whole device pipeline  [1] point conversion  [2] digit sort (count+scan+scatter)
+ * [0] whole device pipeline  [1] k_accumulate kernel alone  [2] digit sort (count+scan+scatter)
  * [3] bucket accumulation (phase 1)  [4] bucket reduce (phase 2)  [5] window combine + affine (phase 3)
  * [6] window bits c  [7] number of windows */
 int blz_msm_last_timings(blz_msm* h, float out[8]);

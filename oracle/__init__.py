@@ -46,6 +46,7 @@ def lib():
         L.orc_msm_pippenger.argtypes = [C.c_int, C.c_void_p, C.c_void_p, u64, C.c_int, C.c_int, C.c_int, u8p]
         L.orc_omega.argtypes = [C.c_int, C.c_int, u8p]
         L.orc_ntt.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.orc_ntt_eval_at.argtypes = [C.c_int, C.c_void_p, C.c_int, u64, u8p]
         L.orc_dft_naive.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_ntt_preprocess.argtypes = [C.c_void_p, C.c_void_p, u64]
         L.orc_ntt_postprocess.argtypes = [C.c_void_p, C.c_void_p, u64, u64]
@@ -165,6 +166,13 @@ def ntt(curve, data, logn: int, inverse: bool = False, threads: int = 1) -> byte
     rc = lib().orc_ntt(_cid(curve), _ptr(data), _ptr(out), logn, int(inverse), threads)
     assert rc == 0
     return out
+
+
+def ntt_eval_at(curve, data, logn: int, k: int) -> int:
+    out = C.create_string_buffer(32)
+    rc = lib().orc_ntt_eval_at(_cid(curve), _ptr(data), logn, k, out)
+    assert rc == 0
+    return int.from_bytes(out.raw, "little")
 
 
 def dft_naive(curve, data, logn: int) -> bytearray:

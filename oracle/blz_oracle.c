@@ -809,6 +809,28 @@ int orc_ntt(int curve, const uint8_t* in, uint8_t* out, int logn, int inverse, i
     free(a); free(tw); free(th); free(jobs);
     return 0;
 }
+/* X[k] = sum_i x[i] (w^k)^i by Horner: one output coefficient of a transform of any size, O(n).
+ * Used to spot-check full-size (2^27) device transforms. */
+int orc_ntt_eval_at(int curve, const uint8_t* in, int logn, u64 k, uint8_t* out32) {
+    const curve_t* c = get_curve(curve);
+    if (!c || logn > c->two_adicity) return -1;
+    const fctx* f = &c->fr;
+    u64 n = (u64)1 << logn;
+    u64 w[MAXL], wk[MAXL], e[1] = {k};
+    memcpy(w, c->root, sizeof(w));
+    for (int i = 0; i < c->two_adicity - logn; ++i) f_sqr(f, w, w);
+    f_pow(f, wk, w, e, 1);
+    u64 acc[MAXL] = {0};
+    for (u64 i = n; i-- > 0;) {
+        u64 t[MAXL];
+        f_mul(f, acc, acc, wk);
+        f_from_bytes(f, t, in + 32 * i);
+        f_add(f, acc, acc, t);
+    }
+    f_to_bytes(f, out32, acc);
+    return 0;
+}
+
 /* O(n^2) DFT for tiny n (independent structure from orc_ntt) */
 int orc_dft_naive(int curve, const uint8_t* in, uint8_t* out, int logn) {
     const curve_t* c = get_curve(curve);

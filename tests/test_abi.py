@@ -1,0 +1,70 @@
+"""The C-ABI boundary without a GPU: the library loads, exports every symbol include/blaze_hip.h
+declares, and fails loudly (FileError, no CPU fallback) when no device is present."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import blaze_amd
+from blaze_amd import DriverClientError
+from blaze_amd._lib import EXPORTED_SYMBOLS
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "blaze_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(blz_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = blaze_amd.lib()
+    declared = _declared_symbols()
+    assert len(declared) >= 40
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/blaze_hip.h but not exported"
+    assert sorted(EXPORTED_SYMBOLS) == declared, "python binding table out of sync with the header"
+
+
+def test_sizes_match_reference_config():
+    L = blaze_amd.lib()
+    # src/ingo_msm/msm_cfg.rs:44-92
+    assert (L.blz_point_size(0), L.blz_result_size(0)) == (96, 144)
+    assert (L.blz_point_size(1), L.blz_result_size(1)) == (96, 144)
+    assert (L.blz_point_size(2), L.blz_result_size(2)) == (64, 96)
+
+
+def test_error_codes_follow_reference_enum():
+    # src/error.rs:6-32 declaration order
+    assert DriverClientError.VARIANTS == {
+        1: "WriteError", 2: "ReadError", 3: "HBICAPNotReady", 4: "InvalidPrimitiveParam",
+        5: "CsvError", 6: "LoadFailed", 7: "FileError", 8: "Unknown"}
+    hdr = open(os.path.join(ROOT, "include", "blaze_hip.h")).read()
+    for code, name in [(1, "BLZ_ERR_WRITE"), (2, "BLZ_ERR_READ"), (4, "BLZ_ERR_INVALID_PARAM"), (7, "BLZ_ERR_FILE"), (8, "BLZ_ERR_UNKNOWN")]:
+        assert re.search(rf"{name}\s*=\s*{code}\b", hdr)
+
+
+@pytest.mark.skipif(blaze_amd.lib().blz_device_count() > 0, reason="a GPU is present")
+def test_no_gpu_means_loud_failure_not_fallback():
+    L = blaze_amd.lib()
+    h = C.c_void_p()
+    rc = L.blz_msm_new(0, 1, 0, 1, C.byref(h))
+    assert rc == 7 and not h.value            # FileError, like the failed open() of /dev/xdma0_*
+    assert b"no CPU path" in L.blz_last_error_message()
+    rc = L.blz_ntt_new(0, 10, C.byref(h))
+    assert rc == 7
+    with pytest.raises(DriverClientError) as ei:
+        blaze_amd.driver_client.DriverClient(0)
+    assert ei.value.variant == "FileError"
+
+
+def test_invalid_arguments_are_rejected_before_touching_a_device():
+    L = blaze_amd.lib()
+    h = C.c_void_p()
+    assert L.blz_msm_new(0, 1, 0, 7, C.byref(h)) == 4      # unknown curve -> InvalidPrimitiveParam
+    assert L.blz_msm_new(0, 5, 0, 1, C.byref(h)) == 4      # unknown mem type
+    assert L.blz_ntt_new(0, 28, C.byref(h)) == 4           # > 2^27
+    assert L.blz_msm_wait_result(None) == 4
+    assert L.blz_msm_initialize(None, 1, 0, 0, 0) == 4

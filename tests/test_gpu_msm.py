@@ -1,0 +1,231 @@
+"""MSM parity on the MI355X through the C ABI: device result bytes == CPU oracle bytes (bit-exact,
+integer arithmetic), on the reference harness's inputs, the committed golden vectors, edge cases,
+every set_data mode, and - at BASELINE.json's full sizes - through linearity."""
+import json
+import os
+
+import pytest
+
+import blaze_amd
+from blaze_amd import DeviceBuffer, DriverClientError
+from blaze_amd.ingo_msm import MSMInput, MSMParams, PointMemoryType
+from gpu_util import msm_client, run_msm, synth
+from oracle import pyref
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+CURVES = ["BLS377", "BLS381", "BN254"]
+
+
+def test_golden_vectors(gpu):
+    with open(os.path.join(HERE, "golden", "msm_vectors.json")) as f:
+        vecs = json.load(f)
+    clients = {}
+    for v in vecs:
+        key = (v["curve"], v["pf"])
+        if key not in clients:
+            clients[key] = msm_client(v["curve"], v["pf"])
+        got = run_msm(clients[key], bytes.fromhex(v["points"]), bytes.fromhex(v["scalars"]), v["n"])
+        assert got == bytes.fromhex(v["result"]), f"{v['curve']} pf={v['pf']} {v['name']}"
+
+
+@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("pf", [1, 8])
+def test_reference_harness_sizes(gpu, orc, curve, pf):
+    """tests/integration_msm.rs: sizes 2, 8192 (default MSM_SIZE) and the 256-tile boundaries; the
+    repeated tile puts equal points in one bucket (doubling / cancellation paths)."""
+    cl = msm_client(curve, pf)
+    for n in (2, 255, 256, 257, 1024, 8192):
+        pts, sc, exp = orc.input_generator(curve, n, pf, 100 + n)
+        got = run_msm(cl, pts, sc, n)
+        assert got == exp, f"{curve} pf={pf} n={n}"
+        xy, on_curve = orc.decode_result(curve, got)      # result_check_*: on-curve + equality
+        assert on_curve
+    cl.close()
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_window_plans_agree(gpu, orc, curve, monkeypatch):
+    """Same input through several forced window sizes / run-splitting thresholds: bytes identical."""
+    n = 3000
+    pts, sc, exp = orc.input_generator(curve, n, 1, 77)
+    for c, L in ((4, 256), (9, 3), (13, 16), (16, 256)):
+        monkeypatch.setenv("BLAZE_MSM_C", str(c))
+        monkeypatch.setenv("BLAZE_MSM_L", str(L))
+        cl = msm_client(curve, 1)
+        assert run_msm(cl, pts, sc, n) == exp, f"c={c} L={L}"
+        assert cl.get_api()["window_bits"] == c
+        cl.close()
+
+
+def test_empty_and_zero(gpu, orc):
+    cl = msm_client("BLS381", 1)
+    inf = orc.result_from_affine("BLS381", None)
+    # n = 0: set_data with points present and nothing in them
+    assert run_msm(cl, b"", b"", 0) == inf
+    # all-zero scalars -> infinity (Z=0: outside the reference checker's domain, defined here)
+    pts, sc, _ = orc.input_generator("BLS381", 10, 1, 3)
+    assert run_msm(cl, pts, bytes(320), 10) == inf
+    cl.close()
+
+
+def test_hbm_modes(gpu, orc):
+    """tests/integration_msm_hbm.rs: points resident in device memory, scalars-only set_data; plus
+    mode (iii) load-then-stream and the raw read-back of msm_api.rs:315-322."""
+    curve, n = "BLS381", 2048
+    blaze_amd.lib().blz_arena_release(0)
+    pts, sc, exp = orc.input_generator(curve, n, 1, 5)
+    cl = msm_client(curve, 1, PointMemoryType.HBM)
+    addr, off = 0x1000, 0x200
+    cl.load_data_to_hbm(pts, addr, off)
+    assert cl.get_data_from_hbm(len(pts), addr, off) == bytes(pts)
+    assert cl.get_data_from_hbm(96, addr, off + 96 * 7) == bytes(pts[96 * 7: 96 * 8])
+    assert run_msm(cl, None, sc, n, hbm=(addr, off)) == exp           # mode (i): scalars only
+    cl.close()
+    # points persist across client instances (integration_msm_hbm.rs:51-56 relies on it),
+    # and a DMA-typed client may still select HBM bases through hbm_point_addr (:41)
+    cl2 = msm_client(curve, 1, PointMemoryType.DMA)
+    assert run_msm(cl2, None, sc, n, hbm=(addr, off)) == exp
+    # mode (iii): points + hbm address -> load_data_to_hbm first, then scalars
+    pts2, sc2, exp2 = orc.input_generator(curve, 500, 1, 6)
+    assert run_msm(cl2, pts2, sc2, 500, hbm=(0x900000, 0)) == exp2
+    assert cl2.get_data_from_hbm(len(pts2), 0x900000, 0) == bytes(pts2)
+    # a sub-range of a loaded extent is a valid base address
+    sub = run_msm(cl2, None, sc[: 32 * 100], 100, hbm=(addr, off + 96 * 256))
+    assert sub == orc.msm_pippenger(curve, pts[96 * 256: 96 * 356], sc[: 3200], 100, 1, threads=4)
+    with pytest.raises(DriverClientError) as ei:
+        run_msm(cl2, None, sc, n, hbm=(0x7000000, 0))                  # nothing loaded there
+    assert ei.value.variant == "InvalidPrimitiveParam"
+    cl2.reset()
+    cl2.close()
+    blaze_amd.lib().blz_arena_release(0)
+
+
+def test_bn254_hbm_precompute_small(gpu, orc):
+    """(BN254, HBM) is todo!() in the reference (msm_cfg.rs:38); defined here by analogy."""
+    blaze_amd.lib().blz_arena_release(0)
+    n = 700
+    pts, sc, exp = orc.input_generator("BN254", n, 8, 21)
+    cl = msm_client("BN254", 8, PointMemoryType.HBM)
+    cl.load_data_to_hbm(pts, 0, 0)
+    assert run_msm(cl, None, sc, n, hbm=(0, 0)) == exp
+    cl.close()
+    blaze_amd.lib().blz_arena_release(0)
+
+
+def test_call_order_and_errors(gpu, orc):
+    curve, n = "BLS381", 300
+    pts, sc, exp = orc.input_generator(curve, n, 1, 8)
+    cl = msm_client(curve, 1)
+    with pytest.raises(DriverClientError) as ei:
+        cl.wait_result()                                   # nothing armed: the reference spins forever
+    assert ei.value.variant == "InvalidPrimitiveParam"
+    with pytest.raises(DriverClientError):
+        cl.start_process()                                 # before initialize
+    params = MSMParams(n, None)
+    # README order (README.md:71-74): set_data before start_process also works
+    cl.initialize(params)
+    cl.set_data(MSMInput(pts, sc, params))
+    assert cl.is_msm_engine_ready() == 1
+    cl.start_process()
+    cl.wait_result()
+    r = cl.result()
+    assert r.result == exp and r.result_label == cl.task_label() == 1
+    assert cl.nof_elements() == n
+    with pytest.raises(DriverClientError) as ei:
+        cl.result()                                        # queue empty after pop
+    assert ei.value.variant == "ReadError"
+    # wrong payload sizes
+    cl.initialize(params)
+    cl.start_process()
+    with pytest.raises(DriverClientError) as ei:
+        cl.set_data(MSMInput(pts[:-96], sc, params))
+    assert ei.value.variant == "InvalidPrimitiveParam"
+    cl.reset()
+    # mem_type HBM without an address: the reference unwraps None (msm_api.rs:84)
+    clh = msm_client(curve, 1, PointMemoryType.HBM)
+    with pytest.raises(DriverClientError) as ei:
+        clh.initialize(MSMParams(n, None))
+    assert ei.value.variant == "InvalidPrimitiveParam"
+    # (None, None): silent no-op like the reference (msm_api.rs:163-216 falls through)
+    cl.initialize(params)
+    cl.set_data(MSMInput(None, sc, params))
+    assert len(cl.loaded_binary_parameters()) == 2
+    cl.close(); clh.close()
+
+
+def test_labels_and_result_queue(gpu, orc):
+    cl = msm_client("BN254", 1)
+    exps = []
+    for i, n in enumerate((10, 20, 30)):
+        pts, sc, exp = orc.input_generator("BN254", n, 1, 50 + i)
+        params = MSMParams(n, None)
+        cl.initialize(params); cl.start_process(); cl.set_data(MSMInput(pts, sc, params)); cl.wait_result()
+        exps.append(exp)
+    for i in range(3):                                     # results pop in task order with their labels
+        r = cl.result()
+        assert r.result == exps[i] and r.result_label == i + 1
+    cl.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# full sizes (BASELINE.json configs), checked through size-independent properties
+# ---------------------------------------------------------------------------------------------
+def _expected_synth(orc, curve, ds, n, start=0):
+    k = orc.index_weighted_sum(curve, ds.download(), n, start)
+    return orc.result_from_affine(curve, orc.generator_mul(curve, k))
+
+
+def test_config2_2e22_bls381_dma_host_buffers(gpu, orc):
+    """2^22 BLS12-381, DMA-mode MSMInput semantics: host Vec<u8>s through set_data."""
+    curve, n = "BLS381", 1 << 22
+    dp, ds = synth(curve, n)
+    pts, sc = dp.download(), ds.download()
+    exp = _expected_synth(orc, curve, ds, n)
+    dp.free(); ds.free()
+    cl = msm_client(curve, 1)
+    assert run_msm(cl, pts, sc, n) == exp
+    cl.close()
+
+
+def test_bench_workload_2e26_bls381_linearity_and_split(gpu, orc):
+    """2^26 BLS12-381 (the bench workload): result == (sum s_i (i+1)) G, and the 8-shard partition
+    of config 4's shape gives identical bytes after combine_partials (rank-ordered add)."""
+    curve, n = "BLS381", 1 << 26
+    dp, ds = synth(curve, n)
+    exp = _expected_synth(orc, curve, ds, n)
+    cl = msm_client(curve, 1)
+    assert run_msm(cl, dp, ds, n) == exp
+    shards = 8
+    per = n // shards
+    parts = b""
+    for s in range(shards):
+        vp = DeviceBuffer.__new__(DeviceBuffer); vp.device_id = 0; vp.ptr = dp.ptr + s * per * 96; vp.nbytes = per * 96
+        vs = DeviceBuffer.__new__(DeviceBuffer); vs.device_id = 0; vs.ptr = ds.ptr + s * per * 32; vs.nbytes = per * 32
+        parts += run_msm(cl, vp, vs, per)
+        vp.ptr = None; vs.ptr = None
+    assert cl.combine_partials(parts, shards) == exp
+    cl.close(); dp.free(); ds.free()
+
+
+def test_config4_2e26_bls377(gpu, orc):
+    curve, n = "BLS377", 1 << 26
+    dp, ds = synth(curve, n, start=12345)
+    exp = _expected_synth(orc, curve, ds, n, start=12345)
+    cl = msm_client(curve, 1)
+    assert run_msm(cl, dp, ds, n) == exp
+    cl.close(); dp.free(); ds.free()
+
+
+def test_config3_2e26_bn254_precompute_hbm_resident(gpu, orc):
+    """2^26 BN254, pf = 8, 32 GiB of bases resident in the device arena, scalars-only set_data."""
+    blaze_amd.lib().blz_arena_release(0)
+    curve, n = "BN254", 1 << 26
+    dp, ds = synth(curve, n, pf=8)
+    exp = _expected_synth(orc, curve, ds, n)
+    cl = msm_client(curve, 8, PointMemoryType.HBM)
+    cl.load_data_to_hbm(dp, 0, 0)
+    dp.free()
+    assert run_msm(cl, None, ds, n, hbm=(0, 0)) == exp
+    cl.close(); ds.free()
+    blaze_amd.lib().blz_arena_release(0)

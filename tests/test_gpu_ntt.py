@@ -1,0 +1,129 @@
+"""NTT parity on the MI355X through the C ABI (bit-exact vs the CPU oracle), golden vectors, the
+double-buffer contract of tests/integration_ntt.rs:62-146, and the full 2^27 shape by properties."""
+import json
+import os
+import random
+
+import pytest
+
+import blaze_amd
+from blaze_amd import DeviceBuffer, DriverClientError
+from blaze_amd.driver_client import DriverClient
+from blaze_amd.ingo_ntt import NTT, NTTClient, NTTInput, NttInit
+from oracle import pyref
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+R = pyref.CURVES["BLS381"]["r"]
+
+
+def _ntt(cl, data, buf=0):
+    # call order of benches/ntt_bench.rs:16-45: set_data, initialize, start_process, wait_result, result
+    cl.set_data(NTTInput(buf, data))
+    cl.initialize(NttInit())
+    cl.start_process(buf)
+    cl.wait_result()
+    return bytes(cl.result(buf))
+
+
+def test_golden_vectors(gpu):
+    with open(os.path.join(HERE, "golden", "ntt_vectors.json")) as f:
+        for v in json.load(f):
+            cl = NTTClient(NTT.Ntt, DriverClient(0), log_size=v["logn"])
+            assert _ntt(cl, bytes.fromhex(v["input"])) == bytes.fromhex(v["output"]), v["logn"]
+            cl.close()
+
+
+@pytest.mark.parametrize("logn", [2, 5, 9, 10, 12, 13, 17, 18, 19, 20])
+def test_against_oracle(gpu, orc, logn):
+    """every pass structure: 1 pass (<=9), 2 passes (10..18), 3 passes (>=19)."""
+    rng = random.Random(logn)
+    n = 1 << logn
+    data = b"".join(rng.randrange(R).to_bytes(32, "little") for _ in range(min(n, 4096)))
+    data = (data * (n // min(n, 4096)))[: 32 * n]
+    if n > 4096:  # de-periodise
+        data = bytearray(data)
+        for i in range(0, n, 97):
+            data[32 * i: 32 * i + 8] = (i * 0x9E3779B97F4A7C15 % (1 << 64)).to_bytes(8, "little")
+        data = bytes(data)
+    cl = NTTClient(NTT.Ntt, DriverClient(0), log_size=logn)
+    got = _ntt(cl, data)
+    assert got == bytes(orc.ntt("BLS381", data, logn, threads=16))
+    # edge values: 0, 1, r-1 everywhere
+    for val in (0, 1, R - 1):
+        d = val.to_bytes(32, "little") * n
+        assert _ntt(cl, d, buf=1) == bytes(orc.ntt("BLS381", d, logn, threads=16))
+    cl.close()
+
+
+def test_double_buffer_contract(gpu, orc):
+    """tests/integration_ntt.rs:102-136: compute on one buffer while the host loads / reads the other."""
+    logn = 14
+    n = 1 << logn
+    rng = random.Random(5)
+    ins = [b"".join(rng.randrange(R).to_bytes(32, "little") for _ in range(n)) for _ in range(3)]
+    cl = NTTClient(NTT.Ntt, DriverClient(0), log_size=logn)
+    cl.set_data(NTTInput(0, ins[0]))
+    outs = []
+    for i in range(3):
+        b = i % 2
+        cl.initialize(NttInit())
+        cl.start_process(b)
+        if i + 1 < 3:
+            cl.set_data(NTTInput(1 - b, ins[i + 1]))     # host writes the other buffer meanwhile
+        cl.wait_result()
+        outs.append(bytes(cl.result(b)))
+    for i in range(3):
+        assert outs[i] == bytes(orc.ntt("BLS381", ins[i], logn, threads=8))
+    with pytest.raises(DriverClientError):
+        cl.wait_result()
+    with pytest.raises(DriverClientError):
+        cl.set_data(NTTInput(0, ins[0][:-32]))
+    cl.close()
+
+
+def test_full_size_2e27_properties(gpu, orc):
+    """The reference shape (2^27 x 32 B = 4 GiB, ntt_data.rs:65-66).  Checked by: delta -> all ones,
+    X[0] = sum x, sum_k X[k] = n x[0], spot coefficients against the O(n) Horner oracle."""
+    logn = 27
+    n = 1 << logn
+    cl = NTTClient(NTT.Ntt, DriverClient(0), log_size=logn)
+    d_in = DeviceBuffer(0, 32 * n)
+    blaze_amd._lib.check(blaze_amd.lib().blz_synth_field_elements(0, d_in.ptr, n, 99))
+    cl.set_data(NTTInput(0, d_in))
+    cl.initialize(NttInit())
+    cl.start_process(0)
+    cl.wait_result()
+    import numpy as np
+    x = np.frombuffer(d_in.download(), dtype=np.uint8)
+    d_in.free()
+    out = cl.result(0)
+    y = np.frombuffer(out, dtype=np.uint8)
+
+    def elem(arr, i):
+        return int.from_bytes(arr[32 * i: 32 * i + 32].tobytes(), "little")
+
+    def field_sum(arr):  # sum of all elements mod r via 64-bit limb sums
+        limbs = arr.view(np.uint64).reshape(-1, 4)
+        tot = 0
+        for j in range(4):
+            lo = int((limbs[:, j] & np.uint64(0xFFFFFFFF)).sum(dtype=np.uint64))
+            hi = int((limbs[:, j] >> np.uint64(32)).sum(dtype=np.uint64))
+            tot += (lo + (hi << 32)) << (64 * j)
+        return tot % R
+
+    assert elem(y, 0) == field_sum(x)
+    assert field_sum(y) == (n * elem(x, 0)) % R
+    for k in (1, 12345678, n - 1):
+        assert elem(y, k) == orc.ntt_eval_at("BLS381", x, logn, k), k
+    # delta at index 1 -> X[k] = w^k
+    delta = np.zeros(32 * n, dtype=np.uint8)
+    delta[32] = 1
+    cl.set_data(NTTInput(1, delta))
+    cl.start_process(1)
+    cl.wait_result()
+    z = np.frombuffer(cl.result(1), dtype=np.uint8)
+    w = orc.omega("BLS381", logn)
+    for k in (0, 1, 2, 511, 512, 513, 1 << 18, (1 << 18) + 1, 99999999, n - 1):
+        assert elem(z, k) == pow(w, k, R), k
+    cl.close()
