@@ -105,8 +105,16 @@ BLZ_DEV void pt_madd(XYZZ<F>& acc, const Affine<F>& q) {
     fp_sub(R, R, acc.y);
     if (__builtin_expect(fp_maybe_zero(P), 0)) {
         if (fp_is_zero(P)) {
-            if (fp_is_zero(R)) pt_mdbl(acc, q);
-            else pt_set_inf(acc);
+            if (fp_is_zero(R)) {
+                // out-of-line doubling through copies: only these temporaries have their address
+                // taken, so `acc` itself stays in registers across the hot loop (no scratch)
+                XYZZ<F> d;
+                Affine<F> qq = q;
+                pt_mdbl(d, qq);
+                acc = d;
+            } else {
+                pt_set_inf(acc);
+            }
             return;
         }
     }
