@@ -68,3 +68,26 @@ def test_invalid_arguments_are_rejected_before_touching_a_device():
     assert L.blz_ntt_new(0, 28, C.byref(h)) == 4           # > 2^27
     assert L.blz_msm_wait_result(None) == 4
     assert L.blz_msm_initialize(None, 1, 0, 0, 0) == 4
+
+
+def _build_cpp_example(tmp_path):
+    import subprocess
+
+    exe = str(tmp_path / "host_example")
+    libdir = os.path.join(ROOT, "blaze_amd", "lib")
+    cmd = ["g++", "-std=c++17", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "host_example.cpp"), "-L" + libdir, "-lblaze_hip", "-Wl,-rpath," + libdir,
+           "-L/opt/rocm/lib", "-lamdhip64", "-o", exe]
+    subprocess.check_call(cmd)
+    return exe
+
+
+@pytest.mark.skipif(blaze_amd.lib().blz_device_count() > 0, reason="a GPU is present")
+def test_cpp_host_mirror_compiles_and_fails_loudly_without_gpu(tmp_path):
+    """include/blaze.hpp (the C++ mirror of DriverPrimitive / MSMClient / NTTClient) builds against
+    the C ABI; without a device it reports FileError (kind 7), it does not fall back."""
+    import subprocess
+
+    exe = _build_cpp_example(tmp_path)
+    p = subprocess.run([exe, "a", "b", "1", "c"], capture_output=True, text=True)
+    assert p.returncode == 1 and "kind 7" in p.stderr

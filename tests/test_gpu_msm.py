@@ -229,3 +229,20 @@ def test_config3_2e26_bn254_precompute_hbm_resident(gpu, orc):
     assert run_msm(cl, None, ds, n, hbm=(0, 0)) == exp
     cl.close(); ds.free()
     blaze_amd.lib().blz_arena_release(0)
+
+
+def test_cpp_host_mirror(gpu, orc, tmp_path):
+    """The C++ mirror (include/blaze.hpp) through the same ABI: tests/host_example.cpp is the C++
+    rendering of msm_bls12_381_test (tests/integration_msm.rs:149-207)."""
+    import subprocess
+
+    from test_abi import _build_cpp_example
+
+    exe = _build_cpp_example(tmp_path)
+    n = 1500
+    pts, sc, exp = orc.input_generator("BLS381", n, 1, 31)
+    (tmp_path / "p.bin").write_bytes(bytes(pts))
+    (tmp_path / "s.bin").write_bytes(bytes(sc))
+    out = tmp_path / "r.bin"
+    subprocess.check_call([exe, str(tmp_path / "p.bin"), str(tmp_path / "s.bin"), str(n), str(out)])
+    assert out.read_bytes() == exp
