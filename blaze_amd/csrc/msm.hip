@@ -5,7 +5,7 @@
 //   k_count        signed c-bit digits of every scalar -> per-(window,bucket) histogram
 //   k_scan_*       exclusive scan: bucket offsets + accumulate-unit offsets (runs split at L)
 //   k_scatter      (point index | sign) written to its bucket's slice of `entries`
-//   k_fill_units   unit -> bucket map
+//   k_fill_units   unit -> bucket map;  k_unit_* order the units by run length (descending)
 //   k_accumulate   one lane per unit: gathers its run of points, XYZZ mixed adds   [phase 1]
 //   k_combine_units   only when a bucket needed more than one unit
 //   k_reduce_level Sum_b b*S_b per window by segmented running sums, a few levels  [phase 2]
@@ -16,6 +16,7 @@
 // the arithmetic (v_mad_u64_u32) bounds every kernel here, not HBM.
 #include "msm_engine.hpp"
 #include "field.cuh"
+#include "msm_digits.cuh"
 
 namespace blz {
 
@@ -44,33 +45,6 @@ MsmPlan make_plan(uint32_t npts, int sbits, int force_c) {
     best.L = 256;
     return best;
 }
-
-// ------------------------------------------------------------------------------------------------
-// scalar -> signed digits
-// ------------------------------------------------------------------------------------------------
-template <int SW>
-struct ScalarWords {
-    uint32_t s[SW];
-    __device__ __forceinline__ void load(const uint32_t* scalars, uint32_t p) {
-        if constexpr (SW == 8) {
-            const uint4* q = reinterpret_cast<const uint4*>(scalars) + 2 * (size_t)p;
-            uint4 a = q[0], b = q[1];
-            s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
-        } else {
-            s[0] = scalars[p];
-        }
-    }
-    // pops the next c-bit window as a signed digit in (-2^(c-1), 2^(c-1)]
-    __device__ __forceinline__ int next(int c, uint32_t mask, uint32_t half, uint32_t& carry) {
-        uint32_t v = (s[0] & mask) + carry;
-#pragma unroll
-        for (int i = 0; i + 1 < SW; ++i) s[i] = __builtin_amdgcn_alignbit(s[i + 1], s[i], c);
-        s[SW - 1] >>= c;
-        if (v > half) { carry = 1; return (int)v - (int)(half << 1); }
-        carry = 0;
-        return (int)v;
-    }
-};
 
 template <int SW>
 __global__ __launch_bounds__(256) void k_count(const uint32_t* __restrict__ scalars, uint32_t npts, int c, int W,
@@ -226,6 +200,63 @@ __global__ __launch_bounds__(256) void k_fill_units(const uint32_t* __restrict__
     for (uint32_t u = u0; u < u1; ++u) unit_bucket[u] = (uint32_t)g;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Units ordered by run length (descending), so the 64 lanes of a wave walk runs of equal length:
+// with uniform scalars the runs are Poisson (mean n/2^(c-1)), and bucket order costs ~30% of the
+// lanes to divergence.  Counting sort over <= 1025 length bins, LDS-privatised.
+// ------------------------------------------------------------------------------------------------
+constexpr int MAX_L = 1024;
+__device__ __forceinline__ uint32_t unit_len(const uint32_t* off, const uint32_t* unit_off, const uint32_t* unit_bucket,
+                                             uint32_t u, uint32_t L) {
+    uint32_t g = unit_bucket[u];
+    uint32_t k = u - unit_off[g];
+    uint32_t rem = off[g + 1] - off[g] - k * L;
+    return rem > L ? L : rem;
+}
+
+__global__ __launch_bounds__(256) void k_unit_len_hist(const uint32_t* __restrict__ off, const uint32_t* __restrict__ unit_off,
+                                                       const uint32_t* __restrict__ unit_bucket, uint32_t U, uint32_t L,
+                                                       uint32_t* __restrict__ hist) {
+    __shared__ uint32_t sh[MAX_L + 1];
+    for (uint32_t i = threadIdx.x; i <= L; i += 256) sh[i] = 0;
+    __syncthreads();
+    uint32_t u = blockIdx.x * 256u + threadIdx.x;
+    if (u < U) atomicAdd(&sh[unit_len(off, unit_off, unit_bucket, u, L)], 1u);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i <= L; i += 256)
+        if (sh[i]) atomicAdd(&hist[i], sh[i]);
+}
+
+// cursor[len] = number of units strictly longer than len (descending order); one block
+__global__ __launch_bounds__(256) void k_unit_len_scan(const uint32_t* __restrict__ hist, uint32_t L,
+                                                       uint32_t* __restrict__ cursor) {
+    if (threadIdx.x != 0) return;
+    uint32_t run = 0;
+    for (int len = (int)L; len >= 0; --len) {
+        cursor[len] = run;
+        run += hist[len];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_unit_order(const uint32_t* __restrict__ off, const uint32_t* __restrict__ unit_off,
+                                                    const uint32_t* __restrict__ unit_bucket, uint32_t U, uint32_t L,
+                                                    uint32_t* __restrict__ cursor, uint32_t* __restrict__ unit_order) {
+    __shared__ uint32_t sh_cnt[MAX_L + 1];
+    __shared__ uint32_t sh_base[MAX_L + 1];
+    for (uint32_t i = threadIdx.x; i <= L; i += 256) sh_cnt[i] = 0;
+    __syncthreads();
+    uint32_t u = blockIdx.x * 256u + threadIdx.x;
+    uint32_t len = 0, rank = 0;
+    if (u < U) {
+        len = unit_len(off, unit_off, unit_bucket, u, L);
+        rank = atomicAdd(&sh_cnt[len], 1u);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i <= L; i += 256)
+        if (sh_cnt[i]) sh_base[i] = atomicAdd(&cursor[i], sh_cnt[i]);
+    __syncthreads();
+    if (u < U) unit_order[sh_base[len] + rank] = u;
+}
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -244,10 +275,25 @@ static const MsmCurveOps* ops_for(int curve) {
     return nullptr;
 }
 
-void launch_fill_units(MsmEngine& E) {
+int launch_fill_units(MsmEngine& E, uint32_t U) {
     const uint64_t G = E.last_plan.G;
-    hipLaunchKernelGGL(k_fill_units, dim3((uint32_t)((G + 255) / 256)), dim3(256), 0, E.stream, E.unit_off.as<uint32_t>(), G,
+    const uint32_t L = E.last_plan.L;
+    hipStream_t st = E.stream;
+    BLZ_TRY(E.unit_order.reserve(((size_t)U + 1) * 4));
+    BLZ_TRY(E.lenhist.reserve(2 * (MAX_L + 1) * 4));
+    uint32_t* hist = E.lenhist.as<uint32_t>();
+    uint32_t* cursor = hist + (MAX_L + 1);
+    BLZ_HIP(hipMemsetAsync(hist, 0, 2 * (MAX_L + 1) * 4, st), BLZ_ERR_UNKNOWN);
+    hipLaunchKernelGGL(k_fill_units, dim3((uint32_t)((G + 255) / 256)), dim3(256), 0, st, E.unit_off.as<uint32_t>(), G,
                        E.unit_bucket.as<uint32_t>());
+    dim3 gu((U + 255) / 256), b(256);
+    hipLaunchKernelGGL(k_unit_len_hist, gu, b, 0, st, E.off.as<uint32_t>(), E.unit_off.as<uint32_t>(),
+                       E.unit_bucket.as<uint32_t>(), U, L, hist);
+    hipLaunchKernelGGL(k_unit_len_scan, dim3(1), b, 0, st, hist, L, cursor);
+    hipLaunchKernelGGL(k_unit_order, gu, b, 0, st, E.off.as<uint32_t>(), E.unit_off.as<uint32_t>(),
+                       E.unit_bucket.as<uint32_t>(), U, L, cursor, E.unit_order.as<uint32_t>());
+    BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
+    return BLZ_OK;
 }
 
 int MsmEngine::init(int device_id, int curve_id) {
@@ -268,7 +314,7 @@ void MsmEngine::destroy() {
     if (!stream) return;
     (void)hipSetDevice(device);
     (void)hipStreamSynchronize(stream);
-    for (DevBuf* b : {&count, &off, &unit_off, &unit_bucket, &entries, &partial, &lvlA[0], &lvlA[1], &lvlC[0],
+    for (DevBuf* b : {&count, &off, &unit_off, &unit_bucket, &entries, &partial, &unit_order, &lenhist, &coarse, &inter, &lvlA[0], &lvlA[1], &lvlC[0],
                       &lvlC[1], &blocksums, &stats, &result})
         b->release();
     for (auto& e : ev)
@@ -300,6 +346,8 @@ int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int 
     MsmPlan P = make_plan(npts, sbits, msm_env_int("BLAZE_MSM_C", 0));
     if (P.c == 0) return fail(BLZ_ERR_INVALID_PARAM, "no window plan for npts=%u sbits=%d", npts, sbits);
     P.L = (uint32_t)msm_env_int("BLAZE_MSM_L", (int)P.L);
+    if (P.L < 1) P.L = 1;
+    if (P.L > (uint32_t)MAX_L) P.L = MAX_L;
     last_plan = P;
     const uint64_t G = P.G;
     const uint64_t max_entries = (uint64_t)npts * P.W;
@@ -317,17 +365,26 @@ int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int 
     BLZ_HIP(hipMemsetAsync(stats.p, 0, 64, st), BLZ_ERR_UNKNOWN);
     const uint32_t* sc = (const uint32_t*)d_scalars;
     dim3 gp((npts + 255) / 256), b256(256);
-    if (sbits == 256) hipLaunchKernelGGL(k_count<8>, gp, b256, 0, st, sc, npts, P.c, P.W, P.Bw, count.as<uint32_t>());
-    else hipLaunchKernelGGL(k_count<1>, gp, b256, 0, st, sc, npts, P.c, P.W, P.Bw, count.as<uint32_t>());
+    // BLAZE_MSM_SORT=0 selects the one-global-atomic-per-entry path (kept for A/B measurements)
+    const bool lds_sort = msm_env_int("BLAZE_MSM_SORT", 1) != 0;
+    if (lds_sort) {
+        BLZ_TRY(msm_sort_lds(E, d_scalars, npts, sbits));
+    } else {
+        if (sbits == 256) hipLaunchKernelGGL(k_count<8>, gp, b256, 0, st, sc, npts, P.c, P.W, P.Bw, count.as<uint32_t>());
+        else hipLaunchKernelGGL(k_count<1>, gp, b256, 0, st, sc, npts, P.c, P.W, P.Bw, count.as<uint32_t>());
+    }
     hipLaunchKernelGGL(k_scan_reduce, dim3(nscan), b256, 0, st, count.as<uint32_t>(), G, P.L, blocksums.as<uint64_t>(),
                        stats.as<uint32_t>());
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, blocksums.as<uint64_t>(), nscan, stats.as<uint32_t>());
     hipLaunchKernelGGL(k_scan_final, dim3(nscan), b256, 0, st, count.as<uint32_t>(), G, P.L, blocksums.as<uint64_t>(),
                        off.as<uint32_t>(), unit_off.as<uint32_t>());
-    if (sbits == 256)
+    if (lds_sort) {
+        BLZ_TRY(msm_sort_lds_scatter(E));
+    } else if (sbits == 256) {
         hipLaunchKernelGGL(k_scatter<8>, gp, b256, 0, st, sc, npts, P.c, P.W, P.Bw, count.as<uint32_t>(), entries.as<uint32_t>());
-    else
+    } else {
         hipLaunchKernelGGL(k_scatter<1>, gp, b256, 0, st, sc, npts, P.c, P.W, P.Bw, count.as<uint32_t>(), entries.as<uint32_t>());
+    }
     BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
     // unit totals are needed on the host to size the accumulate launch
     BLZ_HIP(hipMemcpyAsync(stats_h, stats.p, 16, hipMemcpyDeviceToHost, st), BLZ_ERR_READ);

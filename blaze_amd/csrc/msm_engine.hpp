@@ -20,13 +20,15 @@ struct MsmEngine {
     int curve = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
-    DevBuf count, off, unit_off, unit_bucket, entries, partial, lvlA[2], lvlC[2], blocksums, stats, result;
+    DevBuf count, off, unit_off, unit_bucket, unit_order, lenhist, coarse, inter, entries, partial, lvlA[2], lvlC[2], blocksums, stats, result;
     uint32_t* stats_h = nullptr;   // pinned: [0] total units, [1] max bucket count, [2] total entries
     uint8_t* result_h = nullptr;   // pinned result bytes
     MsmPlan last_plan;
     float last_ms[8] = {};
     bool timings_pending = false;
     bool accum_timed = false;
+    uint32_t sort_slices = 1, sort_nc = 0;  // geometry of the last LDS sort (msm_sort.hip)
+    int sort_cl = 0;
 
     int init(int device_id, int curve_id);
     void destroy();
@@ -42,7 +44,10 @@ struct MsmEngine {
 
 size_t fq_bytes(int curve);
 int msm_env_int(const char* name, int dflt);
-void launch_fill_units(MsmEngine& E);
+// two-level LDS-privatised digit sort (msm_sort.hip): fills count[], then (after the scan) entries[]
+int msm_sort_lds(MsmEngine& E, const void* d_scalars, uint32_t npts, int sbits);
+int msm_sort_lds_scatter(MsmEngine& E);
+int launch_fill_units(MsmEngine& E, uint32_t units);  // unit->bucket map + length-ordered unit list
 
 // per-curve entry points (one translation unit per curve: msm_<curve>.hip)
 struct MsmCurveOps {

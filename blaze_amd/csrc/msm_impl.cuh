@@ -53,10 +53,12 @@ BLZ_DEV void store_xyzz(uint32_t* base, size_t idx, const XYZZ<F>& a) {
 template <class F>
 __global__ __launch_bounds__(128) void k_accumulate(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ entries,
                                                     const uint32_t* __restrict__ off, const uint32_t* __restrict__ unit_off,
-                                                    const uint32_t* __restrict__ unit_bucket, uint32_t U, uint32_t L,
+                                                    const uint32_t* __restrict__ unit_bucket,
+                                                    const uint32_t* __restrict__ unit_order, uint32_t U, uint32_t L,
                                                     uint32_t* __restrict__ partial) {
-    uint32_t u = blockIdx.x * 128u + threadIdx.x;
-    if (u >= U) return;
+    uint32_t t = blockIdx.x * 128u + threadIdx.x;
+    if (t >= U) return;
+    const uint32_t u = unit_order[t];  // units of equal run length sit in the same wave
     uint32_t g = unit_bucket[u];
     uint32_t k = u - unit_off[g];
     uint32_t start = off[g] + k * L;
@@ -251,11 +253,11 @@ int run_tail_t(MsmEngine& E, const void* d_pts, uint32_t U, uint32_t maxcount) {
     // ---- phase 1
     E.accum_timed = U != 0;
     if (U) {
-        launch_fill_units(E);
+        BLZ_TRY(launch_fill_units(E, U));
         BLZ_HIP(hipEventRecord(E.ev[5], st), BLZ_ERR_UNKNOWN);  // ev5..ev6 bracket the dominant kernel alone
         hipLaunchKernelGGL(k_accumulate<F>, dim3((U + 127) / 128), dim3(128), 0, st, (const uint32_t*)d_pts,
                            E.entries.as<uint32_t>(), E.off.as<uint32_t>(), E.unit_off.as<uint32_t>(),
-                           E.unit_bucket.as<uint32_t>(), U, P.L, E.partial.as<uint32_t>());
+                           E.unit_bucket.as<uint32_t>(), E.unit_order.as<uint32_t>(), U, P.L, E.partial.as<uint32_t>());
         BLZ_HIP(hipEventRecord(E.ev[6], st), BLZ_ERR_UNKNOWN);
         uint32_t maxunits = (maxcount + P.L - 1) / P.L;
         for (uint32_t stride = 1; stride < maxunits; stride *= 16)
