@@ -44,13 +44,13 @@ __global__ void k_ntt_table(uint32_t* out, int count, int logn, uint64_t mult) {
     fp_store(out + (size_t)j * 8, acc);
 }
 
-BLZ_DEV void lds_load(E& r, const uint32_t* lds, uint32_t idx) {
-    const uint4* q = reinterpret_cast<const uint4*>(lds) + 2 * (size_t)idx;
+BLZ_DEV void lds_load(E& r, const uint32_t* lds, uint32_t dw) {  // dw: dword offset, multiple of 8
+    const uint4* q = reinterpret_cast<const uint4*>(lds + dw);
     uint4 a = q[0], b = q[1];
     r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
 }
-BLZ_DEV void lds_store(uint32_t* lds, uint32_t idx, const E& r) {
-    uint4* q = reinterpret_cast<uint4*>(lds) + 2 * (size_t)idx;
+BLZ_DEV void lds_store(uint32_t* lds, uint32_t dw, const E& r) {
+    uint4* q = reinterpret_cast<uint4*>(lds + dw);
     q[0] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
     q[1] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
 }
@@ -68,37 +68,48 @@ struct NttGeom {
     int logA, logB, logC, logn;
 };
 
-// PASS 1..3 as in the header comment.  Tile = COLS columns x (1 << lr) rows, 256 threads.
+constexpr int NTT_THREADS = 1024;  // 4 waves per SIMD: the 128-147 KiB tile allows one block per CU
+
+// LDS tile: element (row, col) at dword offset row * RS + col * 8 with RS = COLS * 8 + 8: the one
+// element of padding per row spreads rows over the banks (a power-of-two row stride puts every row
+// of a column on the same banks, and the bit-reversed row order of the load makes that the norm).
+BLZ_DEV uint32_t ntt_rs(uint32_t cols) { return cols * 8u + 8u; }
+
+// PASS 1..3 as in the header comment.  Tile = COLS columns x (1 << lr) rows.
+// Inter-pass twiddles (the w^(i0 k2) factor of pass 2 is applied in pass 1: it does not depend on
+// the index pass 2 transforms over):
+//   after pass 1: x(i0, i1, k2) *= w^(k2 (i0 + A i1))      step along i0: w^k2
+//   after pass 2: x(i0, k1, k2) *= w^(C i0 k1)             step along i0: w^(C k1)
+// so a lane that owns a few adjacent columns of one row derives its twiddles by repeated
+// multiplication from one table look-up.
 template <int PASS>
-__global__ __launch_bounds__(256) void k_ntt_pass(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, NttGeom g,
-                                                  NttTables T, int cols_log) {
+__global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                          NttGeom g, NttTables T, int cols_log) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int lr = PASS == 1 ? g.logC : PASS == 2 ? g.logB : g.logA;  // log radix of this pass
     const uint32_t radix = 1u << lr;
     const uint32_t COLS = 1u << cols_log;
+    const uint32_t RS = ntt_rs(COLS);
     const uint32_t A = 1u << g.logA, B = 1u << g.logB, C = 1u << g.logC;
-    // tile coordinates
-    uint64_t col_base;    // first column (the "other" index that is contiguous in the tile)
-    uint64_t fixed;       // the remaining fixed index
-    uint64_t in_base, in_rstride, in_cstride;
+    uint64_t col_base, fixed, in_base, in_rstride, in_cstride;
     const uint64_t tile = blockIdx.x;
     if (PASS == 1) {  // rows i2 (stride AB), cols i0 (stride 1), fixed i1
         uint64_t tiles_per = A >> cols_log;
-        fixed = tile / tiles_per;  // i1
+        fixed = tile / tiles_per;
         col_base = (tile % tiles_per) << cols_log;
         in_base = col_base + (uint64_t)A * fixed;
         in_rstride = (uint64_t)A * B;
         in_cstride = 1;
     } else if (PASS == 2) {  // rows i1 (stride A), cols i0, fixed k2
         uint64_t tiles_per = A >> cols_log;
-        fixed = tile / tiles_per;  // k2
+        fixed = tile / tiles_per;
         col_base = (tile % tiles_per) << cols_log;
         in_base = col_base + (uint64_t)A * B * fixed;
         in_rstride = A;
         in_cstride = 1;
     } else {  // rows i0 (stride 1), cols k2 (stride AB), fixed k1
         uint64_t tiles_per = C >> cols_log;
-        fixed = tile / tiles_per;  // k1
+        fixed = tile / tiles_per;
         col_base = (tile % tiles_per) << cols_log;
         in_base = (uint64_t)A * fixed + (uint64_t)A * B * col_base;
         in_rstride = 1;
@@ -106,14 +117,14 @@ __global__ __launch_bounds__(256) void k_ntt_pass(const uint32_t* __restrict__ i
     }
     const uint32_t total = radix << cols_log;
     // ---- load, rows bit-reversed (decimation in time)
-    for (uint32_t e = threadIdx.x; e < total; e += 256) {
+    for (uint32_t e = threadIdx.x; e < total; e += NTT_THREADS) {
         uint32_t row, col;
         if (PASS == 3) { row = e & (radix - 1); col = e >> lr; }   // contiguous along rows
         else { col = e & (COLS - 1); row = e >> cols_log; }         // contiguous along cols
         E x;
         fp_load(x, in + (in_base + row * in_rstride + col * in_cstride) * 8);
         uint32_t rrow = lr ? (__brev(row) >> (32 - lr)) : 0;
-        lds_store(lds, rrow * COLS + col, x);
+        lds_store(lds, rrow * RS + col * 8, x);
     }
     __syncthreads();
     // ---- radix-2 stages
@@ -121,13 +132,13 @@ __global__ __launch_bounds__(256) void k_ntt_pass(const uint32_t* __restrict__ i
     const uint32_t nbf = (radix >> 1) << cols_log;
     for (int s = 1; s <= lr; ++s) {
         const uint32_t half = 1u << (s - 1);
-        for (uint32_t e = threadIdx.x; e < nbf; e += 256) {
+        for (uint32_t e = threadIdx.x; e < nbf; e += NTT_THREADS) {
             uint32_t col = e & (COLS - 1), b = e >> cols_log;
             uint32_t blk = b >> (s - 1), k = b & (half - 1);
             uint32_t u = (blk << s) + k, v = u + half;
             E xu, xv;
-            lds_load(xu, lds, u * COLS + col);
-            lds_load(xv, lds, v * COLS + col);
+            lds_load(xu, lds, u * RS + col * 8);
+            lds_load(xv, lds, v * RS + col * 8);
             uint32_t tw = k << (lr - s);
             if (tw) {
                 E w;
@@ -137,35 +148,48 @@ __global__ __launch_bounds__(256) void k_ntt_pass(const uint32_t* __restrict__ i
             E sum, dif;
             fp_add(sum, xu, xv);
             fp_sub(dif, xu, xv);
-            lds_store(lds, u * COLS + col, sum);
-            lds_store(lds, v * COLS + col, dif);
+            lds_store(lds, u * RS + col * 8, sum);
+            lds_store(lds, v * RS + col * 8, dif);
         }
         __syncthreads();
     }
-    // ---- inter-pass twiddle + store
-    for (uint32_t e = threadIdx.x; e < total; e += 256) {
-        uint32_t row, col;
-        if (PASS == 3) { col = e & (COLS - 1); row = e >> cols_log; }  // output contiguous along k2 (cols)
-        else { col = e & (COLS - 1); row = e >> cols_log; }
-        E x;
-        lds_load(x, lds, row * COLS + col);
-        uint64_t oaddr;
+    // ---- inter-pass twiddle + store: one lane owns CG adjacent columns of one row
+    const uint32_t cg_log = cols_log < 2 ? cols_log : 2;
+    const uint32_t CG = 1u << cg_log;
+    const uint32_t ntask = total >> cg_log;
+    for (uint32_t t = threadIdx.x; t < ntask; t += NTT_THREADS) {
+        const uint32_t grp = t & ((COLS >> cg_log) - 1), row = t >> (cols_log - cg_log);
+        const uint32_t col0 = grp << cg_log;
+        E w, step;
+        bool tw = false;
         if (PASS == 1) {
-            // element (i0 = col_base+col, i1 = fixed, k2 = row): * w^(A i1 k2)
-            uint32_t ex = (uint32_t)(((uint64_t)fixed * row) << g.logA);
-            if (ex) { E w; tw_pow(w, T, ex); fp_mul(x, x, w); }
-            oaddr = in_base + row * in_rstride + col;
+            // k2 = row, i1 = fixed, i0 = col_base + col0 + j
+            uint32_t ex = (uint32_t)((uint64_t)row * (col_base + col0 + ((uint64_t)fixed << g.logA)));
+            tw = row != 0;
+            if (tw) { tw_pow(w, T, ex); fp_load(step, T.t0 + (size_t)row * 8); }
         } else if (PASS == 2) {
-            // element (i0, k1 = row, k2 = fixed): * w^(i0 (k2 + C k1))
-            uint64_t i0 = col_base + col;
-            uint32_t ex = (uint32_t)(i0 * (fixed + ((uint64_t)row << g.logC)));
-            if (ex) { E w; tw_pow(w, T, ex); fp_mul(x, x, w); }
-            oaddr = in_base + row * in_rstride + col;
-        } else {
-            // element (k0 = row, k1 = fixed, k2 = col_base+col) -> natural address k2 + C k1 + CB k0
-            oaddr = (col_base + col) + (uint64_t)C * fixed + (uint64_t)C * B * row;
+            // k1 = row, i0 = col_base + col0 + j
+            uint32_t ex = (uint32_t)(((uint64_t)row * (col_base + col0)) << g.logC);
+            tw = row != 0;
+            if (tw) { tw_pow(w, T, ex); tw_pow(step, T, row << g.logC); }
         }
-        fp_store(out + oaddr * 8, x);
+#pragma unroll 4
+        for (uint32_t j = 0; j < CG; ++j) {
+            E x;
+            lds_load(x, lds, row * RS + (col0 + j) * 8);
+            uint64_t oaddr;
+            if (PASS == 3) {
+                // element (k0 = row, k1 = fixed, k2 = col_base + col) -> natural address k2 + C k1 + CB k0
+                oaddr = (col_base + col0 + j) + (uint64_t)C * fixed + (uint64_t)C * B * row;
+            } else {
+                if (tw) {
+                    fp_mul(x, x, w);
+                    if (j + 1 < CG) fp_mul(w, w, step);
+                }
+                oaddr = in_base + row * in_rstride + col0 + j;
+            }
+            fp_store(out + oaddr * 8, x);
+        }
     }
 }
 
@@ -200,7 +224,7 @@ int ntt_setup(blz_ntt* h) {
     int lc = l - la - lb;
     if (lc > 9) return fail(BLZ_ERR_INVALID_PARAM, "log_size %d not supported (max 27)", l);
     h->geom = NttGeom{la, lb, lc, l};
-    // columns per tile: LDS = radix * COLS * 32 B <= 128 KiB, and COLS <= extent of the column index
+    // columns per tile: LDS = radix * (COLS + 1) * 32 B <= 160 KiB, and COLS <= extent of the column index
     auto pick = [](int lr, int lcols_avail) {
         int c = 17 - 5 - lr;  // log2(128 KiB / 32 B / radix)
         if (c > 3) c = 3;
@@ -237,7 +261,7 @@ int launch_pass(blz_ntt* h, const void* in, void* out) {
     const NttGeom& g = h->geom;
     int lr = PASS == 1 ? g.logC : PASS == 2 ? g.logB : g.logA;
     int cl = h->cols_log[PASS - 1];
-    size_t lds = ((size_t)32 << lr) << cl;
+    size_t lds = ((size_t)4 << lr) * (((size_t)8 << cl) + 8);  // rows x (COLS*8 + 8) dwords
     uint64_t tiles = (1ull << g.logn) >> (lr + cl);
     static bool attr_set = false;
     if (!attr_set) {
@@ -245,7 +269,7 @@ int launch_pass(blz_ntt* h, const void* in, void* out) {
                 BLZ_ERR_UNKNOWN);
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_ntt_pass<PASS>, dim3((unsigned)tiles), dim3(256), lds, h->stream, (const uint32_t*)in,
+    hipLaunchKernelGGL(k_ntt_pass<PASS>, dim3((unsigned)tiles), dim3(NTT_THREADS), lds, h->stream, (const uint32_t*)in,
                        (uint32_t*)out, g, h->T, cl);
     BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
     return BLZ_OK;
