@@ -51,10 +51,16 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # "nccl" is RCCL on ROCm (xGMI between the GPUs of the node).  BLAZE_BENCH_BACKEND=gloo with
+        # BLAZE_BENCH_ONE_GPU=1 lets the sharded path be exercised by several ranks on a 1-GPU box.
+        backend = os.environ.get("BLAZE_BENCH_BACKEND", "nccl")
+        if os.environ.get("BLAZE_BENCH_ONE_GPU") == "1":
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     dev = local_rank
     tdev = torch.device("cuda", dev)
+    gather_dev = tdev if (world == 1 or dist.get_backend() == "nccl") else None
 
     import blaze_amd
     from blaze_amd import DeviceBuffer
@@ -73,7 +79,7 @@ def main():
     d_pts = DeviceBuffer(dev, n_loc * 96)
     d_sc = DeviceBuffer(dev, n_loc * 32)
     check(L.blz_synth_points(dev, cid, d_pts.ptr, n_loc, 1, lo))
-    check(L.blz_synth_scalars(dev, cid, d_sc.ptr, n_loc, 0xB1A2E + rank))
+    check(L.blz_synth_scalars_at(dev, cid, d_sc.ptr, n_loc, 0xB1A2E, lo))  # same global set for every N
 
     client = MSMClient(MSMInit(PointMemoryType.DMA, False, Curve[CURVE]), DriverClient(dev))
     params = MSMParams(n_loc, None)
@@ -85,7 +91,7 @@ def main():
         client.wait_result()
         part = client.result().result
         if world > 1:
-            return sharded_msm(part, client.combine_partials, dist, tdev)
+            return sharded_msm(part, client.combine_partials, dist, gather_dev)
         return part
 
     def fence():
@@ -106,7 +112,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=tdev)
+        t = torch.tensor([dt], dtype=torch.float64, device=gather_dev if gather_dev is not None else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
@@ -191,6 +197,8 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "ntt_2e27": ntt,
             "phases_ms": {k: round(v, 3) for k, v in api.items() if k.endswith("_ms")},
         }
+        if os.environ.get("BLAZE_BENCH_EMIT_RESULT") == "1":
+            line["result_hex"] = res.hex()
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

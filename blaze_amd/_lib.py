@@ -76,6 +76,7 @@ _SIGS = {
     "blz_memcpy_h2d": (C.c_int, [C.c_int, C.c_void_p, _u8p, C.c_size_t]),
     "blz_memcpy_d2h": (C.c_int, [C.c_int, _u8p, C.c_void_p, C.c_size_t]),
     "blz_synth_scalars": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_uint64]),
+    "blz_synth_scalars_at": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]),
     "blz_synth_points": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_int, C.c_uint64]),
     "blz_synth_field_elements": (C.c_int, [C.c_int, C.c_void_p, C.c_uint64, C.c_uint64]),
     "blz_test_field_op": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _u8p, _u8p, _u8p, C.c_size_t]),

@@ -16,13 +16,13 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
 
 // n x 32 B little-endian values in [0, m) of the 8-limb field P
 template <class P>
-__global__ __launch_bounds__(256) void k_synth_scalars(uint32_t* out, uint64_t n, uint64_t seed) {
+__global__ __launch_bounds__(256) void k_synth_scalars(uint32_t* out, uint64_t n, uint64_t seed, uint64_t start) {
     uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     Fp<P> v;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        uint64_t r = splitmix64(seed * 0x2545f4914f6cdd1dull + 4 * i + k);
+        uint64_t r = splitmix64(seed * 0x2545f4914f6cdd1dull + 4 * (start + i) + k);
         v.v[2 * k] = (uint32_t)r;
         v.v[2 * k + 1] = (uint32_t)(r >> 32);
     }
@@ -126,8 +126,8 @@ int synth_points_t(void* d_out, uint64_t n, int pf, uint64_t start) {
 }
 
 template <class P>
-int synth_scalars_t(void* d_out, uint64_t n, uint64_t seed) {
-    if (n) hipLaunchKernelGGL(k_synth_scalars<P>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (uint32_t*)d_out, n, seed);
+int synth_scalars_t(void* d_out, uint64_t n, uint64_t seed, uint64_t start) {
+    if (n) hipLaunchKernelGGL(k_synth_scalars<P>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (uint32_t*)d_out, n, seed, start);
     BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
     BLZ_HIP(hipDeviceSynchronize(), BLZ_ERR_UNKNOWN);
     return BLZ_OK;
@@ -139,14 +139,18 @@ using namespace blz;
 
 extern "C" {
 
-int blz_synth_scalars(int device_id, int curve, void* d_out, uint64_t n, uint64_t seed) {
+int blz_synth_scalars_at(int device_id, int curve, void* d_out, uint64_t n, uint64_t seed, uint64_t start) {
     BLZ_TRY(use_device(device_id));
     switch (curve) {
-        case BLZ_BLS377: return synth_scalars_t<Fr_BLS377>(d_out, n, seed);
-        case BLZ_BLS381: return synth_scalars_t<Fr_BLS381>(d_out, n, seed);
-        case BLZ_BN254: return synth_scalars_t<Fr_BN254>(d_out, n, seed);
+        case BLZ_BLS377: return synth_scalars_t<Fr_BLS377>(d_out, n, seed, start);
+        case BLZ_BLS381: return synth_scalars_t<Fr_BLS381>(d_out, n, seed, start);
+        case BLZ_BN254: return synth_scalars_t<Fr_BN254>(d_out, n, seed, start);
     }
     return fail(BLZ_ERR_INVALID_PARAM, "unknown curve %d", curve);
+}
+
+int blz_synth_scalars(int device_id, int curve, void* d_out, uint64_t n, uint64_t seed) {
+    return blz_synth_scalars_at(device_id, curve, d_out, n, seed, 0);
 }
 
 int blz_synth_points(int device_id, int curve, void* d_out, uint64_t n, int pf, uint64_t start) {
@@ -162,7 +166,7 @@ int blz_synth_points(int device_id, int curve, void* d_out, uint64_t n, int pf, 
 
 int blz_synth_field_elements(int device_id, void* d_out, uint64_t n, uint64_t seed) {
     BLZ_TRY(use_device(device_id));
-    return synth_scalars_t<Fr_BLS381>(d_out, n, seed);
+    return synth_scalars_t<Fr_BLS381>(d_out, n, seed, 0);
 }
 
 }  // extern "C"

@@ -165,6 +165,8 @@ int blz_memcpy_h2d(int device_id, void* d_dst, const void* src, size_t bytes);
 int blz_memcpy_d2h(int device_id, void* dst, const void* d_src, size_t bytes);
 /* scalars: n x 32 B, uniform-ish in [0, r) from a counter-based generator */
 int blz_synth_scalars(int device_id, int curve, void* d_out, uint64_t n, uint64_t seed);
+/* same stream of values, elements [start, start+n): a shard of a larger synthetic set */
+int blz_synth_scalars_at(int device_id, int curve, void* d_out, uint64_t n, uint64_t seed, uint64_t start);
 /* points: element i gets pf bases B_{i,j} = 2^(32 j) * (start+i+1) * G, wire format x||y canonical */
 int blz_synth_points(int device_id, int curve, void* d_out, uint64_t n, int pf, uint64_t start);
 /* NTT input: n x 32 B uniform-ish in [0, r) of BLS12-381 Fr */
