@@ -70,6 +70,13 @@ __device__ __noinline__ void pt_mdbl(XYZZ<F>& r, const Affine<F>& a) {
     r.zzz = W;
 }
 
+template <class F>
+__device__ __noinline__ XYZZ<F> pt_mdbl_val(Affine<F> a) {
+    XYZZ<F> r;
+    pt_mdbl(r, a);
+    return r;
+}
+
 // r = 2*p
 template <class F>
 __device__ __noinline__ void pt_dbl(XYZZ<F>& r, const XYZZ<F>& p) {
@@ -106,12 +113,11 @@ BLZ_DEV void pt_madd(XYZZ<F>& acc, const Affine<F>& q) {
     if (__builtin_expect(fp_maybe_zero(P), 0)) {
         if (fp_is_zero(P)) {
             if (fp_is_zero(R)) {
-                // out-of-line doubling through copies: only these temporaries have their address
-                // taken, so `acc` itself stays in registers across the hot loop (no scratch)
-                XYZZ<F> d;
-                Affine<F> qq = q;
-                pt_mdbl(d, qq);
-                acc = d;
+                // out-of-line doubling, operands BY VALUE: neither `acc` nor `q` has its address
+                // taken, so both stay in registers across the hot loop (a by-reference call made
+                // hipcc keep the point in scratch and store it every iteration: 80 GB of HBM writes
+                // per 2^26 MSM in the PMC counters)
+                acc = pt_mdbl_val(q);
             } else {
                 pt_set_inf(acc);
             }

@@ -51,7 +51,7 @@ BLZ_DEV void store_xyzz(uint32_t* base, size_t idx, const XYZZ<F>& a) {
 // phase 1: bucket accumulation.  One lane per unit (a run of <= L entries of one bucket).
 // ------------------------------------------------------------------------------------------------
 template <class F>
-__global__ __launch_bounds__(128) void k_accumulate(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ entries,
+__global__ __launch_bounds__(128, 3) void k_accumulate(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ entries,
                                                     const uint32_t* __restrict__ off, const uint32_t* __restrict__ unit_off,
                                                     const uint32_t* __restrict__ unit_bucket,
                                                     const uint32_t* __restrict__ unit_order, uint32_t U, uint32_t L,
@@ -268,13 +268,18 @@ int run_tail_t(MsmEngine& E, const void* d_pts, uint32_t U, uint32_t maxcount) {
     BLZ_HIP(hipEventRecord(E.ev[2], st), BLZ_ERR_UNKNOWN);
 
     // ---- phase 2
-    const uint32_t SEG = (uint32_t)msm_env_int("BLAZE_MSM_SEG", 32);
+    // level 0 is throughput-bound (2 adds per bucket): long segments; the upper levels have few
+    // lanes and are latency-bound on their sequential chain: short segments, more levels
+    const uint32_t SEG0 = (uint32_t)msm_env_int("BLAZE_MSM_SEG", 32);
+    const uint32_t SEGU = (uint32_t)msm_env_int("BLAZE_MSM_SEG_UPPER", 8);
     uint32_t M = P.Bw;
-    int level = 0, shift = 0, seglog = 0;
-    while ((1u << seglog) < SEG) ++seglog;
+    int level = 0, shift = 0;
     const uint32_t* curA = E.partial.as<uint32_t>();
     const uint32_t* curC = nullptr;
     for (;;) {
+        const uint32_t SEG = level == 0 ? SEG0 : SEGU;
+        int seglog = 0;
+        while ((1u << seglog) < SEG) ++seglog;
         uint32_t T = (M + SEG - 1) / SEG;
         DevBuf& oA = E.lvlA[level & 1];
         DevBuf& oC = E.lvlC[level & 1];
