@@ -166,29 +166,90 @@ __global__ __launch_bounds__(FINE_THREADS) void k_fine_count(const uint2* __rest
     }
 }
 
-__global__ __launch_bounds__(FINE_THREADS) void k_fine_scatter(const uint2* __restrict__ inter, const uint32_t* __restrict__ coarse_off,
-                                                               int cl, uint32_t S, uint32_t* __restrict__ cursor,
-                                                               uint32_t* __restrict__ entries) {
+// Final scatter, LDS-staged: a block takes its slice in rounds of up to FS_ROUND entries held in
+// registers; ranks come from an LDS histogram, the round is laid out bucket-major in an LDS staging
+// buffer, and ONE lane per bucket copies that bucket's run to its reserved global range - so HBM sees
+// contiguous runs instead of one 4-byte write per entry (the unstaged version wrote 17.6 GB for
+// 3.2 GB of entries in the WRITE_SIZE counter).
+constexpr int FS_THREADS = 1024;
+constexpr int FS_PER_THREAD = 32;
+constexpr int FS_ROUND = FS_THREADS * FS_PER_THREAD;  // 32768 entries = 128 KiB of staging
+
+__global__ __launch_bounds__(FS_THREADS) void k_fine_scatter(const uint2* __restrict__ inter, const uint32_t* __restrict__ coarse_off,
+                                                             int cl, uint32_t S, uint32_t* __restrict__ cursor,
+                                                             uint32_t* __restrict__ entries) {
     extern __shared__ __attribute__((aligned(16))) uint32_t sh[];
     const uint32_t nf = 1u << cl;
+    uint32_t* hist = sh;             // [nf]  counts, then exclusive local base
+    uint32_t* gbase = sh + nf;       // [nf]  reserved global base per bucket
+    uint32_t* cnt = sh + 2 * nf;     // [nf]  counts of this round
+    uint32_t* stage = sh + 3 * nf;   // [FS_ROUND]
+    __shared__ uint32_t wave_tot[FS_THREADS / 64];
     const uint32_t k = blockIdx.x / S, s = blockIdx.x % S;
     uint32_t lo, hi;
     slice_range(coarse_off, k, s, S, lo, hi);
     if (lo >= hi) return;
-    for (uint32_t i = threadIdx.x; i < nf; i += FINE_THREADS) sh[i] = 0;
-    __syncthreads();
-    for (uint32_t j = lo + threadIdx.x; j < hi; j += FINE_THREADS) atomicAdd(&sh[inter[j].y], 1u);
-    __syncthreads();
     uint32_t* cur = cursor + ((size_t)k << cl);
-    for (uint32_t i = threadIdx.x; i < nf; i += FINE_THREADS) {
-        uint32_t v = sh[i];
-        sh[i] = v ? atomicAdd(&cur[i], v) : 0u;
-    }
-    __syncthreads();
-    for (uint32_t j = lo + threadIdx.x; j < hi; j += FINE_THREADS) {
-        uint2 e = inter[j];
-        uint32_t pos = atomicAdd(&sh[e.y], 1u);
-        entries[pos] = e.x;
+    uint32_t* dst = entries;
+    const uint32_t per_thr_bins = (nf + FS_THREADS - 1) / FS_THREADS;
+    for (uint32_t r0 = lo; r0 < hi; r0 += FS_ROUND) {
+        const uint32_t rn = (hi - r0) < (uint32_t)FS_ROUND ? (hi - r0) : (uint32_t)FS_ROUND;
+        for (uint32_t i = threadIdx.x; i < nf; i += FS_THREADS) hist[i] = 0;
+        __syncthreads();
+        uint32_t ex[FS_PER_THREAD], ey[FS_PER_THREAD];
+#pragma unroll
+        for (int t = 0; t < FS_PER_THREAD; ++t) {
+            uint32_t j = t * FS_THREADS + threadIdx.x;
+            if (j < rn) {
+                uint2 e = inter[r0 + j];
+                uint32_t rank = atomicAdd(&hist[e.y], 1u);
+                ex[t] = e.x;
+                ey[t] = e.y | (rank << 12);
+            }
+        }
+        __syncthreads();
+        // exclusive scan of hist (each lane owns per_thr_bins consecutive buckets) + global reservation
+        {
+            uint32_t b0 = threadIdx.x * per_thr_bins;
+            uint32_t loc[4];
+            uint32_t sum = 0;
+            for (uint32_t q = 0; q < per_thr_bins; ++q) {
+                uint32_t v = (b0 + q) < nf ? hist[b0 + q] : 0;
+                loc[q] = v;
+                sum += v;
+            }
+            uint32_t incl = sum;
+            for (int o = 1; o < 64; o <<= 1) {
+                uint32_t t2 = __shfl_up(incl, o, 64);
+                if ((threadIdx.x & 63) >= (uint32_t)o) incl += t2;
+            }
+            if ((threadIdx.x & 63) == 63) wave_tot[threadIdx.x >> 6] = incl;
+            __syncthreads();
+            uint32_t wbase = 0;
+            for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) wbase += wave_tot[w];
+            uint32_t run = wbase + incl - sum;
+            for (uint32_t q = 0; q < per_thr_bins; ++q) {
+                if ((b0 + q) < nf) {
+                    uint32_t v = loc[q];
+                    cnt[b0 + q] = v;
+                    hist[b0 + q] = run;
+                    gbase[b0 + q] = v ? atomicAdd(&cur[b0 + q], v) : 0u;
+                    run += v;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < FS_PER_THREAD; ++t) {
+            uint32_t j = t * FS_THREADS + threadIdx.x;
+            if (j < rn) stage[hist[ey[t] & 0xfffu] + (ey[t] >> 12)] = ex[t];
+        }
+        __syncthreads();
+        for (uint32_t f = threadIdx.x; f < nf; f += FS_THREADS) {
+            uint32_t n = cnt[f], src = hist[f], g0 = gbase[f];
+            for (uint32_t q = 0; q < n; ++q) dst[g0 + q] = stage[src + q];
+        }
+        __syncthreads();
     }
 }
 
@@ -261,8 +322,14 @@ int msm_sort_lds(MsmEngine& E, const void* d_scalars, uint32_t npts, int sbits) 
 int msm_sort_lds_scatter(MsmEngine& E) {
     hipStream_t st = E.stream;
     uint32_t* coarse_off = E.coarse.as<uint32_t>() + E.sort_nc;
-    hipLaunchKernelGGL(k_fine_scatter, dim3(E.sort_nc * E.sort_slices), dim3(FINE_THREADS), (size_t)4 << E.sort_cl, st,
-                       E.inter.as<uint2>(), coarse_off, E.sort_cl, E.sort_slices, E.count.as<uint32_t>(), E.entries.as<uint32_t>());
+    static bool attr_done = false;
+    if (!attr_done) {
+        BLZ_HIP(hipFuncSetAttribute((const void*)k_fine_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256), BLZ_ERR_UNKNOWN);
+        attr_done = true;
+    }
+    const size_t lds = ((size_t)3 << E.sort_cl) * 4 + (size_t)FS_ROUND * 4;
+    hipLaunchKernelGGL(k_fine_scatter, dim3(E.sort_nc * E.sort_slices), dim3(FS_THREADS), lds, st, E.inter.as<uint2>(), coarse_off,
+                       E.sort_cl, E.sort_slices, E.count.as<uint32_t>(), E.entries.as<uint32_t>());
     BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
     return BLZ_OK;
 }
