@@ -228,6 +228,80 @@ BLZ_DEV void mac_pair4(uint64_t& alo, uint32_t& ahi, uint64_t& mlo, uint32_t& mh
           [x2] "v"(x2), [y2] "v"(y2), [q2] "v"(q2), [k2] "s"(k2), [x3] "v"(x3), [y3] "v"(y3), [q3] "v"(q3), [k3] "s"(k3));
 }
 
+#ifndef BLZ_PS_SINGLE
+#define BLZ_PS_SINGLE 1
+#endif
+// Single-accumulator forms: the same MACs, all into (ahi:alo).  No per-column merge of two
+// accumulators (3 adds + hazard pads + 3 zeroing moves per column); the dependent v_mad chain is
+// covered by the other waves on the SIMD.
+#define BLZ_MAC_QS(n, c) "v_mad_u64_u32 %[alo], %[" #c "], %[q" #n "], %[k" #n "], %[alo]\n\t"
+#define BLZ_QUAD1(n0, n1) \
+    BLZ_MAC_AB(n0, c0) BLZ_MAC_QS(n0, c1) BLZ_MAC_AB(n1, c2) BLZ_MAC_QS(n1, c3) BLZ_CARRY_A(c0) BLZ_CARRY_A(c1) BLZ_CARRY_A(c2) BLZ_CARRY_A(c3)
+BLZ_DEV void mac1_pair1(uint64_t& alo, uint32_t& ahi, uint32_t x0, uint32_t y0, uint32_t q0, uint32_t k0) {
+    uint64_t c0, c1;
+    asm(BLZ_MAC_AB(0, c0) BLZ_MAC_QS(0, c1) "s_nop 0\n\t" BLZ_CARRY_A(c0) BLZ_CARRY_A(c1)
+        : [alo] "+&v"(alo), [ahi] "+&v"(ahi), [c0] "=&s"(c0), [c1] "=&s"(c1)
+        : [x0] "v"(x0), [y0] "v"(y0), [q0] "v"(q0), [k0] "s"(k0));
+}
+BLZ_DEV void mac1_pair2(uint64_t& alo, uint32_t& ahi, uint32_t x0, uint32_t y0, uint32_t q0, uint32_t k0, uint32_t x1,
+                        uint32_t y1, uint32_t q1, uint32_t k1) {
+    uint64_t c0, c1, c2, c3;
+    asm(BLZ_QUAD1(0, 1)
+        : [alo] "+&v"(alo), [ahi] "+&v"(ahi), [c0] "=&s"(c0), [c1] "=&s"(c1), [c2] "=&s"(c2), [c3] "=&s"(c3)
+        : [x0] "v"(x0), [y0] "v"(y0), [q0] "v"(q0), [k0] "s"(k0), [x1] "v"(x1), [y1] "v"(y1), [q1] "v"(q1), [k1] "s"(k1));
+}
+BLZ_DEV void mac1_pair4(uint64_t& alo, uint32_t& ahi, uint32_t x0, uint32_t y0, uint32_t q0, uint32_t k0, uint32_t x1,
+                        uint32_t y1, uint32_t q1, uint32_t k1, uint32_t x2, uint32_t y2, uint32_t q2, uint32_t k2,
+                        uint32_t x3, uint32_t y3, uint32_t q3, uint32_t k3) {
+    uint64_t c0, c1, c2, c3;
+    asm(BLZ_QUAD1(0, 1) BLZ_QUAD1(2, 3)
+        : [alo] "+&v"(alo), [ahi] "+&v"(ahi), [c0] "=&s"(c0), [c1] "=&s"(c1), [c2] "=&s"(c2), [c3] "=&s"(c3)
+        : [x0] "v"(x0), [y0] "v"(y0), [q0] "v"(q0), [k0] "s"(k0), [x1] "v"(x1), [y1] "v"(y1), [q1] "v"(q1), [k1] "s"(k1),
+          [x2] "v"(x2), [y2] "v"(y2), [q2] "v"(q2), [k2] "s"(k2), [x3] "v"(x3), [y3] "v"(y3), [q3] "v"(q3), [k3] "s"(k3));
+}
+template <class P, int K>
+BLZ_DEV void ps1_column(const Fp<P>& a, const Fp<P>& b, uint32_t (&q)[P::N], uint32_t (&t)[P::N], uint64_t& alo,
+                        uint32_t& ahi) {
+    constexpr int N = P::N;
+    constexpr int ilo = K < N ? 0 : K - N + 1;
+    constexpr int ihq = K < N ? K - 1 : N - 1;
+    constexpr int npair = ihq - ilo + 1;
+    constexpr int n4 = npair > 0 ? npair / 4 : 0;
+    constexpr int rem = npair > 0 ? npair % 4 : 0;
+#pragma unroll
+    for (int g = 0; g < n4; ++g) {
+        const int i = ilo + 4 * g;
+        mac1_pair4(alo, ahi, a.v[i], b.v[K - i], q[i], P::MOD[K - i], a.v[i + 1], b.v[K - i - 1], q[i + 1], P::MOD[K - i - 1],
+                   a.v[i + 2], b.v[K - i - 2], q[i + 2], P::MOD[K - i - 2], a.v[i + 3], b.v[K - i - 3], q[i + 3],
+                   P::MOD[K - i - 3]);
+    }
+    {
+        constexpr int i = ilo + 4 * n4;
+        if constexpr (rem >= 2)
+            mac1_pair2(alo, ahi, a.v[i], b.v[K - i], q[i], P::MOD[K - i], a.v[i + 1], b.v[K - i - 1], q[i + 1], P::MOD[K - i - 1]);
+        if constexpr (rem == 1 || rem == 3) {
+            constexpr int i2 = i + (rem == 3 ? 2 : 0);
+            mac1_pair1(alo, ahi, a.v[i2], b.v[K - i2], q[i2], P::MOD[K - i2]);
+        }
+    }
+    if constexpr (K < N) {
+        mac_vv(alo, ahi, a.v[K], b.v[0]);  // the a*b product that has no q*m partner yet
+        q[K] = (uint32_t)alo * P::N0;
+        mac_vs(alo, ahi, q[K], P::MOD[0]);  // low word becomes zero
+        alo = (alo >> 32) | ((uint64_t)ahi << 32);
+    } else {
+        t[K - N] = (uint32_t)alo;
+        alo = (alo >> 32) | ((uint64_t)ahi << 32);
+    }
+    ahi = 0;
+}
+
+template <class P, int... Ks>
+BLZ_DEV void ps1_columns(const Fp<P>& a, const Fp<P>& b, uint32_t (&q)[P::N], uint32_t (&t)[P::N], uint64_t& alo,
+                         uint32_t& ahi, std::integer_sequence<int, Ks...>) {
+    (ps1_column<P, Ks>(a, b, q, t, alo, ahi), ...);
+}
+
 // column K of the product scan: all a_i b_j and q_i m_j with i + j = K
 template <class P, int K>
 BLZ_DEV void ps_column(const Fp<P>& a, const Fp<P>& b, uint32_t (&q)[P::N], uint32_t (&t)[P::N], uint64_t& alo,
@@ -292,7 +366,11 @@ BLZ_DEV void fp_mul_ps(Fp<P>& r, const Fp<P>& a, const Fp<P>& b) {
     uint32_t t[N];
     uint64_t alo = 0;
     uint32_t ahi = 0;
+#if BLZ_PS_SINGLE
+    ps1_columns<P>(a, b, q, t, alo, ahi, std::make_integer_sequence<int, 2 * N>{});
+#else
     ps_columns<P>(a, b, q, t, alo, ahi, std::make_integer_sequence<int, 2 * N>{});
+#endif
     // alo now holds the word above the result (0 in the lazy representation)
     if constexpr (P::LAZY) {
 #pragma unroll
