@@ -124,8 +124,8 @@ BLZ_DEV void fp_dbl(Fp<P>& r, const Fp<P>& a) { fp_add(r, a, a); }
 // fp_mul_ps:   finely-integrated PRODUCT scanning with a 96-bit column accumulator (lo64, hi32):
 //   every MAC is exactly  v_mad_u64_u32 lo64 += x*y (carry -> SGPR pair) ; v_addc_co_u32 hi32 += carry
 //   i.e. 2 issue slots per 32x32 MAC and no register shuffling; modulus limbs ride the constant bus
-//   as SGPRs.  a*b and q*m products go to two independent accumulators so one wave has two
-//   dependency chains in flight.
+//   as SGPRs.  One accumulator for a*b and q*m products (a second one costs a 3-add merge per
+//   column and measured slower); the dependent v_mad chain is covered by the other waves.
 // ------------------------------------------------------------------------------------------
 template <class P>
 BLZ_DEV void fp_mul_cios(Fp<P>& r, const Fp<P>& a, const Fp<P>& b) {
@@ -193,170 +193,74 @@ BLZ_DEV void mac_vs(uint64_t& lo, uint32_t& hi, uint32_t x, uint32_t k) {
         : [lo] "+&v"(lo), [hi] "+&v"(hi), [cr] "=&s"(cr)
         : [x] "v"(x), [k] "s"(k));
 }
-// One statement = n MACs into the a*b accumulator interleaved with n MACs into the q*m accumulator
-// (two independent dependency chains, four carry SGPR pairs in rotation).  hipcc pads every asm
-// statement boundary with an s_nop, so MACs are batched per statement.
-#define BLZ_MAC_AB(n, c) "v_mad_u64_u32 %[alo], %[" #c "], %[x" #n "], %[y" #n "], %[alo]\n\t"
-#define BLZ_MAC_QM(n, c) "v_mad_u64_u32 %[mlo], %[" #c "], %[q" #n "], %[k" #n "], %[mlo]\n\t"
-#define BLZ_CARRY_A(c) "v_addc_co_u32 %[ahi], %[" #c "], 0, %[ahi], %[" #c "]\n\t"
-#define BLZ_CARRY_M(c) "v_addc_co_u32 %[mhi], %[" #c "], 0, %[mhi], %[" #c "]\n\t"
-#define BLZ_PAIR2(n0, n1) \
-    BLZ_MAC_AB(n0, c0) BLZ_MAC_QM(n0, c1) BLZ_MAC_AB(n1, c2) BLZ_MAC_QM(n1, c3) BLZ_CARRY_A(c0) BLZ_CARRY_M(c1) BLZ_CARRY_A(c2) BLZ_CARRY_M(c3)
-BLZ_DEV void mac_pair1(uint64_t& alo, uint32_t& ahi, uint64_t& mlo, uint32_t& mhi, uint32_t x0, uint32_t y0, uint32_t q0,
-                       uint32_t k0) {
-    uint64_t c0, c1;
-    asm(BLZ_MAC_AB(0, c0) BLZ_MAC_QM(0, c1) "s_nop 0\n\t" BLZ_CARRY_A(c0) BLZ_CARRY_M(c1)
-        : [alo] "+&v"(alo), [ahi] "+&v"(ahi), [mlo] "+&v"(mlo), [mhi] "+&v"(mhi), [c0] "=&s"(c0), [c1] "=&s"(c1)
-        : [x0] "v"(x0), [y0] "v"(y0), [q0] "v"(q0), [k0] "s"(k0));
-}
-BLZ_DEV void mac_pair2(uint64_t& alo, uint32_t& ahi, uint64_t& mlo, uint32_t& mhi, uint32_t x0, uint32_t y0, uint32_t q0,
-                       uint32_t k0, uint32_t x1, uint32_t y1, uint32_t q1, uint32_t k1) {
-    uint64_t c0, c1, c2, c3;
-    asm(BLZ_PAIR2(0, 1)
-        : [alo] "+&v"(alo), [ahi] "+&v"(ahi), [mlo] "+&v"(mlo), [mhi] "+&v"(mhi), [c0] "=&s"(c0), [c1] "=&s"(c1),
-          [c2] "=&s"(c2), [c3] "=&s"(c3)
-        : [x0] "v"(x0), [y0] "v"(y0), [q0] "v"(q0), [k0] "s"(k0), [x1] "v"(x1), [y1] "v"(y1), [q1] "v"(q1), [k1] "s"(k1));
-}
-BLZ_DEV void mac_pair4(uint64_t& alo, uint32_t& ahi, uint64_t& mlo, uint32_t& mhi, uint32_t x0, uint32_t y0, uint32_t q0,
-                       uint32_t k0, uint32_t x1, uint32_t y1, uint32_t q1, uint32_t k1, uint32_t x2, uint32_t y2,
-                       uint32_t q2, uint32_t k2, uint32_t x3, uint32_t y3, uint32_t q3, uint32_t k3) {
-    uint64_t c0, c1, c2, c3;
-    asm(BLZ_PAIR2(0, 1) BLZ_PAIR2(2, 3)
-        : [alo] "+&v"(alo), [ahi] "+&v"(ahi), [mlo] "+&v"(mlo), [mhi] "+&v"(mhi), [c0] "=&s"(c0), [c1] "=&s"(c1),
-          [c2] "=&s"(c2), [c3] "=&s"(c3)
-        : [x0] "v"(x0), [y0] "v"(y0), [q0] "v"(q0), [k0] "s"(k0), [x1] "v"(x1), [y1] "v"(y1), [q1] "v"(q1), [k1] "s"(k1),
-          [x2] "v"(x2), [y2] "v"(y2), [q2] "v"(q2), [k2] "s"(k2), [x3] "v"(x3), [y3] "v"(y3), [q3] "v"(q3), [k3] "s"(k3));
+// MAC batches (one asm statement each; hipcc pads every statement boundary with an s_nop, so MACs
+// are batched): generated by tools/gen_mac_asm.py.
+#include "mac_gen.inc"
+
+// One chunk of column K: NP (a_i b_(K-i), q_i m_(K-i)) pairs starting at i = I0, optionally opening
+// the column (FIRST: the carry word is written, not accumulated) and optionally closing its a*b
+// products with a_K b_0 (EXTRA, columns K < N).
+template <class P, int K, int I0, int NP, bool FIRST, bool EXTRA>
+BLZ_DEV void ps_chunk(const Fp<P>& a, const Fp<P>& b, const uint32_t (&q)[P::N], uint64_t& alo, uint32_t& ahi) {
+#define BLZ_PA(d) a.v[I0 + d], b.v[K - I0 - d], q[I0 + d], P::MOD[K - I0 - d]
+#define BLZ_DISPATCH(NPV, ...)                                                                        \
+    if constexpr (NP == NPV) {                                                                        \
+        if constexpr (FIRST && EXTRA) mac1_p##NPV##fx(alo, ahi, __VA_ARGS__, a.v[K], b.v[0]);         \
+        else if constexpr (FIRST) mac1_p##NPV##f(alo, ahi, __VA_ARGS__);                              \
+        else if constexpr (EXTRA) mac1_p##NPV##x(alo, ahi, __VA_ARGS__, a.v[K], b.v[0]);              \
+        else mac1_p##NPV(alo, ahi, __VA_ARGS__);                                                      \
+    }
+    if constexpr (NP == 0) {
+        static_assert(NP != 0 || EXTRA, "empty chunk");
+        if constexpr (FIRST) mac1_p0fx(alo, ahi, a.v[K], b.v[0]);
+        else mac1_p0x(alo, ahi, a.v[K], b.v[0]);
+    }
+    BLZ_DISPATCH(1, BLZ_PA(0))
+    BLZ_DISPATCH(2, BLZ_PA(0), BLZ_PA(1))
+    BLZ_DISPATCH(3, BLZ_PA(0), BLZ_PA(1), BLZ_PA(2))
+    BLZ_DISPATCH(4, BLZ_PA(0), BLZ_PA(1), BLZ_PA(2), BLZ_PA(3))
+#undef BLZ_DISPATCH
+#undef BLZ_PA
 }
 
-#ifndef BLZ_PS_SINGLE
-#define BLZ_PS_SINGLE 1
-#endif
-// Single-accumulator forms: the same MACs, all into (ahi:alo).  No per-column merge of two
-// accumulators (3 adds + hazard pads + 3 zeroing moves per column); the dependent v_mad chain is
-// covered by the other waves on the SIMD.
-#define BLZ_MAC_QS(n, c) "v_mad_u64_u32 %[alo], %[" #c "], %[q" #n "], %[k" #n "], %[alo]\n\t"
-#define BLZ_QUAD1(n0, n1) \
-    BLZ_MAC_AB(n0, c0) BLZ_MAC_QS(n0, c1) BLZ_MAC_AB(n1, c2) BLZ_MAC_QS(n1, c3) BLZ_CARRY_A(c0) BLZ_CARRY_A(c1) BLZ_CARRY_A(c2) BLZ_CARRY_A(c3)
-BLZ_DEV void mac1_pair1(uint64_t& alo, uint32_t& ahi, uint32_t x0, uint32_t y0, uint32_t q0, uint32_t k0) {
-    uint64_t c0, c1;
-    asm(BLZ_MAC_AB(0, c0) BLZ_MAC_QS(0, c1) "s_nop 0\n\t" BLZ_CARRY_A(c0) BLZ_CARRY_A(c1)
-        : [alo] "+&v"(alo), [ahi] "+&v"(ahi), [c0] "=&s"(c0), [c1] "=&s"(c1)
-        : [x0] "v"(x0), [y0] "v"(y0), [q0] "v"(q0), [k0] "s"(k0));
+template <class P, int K, int I0, int LEFT, bool FIRST, bool EXTRA>
+BLZ_DEV void ps_chunks(const Fp<P>& a, const Fp<P>& b, const uint32_t (&q)[P::N], uint64_t& alo, uint32_t& ahi) {
+    if constexpr (LEFT > 4) {
+        ps_chunk<P, K, I0, 4, FIRST, false>(a, b, q, alo, ahi);
+        ps_chunks<P, K, I0 + 4, LEFT - 4, false, EXTRA>(a, b, q, alo, ahi);
+    } else if constexpr (LEFT > 0 || EXTRA) {
+        ps_chunk<P, K, I0, LEFT, FIRST, EXTRA>(a, b, q, alo, ahi);
+    }
 }
-BLZ_DEV void mac1_pair2(uint64_t& alo, uint32_t& ahi, uint32_t x0, uint32_t y0, uint32_t q0, uint32_t k0, uint32_t x1,
-                        uint32_t y1, uint32_t q1, uint32_t k1) {
-    uint64_t c0, c1, c2, c3;
-    asm(BLZ_QUAD1(0, 1)
-        : [alo] "+&v"(alo), [ahi] "+&v"(ahi), [c0] "=&s"(c0), [c1] "=&s"(c1), [c2] "=&s"(c2), [c3] "=&s"(c3)
-        : [x0] "v"(x0), [y0] "v"(y0), [q0] "v"(q0), [k0] "s"(k0), [x1] "v"(x1), [y1] "v"(y1), [q1] "v"(q1), [k1] "s"(k1));
-}
-BLZ_DEV void mac1_pair4(uint64_t& alo, uint32_t& ahi, uint32_t x0, uint32_t y0, uint32_t q0, uint32_t k0, uint32_t x1,
-                        uint32_t y1, uint32_t q1, uint32_t k1, uint32_t x2, uint32_t y2, uint32_t q2, uint32_t k2,
-                        uint32_t x3, uint32_t y3, uint32_t q3, uint32_t k3) {
-    uint64_t c0, c1, c2, c3;
-    asm(BLZ_QUAD1(0, 1) BLZ_QUAD1(2, 3)
-        : [alo] "+&v"(alo), [ahi] "+&v"(ahi), [c0] "=&s"(c0), [c1] "=&s"(c1), [c2] "=&s"(c2), [c3] "=&s"(c3)
-        : [x0] "v"(x0), [y0] "v"(y0), [q0] "v"(q0), [k0] "s"(k0), [x1] "v"(x1), [y1] "v"(y1), [q1] "v"(q1), [k1] "s"(k1),
-          [x2] "v"(x2), [y2] "v"(y2), [q2] "v"(q2), [k2] "s"(k2), [x3] "v"(x3), [y3] "v"(y3), [q3] "v"(q3), [k3] "s"(k3));
-}
+
+// column K of the product scan: all a_i b_j and q_i m_j with i + j = K, single 96-bit accumulator
 template <class P, int K>
-BLZ_DEV void ps1_column(const Fp<P>& a, const Fp<P>& b, uint32_t (&q)[P::N], uint32_t (&t)[P::N], uint64_t& alo,
-                        uint32_t& ahi) {
+BLZ_DEV void ps_column(const Fp<P>& a, const Fp<P>& b, uint32_t (&q)[P::N], uint32_t (&t)[P::N], uint64_t& alo) {
     constexpr int N = P::N;
     constexpr int ilo = K < N ? 0 : K - N + 1;
-    constexpr int ihq = K < N ? K - 1 : N - 1;
-    constexpr int npair = ihq - ilo + 1;
-    constexpr int n4 = npair > 0 ? npair / 4 : 0;
-    constexpr int rem = npair > 0 ? npair % 4 : 0;
-#pragma unroll
-    for (int g = 0; g < n4; ++g) {
-        const int i = ilo + 4 * g;
-        mac1_pair4(alo, ahi, a.v[i], b.v[K - i], q[i], P::MOD[K - i], a.v[i + 1], b.v[K - i - 1], q[i + 1], P::MOD[K - i - 1],
-                   a.v[i + 2], b.v[K - i - 2], q[i + 2], P::MOD[K - i - 2], a.v[i + 3], b.v[K - i - 3], q[i + 3],
-                   P::MOD[K - i - 3]);
-    }
-    {
-        constexpr int i = ilo + 4 * n4;
-        if constexpr (rem >= 2)
-            mac1_pair2(alo, ahi, a.v[i], b.v[K - i], q[i], P::MOD[K - i], a.v[i + 1], b.v[K - i - 1], q[i + 1], P::MOD[K - i - 1]);
-        if constexpr (rem == 1 || rem == 3) {
-            constexpr int i2 = i + (rem == 3 ? 2 : 0);
-            mac1_pair1(alo, ahi, a.v[i2], b.v[K - i2], q[i2], P::MOD[K - i2]);
-        }
-    }
-    if constexpr (K < N) {
-        mac_vv(alo, ahi, a.v[K], b.v[0]);  // the a*b product that has no q*m partner yet
-        q[K] = (uint32_t)alo * P::N0;
-        mac_vs(alo, ahi, q[K], P::MOD[0]);  // low word becomes zero
-        alo = (alo >> 32) | ((uint64_t)ahi << 32);
-    } else {
+    constexpr int ihq = K < N ? K - 1 : N - 1;  // q*m products: i in [ilo, ihq] (q_K m_0 comes after q_K exists)
+    constexpr int npair = ihq - ilo + 1 > 0 ? ihq - ilo + 1 : 0;
+    constexpr bool extra = K < N;                // a_K b_0
+    if constexpr (npair == 0 && !extra) {        // K = 2N-1: nothing left to add
         t[K - N] = (uint32_t)alo;
+        alo >>= 32;
+    } else {
+        uint32_t ahi;  // written by the column's first batch
+        ps_chunks<P, K, ilo, npair, true, extra>(a, b, q, alo, ahi);
+        if constexpr (K < N) {
+            q[K] = (uint32_t)alo * P::N0;
+            mac_vs(alo, ahi, q[K], P::MOD[0]);  // low word becomes zero
+        } else {
+            t[K - N] = (uint32_t)alo;
+        }
         alo = (alo >> 32) | ((uint64_t)ahi << 32);
     }
-    ahi = 0;
-}
-
-template <class P, int... Ks>
-BLZ_DEV void ps1_columns(const Fp<P>& a, const Fp<P>& b, uint32_t (&q)[P::N], uint32_t (&t)[P::N], uint64_t& alo,
-                         uint32_t& ahi, std::integer_sequence<int, Ks...>) {
-    (ps1_column<P, Ks>(a, b, q, t, alo, ahi), ...);
-}
-
-// column K of the product scan: all a_i b_j and q_i m_j with i + j = K
-template <class P, int K>
-BLZ_DEV void ps_column(const Fp<P>& a, const Fp<P>& b, uint32_t (&q)[P::N], uint32_t (&t)[P::N], uint64_t& alo,
-                       uint32_t& ahi) {
-    constexpr int N = P::N;
-    constexpr int ilo = K < N ? 0 : K - N + 1;
-    constexpr int ihi = K < N ? K : N - 1;           // a*b products: i in [ilo, ihi]
-    constexpr int ihq = K < N ? K - 1 : N - 1;       // q*m products: i in [ilo, ihq] (q_K m_0 comes after q_K exists)
-    uint64_t mlo = 0;
-    uint32_t mhi = 0;
-    constexpr int npair = ihq - ilo + 1;
-    constexpr int n4 = npair > 0 ? npair / 4 : 0;
-    constexpr int rem = npair > 0 ? npair % 4 : 0;
-#pragma unroll
-    for (int g = 0; g < n4; ++g) {
-        const int i = ilo + 4 * g;
-        mac_pair4(alo, ahi, mlo, mhi, a.v[i], b.v[K - i], q[i], P::MOD[K - i], a.v[i + 1], b.v[K - i - 1], q[i + 1],
-                  P::MOD[K - i - 1], a.v[i + 2], b.v[K - i - 2], q[i + 2], P::MOD[K - i - 2], a.v[i + 3], b.v[K - i - 3],
-                  q[i + 3], P::MOD[K - i - 3]);
-    }
-    {
-        constexpr int i = ilo + 4 * n4;
-        if constexpr (rem >= 2)
-            mac_pair2(alo, ahi, mlo, mhi, a.v[i], b.v[K - i], q[i], P::MOD[K - i], a.v[i + 1], b.v[K - i - 1], q[i + 1],
-                      P::MOD[K - i - 1]);
-        if constexpr (rem == 1 || rem == 3) {
-            constexpr int i2 = i + (rem == 3 ? 2 : 0);
-            mac_pair1(alo, ahi, mlo, mhi, a.v[i2], b.v[K - i2], q[i2], P::MOD[K - i2]);
-        }
-    }
-    if constexpr (K < N) mac_vv(alo, ahi, a.v[K], b.v[0]);  // the a*b product that has no q*m partner yet
-    // ---- merge the two accumulators: (ahi:alo) += (mhi:mlo)
-    uint32_t l0 = (uint32_t)alo, l1 = (uint32_t)(alo >> 32);
-    if constexpr (npair > 0) {
-        uint32_t c = 0;
-        l0 = add_cc(l0, (uint32_t)mlo, c);
-        l1 = add_cc(l1, (uint32_t)(mlo >> 32), c);
-        ahi = ahi + mhi + c;
-    }
-    if constexpr (K < N) {
-        q[K] = l0 * P::N0;
-        uint64_t lo2 = ((uint64_t)l1 << 32) | l0;
-        mac_vs(lo2, ahi, q[K], P::MOD[0]);  // low word becomes zero
-        alo = (lo2 >> 32) | ((uint64_t)ahi << 32);
-    } else {
-        t[K - N] = l0;
-        alo = (uint64_t)l1 | ((uint64_t)ahi << 32);
-    }
-    ahi = 0;
 }
 
 template <class P, int... Ks>
 BLZ_DEV void ps_columns(const Fp<P>& a, const Fp<P>& b, uint32_t (&q)[P::N], uint32_t (&t)[P::N], uint64_t& alo,
-                        uint32_t& ahi, std::integer_sequence<int, Ks...>) {
-    (ps_column<P, Ks>(a, b, q, t, alo, ahi), ...);
+                        std::integer_sequence<int, Ks...>) {
+    (ps_column<P, Ks>(a, b, q, t, alo), ...);
 }
 
 template <class P>
@@ -365,12 +269,7 @@ BLZ_DEV void fp_mul_ps(Fp<P>& r, const Fp<P>& a, const Fp<P>& b) {
     uint32_t q[N];
     uint32_t t[N];
     uint64_t alo = 0;
-    uint32_t ahi = 0;
-#if BLZ_PS_SINGLE
-    ps1_columns<P>(a, b, q, t, alo, ahi, std::make_integer_sequence<int, 2 * N>{});
-#else
-    ps_columns<P>(a, b, q, t, alo, ahi, std::make_integer_sequence<int, 2 * N>{});
-#endif
+    ps_columns<P>(a, b, q, t, alo, std::make_integer_sequence<int, 2 * N>{});
     // alo now holds the word above the result (0 in the lazy representation)
     if constexpr (P::LAZY) {
 #pragma unroll
