@@ -82,13 +82,18 @@ __global__ __launch_bounds__(128, 3) void k_accumulate(const uint32_t* __restric
     store_xyzz(partial, u, acc);
 }
 
-// buckets that needed several units: fold partial[u0 + k*stride] for k in the same 16-group
+// buckets that needed several units: fold partial[u0 + k*stride] for k in the same 16-group.
+// Every unit that leads such a group is a full-length unit, and those are the first hist[L]
+// entries of the length-ordered unit list, so only that prefix is visited.
 template <class F>
 __global__ __launch_bounds__(128) void k_combine_units(const uint32_t* __restrict__ unit_off,
-                                                       const uint32_t* __restrict__ unit_bucket, uint32_t U,
+                                                       const uint32_t* __restrict__ unit_bucket,
+                                                       const uint32_t* __restrict__ unit_order,
+                                                       const uint32_t* __restrict__ nfull_ptr,
                                                        uint32_t stride, uint32_t* __restrict__ partial) {
-    uint32_t u = blockIdx.x * 128u + threadIdx.x;
-    if (u >= U) return;
+    uint32_t t0 = blockIdx.x * 128u + threadIdx.x;
+    if (t0 >= *nfull_ptr) return;
+    uint32_t u = unit_order[t0];
     uint32_t g = unit_bucket[u];
     uint32_t u0 = unit_off[g], u1 = unit_off[g + 1];
     uint32_t k = u - u0;
@@ -260,9 +265,12 @@ int run_tail_t(MsmEngine& E, const void* d_pts, uint32_t U, uint32_t maxcount) {
                            E.unit_bucket.as<uint32_t>(), E.unit_order.as<uint32_t>(), U, P.L, E.partial.as<uint32_t>());
         BLZ_HIP(hipEventRecord(E.ev[6], st), BLZ_ERR_UNKNOWN);
         uint32_t maxunits = (maxcount + P.L - 1) / P.L;
+        uint64_t full_bound = (uint64_t)P.npts * P.W / P.L + 1;  // units of length L: at most entries / L
+        if (full_bound > U) full_bound = U;
         for (uint32_t stride = 1; stride < maxunits; stride *= 16)
-            hipLaunchKernelGGL(k_combine_units<F>, dim3((U + 127) / 128), dim3(128), 0, st, E.unit_off.as<uint32_t>(),
-                               E.unit_bucket.as<uint32_t>(), U, stride, E.partial.as<uint32_t>());
+            hipLaunchKernelGGL(k_combine_units<F>, dim3((uint32_t)((full_bound + 127) / 128)), dim3(128), 0, st,
+                               E.unit_off.as<uint32_t>(), E.unit_bucket.as<uint32_t>(), E.unit_order.as<uint32_t>(),
+                               E.lenhist.as<uint32_t>() + P.L, stride, E.partial.as<uint32_t>());
         BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
     }
     BLZ_HIP(hipEventRecord(E.ev[2], st), BLZ_ERR_UNKNOWN);
