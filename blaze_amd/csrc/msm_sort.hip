@@ -20,6 +20,7 @@ namespace blz {
 
 constexpr int SORT_THREADS = 1024;
 constexpr int FINE_THREADS = 512;
+constexpr int SORT_UNROLL = 4;
 
 struct SortGeom {
     int c, W, ch, cl;      // window bits, windows, coarse / fine bits of the bucket index
@@ -38,15 +39,25 @@ __global__ __launch_bounds__(SORT_THREADS) void k_coarse_count(const uint32_t* _
     uint32_t end = base + g.pts_per_block;
     if (end > npts) end = npts;
     const uint32_t mask = (1u << g.c) - 1u, half = 1u << (g.c - 1);
-    for (uint32_t p = base + threadIdx.x; p < end; p += SORT_THREADS) {
-        ScalarWords<SW> sw;
-        sw.load(scalars, p);
-        uint32_t carry = 0;
-        for (int w = 0; w < g.W; ++w) {
-            int d = sw.next(g.c, mask, half, carry);
-            if (d != 0) {
-                uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1u;
-                atomicAdd(&sh[((uint32_t)w << g.ch) + (b >> g.cl)], 1u);
+    // SORT_UNROLL scalars in flight per lane before their digits are consumed (latency, not bandwidth,
+    // bounds the one-scalar-per-iteration form)
+    for (uint32_t p0 = base + threadIdx.x; p0 < end; p0 += SORT_UNROLL * SORT_THREADS) {
+        ScalarWords<SW> sw[SORT_UNROLL];
+#pragma unroll
+        for (int u = 0; u < SORT_UNROLL; ++u) {
+            uint32_t p = p0 + u * SORT_THREADS;
+            sw[u].load(scalars, p < end ? p : p0);
+        }
+#pragma unroll
+        for (int u = 0; u < SORT_UNROLL; ++u) {
+            if (p0 + u * SORT_THREADS >= end) break;
+            uint32_t carry = 0;
+            for (int w = 0; w < g.W; ++w) {
+                int d = sw[u].next(g.c, mask, half, carry);
+                if (d != 0) {
+                    uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1u;
+                    atomicAdd(&sh[((uint32_t)w << g.ch) + (b >> g.cl)], 1u);
+                }
             }
         }
     }
@@ -98,15 +109,25 @@ __global__ __launch_bounds__(SORT_THREADS) void k_coarse_scatter(const uint32_t*
     uint32_t end = base + g.pts_per_block;
     if (end > npts) end = npts;
     const uint32_t mask = (1u << g.c) - 1u, half = 1u << (g.c - 1);
-    for (uint32_t p = base + threadIdx.x; p < end; p += SORT_THREADS) {
-        ScalarWords<SW> sw;
-        sw.load(scalars, p);
-        uint32_t carry = 0;
-        for (int w = 0; w < g.W; ++w) {
-            int d = sw.next(g.c, mask, half, carry);
-            if (d != 0) {
-                uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1u;
-                atomicAdd(&sh[((uint32_t)w << g.ch) + (b >> g.cl)], 1u);
+    // SORT_UNROLL scalars in flight per lane before their digits are consumed (latency, not bandwidth,
+    // bounds the one-scalar-per-iteration form)
+    for (uint32_t p0 = base + threadIdx.x; p0 < end; p0 += SORT_UNROLL * SORT_THREADS) {
+        ScalarWords<SW> sw[SORT_UNROLL];
+#pragma unroll
+        for (int u = 0; u < SORT_UNROLL; ++u) {
+            uint32_t p = p0 + u * SORT_THREADS;
+            sw[u].load(scalars, p < end ? p : p0);
+        }
+#pragma unroll
+        for (int u = 0; u < SORT_UNROLL; ++u) {
+            if (p0 + u * SORT_THREADS >= end) break;
+            uint32_t carry = 0;
+            for (int w = 0; w < g.W; ++w) {
+                int d = sw[u].next(g.c, mask, half, carry);
+                if (d != 0) {
+                    uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1u;
+                    atomicAdd(&sh[((uint32_t)w << g.ch) + (b >> g.cl)], 1u);
+                }
             }
         }
     }
@@ -118,16 +139,25 @@ __global__ __launch_bounds__(SORT_THREADS) void k_coarse_scatter(const uint32_t*
     }
     __syncthreads();
     const uint32_t fmask = (1u << g.cl) - 1u;
-    for (uint32_t p = base + threadIdx.x; p < end; p += SORT_THREADS) {
-        ScalarWords<SW> sw;
-        sw.load(scalars, p);
-        uint32_t carry = 0;
-        for (int w = 0; w < g.W; ++w) {
-            int d = sw.next(g.c, mask, half, carry);
-            if (d != 0) {
-                uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1u;
-                uint32_t pos = atomicAdd(&sh[((uint32_t)w << g.ch) + (b >> g.cl)], 1u);
-                inter[pos] = make_uint2(p | (d < 0 ? 0x80000000u : 0u), b & fmask);
+    for (uint32_t p0 = base + threadIdx.x; p0 < end; p0 += SORT_UNROLL * SORT_THREADS) {
+        ScalarWords<SW> sw[SORT_UNROLL];
+#pragma unroll
+        for (int u = 0; u < SORT_UNROLL; ++u) {
+            uint32_t p = p0 + u * SORT_THREADS;
+            sw[u].load(scalars, p < end ? p : p0);
+        }
+#pragma unroll
+        for (int u = 0; u < SORT_UNROLL; ++u) {
+            const uint32_t p = p0 + u * SORT_THREADS;
+            if (p >= end) break;
+            uint32_t carry = 0;
+            for (int w = 0; w < g.W; ++w) {
+                int d = sw[u].next(g.c, mask, half, carry);
+                if (d != 0) {
+                    uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1u;
+                    uint32_t pos = atomicAdd(&sh[((uint32_t)w << g.ch) + (b >> g.cl)], 1u);
+                    inter[pos] = make_uint2(p | (d < 0 ? 0x80000000u : 0u), b & fmask);
+                }
             }
         }
     }
@@ -154,7 +184,17 @@ __global__ __launch_bounds__(FINE_THREADS) void k_fine_count(const uint2* __rest
     if (lo >= hi) return;
     for (uint32_t i = threadIdx.x; i < nf; i += FINE_THREADS) sh[i] = 0;
     __syncthreads();
-    for (uint32_t j = lo + threadIdx.x; j < hi; j += FINE_THREADS) atomicAdd(&sh[inter[j].y], 1u);
+    // 8 independent loads in flight per lane before the dependent LDS atomics (the one-load-per-
+    // iteration form was HBM-latency bound: 1.2 TB/s)
+    uint32_t j = lo + threadIdx.x;
+    for (; j + 7 * FINE_THREADS < hi; j += 8 * FINE_THREADS) {
+        uint32_t key[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) key[u] = inter[j + u * FINE_THREADS].y;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) atomicAdd(&sh[key[u]], 1u);
+    }
+    for (; j < hi; j += FINE_THREADS) atomicAdd(&sh[inter[j].y], 1u);
     __syncthreads();
     uint32_t* dst = count + ((size_t)k << cl);
     for (uint32_t i = threadIdx.x; i < nf; i += FINE_THREADS) {
