@@ -24,15 +24,16 @@ struct NttTables {  // all Montgomery form, device memory
     uint32_t* t0;        // w^j            j < 512
     uint32_t* t1;        // w^(512 j)      j < 512
     uint32_t* t2;        // w^(2^18 j)     j < 512
+    uint32_t* ninv;      // n^-1 (Montgomery) for the inverse transform, else nullptr
 };
 
 // out[j] = base^(j * mult) where base = ROOT^(2^(TWO_ADICITY - logn))
-__global__ void k_ntt_table(uint32_t* out, int count, int logn, uint64_t mult) {
+__global__ void k_ntt_table(uint32_t* out, int count, int logn, uint64_t mult, int inverse) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= count) return;
     E w;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) w.v[i] = Fr::ROOT[i];
+    for (int i = 0; i < 8; ++i) w.v[i] = inverse ? Fr::ROOT_INV[i] : Fr::ROOT[i];
     for (int i = 0; i < Fr::TWO_ADICITY - logn; ++i) fp_sqr(w, w);
     uint64_t e = (uint64_t)j * mult;
     E acc;
@@ -42,6 +43,45 @@ __global__ void k_ntt_table(uint32_t* out, int count, int logn, uint64_t mult) {
         if ((e >> b) & 1) fp_mul(acc, acc, w);
     }
     fp_store(out + (size_t)j * 8, acc);
+}
+
+// out = (2^logn)^-1 in Montgomery form
+__global__ void k_ntt_ninv(uint32_t* out, int logn) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    E two, acc;
+    fp_one(two);
+    fp_add(two, two, two);
+    fp_one(acc);
+    for (int i = 0; i < logn; ++i) fp_mul(acc, acc, two);
+    E inv;
+    fp_inv(inv, acc);
+    fp_store(out, inv);
+}
+
+// NTTBanks::preprocess / postprocess (src/ingo_ntt/ntt_data.rs:80-156) as device permutations of
+// 32-byte elements, from the closed forms of the reference loops:
+//   preprocess : element e = 512 blk + j  ->  bank (blk%2)*8 + j%8, slot (blk/2)*64 + j/8
+//   postprocess: output a = 512 isub + i, isub = ic*G + g + 2G*blk
+//                <- bank ((ic ^ (g&1))*8 + i%8), slot (g*Bg + blk)*64 + i/8      (G groups, Bg blocks each)
+__global__ __launch_bounds__(256) void k_ntt_banks_pre(const uint4* __restrict__ in, uint4* __restrict__ banks, uint64_t n) {
+    uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    uint64_t blk = e >> 9, j = e & 511;
+    uint64_t bank = (blk & 1) * 8 + (j & 7), slot = (blk >> 1) * 64 + (j >> 3);
+    uint64_t dst = bank * (n >> 4) + slot;
+    banks[2 * dst] = in[2 * e];
+    banks[2 * dst + 1] = in[2 * e + 1];
+}
+__global__ __launch_bounds__(256) void k_ntt_banks_post(const uint4* __restrict__ banks, uint4* __restrict__ out, uint64_t n,
+                                                        uint64_t G, uint64_t Bg) {
+    uint64_t a = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (a >= n) return;
+    uint64_t isub = a >> 9, i = a & 511;
+    uint64_t blk = isub / (2 * G), ic = (isub % (2 * G)) / G, g = isub % G;
+    uint64_t bank = ((ic ^ (g & 1)) * 8) + (i & 7), slot = (g * Bg + blk) * 64 + (i >> 3);
+    uint64_t src = bank * (n >> 4) + slot;
+    out[2 * a] = banks[2 * src];
+    out[2 * a + 1] = banks[2 * src + 1];
 }
 
 BLZ_DEV void lds_load(E& r, const uint32_t* lds, uint32_t dw) {  // dw: dword offset, multiple of 8
@@ -180,6 +220,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const uint32_t* __rest
             uint64_t oaddr;
             if (PASS == 3) {
                 // element (k0 = row, k1 = fixed, k2 = col_base + col) -> natural address k2 + C k1 + CB k0
+                if (T.ninv) { E s; fp_load(s, T.ninv); fp_mul(x, x, s); }  // inverse transform: * n^-1
                 oaddr = (col_base + col0 + j) + (uint64_t)C * fixed + (uint64_t)C * B * row;
             } else {
                 if (tw) {
@@ -200,6 +241,7 @@ using namespace blz;
 struct blz_ntt {
     int device = 0;
     int logn = 27;
+    int inverse = 0;
     NttGeom geom{};
     int cols_log[3] = {0, 0, 0};
     hipStream_t stream = nullptr;
@@ -235,22 +277,27 @@ int ntt_setup(blz_ntt* h) {
     h->cols_log[0] = pick(lc, la);  // pass 1: cols i0 (< A)
     h->cols_log[1] = pick(lb, la);  // pass 2: cols i0 (< A)
     h->cols_log[2] = pick(la, lc);  // pass 3: cols k2 (< C)
-    size_t tb = (size_t)(3 * 256 + 3 * 512) * 32;
+    size_t tb = (size_t)(3 * 256 + 3 * 512 + 1) * 32;
     BLZ_TRY(h->tables.reserve(tb));
     uint32_t* p = h->tables.as<uint32_t>();
     for (int i = 0; i < 3; ++i) { h->T.wpass[i] = p; p += 256 * 8; }
     h->T.t0 = p; p += 512 * 8;
     h->T.t1 = p; p += 512 * 8;
     h->T.t2 = p; p += 512 * 8;
+    h->T.ninv = nullptr;
+    if (h->inverse) {
+        h->T.ninv = p;
+        hipLaunchKernelGGL(k_ntt_ninv, dim3(1), dim3(64), 0, h->stream, p, l);
+    }
     const uint64_t n = 1ull << l;
     int lrs[3] = {lc, lb, la};
     for (int i = 0; i < 3; ++i) {
         int cnt = lrs[i] ? (1 << (lrs[i] - 1)) : 1;
-        hipLaunchKernelGGL(k_ntt_table, dim3(1), dim3(256), 0, h->stream, h->T.wpass[i], cnt, l, n >> lrs[i]);
+        hipLaunchKernelGGL(k_ntt_table, dim3(1), dim3(256), 0, h->stream, h->T.wpass[i], cnt, l, n >> lrs[i], h->inverse);
     }
-    hipLaunchKernelGGL(k_ntt_table, dim3(2), dim3(256), 0, h->stream, h->T.t0, 512, l, (uint64_t)1);
-    hipLaunchKernelGGL(k_ntt_table, dim3(2), dim3(256), 0, h->stream, h->T.t1, 512, l, (uint64_t)512);
-    hipLaunchKernelGGL(k_ntt_table, dim3(2), dim3(256), 0, h->stream, h->T.t2, 512, l, (uint64_t)1 << 18);
+    hipLaunchKernelGGL(k_ntt_table, dim3(2), dim3(256), 0, h->stream, h->T.t0, 512, l, (uint64_t)1, h->inverse);
+    hipLaunchKernelGGL(k_ntt_table, dim3(2), dim3(256), 0, h->stream, h->T.t1, 512, l, (uint64_t)512, h->inverse);
+    hipLaunchKernelGGL(k_ntt_table, dim3(2), dim3(256), 0, h->stream, h->T.t2, 512, l, (uint64_t)1 << 18, h->inverse);
     BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
     BLZ_HIP(hipStreamSynchronize(h->stream), BLZ_ERR_UNKNOWN);
     return BLZ_OK;
@@ -279,7 +326,9 @@ int launch_pass(blz_ntt* h, const void* in, void* out) {
 
 extern "C" {
 
-int blz_ntt_new(int device_id, int log_size, blz_ntt** out) {
+int blz_ntt_new(int device_id, int log_size, blz_ntt** out) { return blz_ntt_new_ex(device_id, log_size, 0, out); }
+
+int blz_ntt_new_ex(int device_id, int log_size, int inverse, blz_ntt** out) {
     if (!out) return fail(BLZ_ERR_INVALID_PARAM, "null out");
     *out = nullptr;
     if (log_size < 1 || log_size > 27) return fail(BLZ_ERR_INVALID_PARAM, "log_size %d out of range [1,27]", log_size);
@@ -287,6 +336,7 @@ int blz_ntt_new(int device_id, int log_size, blz_ntt** out) {
     blz_ntt* h = new blz_ntt();
     h->device = device_id;
     h->logn = log_size;
+    h->inverse = inverse ? 1 : 0;
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&h->ev0);
@@ -400,13 +450,35 @@ int blz_ntt_last_kernel_ms(blz_ntt* h, float* out) {
     return BLZ_OK;
 }
 
+static int banks_geometry(blz_ntt* h, uint64_t& n, uint64_t& G, uint64_t& Bg) {
+    if (!h) return fail(BLZ_ERR_INVALID_PARAM, "null handle");
+    if (h->logn < 10) return fail(BLZ_ERR_INVALID_PARAM, "bank layout needs log_size >= 10 (512-element blocks in pairs)");
+    n = 1ull << h->logn;
+    G = n >= (1ull << 18) ? n >> 18 : 1;   // the reference shape: 2^27 -> 512 groups of 256 block pairs
+    Bg = (n >> 10) / G;
+    return BLZ_OK;
+}
 int blz_ntt_banks_preprocess_device(blz_ntt* h, const void* d_in, void* d_banks) {
-    (void)h; (void)d_in; (void)d_banks;
-    return fail(BLZ_ERR_INVALID_PARAM, "bank permutation kernels are not built yet (SURVEY.md 8(f) rank 3)");
+    uint64_t n, G, Bg;
+    BLZ_TRY(banks_geometry(h, n, G, Bg));
+    if (!d_in || !d_banks) return fail(BLZ_ERR_INVALID_PARAM, "null argument");
+    BLZ_TRY(use_device(h->device));
+    hipLaunchKernelGGL(k_ntt_banks_pre, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->copy_stream, (const uint4*)d_in,
+                       (uint4*)d_banks, n);
+    BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
+    BLZ_HIP(hipStreamSynchronize(h->copy_stream), BLZ_ERR_UNKNOWN);
+    return BLZ_OK;
 }
 int blz_ntt_banks_postprocess_device(blz_ntt* h, const void* d_banks, void* d_out) {
-    (void)h; (void)d_banks; (void)d_out;
-    return fail(BLZ_ERR_INVALID_PARAM, "bank permutation kernels are not built yet (SURVEY.md 8(f) rank 3)");
+    uint64_t n, G, Bg;
+    BLZ_TRY(banks_geometry(h, n, G, Bg));
+    if (!d_out || !d_banks) return fail(BLZ_ERR_INVALID_PARAM, "null argument");
+    BLZ_TRY(use_device(h->device));
+    hipLaunchKernelGGL(k_ntt_banks_post, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->copy_stream, (const uint4*)d_banks,
+                       (uint4*)d_out, n, G, Bg);
+    BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
+    BLZ_HIP(hipStreamSynchronize(h->copy_stream), BLZ_ERR_UNKNOWN);
+    return BLZ_OK;
 }
 
 }  // extern "C"

@@ -32,12 +32,13 @@ class NTTClient(DriverPrimitive[NTT, NttInit, NTTInput, bytes]):
     """ntt_api.rs:12-15, 25-125.  `log_size` defaults to the reference's fixed 2^27; smaller
     transforms exist for tests (the reference has no such knob)."""
 
-    def __init__(self, _ptype: NTT, dclient: DriverClient, log_size: int = NTT_LOG_SIZE):
+    def __init__(self, _ptype: NTT, dclient: DriverClient, log_size: int = NTT_LOG_SIZE, inverse: bool = False):
         self.driver_client = dclient
         self.log_size = log_size
+        self.inverse = inverse
         self.nbytes = NTT_WORD_SIZE << log_size
         h = C.c_void_p()
-        check(lib().blz_ntt_new(dclient.id, log_size, C.byref(h)))
+        check(lib().blz_ntt_new_ex(dclient.id, log_size, int(inverse), C.byref(h)))
         self._h = h
 
     def close(self):
@@ -85,6 +86,13 @@ class NTTClient(DriverPrimitive[NTT, NttInit, NTTInput, bytes]):
 
     def reset(self) -> None:
         check(lib().blz_ntt_reset(self._h))
+
+    # NTTBanks::preprocess / postprocess (ntt_data.rs:80-156) on device buffers
+    def banks_preprocess(self, d_in: DeviceBuffer, d_banks: DeviceBuffer) -> None:
+        check(lib().blz_ntt_banks_preprocess_device(self._h, d_in.ptr, d_banks.ptr))
+
+    def banks_postprocess(self, d_banks: DeviceBuffer, d_out: DeviceBuffer) -> None:
+        check(lib().blz_ntt_banks_postprocess_device(self._h, d_banks.ptr, d_out.ptr))
 
     def last_kernel_ms(self) -> float:
         v = C.c_float()

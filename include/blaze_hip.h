@@ -134,6 +134,9 @@ int blz_msm_combine_partials(blz_msm* h, const uint8_t* partials, size_t count, 
  * (BASELINE.json), forward transform, natural order in/out, omega = 2^log_size-th root derived from
  * the multiplicative generator 7. */
 int blz_ntt_new(int device_id, int log_size, blz_ntt** out);
+/* same, with the transform direction: inverse != 0 gives x[i] = n^-1 sum_k X[k] omega^(-ik) (natural order;
+ * the reference has no such knob: SURVEY.md 8(f) rank 3) */
+int blz_ntt_new_ex(int device_id, int log_size, int inverse, blz_ntt** out);
 void blz_ntt_free(blz_ntt* h);
 /* NTTClient::initialize(NttInit{}) (ntt_api.rs:37-56) */
 int blz_ntt_initialize(blz_ntt* h);
@@ -152,7 +155,9 @@ int blz_ntt_reset(blz_ntt* h);
 /* kernel time of the last transform in ms (what benches/ntt_bench.rs:34-39 times, minus reset()) */
 int blz_ntt_last_kernel_ms(blz_ntt* h, float* out);
 /* NTTBanks::preprocess / postprocess (ntt_data.rs:80-156) as device permutations, for byte
- * compatibility with bank files of the FPGA flow; n = 2^log_size elements, 16 banks contiguous. */
+ * compatibility with bank files of the FPGA flow; n = 2^log_size elements (log_size >= 10), 16 banks
+ * contiguous (n/16 elements each); 2^27 uses the reference's 512 groups x 256 block pairs, smaller sizes
+ * scale the group count (n >> 18, at least 1). */
 int blz_ntt_banks_preprocess_device(blz_ntt* h, const void* d_in, void* d_banks);
 int blz_ntt_banks_postprocess_device(blz_ntt* h, const void* d_banks, void* d_out);
 

@@ -127,3 +127,44 @@ def test_full_size_2e27_properties(gpu, orc):
     for k in (0, 1, 2, 511, 512, 513, 1 << 18, (1 << 18) + 1, 99999999, n - 1):
         assert elem(z, k) == pow(w, k, R), k
     cl.close()
+
+
+@pytest.mark.parametrize("logn", [3, 11, 19])
+def test_inverse_transform(gpu, orc, logn):
+    """the inverse direction (omega^-1, scaled by n^-1), against the oracle and
+    as a round trip."""
+    rng = random.Random(100 + logn)
+    n = 1 << logn
+    base = b"".join(rng.randrange(R).to_bytes(32, "little") for _ in range(min(n, 2048)))
+    data = bytearray((base * (n // min(n, 2048)))[: 32 * n])
+    for i in range(0, n, 61):
+        data[32 * i: 32 * i + 8] = (i * 0x9E3779B97F4A7C15 % (1 << 64)).to_bytes(8, "little")
+    data = bytes(data)
+    fwd = NTTClient(NTT.Ntt, DriverClient(0), log_size=logn)
+    inv = NTTClient(NTT.Ntt, DriverClient(0), log_size=logn, inverse=True)
+    y = _ntt(fwd, data)
+    assert _ntt(inv, data) == bytes(orc.ntt("BLS381", data, logn, inverse=True, threads=8))
+    assert _ntt(inv, y) == data
+    fwd.close(); inv.close()
+
+
+@pytest.mark.parametrize("logn", [10, 12, 19])
+def test_bank_wire_permutation(gpu, orc, logn):
+    """NTTBanks::preprocess / postprocess (ntt_data.rs:80-156) as device kernels == the oracle's
+    restatement of the reference loops, at scaled shapes (2^27 itself is the same closed form)."""
+    n = 1 << logn
+    groups = max(1, n >> 18)
+    data = bytearray(32 * n)
+    for i in range(n):
+        data[32 * i: 32 * i + 8] = (i * 0x9E3779B97F4A7C15 % (1 << 64)).to_bytes(8, "little")
+    cl = NTTClient(NTT.Ntt, DriverClient(0), log_size=logn)
+    d_in, d_banks, d_out = DeviceBuffer(0, 32 * n), DeviceBuffer(0, 32 * n), DeviceBuffer(0, 32 * n)
+    d_in.upload(data)
+    cl.banks_preprocess(d_in, d_banks)
+    banks = d_banks.download()
+    assert bytes(banks) == bytes(orc.ntt_preprocess(data, n))
+    cl.banks_postprocess(d_banks, d_out)
+    assert bytes(d_out.download()) == bytes(orc.ntt_postprocess(banks, n, groups))
+    cl.close()
+    for b in (d_in, d_banks, d_out):
+        b.free()

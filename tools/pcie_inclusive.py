@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Config 2 of BASELINE.json: 2^22 BLS12-381 MSM with DMA-mode MSMInput semantics (host Vec<u8>
+buffers through set_data).  Prints the reference's three timers (tests/integration_msm.rs:338-355:
+dur_set_data, dur_wait_result, dur_full) so the PCIe-inclusive rate is on record next to the
+HBM-resident rate bench.py reports."""
+import sys, os, time, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from blaze_amd.driver_client import DriverClient
+from blaze_amd.ingo_msm import *
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from gpu_util import synth
+
+logn = int(sys.argv[1]) if len(sys.argv) > 1 else 22
+n = 1 << logn
+dp, ds = synth("BLS381", n)
+pts, sc = dp.download(), ds.download()
+cl = MSMClient(MSMInit(PointMemoryType.DMA, False, Curve.BLS381), DriverClient(0))
+params = MSMParams(n, None)
+rows = []
+for rep in range(6):
+    t0 = time.perf_counter(); cl.initialize(params); cl.start_process()
+    t1 = time.perf_counter(); cl.set_data(MSMInput(pts, sc, params))
+    t2 = time.perf_counter(); cl.wait_result(); r = cl.result()
+    t3 = time.perf_counter()
+    rows.append((t2 - t1, t3 - t2, t3 - t0, cl.get_api()["total_ms"]))
+best = min(rows[1:], key=lambda r: r[2])
+out = {"config": f"2^{logn} BLS12-381 MSM, DMA mode, pageable host buffers", "host_bytes": n * 128,
+       "dur_set_data_ms": round(best[0] * 1e3, 2), "dur_wait_result_ms": round(best[1] * 1e3, 2),
+       "dur_full_ms": round(best[2] * 1e3, 2), "device_pipeline_ms": round(best[3], 2),
+       "h2d_GBps": round(n * 128 / best[0] / 1e9, 2), "msm_per_s_pcie_inclusive": round(1 / best[2], 2),
+       "msm_per_s_device_only": round(1e3 / best[3], 2)}
+print(json.dumps(out))
