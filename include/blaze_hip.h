@@ -122,6 +122,11 @@ int blz_msm_reset(blz_msm* h);
  * [6] window bits c  [7] number of windows */
 int blz_msm_last_timings(blz_msm* h, float out[8]);
 
+/* precompute_base_* (tests/msm/mod.rs:360-380) on the device: for each of the n base points (x||y)
+ * write PRECOMPUTE_FACTOR = 8 points P, 2^32 P, ..., 2^224 P contiguously to d_out (n*8 points).
+ * The reference builds this table on the host before set_data / load_data_to_hbm. */
+int blz_msm_precompute_bases_device(int device_id, int curve, const void* d_points, void* d_out, uint64_t n);
+
 /* Multi-GPU: add G partial results (each result_size bytes, as returned by blz_msm_result on each
  * rank, in rank order) on this handle's device and emit the normalised sum.  The exchange itself
  * (RCCL all-gather of the 144-byte partials) is the host's: SURVEY.md 8(e). */

@@ -271,3 +271,22 @@ def test_bench_sharded_path_two_ranks_one_gpu(gpu):
     j2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
     assert j2["n_gpus"] == 2 and j2["config"]["elements_per_gpu"] == (1 << 17) and j2["scaling"] == "strong"
     assert j2["result_hex"] == j1["result_hex"] and len(j1["result_hex"]) == 288   # same job, same bytes
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_device_precompute_expansion(gpu, orc, curve):
+    """the x8 base table (tests/msm/mod.rs:360-380) built on the device is
+    byte-identical to the oracle's precompute_base, and the pf=8 MSM over it equals the pf=1 MSM."""
+    n = 200
+    pts, sc, exp = orc.input_generator(curve, n, 1, 808)
+    ps = orc.point_bytes(curve)
+    cid = pyref.CURVES[curve]["id"]
+    d_in, d_out = DeviceBuffer(0, n * ps), DeviceBuffer(0, n * 8 * ps)
+    d_in.upload(pts)
+    blaze_amd._lib.check(gpu.blz_msm_precompute_bases_device(0, cid, d_in.ptr, d_out.ptr, n))
+    table = bytes(d_out.download())
+    for i in (0, 1, 57, n - 1):
+        assert table[i * 8 * ps: (i + 1) * 8 * ps] == orc.precompute_base(curve, bytes(pts[i * ps: (i + 1) * ps]), 8), i
+    cl = msm_client(curve, 8)
+    assert run_msm(cl, table, sc, n) == exp
+    cl.close(); d_in.free(); d_out.free()
