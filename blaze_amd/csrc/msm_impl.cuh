@@ -201,28 +201,57 @@ __global__ void k_emit_infinity(uint32_t* __restrict__ out) {
 
 // partials: count x (Z | Y | X) canonical, homogeneous projective x = X/Z, y = Y/Z
 template <class F>
-__global__ void k_combine_partials(const uint32_t* __restrict__ partials, uint32_t count, uint32_t* __restrict__ out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(64) void k_combine_partials(const uint32_t* __restrict__ partials, uint32_t count,
+                                                         uint32_t* __restrict__ out) {
+    // lanes normalise the partials in parallel (a partial with Z = 1, which is all this build ever
+    // emits, needs no inversion); lane 0 then adds them in rank order and emits
+    __shared__ uint32_t sh_xy[64][2 * F::N];
+    __shared__ uint32_t sh_inf[64];
     XYZZ<F> acc;
     pt_set_inf(acc);
-    for (uint32_t i = 0; i < count; ++i) {
-        const uint32_t* q = partials + (size_t)i * 3 * F::N;
-        Fp<F> Z, Y, X;
-        fp_load(Z, q);
-        fp_load(Y, q + F::N);
-        fp_load(X, q + 2 * F::N);
-        fp_to_mont(Z, Z);
-        if (fp_is_zero(Z)) continue;
-        fp_to_mont(Y, Y);
-        fp_to_mont(X, X);
-        Fp<F> zi;
-        fp_inv(zi, Z);
-        Affine<F> a;
-        fp_mul(a.x, X, zi);
-        fp_mul(a.y, Y, zi);
-        pt_madd(acc, a);
+    for (uint32_t base = 0; base < count; base += 64) {
+        uint32_t i = base + threadIdx.x;
+        if (i < count) {
+            const uint32_t* q = partials + (size_t)i * 3 * F::N;
+            Fp<F> Z, Y, X;
+            fp_load(Z, q);
+            fp_load(Y, q + F::N);
+            fp_load(X, q + 2 * F::N);
+            uint32_t rest = 0;
+#pragma unroll
+            for (int k = 1; k < F::N; ++k) rest |= Z.v[k];
+            const bool z_one = rest == 0 && Z.v[0] == 1u;
+            fp_to_mont(Y, Y);
+            fp_to_mont(X, X);
+            bool inf = false;
+            if (!z_one) {
+                fp_to_mont(Z, Z);
+                inf = fp_is_zero(Z);
+                if (!inf) {
+                    Fp<F> zi;
+                    fp_inv(zi, Z);
+                    fp_mul(X, X, zi);
+                    fp_mul(Y, Y, zi);
+                }
+            }
+            fp_store(&sh_xy[threadIdx.x][0], X);
+            fp_store(&sh_xy[threadIdx.x][F::N], Y);
+            sh_inf[threadIdx.x] = inf ? 1u : 0u;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t m = count - base < 64 ? count - base : 64;
+            for (uint32_t k = 0; k < m; ++k) {
+                if (sh_inf[k]) continue;
+                Affine<F> a;
+                fp_load(a.x, &sh_xy[k][0]);
+                fp_load(a.y, &sh_xy[k][F::N]);
+                pt_madd(acc, a);
+            }
+        }
+        __syncthreads();
     }
-    emit_result(out, acc);
+    if (threadIdx.x == 0) emit_result(out, acc);
 }
 
 
@@ -321,9 +350,13 @@ template <class F>
 int combine_t(MsmEngine& E, const uint8_t* partials, size_t count, uint8_t* out) {
     size_t rs = 3 * F::N * 4;
     DevBuf tmp;
-    BLZ_TRY(tmp.reserve(rs * (count ? count : 1)));
-    if (count) BLZ_HIP(hipMemcpyAsync(tmp.p, partials, rs * count, hipMemcpyHostToDevice, E.stream), BLZ_ERR_WRITE);
-    hipLaunchKernelGGL(k_combine_partials<F>, dim3(1), dim3(64), 0, E.stream, tmp.as<uint32_t>(), (uint32_t)count,
+    uint32_t* d_in = E.result.as<uint32_t>() + 256;  // 15 KiB of the result buffer: up to 100 partials without an allocation
+    if (rs * count > 15 * 1024) {
+        BLZ_TRY(tmp.reserve(rs * count));
+        d_in = tmp.as<uint32_t>();
+    }
+    if (count) BLZ_HIP(hipMemcpyAsync(d_in, partials, rs * count, hipMemcpyHostToDevice, E.stream), BLZ_ERR_WRITE);
+    hipLaunchKernelGGL(k_combine_partials<F>, dim3(1), dim3(64), 0, E.stream, d_in, (uint32_t)count,
                        E.result.as<uint32_t>() + 64);
     BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
     BLZ_HIP(hipMemcpyAsync(E.result_h, E.result.as<uint32_t>() + 64, rs, hipMemcpyDeviceToHost, E.stream), BLZ_ERR_READ);

@@ -290,3 +290,28 @@ def test_device_precompute_expansion(gpu, orc, curve):
     cl = msm_client(curve, 8)
     assert run_msm(cl, table, sc, n) == exp
     cl.close(); d_in.free(); d_out.free()
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_combine_partials_general_projective(gpu, orc, curve):
+    """blz_msm_combine_partials accepts any homogeneous projective partial (x = X/Z, y = Y/Z, the format
+    tests/msm/mod.rs:397-403 decodes): Z = 1, Z = k, and Z = 0 (infinity), added in order."""
+    c = pyref.CURVES[curve]
+    q, fb = c["q"], c["fq_bytes"]
+    G = pyref.generator(curve)
+    P1, P2, P3 = pyref.mul(curve, G, 5), pyref.mul(curve, G, 77), pyref.mul(curve, G, c["r"] - 82)
+
+    def enc(P, z):
+        if P is None:
+            return (0).to_bytes(fb, "little") + (1).to_bytes(fb, "little") + (0).to_bytes(fb, "little")
+        return (z % q).to_bytes(fb, "little") + (P[1] * z % q).to_bytes(fb, "little") + (P[0] * z % q).to_bytes(fb, "little")
+
+    parts = enc(P1, 1) + enc(None, 0) + enc(P2, 0x1234567890ABCDEF) + enc(P3, q - 2) + enc(P1, 1)
+    cl = msm_client(curve, 1)
+    expect = pyref.add(curve, pyref.add(curve, pyref.add(curve, P1, P2), P3), P1)
+    assert cl.combine_partials(parts, 5) == pyref.enc_result(curve, expect)
+    assert cl.combine_partials(enc(P1, 3) + enc(pyref.neg(curve, P1), 9), 2) == pyref.enc_result(curve, None)
+    assert cl.combine_partials(b"", 0) == pyref.enc_result(curve, None)
+    many = enc(P2, 1) * 130                              # more than one 64-lane round
+    assert cl.combine_partials(many, 130) == pyref.enc_result(curve, pyref.mul(curve, P2, 130))
+    cl.close()
