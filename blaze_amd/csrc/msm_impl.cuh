@@ -4,6 +4,7 @@
 #pragma once
 #include "msm_engine.hpp"
 #include "ec.cuh"
+#include "ec_quad.cuh"
 
 namespace blz {
 
@@ -47,6 +48,12 @@ BLZ_DEV void store_xyzz(uint32_t* base, size_t idx, const XYZZ<F>& a) {
     fp_store(q + 3 * F::N, a.zzz);
 }
 
+// NOTE on __launch_bounds__(T, 3) below: the out-of-line group-law routines (pt_mdbl, pt_add, pt_dbl,
+// quad_*) are compiled once per translation unit with the register budget of their MOST permissive
+// caller, and a kernel's VGPR count is the maximum over its callees.  One kernel left at the default
+// (1 wave per SIMD, 512 VGPRs) let pt_mdbl grow to 178 VGPRs and silently dropped k_accumulate from
+// 3 to 2 waves per SIMD (-7 %).  Every kernel of this file that reaches those routines therefore
+// declares >= 3 waves per SIMD.
 // ------------------------------------------------------------------------------------------------
 // phase 1: bucket accumulation.  One lane per unit (a run of <= L entries of one bucket).
 // ------------------------------------------------------------------------------------------------
@@ -86,7 +93,7 @@ __global__ __launch_bounds__(128, 3) void k_accumulate(const uint32_t* __restric
 // Every unit that leads such a group is a full-length unit, and those are the first hist[L]
 // entries of the length-ordered unit list, so only that prefix is visited.
 template <class F>
-__global__ __launch_bounds__(128) void k_combine_units(const uint32_t* __restrict__ unit_off,
+__global__ __launch_bounds__(128, 3) void k_combine_units(const uint32_t* __restrict__ unit_off,
                                                        const uint32_t* __restrict__ unit_bucket,
                                                        const uint32_t* __restrict__ unit_order,
                                                        const uint32_t* __restrict__ nfull_ptr,
@@ -117,11 +124,15 @@ __global__ __launch_bounds__(128) void k_combine_units(const uint32_t* __restric
 // outA[t] = r_t (weights t at the next level, woff = 0), outC[t] = Sum C_in + 2^shift * s_t.
 // ------------------------------------------------------------------------------------------------
 template <class F, bool FIRST>
-__global__ __launch_bounds__(64) void k_reduce_level(const uint32_t* __restrict__ inA, const uint32_t* __restrict__ inC,
+__global__ __launch_bounds__(64, 3) void k_reduce_level(const uint32_t* __restrict__ inA, const uint32_t* __restrict__ inC,
                                                      const uint32_t* __restrict__ unit_off, uint32_t M, uint32_t SEG,
                                                      uint32_t T, int W, int shift, uint32_t* __restrict__ outA,
                                                      uint32_t* __restrict__ outC) {
-    uint32_t tid = blockIdx.x * 64u + threadIdx.x;
+    // level 0 (FIRST): one lane per segment, throughput-bound.  Upper levels: one DPP quad per
+    // segment (ec_quad.cuh), because there the sequential chain, not the work, is the cost.
+    const uint32_t gtid = blockIdx.x * 64u + threadIdx.x;
+    const uint32_t tid = FIRST ? gtid : gtid >> 2;
+    const uint32_t ql = gtid & 3u;
     if (tid >= T * (uint32_t)W) return;
     uint32_t w = tid / T, t = tid - w * T;
     uint32_t lo = t * SEG;
@@ -138,17 +149,25 @@ __global__ __launch_bounds__(64) void k_reduce_level(const uint32_t* __restrict_
             uint32_t u0 = unit_off[idx], u1 = unit_off[idx + 1];
             if (u1 > u0) load_xyzz(a, inA, u0);
             else pt_set_inf(a);
+            pt_add(run, a);
+            pt_add(s, run);  // weights i + 1 at the first level
         } else {
             load_xyzz(a, inA, idx);
             XYZZ<F> cc;
             load_xyzz(cc, inC, idx);
-            pt_add(cs, cc);
+            quad_add(cs, cc, ql);
+            quad_add(run, a, ql);
+            if (i != lo) quad_add(s, run, ql);  // weights i afterwards
         }
-        pt_add(run, a);
-        if (FIRST || i != lo) pt_add(s, run);  // woff = 1 at the first level, 0 afterwards
     }
-    for (int d = 0; d < shift; ++d) { XYZZ<F> t2; pt_dbl(t2, s); s = t2; }
-    pt_add(cs, s);
+    if constexpr (FIRST) {
+        for (int d = 0; d < shift; ++d) { XYZZ<F> t2; pt_dbl(t2, s); s = t2; }
+        pt_add(cs, s);
+    } else {
+        for (int d = 0; d < shift; ++d) quad_dbl(s, ql);
+        quad_add(cs, s, ql);
+        if (ql != 0) return;
+    }
     store_xyzz(outA, (size_t)w * T + t, run);
     store_xyzz(outC, (size_t)w * T + t, cs);
 }
@@ -178,17 +197,19 @@ __device__ void emit_result(uint32_t* out, const XYZZ<F>& p) {
 }
 
 template <class F>
-__global__ void k_finish(const uint32_t* __restrict__ winsum, int W, int c, uint32_t* __restrict__ out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(64, 3) void k_finish(const uint32_t* __restrict__ winsum, int W, int c, uint32_t* __restrict__ out) {
+    // one wave; every DPP quad runs the same Horner chain cooperatively (ec_quad.cuh), lane 0 emits
+    if (blockIdx.x != 0) return;
+    const uint32_t ql = threadIdx.x & 3u;
     XYZZ<F> acc;
     pt_set_inf(acc);
     for (int w = W - 1; w >= 0; --w) {
-        for (int d = 0; d < c; ++d) { XYZZ<F> t; pt_dbl(t, acc); acc = t; }
+        for (int d = 0; d < c; ++d) quad_dbl(acc, ql);
         XYZZ<F> tw;
         load_xyzz(tw, winsum, (size_t)w);
-        pt_add(acc, tw);
+        quad_add(acc, tw, ql);
     }
-    emit_result(out, acc);
+    if (threadIdx.x == 0) emit_result(out, acc);
 }
 
 template <class F>
@@ -201,7 +222,7 @@ __global__ void k_emit_infinity(uint32_t* __restrict__ out) {
 
 // partials: count x (Z | Y | X) canonical, homogeneous projective x = X/Z, y = Y/Z
 template <class F>
-__global__ __launch_bounds__(64) void k_combine_partials(const uint32_t* __restrict__ partials, uint32_t count,
+__global__ __launch_bounds__(64, 3) void k_combine_partials(const uint32_t* __restrict__ partials, uint32_t count,
                                                          uint32_t* __restrict__ out) {
     // lanes normalise the partials in parallel (a partial with Z = 1, which is all this build ever
     // emits, needs no inversion); lane 0 then adds them in rank order and emits
@@ -327,7 +348,7 @@ int run_tail_t(MsmEngine& E, const void* d_pts, uint32_t U, uint32_t maxcount) {
             hipLaunchKernelGGL((k_reduce_level<F, true>), dim3((nthreads + 63) / 64), dim3(64), 0, st, curA, curC,
                                E.unit_off.as<uint32_t>(), M, SEG, T, P.W, shift, oA.as<uint32_t>(), oC.as<uint32_t>());
         else
-            hipLaunchKernelGGL((k_reduce_level<F, false>), dim3((nthreads + 63) / 64), dim3(64), 0, st, curA, curC,
+            hipLaunchKernelGGL((k_reduce_level<F, false>), dim3((nthreads * 4 + 63) / 64), dim3(64), 0, st, curA, curC,
                                E.unit_off.as<uint32_t>(), M, SEG, T, P.W, shift, oA.as<uint32_t>(), oC.as<uint32_t>());
         curA = oA.as<uint32_t>();
         curC = oC.as<uint32_t>();
