@@ -140,6 +140,50 @@ BLZ_DEV void pt_madd(XYZZ<F>& acc, const Affine<F>& q) {
     fp_mul(acc.zzz, acc.zzz, PPP);
 }
 
+template <class F>
+__device__ __noinline__ XYZZ<F> pt_dbl_val(XYZZ<F> p) {
+    XYZZ<F> r;
+    pt_dbl(r, p);
+    return r;
+}
+
+// acc += q   (both XYZZ), inlined form for throughput-bound kernels (operands stay in registers)
+template <class F>
+BLZ_DEV void pt_add_inl(XYZZ<F>& acc, const XYZZ<F>& q) {
+    if (pt_is_inf(q)) return;
+    if (pt_is_inf(acc)) { acc = q; return; }
+    Fp<F> U1, S1, P, R, PP, PPP, Q, t;
+    fp_mul(U1, acc.x, q.zz);
+    fp_mul(P, q.x, acc.zz);
+    fp_mul(S1, acc.y, q.zzz);
+    fp_mul(R, q.y, acc.zzz);
+    fp_sub(P, P, U1);
+    fp_sub(R, R, S1);
+    if (__builtin_expect(fp_maybe_zero(P), 0)) {
+        if (fp_is_zero(P)) {
+            if (fp_is_zero(R)) acc = pt_dbl_val(q);
+            else pt_set_inf(acc);
+            return;
+        }
+    }
+    fp_sqr(PP, P);
+    fp_mul(PPP, P, PP);
+    fp_mul(Q, U1, PP);
+    fp_sqr(t, R);
+    fp_sub(t, t, PPP);
+    fp_sub(t, t, Q);
+    fp_sub(t, t, Q);  // X3
+    fp_sub(Q, Q, t);
+    fp_mul(Q, R, Q);
+    fp_mul(S1, S1, PPP);
+    acc.x = t;
+    fp_sub(acc.y, Q, S1);
+    fp_mul(t, acc.zz, q.zz);
+    fp_mul(acc.zz, t, PP);
+    fp_mul(t, acc.zzz, q.zzz);
+    fp_mul(acc.zzz, t, PPP);
+}
+
 // acc += q   (both XYZZ)
 template <class F>
 __device__ __noinline__ void pt_add(XYZZ<F>& acc, const XYZZ<F>& q) {

@@ -149,8 +149,8 @@ __global__ __launch_bounds__(64, 3) void k_reduce_level(const uint32_t* __restri
             uint32_t u0 = unit_off[idx], u1 = unit_off[idx + 1];
             if (u1 > u0) load_xyzz(a, inA, u0);
             else pt_set_inf(a);
-            pt_add(run, a);
-            pt_add(s, run);  // weights i + 1 at the first level
+            pt_add_inl(run, a);
+            pt_add_inl(s, run);  // weights i + 1 at the first level
         } else {
             load_xyzz(a, inA, idx);
             XYZZ<F> cc;
