@@ -124,20 +124,23 @@ BLZ_DEV void pt_madd(XYZZ<F>& acc, const Affine<F>& q) {
             return;
         }
     }
+    // ordered so that every input coordinate dies as early as possible (ZZ1, ZZZ1, X1, Y1 are
+    // overwritten as soon as their last product is formed): peak liveness decides whether the hot
+    // loop fits 3 waves per SIMD without scratch spills
     fp_sqr(PP, P);
+    fp_mul(acc.zz, acc.zz, PP);    // ZZ3
     fp_mul(PPP, P, PP);
+    fp_mul(acc.zzz, acc.zzz, PPP); // ZZZ3
     fp_mul(Q, acc.x, PP);
+    fp_mul(PP, acc.y, PPP);        // Y1 * PPP
     fp_sqr(t, R);
     fp_sub(t, t, PPP);
     fp_sub(t, t, Q);
-    fp_sub(t, t, Q);  // X3
+    fp_sub(t, t, Q);               // X3
+    acc.x = t;
     fp_sub(Q, Q, t);
     fp_mul(Q, R, Q);
-    fp_mul(R, acc.y, PPP);
-    acc.x = t;
-    fp_sub(acc.y, Q, R);
-    fp_mul(acc.zz, acc.zz, PP);
-    fp_mul(acc.zzz, acc.zzz, PPP);
+    fp_sub(acc.y, Q, PP);
 }
 
 template <class F>

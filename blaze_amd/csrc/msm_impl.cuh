@@ -6,6 +6,10 @@
 #include "ec.cuh"
 #include "ec_quad.cuh"
 
+#ifndef BLZ_ACC_PREFETCH
+#define BLZ_ACC_PREFETCH 0
+#endif
+
 namespace blz {
 
 // ------------------------------------------------------------------------------------------------
@@ -73,6 +77,7 @@ __global__ __launch_bounds__(128, 3) void k_accumulate(const uint32_t* __restric
     if (end - start > L) end = start + L;
     XYZZ<F> acc;
     pt_set_inf(acc);
+#if BLZ_ACC_PREFETCH
     Affine<F> nxt;
     uint32_t e = entries[start];
     load_affine(nxt, pts, e & 0x7fffffffu);
@@ -86,6 +91,20 @@ __global__ __launch_bounds__(128, 3) void k_accumulate(const uint32_t* __restric
         if (ecur & 0x80000000u) fp_neg(cur.y, cur.y);
         pt_madd(acc, cur);
     }
+#else
+    // only the next entry INDEX is prefetched: holding the next point as well costs 24 VGPRs, which at
+    // 3 waves per SIMD (168 VGPRs) turned into scratch spills (100 GB of HBM writes per 2^26 MSM in
+    // the WRITE_SIZE counter); the other two waves of the SIMD cover the gather latency instead
+    uint32_t e = entries[start];
+    for (uint32_t j = start; j < end; ++j) {
+        Affine<F> cur;
+        load_affine(cur, pts, e & 0x7fffffffu);
+        const uint32_t ecur = e;
+        if (j + 1 < end) e = entries[j + 1];
+        if (ecur & 0x80000000u) fp_neg(cur.y, cur.y);
+        pt_madd(acc, cur);
+    }
+#endif
     store_xyzz(partial, u, acc);
 }
 
