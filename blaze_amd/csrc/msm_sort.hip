@@ -2,7 +2,8 @@
 //
 // Two-level LDS-privatised counting sort (replaces one global atomic per entry, which ran at
 // ~25 G atomics/s and cost 105 ms of a 2^26 MSM):
-//   bucket index (c-1 bits) = coarse (ch bits) | fine (cl bits),  W * 2^ch <= 24576 coarse bins
+//   bucket index (c-1 bits) = coarse (ch bits) | fine (cl bits, 11 by default: fewer, fuller coarse bins
+//   combine writes better than more bins do),  W * 2^ch <= 24576 coarse bins
 //   k_coarse_count    per block: LDS histogram of its points' digits over all coarse bins, flushed
 //                     with one global atomic per (block, non-empty bin)
 //   k_coarse_scan     exclusive scan over the coarse bins (one block)
@@ -216,8 +217,8 @@ constexpr int FS_PER_THREAD = 32;
 constexpr int FS_ROUND = FS_THREADS * FS_PER_THREAD;  // 32768 entries = 128 KiB of staging
 
 __global__ __launch_bounds__(FS_THREADS) void k_fine_scatter(const uint2* __restrict__ inter, const uint32_t* __restrict__ coarse_off,
-                                                             int cl, uint32_t S, uint32_t* __restrict__ cursor,
-                                                             uint32_t* __restrict__ entries) {
+                                                             int cl, uint32_t S, uint32_t round_cap,
+                                                             uint32_t* __restrict__ cursor, uint32_t* __restrict__ entries) {
     extern __shared__ __attribute__((aligned(16))) uint32_t sh[];
     const uint32_t nf = 1u << cl;
     uint32_t* hist = sh;             // [nf]  counts, then exclusive local base
@@ -232,8 +233,8 @@ __global__ __launch_bounds__(FS_THREADS) void k_fine_scatter(const uint2* __rest
     uint32_t* cur = cursor + ((size_t)k << cl);
     uint32_t* dst = entries;
     const uint32_t per_thr_bins = (nf + FS_THREADS - 1) / FS_THREADS;
-    for (uint32_t r0 = lo; r0 < hi; r0 += FS_ROUND) {
-        const uint32_t rn = (hi - r0) < (uint32_t)FS_ROUND ? (hi - r0) : (uint32_t)FS_ROUND;
+    for (uint32_t r0 = lo; r0 < hi; r0 += round_cap) {
+        const uint32_t rn = (hi - r0) < round_cap ? (hi - r0) : round_cap;
         for (uint32_t i = threadIdx.x; i < nf; i += FS_THREADS) hist[i] = 0;
         __syncthreads();
         uint32_t ex[FS_PER_THREAD], ey[FS_PER_THREAD];
@@ -300,7 +301,8 @@ static SortGeom make_geom(const MsmPlan& P) {
     g.W = P.W;
     g.Bw = P.Bw;
     int cb = P.c - 1;
-    int cl = cb < 10 ? cb : 10;
+    const int cl_pref = msm_env_int("BLAZE_SORT_CL", 11);
+    int cl = cb < cl_pref ? cb : cl_pref;
     int ch = cb - cl;
     while (((uint32_t)P.W << ch) > 24576u && ch > 0) { --ch; ++cl; }
     g.ch = ch;
@@ -367,9 +369,14 @@ int msm_sort_lds_scatter(MsmEngine& E) {
         BLZ_HIP(hipFuncSetAttribute((const void*)k_fine_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256), BLZ_ERR_UNKNOWN);
         attr_done = true;
     }
-    const size_t lds = ((size_t)3 << E.sort_cl) * 4 + (size_t)FS_ROUND * 4;
+    // staging entries per round: what is left of the LDS after the three per-bucket arrays
+    size_t budget = (size_t)158 * 1024 - ((size_t)3 << E.sort_cl) * 4;
+    uint32_t round_cap = (uint32_t)(budget / 4);
+    if (round_cap > (uint32_t)FS_ROUND) round_cap = FS_ROUND;
+    round_cap &= ~1023u;
+    const size_t lds = ((size_t)3 << E.sort_cl) * 4 + (size_t)round_cap * 4;
     hipLaunchKernelGGL(k_fine_scatter, dim3(E.sort_nc * E.sort_slices), dim3(FS_THREADS), lds, st, E.inter.as<uint2>(), coarse_off,
-                       E.sort_cl, E.sort_slices, E.count.as<uint32_t>(), E.entries.as<uint32_t>());
+                       E.sort_cl, E.sort_slices, round_cap, E.count.as<uint32_t>(), E.entries.as<uint32_t>());
     BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
     return BLZ_OK;
 }
