@@ -81,13 +81,25 @@ def main():
     check(L.blz_synth_points(dev, cid, d_pts.ptr, n_loc, 1, lo))
     check(L.blz_synth_scalars_at(dev, cid, d_sc.ptr, n_loc, 0xB1A2E, lo))  # same global set for every N
 
-    client = MSMClient(MSMInit(PointMemoryType.DMA, False, Curve[CURVE]), DriverClient(dev))
-    params = MSMParams(n_loc, None)
+    # Points live in the device arena, as in the reference's HBM flow (tests/integration_msm_hbm.rs:
+    # load_data_to_hbm once, then scalars-only set_data with hbm_point_addr): the bases of a prover are
+    # fixed, the scalars change per MSM.  BLAZE_BENCH_MODE=dma streams points + scalars every step instead.
+    hbm_mode = os.environ.get("BLAZE_BENCH_MODE", "hbm") == "hbm"
+    if hbm_mode:
+        L.blz_arena_release(dev)
+        client = MSMClient(MSMInit(PointMemoryType.HBM, False, Curve[CURVE]), DriverClient(dev))
+        client.load_data_to_hbm(d_pts, 0, 0)
+        params = MSMParams(n_loc, (0, 0))
+        step_points = None
+    else:
+        client = MSMClient(MSMInit(PointMemoryType.DMA, False, Curve[CURVE]), DriverClient(dev))
+        params = MSMParams(n_loc, None)
+        step_points = d_pts
 
     def step():
         client.initialize(params)
         client.start_process()
-        client.set_data(MSMInput(d_pts, d_sc, params))
+        client.set_data(MSMInput(step_points, d_sc, params))
         client.wait_result()
         part = client.result().result
         if world > 1:
@@ -191,7 +203,8 @@ def main():
             "metric": f"BLS12-381 MSM/s at 2^{LOG_N}", "value": round(value, 4), "unit": "MSM/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "u32 limbs (381-bit Fq Montgomery)", "data": "synthetic",
-            "config": {"workload": f"2^{LOG_N} BLS12-381 G1 MSM, pf=1, scalars+points resident in HBM",
+            "config": {"workload": f"2^{LOG_N} BLS12-381 G1 MSM, pf=1, scalars+points resident in HBM"
+                                   + (" (points in the device arena, scalars-only set_data)" if hbm_mode else " (DMA-mode set_data with device pointers)"),
                        "elements": n, "elements_per_gpu": n_loc, "parallelism": f"shard{world}" if world > 1 else "single",
                        "window_bits": int(api["window_bits"]), "windows": int(api["windows"])},
             "roofline": roofline, "cpu_baseline": cpu, "ntt_2e27": ntt,
