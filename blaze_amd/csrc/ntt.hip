@@ -20,7 +20,7 @@ using Fr = Fr_BLS381;
 using E = Fp<Fr>;
 
 struct NttTables {  // all Montgomery form, device memory
-    uint32_t* wpass[3];  // wpass[p][j] = root_p^j, j < radix_p/2   (root_p = primitive radix_p-th root)
+    uint32_t* wpass[3];  // wpass[p][j] = root_p^j, j < radix_p       (root_p = primitive radix_p-th root)
     uint32_t* t0;        // w^j            j < 512
     uint32_t* t1;        // w^(512 j)      j < 512
     uint32_t* t2;        // w^(2^18 j)     j < 512
@@ -234,6 +234,163 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const uint32_t* __rest
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// 512-point passes, register resident: 512 = 8 * 8 * 8.  A lane holds 8 elements (64 VGPRs) and runs
+// a whole 8-point DFT (three radix-2 stages, 5 non-trivial twiddles) in registers; the tile goes
+// through LDS only twice (between the three radix-8 steps) instead of once per radix-2 stage, the
+// loads come straight from global memory and the last step stores straight to it with the
+// inter-pass twiddle applied by stepping along the lane's own 8 outputs.  PMC counters of the
+// radix-2-in-LDS kernel: VALU busy 22 %, 44 % of wave cycles parked on barriers / waitcnt, 58 % of
+// LDS cycles bank conflicts.  COLS = 4 columns x 512 rows per 256-lane block (80 KiB of LDS), two
+// blocks per CU so one block's global traffic overlaps the other's arithmetic.
+// ------------------------------------------------------------------------------------------------
+constexpr int N8_COLS_LOG = 2;
+constexpr int N8_COLS = 1 << N8_COLS_LOG;
+constexpr int N8_THREADS = 64 * N8_COLS;
+constexpr uint32_t N8_RS = N8_COLS * 8 + 8;  // padded row stride in dwords
+
+// in-register 8-point DFT, decimation in time: a[] must hold x[0],x[4],x[2],x[6],x[1],x[5],x[3],x[7];
+// output natural order.  w1,w2,w3 = w8, w8^2, w8^3 (Montgomery).
+BLZ_DEV void bfly(E& u, E& v) {
+    E s, d;
+    fp_add(s, u, v);
+    fp_sub(d, u, v);
+    u = s;
+    v = d;
+}
+BLZ_DEV void dft8(E (&a)[8], const E& w1, const E& w2, const E& w3) {
+    bfly(a[0], a[1]); bfly(a[2], a[3]); bfly(a[4], a[5]); bfly(a[6], a[7]);
+    fp_mul(a[3], a[3], w2);
+    fp_mul(a[7], a[7], w2);
+    bfly(a[0], a[2]); bfly(a[1], a[3]); bfly(a[4], a[6]); bfly(a[5], a[7]);
+    fp_mul(a[5], a[5], w1);
+    fp_mul(a[6], a[6], w2);
+    fp_mul(a[7], a[7], w3);
+    bfly(a[0], a[4]); bfly(a[1], a[5]); bfly(a[2], a[6]); bfly(a[3], a[7]);
+}
+// order in which a DIT 8-point DFT wants its inputs
+__device__ constexpr int BR8[8] = {0, 4, 2, 6, 1, 5, 3, 7};
+
+template <int PASS>
+__global__ __launch_bounds__(N8_THREADS, 2) void k_ntt512(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                         NttGeom g, NttTables T) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t A = 1u << g.logA, B = 1u << g.logB, C = 1u << g.logC;
+    uint64_t col_base, fixed, in_base, in_rstride, in_cstride;
+    const uint64_t tile = blockIdx.x;
+    uint32_t col, n2;  // this lane's column and its index in [0,64)
+    if (PASS == 1) {   // rows i2 (stride AB), cols i0 (stride 1), fixed i1
+        uint64_t tiles_per = A >> N8_COLS_LOG;
+        fixed = tile / tiles_per;
+        col_base = (tile % tiles_per) << N8_COLS_LOG;
+        in_base = col_base + (uint64_t)A * fixed;
+        in_rstride = (uint64_t)A * B;
+        in_cstride = 1;
+        col = threadIdx.x & (N8_COLS - 1);
+        n2 = threadIdx.x >> N8_COLS_LOG;
+    } else if (PASS == 2) {  // rows i1 (stride A), cols i0, fixed k2
+        uint64_t tiles_per = A >> N8_COLS_LOG;
+        fixed = tile / tiles_per;
+        col_base = (tile % tiles_per) << N8_COLS_LOG;
+        in_base = col_base + (uint64_t)A * B * fixed;
+        in_rstride = A;
+        in_cstride = 1;
+        col = threadIdx.x & (N8_COLS - 1);
+        n2 = threadIdx.x >> N8_COLS_LOG;
+    } else {  // rows i0 (stride 1, contiguous), cols k2 (stride AB), fixed k1
+        uint64_t tiles_per = C >> N8_COLS_LOG;
+        fixed = tile / tiles_per;
+        col_base = (tile % tiles_per) << N8_COLS_LOG;
+        in_base = (uint64_t)A * fixed + (uint64_t)A * B * col_base;
+        in_rstride = 1;
+        in_cstride = (uint64_t)A * B;
+        n2 = threadIdx.x & 63u;   // consecutive lanes read consecutive rows
+        col = threadIdx.x >> 6;
+    }
+    const uint32_t* wp = T.wpass[PASS - 1];  // w512^j, j < 512
+    E w1, w2, w3;
+    fp_load(w1, wp + 64 * 8);
+    fp_load(w2, wp + 128 * 8);
+    fp_load(w3, wp + 192 * 8);
+    E a[8];
+    // ---- step 1: 8-point DFTs over n1 (rows 64 n1 + n2), straight from global memory
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        uint32_t row = 64u * BR8[j] + n2;
+        fp_load(a[j], in + (in_base + row * in_rstride + col * in_cstride) * 8);
+    }
+    dft8(a, w1, w2, w3);
+#pragma unroll
+    for (int k1 = 0; k1 < 8; ++k1) {
+        if (k1 != 0 && n2 != 0) {  // * w512^(n2 k1)
+            E w;
+            fp_load(w, wp + (size_t)(n2 * k1) * 8);
+            fp_mul(a[k1], a[k1], w);
+        }
+        lds_store(lds, (64u * k1 + n2) * N8_RS + col * 8, a[k1]);
+    }
+    __syncthreads();
+    // ---- step 2a: lane (k1, n2', col): 8-point DFTs over n1' (rows 64 k1 + 8 n1' + n2')
+    {
+        const uint32_t k1 = n2 >> 3, n2p = n2 & 7u;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) lds_load(a[j], lds, (64u * k1 + 8u * BR8[j] + n2p) * N8_RS + col * 8);
+        dft8(a, w1, w2, w3);
+        __syncthreads();
+#pragma unroll
+        for (int k1p = 0; k1p < 8; ++k1p) {
+            if (k1p != 0 && n2p != 0) {  // * w64^(n2' k1') = w512^(8 n2' k1')
+                E w;
+                fp_load(w, wp + (size_t)(8u * n2p * k1p) * 8);
+                fp_mul(a[k1p], a[k1p], w);
+            }
+            lds_store(lds, (64u * k1 + 8u * k1p + n2p) * N8_RS + col * 8, a[k1p]);
+        }
+    }
+    __syncthreads();
+    // ---- step 2b: lane (k1, k1', col): 8-point DFTs over n2' (rows 64 k1 + 8 k1' + n2'), outputs
+    // k = k1 + 8 k1' + 64 k2' go to global memory with the inter-pass twiddle
+    {
+        const uint32_t k1 = n2 >> 3, k1p = n2 & 7u;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) lds_load(a[j], lds, (64u * k1 + 8u * k1p + BR8[j]) * N8_RS + col * 8);
+        dft8(a, w1, w2, w3);
+        const uint32_t kb = k1 + 8u * k1p;  // output row of a[k2'] is kb + 64 k2'
+        E w, step;
+        bool tw = false;
+        if (PASS == 1) {
+            // x(i0, i1, k2 = row) *= w^(row * (i0 + A i1)),  m = i0 + A i1 < 2^18
+            const uint64_t m = col_base + col + ((uint64_t)fixed << g.logA);
+            tw = m != 0;
+            if (tw) { tw_pow(w, T, (uint32_t)(kb * m)); tw_pow(step, T, (uint32_t)(64u * m)); }
+        } else if (PASS == 2) {
+            // x(i0, k1 = row, k2) *= w^(C i0 row)
+            const uint64_t m = (col_base + col) << g.logC;
+            tw = m != 0;
+            if (tw) { tw_pow(w, T, (uint32_t)(kb * m)); tw_pow(step, T, (uint32_t)(64u * m)); }
+        }
+        E sc;
+        if (PASS == 3 && T.ninv) fp_load(sc, T.ninv);
+#pragma unroll
+        for (int k2p = 0; k2p < 8; ++k2p) {
+            const uint32_t row = kb + 64u * k2p;
+            uint64_t oaddr;
+            if (PASS == 3) {
+                if (T.ninv) fp_mul(a[k2p], a[k2p], sc);  // inverse transform: * n^-1
+                oaddr = (col_base + col) + (uint64_t)C * fixed + (uint64_t)C * B * row;
+            } else {
+                if (tw) {
+                    if (k2p != 0 || kb != 0) fp_mul(a[k2p], a[k2p], w);
+                    if (k2p != 7) fp_mul(w, w, step);
+                }
+                oaddr = in_base + row * in_rstride + col;
+            }
+            fp_store(out + oaddr * 8, a[k2p]);
+        }
+    }
+}
+
 }  // namespace blz
 
 using namespace blz;
@@ -242,6 +399,7 @@ struct blz_ntt {
     int device = 0;
     int logn = 27;
     int inverse = 0;
+    bool force_generic = false;  // BLAZE_NTT_GENERIC=1: radix-2-in-LDS kernel for every pass (A/B runs)
     NttGeom geom{};
     int cols_log[3] = {0, 0, 0};
     hipStream_t stream = nullptr;
@@ -277,10 +435,10 @@ int ntt_setup(blz_ntt* h) {
     h->cols_log[0] = pick(lc, la);  // pass 1: cols i0 (< A)
     h->cols_log[1] = pick(lb, la);  // pass 2: cols i0 (< A)
     h->cols_log[2] = pick(la, lc);  // pass 3: cols k2 (< C)
-    size_t tb = (size_t)(3 * 256 + 3 * 512 + 1) * 32;
+    size_t tb = (size_t)(3 * 512 + 3 * 512 + 1) * 32;
     BLZ_TRY(h->tables.reserve(tb));
     uint32_t* p = h->tables.as<uint32_t>();
-    for (int i = 0; i < 3; ++i) { h->T.wpass[i] = p; p += 256 * 8; }
+    for (int i = 0; i < 3; ++i) { h->T.wpass[i] = p; p += 512 * 8; }
     h->T.t0 = p; p += 512 * 8;
     h->T.t1 = p; p += 512 * 8;
     h->T.t2 = p; p += 512 * 8;
@@ -292,8 +450,8 @@ int ntt_setup(blz_ntt* h) {
     const uint64_t n = 1ull << l;
     int lrs[3] = {lc, lb, la};
     for (int i = 0; i < 3; ++i) {
-        int cnt = lrs[i] ? (1 << (lrs[i] - 1)) : 1;
-        hipLaunchKernelGGL(k_ntt_table, dim3(1), dim3(256), 0, h->stream, h->T.wpass[i], cnt, l, n >> lrs[i], h->inverse);
+        int cnt = lrs[i] ? (1 << lrs[i]) : 1;  // the whole circle: the radix-8 kernel indexes exponents up to radix-1
+        hipLaunchKernelGGL(k_ntt_table, dim3(2), dim3(256), 0, h->stream, h->T.wpass[i], cnt, l, n >> lrs[i], h->inverse);
     }
     hipLaunchKernelGGL(k_ntt_table, dim3(2), dim3(256), 0, h->stream, h->T.t0, 512, l, (uint64_t)1, h->inverse);
     hipLaunchKernelGGL(k_ntt_table, dim3(2), dim3(256), 0, h->stream, h->T.t1, 512, l, (uint64_t)512, h->inverse);
@@ -307,6 +465,21 @@ template <int PASS>
 int launch_pass(blz_ntt* h, const void* in, void* out) {
     const NttGeom& g = h->geom;
     int lr = PASS == 1 ? g.logC : PASS == 2 ? g.logB : g.logA;
+    const int cols_avail = PASS == 3 ? g.logC : g.logA;  // extent of the tile's column index
+    if (lr == 9 && cols_avail >= N8_COLS_LOG && !h->force_generic) {
+        static bool attr8 = false;
+        if (!attr8) {
+            BLZ_HIP(hipFuncSetAttribute((const void*)k_ntt512<PASS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                    BLZ_ERR_UNKNOWN);
+            attr8 = true;
+        }
+        size_t lds8 = (size_t)512 * N8_RS * 4;
+        uint64_t tiles8 = (1ull << g.logn) >> (9 + N8_COLS_LOG);
+        hipLaunchKernelGGL(k_ntt512<PASS>, dim3((unsigned)tiles8), dim3(N8_THREADS), lds8, h->stream, (const uint32_t*)in,
+                           (uint32_t*)out, g, h->T);
+        BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
+        return BLZ_OK;
+    }
     int cl = h->cols_log[PASS - 1];
     size_t lds = ((size_t)4 << lr) * (((size_t)8 << cl) + 8);  // rows x (COLS*8 + 8) dwords
     uint64_t tiles = (1ull << g.logn) >> (lr + cl);
@@ -337,6 +510,7 @@ int blz_ntt_new_ex(int device_id, int log_size, int inverse, blz_ntt** out) {
     h->device = device_id;
     h->logn = log_size;
     h->inverse = inverse ? 1 : 0;
+    { const char* e = getenv("BLAZE_NTT_GENERIC"); h->force_generic = e && *e == '1'; }
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&h->ev0);
