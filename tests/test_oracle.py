@@ -123,3 +123,15 @@ def test_ntt_bank_permutation_roundtrip(orc):
     assert sorted(got) == list(range(n))           # a permutation
     for a in range(0, n, 512):                     # whole 512-blocks move together, order kept
         assert got[a + 1] == got[a] + 1 and got[a + 511] == got[a] + 511 and got[a] % 512 == 0
+
+
+def test_oracle_under_sanitizers():
+    """ASan + UBSan build of the C restatement, every entry point on small inputs (CPU only: GPU
+    sanitizers are not available on the pool)."""
+    import subprocess
+
+    odir = os.path.join(os.path.dirname(HERE), "oracle")
+    subprocess.check_call(["make", "-C", odir, "selftest_asan"], stdout=subprocess.DEVNULL)
+    p = subprocess.run([os.path.join(odir, "selftest_asan")], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "oracle selftest ok" in p.stdout
