@@ -286,6 +286,8 @@ __global__ __launch_bounds__(FS_THREADS) void k_fine_scatter(const uint2* __rest
             if (j < rn) stage[hist[ey[t] & 0xfffu] + (ey[t] >> 12)] = ex[t];
         }
         __syncthreads();
+        // one lane copies one bucket's run (a slot-major copy with a binary search for the bucket
+        // measured slower: 27.7 vs 23.5 ms for the whole sort)
         for (uint32_t f = threadIdx.x; f < nf; f += FS_THREADS) {
             uint32_t n = cnt[f], src = hist[f], g0 = gbase[f];
             for (uint32_t q = 0; q < n; ++q) dst[g0 + q] = stage[src + q];
@@ -318,7 +320,7 @@ int msm_sort_lds(MsmEngine& E, const void* d_scalars, uint32_t npts, int sbits) 
     SortGeom g = make_geom(P);
     if (g.cl > 12 || g.NC > 24576u) return fail(BLZ_ERR_UNKNOWN, "sort geometry out of range (c=%d W=%d)", P.c, P.W);
     // points per block: enough entries per block to amortise the NC-sized LDS sweeps, enough blocks to fill the chip
-    uint32_t ppb = (uint32_t)(((uint64_t)g.NC * 16 + P.W - 1) / P.W);
+    uint32_t ppb = (uint32_t)(((uint64_t)g.NC * (uint32_t)msm_env_int("BLAZE_SORT_EPB", 64) + P.W - 1) / P.W);
     if (ppb < 4096) ppb = 4096;
     if (ppb > 65536) ppb = 65536;
     ppb = (ppb + SORT_THREADS - 1) / SORT_THREADS * SORT_THREADS;
