@@ -314,7 +314,7 @@ void MsmEngine::destroy() {
     if (!stream) return;
     (void)hipSetDevice(device);
     (void)hipStreamSynchronize(stream);
-    for (DevBuf* b : {&count, &off, &unit_off, &unit_bucket, &entries, &partial, &unit_order, &lenhist, &coarse, &inter, &lvlA[0], &lvlA[1], &lvlC[0],
+    for (DevBuf* b : {&count, &off, &unit_off, &unit_bucket, &entries, &partial, &unit_order, &lenhist, &coarse, &inter, &slice_map, &lvlA[0], &lvlA[1], &lvlC[0],
                       &lvlC[1], &blocksums, &stats, &result})
         b->release();
     for (auto& e : ev)

@@ -20,7 +20,7 @@ struct MsmEngine {
     int curve = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
-    DevBuf count, off, unit_off, unit_bucket, unit_order, lenhist, coarse, inter, entries, partial, lvlA[2], lvlC[2], blocksums, stats, result;
+    DevBuf count, off, unit_off, unit_bucket, unit_order, lenhist, coarse, inter, slice_map, entries, partial, lvlA[2], lvlC[2], blocksums, stats, result;
     uint32_t* stats_h = nullptr;   // pinned: [0] total units, [1] max bucket count, [2] total entries
     uint8_t* result_h = nullptr;   // pinned result bytes
     MsmPlan last_plan;

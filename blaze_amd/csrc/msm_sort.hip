@@ -9,6 +9,7 @@
 //   k_coarse_scan     exclusive scan over the coarse bins (one block)
 //   k_coarse_scatter  per block: LDS count, one global reservation per (block, bin), then every
 //                     entry gets base + LDS rank; writes (entry, fine) pairs grouped by coarse bin
+//   k_slice_map       device-built work list: every coarse bin cut into slices of <= 65536 entries
 //   k_fine_count      per (coarse bin, slice): LDS histogram over the 2^cl fine buckets -> count[]
 //   (k_scan_* of msm.hip: bucket offsets + unit offsets, unchanged)
 //   k_fine_scatter    per (coarse bin, slice): LDS count, reservation per (block, bucket) on the
@@ -164,25 +165,61 @@ __global__ __launch_bounds__(SORT_THREADS) void k_coarse_scatter(const uint32_t*
     }
 }
 
-// slice s of S of coarse bin k: entries [lo, hi)
-__device__ __forceinline__ void slice_range(const uint32_t* coarse_off, uint32_t k, uint32_t s, uint32_t S, uint32_t& lo,
-                                            uint32_t& hi) {
+// Work list of the fine passes: coarse bin k is cut into ceil(size_k / SLICE) slices, so a bin that
+// holds far more than the mean (the short top window puts 1/W of all entries into a handful of bins;
+// the reference harness's repeated tile does the same everywhere) is spread over many blocks.  Built on
+// the device (one block), no host round trip: the launch uses the bound entries/SLICE + NC.
+constexpr uint32_t SLICE = 65536;
+
+__global__ __launch_bounds__(1024) void k_slice_map(const uint32_t* __restrict__ coarse_off, uint32_t NC,
+                                                    uint2* __restrict__ slice_map, uint32_t* __restrict__ nslices) {
+    __shared__ uint32_t sh[1024];
+    __shared__ uint32_t carry_sh;
+    if (threadIdx.x == 0) carry_sh = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < NC; base += 1024) {
+        uint32_t i = base + threadIdx.x;
+        uint32_t size = i < NC ? coarse_off[i + 1] - coarse_off[i] : 0;
+        uint32_t v = (size + SLICE - 1) / SLICE;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            uint32_t t = threadIdx.x >= (uint32_t)o ? sh[threadIdx.x - o] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += t;
+            __syncthreads();
+        }
+        uint32_t incl = sh[threadIdx.x], carry = carry_sh;
+        uint32_t first = carry + incl - v;
+        for (uint32_t j = 0; j < v; ++j) slice_map[first + j] = make_uint2(i, j);
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_sh = carry + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *nslices = carry_sh;
+}
+
+// entries [lo, hi) of work item `sid`; multi = the bin has other slices too
+__device__ __forceinline__ bool slice_range(const uint32_t* coarse_off, const uint2* slice_map, const uint32_t* nslices,
+                                            uint32_t sid, uint32_t& k, uint32_t& lo, uint32_t& hi, bool& multi) {
+    if (sid >= *nslices) return false;
+    uint2 m = slice_map[sid];
+    k = m.x;
     uint32_t a = coarse_off[k], b = coarse_off[k + 1];
-    uint32_t per = (b - a + S - 1) / S;
-    lo = a + s * per;
-    hi = lo + per;
-    if (lo > b) lo = b;
-    if (hi > b) hi = b;
+    lo = a + m.y * SLICE;
+    hi = lo + SLICE < b ? lo + SLICE : b;
+    multi = b - a > SLICE;
+    return lo < hi;
 }
 
 __global__ __launch_bounds__(FINE_THREADS) void k_fine_count(const uint2* __restrict__ inter, const uint32_t* __restrict__ coarse_off,
-                                                             int cl, uint32_t S, uint32_t* __restrict__ count) {
+                                                             const uint2* __restrict__ slice_map, const uint32_t* __restrict__ nslices,
+                                                             int cl, uint32_t* __restrict__ count) {
     extern __shared__ __attribute__((aligned(16))) uint32_t sh[];
     const uint32_t nf = 1u << cl;
-    const uint32_t k = blockIdx.x / S, s = blockIdx.x % S;
-    uint32_t lo, hi;
-    slice_range(coarse_off, k, s, S, lo, hi);
-    if (lo >= hi) return;
+    uint32_t k, lo, hi;
+    bool multi;
+    if (!slice_range(coarse_off, slice_map, nslices, blockIdx.x, k, lo, hi, multi)) return;
     for (uint32_t i = threadIdx.x; i < nf; i += FINE_THREADS) sh[i] = 0;
     __syncthreads();
     // 8 independent loads in flight per lane before the dependent LDS atomics (the one-load-per-
@@ -201,7 +238,7 @@ __global__ __launch_bounds__(FINE_THREADS) void k_fine_count(const uint2* __rest
     for (uint32_t i = threadIdx.x; i < nf; i += FINE_THREADS) {
         uint32_t v = sh[i];
         if (v) {
-            if (S == 1) dst[i] = v;
+            if (!multi) dst[i] = v;
             else atomicAdd(&dst[i], v);
         }
     }
@@ -217,7 +254,8 @@ constexpr int FS_PER_THREAD = 32;
 constexpr int FS_ROUND = FS_THREADS * FS_PER_THREAD;  // 32768 entries = 128 KiB of staging
 
 __global__ __launch_bounds__(FS_THREADS) void k_fine_scatter(const uint2* __restrict__ inter, const uint32_t* __restrict__ coarse_off,
-                                                             int cl, uint32_t S, uint32_t round_cap,
+                                                             const uint2* __restrict__ slice_map, const uint32_t* __restrict__ nslices,
+                                                             int cl, uint32_t round_cap,
                                                              uint32_t* __restrict__ cursor, uint32_t* __restrict__ entries) {
     extern __shared__ __attribute__((aligned(16))) uint32_t sh[];
     const uint32_t nf = 1u << cl;
@@ -226,10 +264,9 @@ __global__ __launch_bounds__(FS_THREADS) void k_fine_scatter(const uint2* __rest
     uint32_t* cnt = sh + 2 * nf;     // [nf]  counts of this round
     uint32_t* stage = sh + 3 * nf;   // [FS_ROUND]
     __shared__ uint32_t wave_tot[FS_THREADS / 64];
-    const uint32_t k = blockIdx.x / S, s = blockIdx.x % S;
-    uint32_t lo, hi;
-    slice_range(coarse_off, k, s, S, lo, hi);
-    if (lo >= hi) return;
+    uint32_t k, lo, hi;
+    bool multi;
+    if (!slice_range(coarse_off, slice_map, nslices, blockIdx.x, k, lo, hi, multi)) return;
     uint32_t* cur = cursor + ((size_t)k << cl);
     uint32_t* dst = entries;
     const uint32_t per_thr_bins = (nf + FS_THREADS - 1) / FS_THREADS;
@@ -349,16 +386,17 @@ int msm_sort_lds(MsmEngine& E, const void* d_scalars, uint32_t npts, int sbits) 
         hipLaunchKernelGGL(k_coarse_scatter<8>, dim3(nblk), dim3(SORT_THREADS), lds, st, sc, npts, g, coarse_count, E.inter.as<uint2>());
     else
         hipLaunchKernelGGL(k_coarse_scatter<1>, dim3(nblk), dim3(SORT_THREADS), lds, st, sc, npts, g, coarse_count, E.inter.as<uint2>());
-    // slices per coarse bin from the mean bin size (no host sync); a block loops over whatever its slice holds
-    uint64_t mean = max_entries / g.NC + 1;
-    uint32_t S = (uint32_t)((4 * mean + 65535) / 65536);
-    if (S < 1) S = 1;
-    if (S > 4096) S = 4096;
-    E.sort_slices = S;
+    // work list of the fine passes (device-built, no host sync)
+    const uint32_t max_slices = (uint32_t)(max_entries / SLICE) + g.NC + 1;
+    BLZ_TRY(E.slice_map.reserve(((size_t)max_slices + 2) * 8));
+    uint2* slice_map = E.slice_map.as<uint2>() + 1;             // element 0 holds the slice count
+    uint32_t* nslices = E.slice_map.as<uint32_t>();
+    hipLaunchKernelGGL(k_slice_map, dim3(1), dim3(1024), 0, st, coarse_off, g.NC, slice_map, nslices);
+    E.sort_slices = max_slices;
     E.sort_cl = g.cl;
     E.sort_nc = g.NC;
-    hipLaunchKernelGGL(k_fine_count, dim3(g.NC * S), dim3(FINE_THREADS), (size_t)4 << g.cl, st, E.inter.as<uint2>(), coarse_off,
-                       g.cl, S, E.count.as<uint32_t>());
+    hipLaunchKernelGGL(k_fine_count, dim3(max_slices), dim3(FINE_THREADS), (size_t)4 << g.cl, st, E.inter.as<uint2>(), coarse_off,
+                       slice_map, nslices, g.cl, E.count.as<uint32_t>());
     BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
     return BLZ_OK;
 }
@@ -377,8 +415,9 @@ int msm_sort_lds_scatter(MsmEngine& E) {
     if (round_cap > (uint32_t)FS_ROUND) round_cap = FS_ROUND;
     round_cap &= ~1023u;
     const size_t lds = ((size_t)3 << E.sort_cl) * 4 + (size_t)round_cap * 4;
-    hipLaunchKernelGGL(k_fine_scatter, dim3(E.sort_nc * E.sort_slices), dim3(FS_THREADS), lds, st, E.inter.as<uint2>(), coarse_off,
-                       E.sort_cl, E.sort_slices, round_cap, E.count.as<uint32_t>(), E.entries.as<uint32_t>());
+    hipLaunchKernelGGL(k_fine_scatter, dim3(E.sort_slices), dim3(FS_THREADS), lds, st, E.inter.as<uint2>(), coarse_off,
+                       E.slice_map.as<uint2>() + 1, E.slice_map.as<uint32_t>(), E.sort_cl, round_cap, E.count.as<uint32_t>(),
+                       E.entries.as<uint32_t>());
     BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
     return BLZ_OK;
 }
