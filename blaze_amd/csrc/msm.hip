@@ -192,36 +192,31 @@ __global__ __launch_bounds__(256) void k_scan_final(uint32_t* __restrict__ count
     }
 }
 
-__global__ __launch_bounds__(256) void k_fill_units(const uint32_t* __restrict__ unit_off, uint64_t G,
-                                                    uint32_t* __restrict__ unit_bucket) {
-    uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (g >= G) return;
-    uint32_t u0 = unit_off[g], u1 = unit_off[g + 1];
-    for (uint32_t u = u0; u < u1; ++u) unit_bucket[u] = (uint32_t)g;
-}
-
 // ------------------------------------------------------------------------------------------------
 // Units ordered by run length (descending), so the 64 lanes of a wave walk runs of equal length:
 // with uniform scalars the runs are Poisson (mean n/2^(c-1)), and bucket order costs ~30% of the
-// lanes to divergence.  Counting sort over <= 1025 length bins, LDS-privatised.
+// lanes to divergence.  Counting sort over <= 1025 length bins, LDS-privatised; both kernels walk the
+// buckets in order (coalesced reads of off / unit_off), one lane per bucket.
 // ------------------------------------------------------------------------------------------------
 constexpr int MAX_L = 1024;
-__device__ __forceinline__ uint32_t unit_len(const uint32_t* off, const uint32_t* unit_off, const uint32_t* unit_bucket,
-                                             uint32_t u, uint32_t L) {
-    uint32_t g = unit_bucket[u];
-    uint32_t k = u - unit_off[g];
-    uint32_t rem = off[g + 1] - off[g] - k * L;
-    return rem > L ? L : rem;
-}
 
-__global__ __launch_bounds__(256) void k_unit_len_hist(const uint32_t* __restrict__ off, const uint32_t* __restrict__ unit_off,
-                                                       const uint32_t* __restrict__ unit_bucket, uint32_t U, uint32_t L,
-                                                       uint32_t* __restrict__ hist) {
+// unit -> bucket map + histogram of unit lengths
+__global__ __launch_bounds__(256) void k_fill_units(const uint32_t* __restrict__ off, const uint32_t* __restrict__ unit_off,
+                                                    uint64_t G, uint32_t L, uint32_t* __restrict__ unit_bucket,
+                                                    uint32_t* __restrict__ hist) {
     __shared__ uint32_t sh[MAX_L + 1];
     for (uint32_t i = threadIdx.x; i <= L; i += 256) sh[i] = 0;
     __syncthreads();
-    uint32_t u = blockIdx.x * 256u + threadIdx.x;
-    if (u < U) atomicAdd(&sh[unit_len(off, unit_off, unit_bucket, u, L)], 1u);
+    uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g < G) {
+        uint32_t u0 = unit_off[g], u1 = unit_off[g + 1];
+        uint32_t cnt = off[g + 1] - off[g];
+        for (uint32_t u = u0; u < u1; ++u) {
+            unit_bucket[u] = (uint32_t)g;
+            uint32_t rem = cnt - (u - u0) * L;
+            atomicAdd(&sh[rem > L ? L : rem], 1u);
+        }
+    }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i <= L; i += 256)
         if (sh[i]) atomicAdd(&hist[i], sh[i]);
@@ -239,23 +234,35 @@ __global__ __launch_bounds__(256) void k_unit_len_scan(const uint32_t* __restric
 }
 
 __global__ __launch_bounds__(256) void k_unit_order(const uint32_t* __restrict__ off, const uint32_t* __restrict__ unit_off,
-                                                    const uint32_t* __restrict__ unit_bucket, uint32_t U, uint32_t L,
-                                                    uint32_t* __restrict__ cursor, uint32_t* __restrict__ unit_order) {
+                                                    uint64_t G, uint32_t L, uint32_t* __restrict__ cursor,
+                                                    uint32_t* __restrict__ unit_order) {
     __shared__ uint32_t sh_cnt[MAX_L + 1];
     __shared__ uint32_t sh_base[MAX_L + 1];
     for (uint32_t i = threadIdx.x; i <= L; i += 256) sh_cnt[i] = 0;
     __syncthreads();
-    uint32_t u = blockIdx.x * 256u + threadIdx.x;
-    uint32_t len = 0, rank = 0;
-    if (u < U) {
-        len = unit_len(off, unit_off, unit_bucket, u, L);
-        rank = atomicAdd(&sh_cnt[len], 1u);
+    uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t u0 = 0, u1 = 0, cnt = 0;
+    if (g < G) {
+        u0 = unit_off[g];
+        u1 = unit_off[g + 1];
+        cnt = off[g + 1] - off[g];
+        for (uint32_t u = u0; u < u1; ++u) {
+            uint32_t rem = cnt - (u - u0) * L;
+            atomicAdd(&sh_cnt[rem > L ? L : rem], 1u);
+        }
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i <= L; i += 256)
-        if (sh_cnt[i]) sh_base[i] = atomicAdd(&cursor[i], sh_cnt[i]);
+    for (uint32_t i = threadIdx.x; i <= L; i += 256) {
+        uint32_t v = sh_cnt[i];
+        sh_base[i] = v ? atomicAdd(&cursor[i], v) : 0u;
+        sh_cnt[i] = 0;
+    }
     __syncthreads();
-    if (u < U) unit_order[sh_base[len] + rank] = u;
+    for (uint32_t u = u0; u < u1; ++u) {
+        uint32_t rem = cnt - (u - u0) * L;
+        uint32_t len = rem > L ? L : rem;
+        unit_order[sh_base[len] + atomicAdd(&sh_cnt[len], 1u)] = u;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -284,14 +291,12 @@ int launch_fill_units(MsmEngine& E, uint32_t U) {
     uint32_t* hist = E.lenhist.as<uint32_t>();
     uint32_t* cursor = hist + (MAX_L + 1);
     BLZ_HIP(hipMemsetAsync(hist, 0, 2 * (MAX_L + 1) * 4, st), BLZ_ERR_UNKNOWN);
-    hipLaunchKernelGGL(k_fill_units, dim3((uint32_t)((G + 255) / 256)), dim3(256), 0, st, E.unit_off.as<uint32_t>(), G,
-                       E.unit_bucket.as<uint32_t>());
-    dim3 gu((U + 255) / 256), b(256);
-    hipLaunchKernelGGL(k_unit_len_hist, gu, b, 0, st, E.off.as<uint32_t>(), E.unit_off.as<uint32_t>(),
-                       E.unit_bucket.as<uint32_t>(), U, L, hist);
+    dim3 gg((uint32_t)((G + 255) / 256)), b(256);
+    hipLaunchKernelGGL(k_fill_units, gg, b, 0, st, E.off.as<uint32_t>(), E.unit_off.as<uint32_t>(), G, L,
+                       E.unit_bucket.as<uint32_t>(), hist);
     hipLaunchKernelGGL(k_unit_len_scan, dim3(1), b, 0, st, hist, L, cursor);
-    hipLaunchKernelGGL(k_unit_order, gu, b, 0, st, E.off.as<uint32_t>(), E.unit_off.as<uint32_t>(),
-                       E.unit_bucket.as<uint32_t>(), U, L, cursor, E.unit_order.as<uint32_t>());
+    hipLaunchKernelGGL(k_unit_order, gg, b, 0, st, E.off.as<uint32_t>(), E.unit_off.as<uint32_t>(), G, L, cursor,
+                       E.unit_order.as<uint32_t>());
     BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
     return BLZ_OK;
 }
