@@ -315,3 +315,41 @@ def test_combine_partials_general_projective(gpu, orc, curve):
     many = enc(P2, 1) * 130                              # more than one 64-lane round
     assert cl.combine_partials(many, 130) == pyref.enc_result(curve, pyref.mul(curve, P2, 130))
     cl.close()
+
+
+def test_randomised_small_cases(gpu, orc):
+    """Seeded random mix of curve / pf / n / scalar patterns (dense, sparse, tiny, r-1, repeated
+    points), each against the oracle's Pippenger: exercises window plans, empty buckets, zero digits,
+    negative digits at every window and the run-splitting threshold."""
+    import random
+
+    rng = random.Random(20261001)
+    clients = {}
+    for case in range(36):
+        curve = rng.choice(CURVES)
+        pf = rng.choice([1, 1, 8])
+        n = rng.choice([1, 2, 3, 7, 64, 100, 257, 511, 1000, 2500])
+        r = pyref.CURVES[curve]["r"]
+        pts, sc, _ = orc.input_generator(curve, n, pf, 9000 + case)
+        sc = bytearray(sc)
+        pattern = rng.choice(["dense", "sparse", "tiny", "rminus", "same"])
+        for i in range(n):
+            if pattern == "sparse" and rng.random() < 0.7:
+                v = 0
+            elif pattern == "tiny":
+                v = rng.randrange(0, 5)
+            elif pattern == "rminus":
+                v = r - 1 - rng.randrange(0, 3)
+            elif pattern == "same":
+                v = (1 << 200) + 12345
+            else:
+                continue
+            sc[32 * i: 32 * i + 32] = v.to_bytes(32, "little")
+        key = (curve, pf)
+        if key not in clients:
+            clients[key] = msm_client(curve, pf)
+        got = run_msm(clients[key], pts, bytes(sc), n)
+        exp = orc.msm_pippenger(curve, pts, bytes(sc), n, pf, threads=8)
+        assert got == exp, f"case {case}: {curve} pf={pf} n={n} {pattern}"
+    for c in clients.values():
+        c.close()
