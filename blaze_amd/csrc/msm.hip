@@ -25,10 +25,20 @@ size_t fq_bytes(int curve) { return curve == BLZ_BN254 ? 32 : 48; }
 // ------------------------------------------------------------------------------------------------
 // plan
 // ------------------------------------------------------------------------------------------------
-MsmPlan make_plan(uint32_t npts, int sbits, int force_c) {
+// Window choice by a cost model fitted to MI355X measurements (tools/sweep_c.py, 2^16..2^26 points):
+//   0.18 ns per entry (digit sort + one mixed add), 0.71 ns per occupied bucket (two full adds in the
+//   bucket reduce, unit bookkeeping), 0.05 ns per empty bucket.
+// `ebits` is the expected significant width of the scalars (bit length of r: 255 / 253 / 254; 32 for a
+// pf = 8 chunk).  It only steers the choice - W always covers sbits + 1 bits, so scalars above 2^ebits
+// are still summed correctly - but it matters: the top window holds ebits - (W-1) c real bits, and when
+// that is 0..3 bits every entry of the window lands in 1..8 buckets (c = 17 on 255-bit scalars: a
+// carry-only window with n/2 entries in ONE bucket), which the run-splitting units and the slice sort
+// handle correctly but at a measured 0.1 - 0.4 ns per entry extra.
+MsmPlan make_plan(uint32_t npts, int sbits, int ebits, int force_c) {
     MsmPlan best;
     double best_cost = 1e300;
-    const double madd = 10.0, padd = 14.0, sort_cost = 1.5;
+    if (ebits <= 0 || ebits > sbits) ebits = sbits;
+    const double t_entry = 0.181, t_bucket = 0.71, t_empty = 0.05, t_hot = 0.15;
     for (int c = 3; c <= 23; ++c) {
         if (force_c > 0 && c != force_c) continue;
         int W = (sbits + 1 + c - 1) / c;
@@ -36,13 +46,34 @@ MsmPlan make_plan(uint32_t npts, int sbits, int force_c) {
         uint64_t G = (uint64_t)W * Bw;
         if (G > (1ull << 26)) continue;                       // workspace bound (partials: 192 B each)
         if ((uint64_t)npts * W >= (1ull << 32)) continue;      // entries are indexed with u32
-        double cost = (double)W * ((double)npts * (madd + sort_cost) + (double)Bw * 2.0 * padd);
+        double cost = 0;
+        for (int w = 0; w < W; ++w) {
+            int t = ebits - w * c;                              // real scalar bits in this window
+            if (t > c) t = c;
+            double entries, active;
+            if (t >= c) { entries = npts; active = (double)Bw; }
+            else if (t > 0) { entries = npts; active = (double)(1ull << t) + 1; if (active > (double)Bw) active = (double)Bw; }
+            else if (t == 0) { entries = 0.5 * npts; active = 1; }   // carry of a full window below
+            else { entries = 0; active = 0; }
+            if (active > entries) active = entries;
+            cost += entries * t_entry + active * t_bucket + ((double)Bw - active) * t_empty;
+            if (active > 0 && entries / active > 8192.0) cost += entries * t_hot;
+        }
         if (cost < best_cost) {
             best_cost = cost;
             best.npts = npts; best.sbits = sbits; best.c = c; best.W = W; best.Bw = (uint32_t)Bw; best.G = G;
         }
     }
-    best.L = 256;
+    // Unit length: a unit is one lane's sequential chain (L mixed adds of ~15 us each when the SIMD has
+    // little else to run), so on small inputs long units ARE the runtime: 2^18 points, c = 13 spent
+    // 3.7 of 7.2 ms waiting for the 256-long units of the short top window.  Keep the longest chain
+    // below about half of the throughput-bound time of the whole accumulation.
+    {
+        double chain = (double)npts * best.W * 5.5e-6;
+        uint32_t L = 16;
+        while (L < 256 && 2.0 * L <= chain) L <<= 1;
+        best.L = L;
+    }
     return best;
 }
 
@@ -199,25 +230,35 @@ __global__ __launch_bounds__(256) void k_scan_final(uint32_t* __restrict__ count
 // buckets in order (coalesced reads of off / unit_off), one lane per bucket.
 // ------------------------------------------------------------------------------------------------
 constexpr int MAX_L = 1024;
+constexpr uint32_t UNITS_INLINE = 8;   // buckets with more units than this are filled by the whole block
 
 // unit -> bucket map + histogram of unit lengths
 __global__ __launch_bounds__(256) void k_fill_units(const uint32_t* __restrict__ off, const uint32_t* __restrict__ unit_off,
                                                     uint64_t G, uint32_t L, uint32_t* __restrict__ unit_bucket,
                                                     uint32_t* __restrict__ hist) {
     __shared__ uint32_t sh[MAX_L + 1];
+    __shared__ uint32_t big[256], nbig;
     for (uint32_t i = threadIdx.x; i <= L; i += 256) sh[i] = 0;
+    if (threadIdx.x == 0) nbig = 0;
     __syncthreads();
-    uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    // a bucket of cnt entries has cnt / L full units and one unit of cnt % L entries
+    const uint64_t g0 = (uint64_t)blockIdx.x * 256;
+    uint64_t g = g0 + threadIdx.x;
     if (g < G) {
         uint32_t u0 = unit_off[g], u1 = unit_off[g + 1];
         uint32_t cnt = off[g + 1] - off[g];
-        for (uint32_t u = u0; u < u1; ++u) {
-            unit_bucket[u] = (uint32_t)g;
-            uint32_t rem = cnt - (u - u0) * L;
-            atomicAdd(&sh[rem > L ? L : rem], 1u);
-        }
+        uint32_t nfull = cnt / L, rem = cnt - nfull * L;
+        if (nfull) atomicAdd(&sh[L], nfull);
+        if (rem) atomicAdd(&sh[rem], 1u);
+        if (u1 - u0 > UNITS_INLINE) big[atomicAdd(&nbig, 1u)] = threadIdx.x;   // hot bucket: the block fills it together
+        else for (uint32_t u = u0; u < u1; ++u) unit_bucket[u] = (uint32_t)g;
     }
     __syncthreads();
+    for (uint32_t b = 0; b < nbig; ++b) {
+        uint64_t gb = g0 + big[b];
+        uint32_t u0 = unit_off[gb], u1 = unit_off[gb + 1];
+        for (uint32_t u = u0 + threadIdx.x; u < u1; u += 256) unit_bucket[u] = (uint32_t)gb;
+    }
     for (uint32_t i = threadIdx.x; i <= L; i += 256)
         if (sh[i]) atomicAdd(&hist[i], sh[i]);
 }
@@ -238,18 +279,20 @@ __global__ __launch_bounds__(256) void k_unit_order(const uint32_t* __restrict__
                                                     uint32_t* __restrict__ unit_order) {
     __shared__ uint32_t sh_cnt[MAX_L + 1];
     __shared__ uint32_t sh_base[MAX_L + 1];
+    __shared__ uint32_t big[256], big_pos[256], nbig;
     for (uint32_t i = threadIdx.x; i <= L; i += 256) sh_cnt[i] = 0;
+    if (threadIdx.x == 0) nbig = 0;
     __syncthreads();
-    uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    uint32_t u0 = 0, u1 = 0, cnt = 0;
+    const uint64_t g0 = (uint64_t)blockIdx.x * 256;
+    uint64_t g = g0 + threadIdx.x;
+    uint32_t u0 = 0, nfull = 0, rem = 0;
     if (g < G) {
         u0 = unit_off[g];
-        u1 = unit_off[g + 1];
-        cnt = off[g + 1] - off[g];
-        for (uint32_t u = u0; u < u1; ++u) {
-            uint32_t rem = cnt - (u - u0) * L;
-            atomicAdd(&sh_cnt[rem > L ? L : rem], 1u);
-        }
+        uint32_t cnt = off[g + 1] - off[g];
+        nfull = cnt / L;
+        rem = cnt - nfull * L;
+        if (nfull) atomicAdd(&sh_cnt[L], nfull);
+        if (rem) atomicAdd(&sh_cnt[rem], 1u);
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i <= L; i += 256) {
@@ -258,10 +301,23 @@ __global__ __launch_bounds__(256) void k_unit_order(const uint32_t* __restrict__
         sh_cnt[i] = 0;
     }
     __syncthreads();
-    for (uint32_t u = u0; u < u1; ++u) {
-        uint32_t rem = cnt - (u - u0) * L;
-        uint32_t len = rem > L ? L : rem;
-        unit_order[sh_base[len] + atomicAdd(&sh_cnt[len], 1u)] = u;
+    if (nfull) {
+        uint32_t pos = sh_base[L] + atomicAdd(&sh_cnt[L], nfull);
+        if (nfull > UNITS_INLINE) {
+            uint32_t q = atomicAdd(&nbig, 1u);
+            big[q] = threadIdx.x;
+            big_pos[q] = pos;
+        } else {
+            for (uint32_t k = 0; k < nfull; ++k) unit_order[pos + k] = u0 + k;
+        }
+    }
+    if (rem) unit_order[sh_base[rem] + atomicAdd(&sh_cnt[rem], 1u)] = u0 + nfull;
+    __syncthreads();
+    for (uint32_t b = 0; b < nbig; ++b) {
+        uint64_t gb = g0 + big[b];
+        uint32_t ub = unit_off[gb];
+        uint32_t nf = (off[gb + 1] - off[gb]) / L, pos = big_pos[b];
+        for (uint32_t k = threadIdx.x; k < nf; k += 256) unit_order[pos + k] = ub + k;
     }
 }
 
@@ -348,7 +404,8 @@ int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int 
         timings_pending = true;
         return BLZ_OK;
     }
-    MsmPlan P = make_plan(npts, sbits, msm_env_int("BLAZE_MSM_C", 0));
+    static const int r_bits[3] = {253, 255, 254};  // bit length of the scalar field modulus (BLS12-377 / 381 / BN254)
+    MsmPlan P = make_plan(npts, sbits, sbits == 256 ? r_bits[curve] : sbits, msm_env_int("BLAZE_MSM_C", 0));
     if (P.c == 0) return fail(BLZ_ERR_INVALID_PARAM, "no window plan for npts=%u sbits=%d", npts, sbits);
     P.L = (uint32_t)msm_env_int("BLAZE_MSM_L", (int)P.L);
     if (P.L < 1) P.L = 1;

@@ -13,7 +13,7 @@ struct MsmPlan {
     uint64_t G = 0;      // W * Bw
     uint32_t L = 0;      // max run length handled by one accumulate unit
 };
-MsmPlan make_plan(uint32_t npts, int sbits, int force_c);
+MsmPlan make_plan(uint32_t npts, int sbits, int ebits, int force_c);
 
 struct MsmEngine {
     int device = 0;

@@ -347,7 +347,12 @@ int run_tail_t(MsmEngine& E, const void* d_pts, uint32_t U, uint32_t maxcount) {
     // ---- phase 2
     // level 0 is throughput-bound (2 adds per bucket): long segments; the upper levels have few
     // lanes and are latency-bound on their sequential chain: short segments, more levels
-    const uint32_t SEG0 = (uint32_t)msm_env_int("BLAZE_MSM_SEG", 32);
+    // (a small bucket space cannot fill the chip with 32-bucket segments: 17 x 2^15 buckets give 272
+    // waves for 1024 SIMDs and the level costs 32 sequential steps; shorter segments put a wave on
+    // every SIMD and the extra segment sums are absorbed by the upper levels)
+    uint32_t seg0_auto = 32;
+    while (seg0_auto > 8 && G / seg0_auto < 65536) seg0_auto >>= 1;
+    const uint32_t SEG0 = (uint32_t)msm_env_int("BLAZE_MSM_SEG", (int)seg0_auto);
     const uint32_t SEGU = (uint32_t)msm_env_int("BLAZE_MSM_SEG_UPPER", 8);
     uint32_t M = P.Bw;
     int level = 0, shift = 0;

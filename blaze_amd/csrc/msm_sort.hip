@@ -252,6 +252,7 @@ __global__ __launch_bounds__(FINE_THREADS) void k_fine_count(const uint2* __rest
 constexpr int FS_THREADS = 1024;
 constexpr int FS_PER_THREAD = 32;
 constexpr int FS_ROUND = FS_THREADS * FS_PER_THREAD;  // 32768 entries = 128 KiB of staging
+constexpr uint32_t FS_BIG_RUN = 128;
 
 __global__ __launch_bounds__(FS_THREADS) void k_fine_scatter(const uint2* __restrict__ inter, const uint32_t* __restrict__ coarse_off,
                                                              const uint2* __restrict__ slice_map, const uint32_t* __restrict__ nslices,
@@ -264,6 +265,8 @@ __global__ __launch_bounds__(FS_THREADS) void k_fine_scatter(const uint2* __rest
     uint32_t* cnt = sh + 2 * nf;     // [nf]  counts of this round
     uint32_t* stage = sh + 3 * nf;   // [FS_ROUND]
     __shared__ uint32_t wave_tot[FS_THREADS / 64];
+    __shared__ uint32_t big[FS_ROUND / FS_BIG_RUN];  // runs longer than FS_BIG_RUN in one round
+    __shared__ uint32_t nbig;
     uint32_t k, lo, hi;
     bool multi;
     if (!slice_range(coarse_off, slice_map, nslices, blockIdx.x, k, lo, hi, multi)) return;
@@ -325,9 +328,23 @@ __global__ __launch_bounds__(FS_THREADS) void k_fine_scatter(const uint2* __rest
         __syncthreads();
         // one lane copies one bucket's run (a slot-major copy with a binary search for the bucket
         // measured slower: 27.7 vs 23.5 ms for the whole sort)
+        // ... except for long runs (a hot bucket: short top window, repeated scalars), which would
+        // serialise the block behind one lane: those are queued and copied a wave per run
+        if (threadIdx.x == 0) nbig = 0;
+        __syncthreads();
         for (uint32_t f = threadIdx.x; f < nf; f += FS_THREADS) {
             uint32_t n = cnt[f], src = hist[f], g0 = gbase[f];
+            if (n > FS_BIG_RUN) {
+                big[atomicAdd(&nbig, 1u)] = f;
+                continue;
+            }
             for (uint32_t q = 0; q < n; ++q) dst[g0 + q] = stage[src + q];
+        }
+        __syncthreads();
+        for (uint32_t b = threadIdx.x >> 6; b < nbig; b += FS_THREADS / 64) {
+            uint32_t f = big[b];
+            uint32_t n = cnt[f], src = hist[f], g0 = gbase[f];
+            for (uint32_t q = threadIdx.x & 63u; q < n; q += 64) dst[g0 + q] = stage[src + q];
         }
         __syncthreads();
     }
@@ -406,11 +423,11 @@ int msm_sort_lds_scatter(MsmEngine& E) {
     uint32_t* coarse_off = E.coarse.as<uint32_t>() + E.sort_nc;
     static bool attr_done = false;
     if (!attr_done) {
-        BLZ_HIP(hipFuncSetAttribute((const void*)k_fine_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256), BLZ_ERR_UNKNOWN);
+        BLZ_HIP(hipFuncSetAttribute((const void*)k_fine_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024), BLZ_ERR_UNKNOWN);
         attr_done = true;
     }
     // staging entries per round: what is left of the LDS after the three per-bucket arrays
-    size_t budget = (size_t)158 * 1024 - ((size_t)3 << E.sort_cl) * 4;
+    size_t budget = (size_t)157 * 1024 - ((size_t)3 << E.sort_cl) * 4;
     uint32_t round_cap = (uint32_t)(budget / 4);
     if (round_cap > (uint32_t)FS_ROUND) round_cap = FS_ROUND;
     round_cap &= ~1023u;
