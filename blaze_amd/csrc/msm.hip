@@ -363,9 +363,16 @@ int MsmEngine::init(int device_id, int curve_id) {
     if (!ops_for(curve)) return fail(BLZ_ERR_INVALID_PARAM, "unknown curve %d", curve);
     BLZ_TRY(use_device(device));
     BLZ_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), BLZ_ERR_UNKNOWN);
-    for (auto& e : ev) BLZ_HIP(hipEventCreate(&e), BLZ_ERR_UNKNOWN);
+    BLZ_HIP(hipStreamCreateWithFlags(&tail_stream, hipStreamNonBlocking), BLZ_ERR_UNKNOWN);
+    BLZ_HIP(hipStreamCreateWithFlags(&aux_stream, hipStreamNonBlocking), BLZ_ERR_UNKNOWN);
+    for (auto& S : slots) {
+        for (auto& e : S.ev) BLZ_HIP(hipEventCreate(&e), BLZ_ERR_UNKNOWN);
+        BLZ_HIP(hipEventCreateWithFlags(&S.ev_l0, hipEventDisableTiming), BLZ_ERR_UNKNOWN);
+        BLZ_HIP(hipEventCreateWithFlags(&S.ev_done, hipEventDisableTiming), BLZ_ERR_UNKNOWN);
+        BLZ_HIP(hipHostMalloc((void**)&S.result_h, 256), BLZ_ERR_UNKNOWN);
+    }
     BLZ_HIP(hipHostMalloc((void**)&stats_h, 64), BLZ_ERR_UNKNOWN);
-    BLZ_HIP(hipHostMalloc((void**)&result_h, 256), BLZ_ERR_UNKNOWN);
+    BLZ_HIP(hipHostMalloc((void**)&combine_h, 256), BLZ_ERR_UNKNOWN);
     BLZ_TRY(stats.reserve(64));
     BLZ_TRY(result.reserve(256 * 64));
     return BLZ_OK;
@@ -375,15 +382,41 @@ void MsmEngine::destroy() {
     if (!stream) return;
     (void)hipSetDevice(device);
     (void)hipStreamSynchronize(stream);
-    for (DevBuf* b : {&count, &off, &unit_off, &unit_bucket, &entries, &partial, &unit_order, &lenhist, &coarse, &inter, &slice_map, &lvlA[0], &lvlA[1], &lvlC[0],
-                      &lvlC[1], &blocksums, &stats, &result})
+    (void)hipStreamSynchronize(tail_stream);
+    for (DevBuf* b : {&count, &off, &unit_off, &unit_bucket, &unit_order, &lenhist, &coarse, &inter, &slice_map, &entries,
+                      &partial, &blocksums, &stats, &result})
         b->release();
-    for (auto& e : ev)
-        if (e) (void)hipEventDestroy(e);
+    for (auto& S : slots) {
+        for (DevBuf* b : {&S.lvlA[0], &S.lvlA[1], &S.lvlC[0], &S.lvlC[1]}) b->release();
+        for (auto& e : S.ev)
+            if (e) (void)hipEventDestroy(e);
+        if (S.ev_l0) (void)hipEventDestroy(S.ev_l0);
+        if (S.ev_done) (void)hipEventDestroy(S.ev_done);
+        if (S.result_h) (void)hipHostFree(S.result_h);
+        S = MsmSlot();
+    }
     if (stats_h) (void)hipHostFree(stats_h);
-    if (result_h) (void)hipHostFree(result_h);
+    if (combine_h) (void)hipHostFree(combine_h);
+    stats_h = nullptr;
+    combine_h = nullptr;
     (void)hipStreamDestroy(stream);
-    stream = nullptr;
+    (void)hipStreamDestroy(tail_stream);
+    (void)hipStreamDestroy(aux_stream);
+    stream = tail_stream = aux_stream = nullptr;
+}
+
+bool MsmEngine::can_accept() const {
+    for (const auto& S : slots)
+        if (!S.busy) return true;
+    return false;
+}
+
+int MsmEngine::sync_all() {
+    BLZ_TRY(use_device(device));
+    BLZ_HIP(hipStreamSynchronize(stream), BLZ_ERR_UNKNOWN);
+    BLZ_HIP(hipStreamSynchronize(tail_stream), BLZ_ERR_UNKNOWN);
+    for (auto& S : slots) S.busy = false;
+    return BLZ_OK;
 }
 
 int MsmEngine::points_to_mont(const void* d_raw, void* d_mont, uint32_t npts) {
@@ -391,17 +424,27 @@ int MsmEngine::points_to_mont(const void* d_raw, void* d_mont, uint32_t npts) {
     return ops_for(curve)->points_to_mont(*this, d_raw, d_mont, npts);
 }
 
-int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int sbits) {
+int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int sbits, int* slot_out) {
     BLZ_TRY(use_device(device));
     const MsmCurveOps* ops = ops_for(curve);
     MsmEngine& E = *this;
     hipStream_t st = stream;
-    BLZ_HIP(hipEventRecord(ev[0], st), BLZ_ERR_UNKNOWN);
+    // slots are handed out round-robin, so results complete in submission order
+    int slot = (cur + 1) % MSM_QUEUE_DEPTH;
+    if (slots[slot].busy) slot = (slot + 1) % MSM_QUEUE_DEPTH;
+    if (slots[slot].busy) return fail(BLZ_ERR_INVALID_PARAM, "task queue full (%d tasks in flight)", MSM_QUEUE_DEPTH);
+    cur = slot;
+    MsmSlot& S = slots[slot];
+    if (slot_out) *slot_out = slot;
+    BLZ_HIP(hipEventRecord(S.ev[0], st), BLZ_ERR_UNKNOWN);
     if (npts == 0) {
         BLZ_TRY(ops->emit_infinity(E));
-        for (int i = 1; i <= 4; ++i) BLZ_HIP(hipEventRecord(ev[i], st), BLZ_ERR_UNKNOWN);
-        last_plan = MsmPlan();
-        timings_pending = true;
+        for (int i = 1; i <= 4; ++i) BLZ_HIP(hipEventRecord(S.ev[i], st), BLZ_ERR_UNKNOWN);
+        BLZ_HIP(hipMemcpyAsync(S.result_h, slot_result(slot), 3 * fq_bytes(curve), hipMemcpyDeviceToHost, st), BLZ_ERR_READ);
+        BLZ_HIP(hipEventRecord(S.ev_done, st), BLZ_ERR_UNKNOWN);
+        last_plan = S.plan = MsmPlan();
+        S.accum_timed = false;
+        S.busy = true;
         return BLZ_OK;
     }
     static const int r_bits[3] = {253, 255, 254};  // bit length of the scalar field modulus (BLS12-377 / 381 / BN254)
@@ -410,7 +453,7 @@ int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int 
     P.L = (uint32_t)msm_env_int("BLAZE_MSM_L", (int)P.L);
     if (P.L < 1) P.L = 1;
     if (P.L > (uint32_t)MAX_L) P.L = MAX_L;
-    last_plan = P;
+    last_plan = S.plan = P;
     const uint64_t G = P.G;
     const uint64_t max_entries = (uint64_t)npts * P.W;
     const uint64_t max_units = G + max_entries / P.L + 1;
@@ -455,30 +498,27 @@ int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int 
     if ((uint64_t)U > max_units) return fail(BLZ_ERR_UNKNOWN, "unit count %u exceeds bound", U);
     BLZ_LOG(2, "msm: units=%u max_bucket=%u entries=%u", U, maxcount, stats_h[2]);
     BLZ_TRY(ops->run_tail(E, d_pts, U, maxcount));
-    timings_pending = true;
+    S.busy = true;
     return BLZ_OK;
 }
 
-int MsmEngine::finish(uint8_t* out) {
+int MsmEngine::finish(int slot, uint8_t* out) {
     BLZ_TRY(use_device(device));
-    size_t rs = 3 * fq_bytes(curve);
-    BLZ_HIP(hipMemcpyAsync(result_h, result.p, rs, hipMemcpyDeviceToHost, stream), BLZ_ERR_READ);
-    BLZ_HIP(hipStreamSynchronize(stream), BLZ_ERR_UNKNOWN);
-    memcpy(out, result_h, rs);
-    if (timings_pending) {
-        float t = 0;
-        // ev0 start, ev1 sort done, ev2 accumulate done, ev3 reduce done, ev4 finish done
-        (void)hipEventElapsedTime(&t, ev[0], ev[4]); last_ms[0] = t;
-        last_ms[1] = 0;
-        if (accum_timed && last_plan.c) { (void)hipEventElapsedTime(&t, ev[5], ev[6]); last_ms[1] = t; }
-        (void)hipEventElapsedTime(&t, ev[0], ev[1]); last_ms[2] = t;
-        (void)hipEventElapsedTime(&t, ev[1], ev[2]); last_ms[3] = t;
-        (void)hipEventElapsedTime(&t, ev[2], ev[3]); last_ms[4] = t;
-        (void)hipEventElapsedTime(&t, ev[3], ev[4]); last_ms[5] = t;
-        last_ms[6] = (float)last_plan.c;
-        last_ms[7] = (float)last_plan.W;
-        timings_pending = false;
-    }
+    if (slot < 0 || slot >= MSM_QUEUE_DEPTH || !slots[slot].busy) return fail(BLZ_ERR_INVALID_PARAM, "no task in slot %d", slot);
+    MsmSlot& S = slots[slot];
+    BLZ_HIP(hipEventSynchronize(S.ev_done), BLZ_ERR_UNKNOWN);
+    S.busy = false;
+    memcpy(out, S.result_h, 3 * fq_bytes(curve));
+    float t = 0;
+    (void)hipEventElapsedTime(&t, S.ev[0], S.ev[4]); last_ms[0] = t;
+    last_ms[1] = 0;
+    if (S.accum_timed && S.plan.c) { (void)hipEventElapsedTime(&t, S.ev[5], S.ev[6]); last_ms[1] = t; }
+    (void)hipEventElapsedTime(&t, S.ev[0], S.ev[1]); last_ms[2] = t;
+    (void)hipEventElapsedTime(&t, S.ev[1], S.ev[2]); last_ms[3] = t;
+    (void)hipEventElapsedTime(&t, S.ev[2], S.ev[3]); last_ms[4] = t;
+    (void)hipEventElapsedTime(&t, S.ev[3], S.ev[4]); last_ms[5] = t;
+    last_ms[6] = (float)S.plan.c;
+    last_ms[7] = (float)S.plan.W;
     return BLZ_OK;
 }
 

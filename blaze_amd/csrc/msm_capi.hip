@@ -19,7 +19,8 @@ struct blz_msm {
     // task / result queues (msm_hw_code.rs:19-25)
     bool armed = false;        // a task was pushed and waits for its data
     bool data_ready = false;   // set_data delivered a complete input
-    bool in_flight = false;    // pipeline enqueued, result not collected yet
+    struct Pending { int slot; uint32_t label; };
+    std::deque<Pending> in_flight;   // pipelines enqueued, results not collected yet (<= MSM_QUEUE_DEPTH)
     uint32_t task_label = 0;
     struct Res { std::vector<uint8_t> bytes; uint32_t label; };
     std::deque<Res> results;
@@ -59,13 +60,15 @@ int arena_points_mont(blz_msm* h, uint64_t pos, uint32_t npts, const void** out)
 
 int launch_if_ready(blz_msm* h) {
     if (!(h->armed && h->data_ready)) return BLZ_OK;
-    if (h->in_flight) return fail(BLZ_ERR_INVALID_PARAM, "a task is already in flight; call wait_result first");
+    if (!h->eng.can_accept())
+        return fail(BLZ_ERR_INVALID_PARAM, "task queue full (%d in flight); call wait_result first", MSM_QUEUE_DEPTH);
     uint32_t npts = h->staged_n * h->pf;
     int sbits = h->pf == 1 ? 256 : 32;
-    BLZ_TRY(h->eng.run(h->d_points_mont, h->d_scalars, npts, sbits));
+    int slot = 0;
+    BLZ_TRY(h->eng.run(h->d_points_mont, h->d_scalars, npts, sbits, &slot));
     h->armed = false;
     h->data_ready = false;
-    h->in_flight = true;
+    h->in_flight.push_back({slot, h->task_label});
     return BLZ_OK;
 }
 
@@ -82,7 +85,8 @@ int stage_common(blz_msm* h, bool have_points, const void* points, size_t points
         return fail(BLZ_ERR_INVALID_PARAM, "points length %zu != nof_elements %u * precompute_factor %u * %zu", points_len,
                     n, h->pf, point_size(h));
     if ((uint64_t)n * h->pf >= (1ull << 31)) return fail(BLZ_ERR_INVALID_PARAM, "too many points");
-    if (h->in_flight) return fail(BLZ_ERR_INVALID_PARAM, "previous task still in flight; call wait_result first");
+    if (!h->eng.can_accept())
+        return fail(BLZ_ERR_INVALID_PARAM, "task queue full (%d in flight); call wait_result first", MSM_QUEUE_DEPTH);
     hipStream_t st = h->eng.stream;
     uint32_t npts = n * h->pf;
 
@@ -215,15 +219,17 @@ int blz_msm_set_data_device(blz_msm* h, const void* d_points, size_t points_len,
 
 int blz_msm_wait_result(blz_msm* h) {
     if (!h) return fail(BLZ_ERR_INVALID_PARAM, "null handle");
-    if (!h->in_flight) {
+    if (h->in_flight.empty()) {
         if (!h->results.empty()) return BLZ_OK;  // RESULT_VALID already set
         return fail(BLZ_ERR_INVALID_PARAM, "wait_result with no task in flight (the reference would spin forever)");
     }
+    // tasks complete in submission order: wait for the oldest, move its bytes to the result queue
+    blz_msm::Pending p = h->in_flight.front();
+    h->in_flight.pop_front();
     blz_msm::Res r;
     r.bytes.resize(result_size(h));
-    r.label = h->task_label;
-    int rc = h->eng.finish(r.bytes.data());
-    h->in_flight = false;
+    r.label = p.label;
+    int rc = h->eng.finish(p.slot, r.bytes.data());
     if (rc != BLZ_OK) return rc;
     h->results.push_back(std::move(r));
     return BLZ_OK;
@@ -280,15 +286,16 @@ int blz_msm_nof_elements(blz_msm* h, uint32_t* out) {
 }
 int blz_msm_is_engine_ready(blz_msm* h, uint32_t* out) {
     if (!h || !out) return fail(BLZ_ERR_INVALID_PARAM, "null argument");
-    *out = h->in_flight ? 0u : 1u;
+    *out = h->eng.can_accept() ? 1u : 0u;
     return BLZ_OK;
 }
 
 int blz_msm_reset(blz_msm* h) {
     if (!h) return fail(BLZ_ERR_INVALID_PARAM, "null handle");
     BLZ_TRY(use_device(h->device));
-    BLZ_HIP(hipStreamSynchronize(h->eng.stream), BLZ_ERR_UNKNOWN);
-    h->armed = h->data_ready = h->in_flight = false;
+    BLZ_TRY(h->eng.sync_all());
+    h->armed = h->data_ready = false;
+    h->in_flight.clear();
     h->results.clear();
     h->staged_n = 0;
     return BLZ_OK;

@@ -15,31 +15,53 @@ struct MsmPlan {
 };
 MsmPlan make_plan(uint32_t npts, int sbits, int ebits, int force_c);
 
+// Task queue (msm_hw_code.rs:19-25: the device has a task queue and a result queue): up to
+// MSM_QUEUE_DEPTH tasks may be in flight.  The throughput-bound part of a task (sort, bucket
+// accumulation, first bucket-reduce level) runs on `stream`; its latency-bound tail (upper reduce
+// levels, Horner, inversion: a few lanes for ~3 ms) runs on `tail_stream`, so it overlaps the next
+// task's sort and accumulation instead of idling the chip.  Everything the tail touches is per slot.
+constexpr int MSM_QUEUE_DEPTH = 2;
+struct MsmSlot {
+    // 0 start, 1 sort done, 2 accumulate done, 5..6 the accumulate kernel alone (stream);
+    // 3 reduce done, 4 finish done (tail_stream)
+    hipEvent_t ev[8] = {};
+    hipEvent_t ev_l0 = nullptr;    // stream: level-0 reduce written -> tail may start
+    hipEvent_t ev_done = nullptr;  // tail_stream: result bytes are in result_h
+    DevBuf lvlA[2], lvlC[2];
+    uint8_t* result_h = nullptr;   // pinned result bytes
+    MsmPlan plan;
+    bool accum_timed = false;
+    bool busy = false;             // enqueued, result not collected yet
+};
+
 struct MsmEngine {
     int device = 0;
     int curve = 0;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev[8] = {};
-    DevBuf count, off, unit_off, unit_bucket, unit_order, lenhist, coarse, inter, slice_map, entries, partial, lvlA[2], lvlC[2], blocksums, stats, result;
+    hipStream_t stream = nullptr, tail_stream = nullptr, aux_stream = nullptr;  // aux: combine_partials
+    MsmSlot slots[MSM_QUEUE_DEPTH];
+    int cur = 0;                   // slot of the task being enqueued
+    DevBuf count, off, unit_off, unit_bucket, unit_order, lenhist, coarse, inter, slice_map, entries, partial, blocksums, stats, result;
     uint32_t* stats_h = nullptr;   // pinned: [0] total units, [1] max bucket count, [2] total entries
-    uint8_t* result_h = nullptr;   // pinned result bytes
+    uint8_t* combine_h = nullptr;  // pinned bytes of combine_partials
     MsmPlan last_plan;
     float last_ms[8] = {};
-    bool timings_pending = false;
-    bool accum_timed = false;
     uint32_t sort_slices = 1, sort_nc = 0;  // geometry of the last LDS sort (msm_sort.hip)
     int sort_cl = 0;
 
     int init(int device_id, int curve_id);
     void destroy();
+    // device result bytes of slot s / scratch of combine_partials inside `result`
+    uint32_t* slot_result(int s) { return result.as<uint32_t>() + (size_t)s * 64; }
+    bool can_accept() const;
     // raw wire-format points (x||y canonical LE) -> Montgomery AoS, npts points
     int points_to_mont(const void* d_raw, void* d_mont, uint32_t npts);
-    // enqueue the whole pipeline on `stream`; result bytes land in result.p (device) when done
-    int run(const void* d_points_mont, const void* d_scalars, uint32_t npts, int sbits);
-    // wait for the stream, copy the result out (result_size bytes), collect phase timings
-    int finish(uint8_t* out);
+    // enqueue the whole pipeline; *slot identifies the task for finish().  Fails when both slots are busy.
+    int run(const void* d_points_mont, const void* d_scalars, uint32_t npts, int sbits, int* slot);
+    // wait for task `slot`, copy the result out (result_size bytes), collect its phase timings
+    int finish(int slot, uint8_t* out);
     // add `count` partial results (host bytes) on the device, normalised output
     int combine_partials(const uint8_t* partials, size_t count, uint8_t* out);
+    int sync_all();
 };
 
 size_t fq_bytes(int curve);

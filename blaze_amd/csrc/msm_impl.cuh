@@ -309,7 +309,7 @@ int points_to_mont_t(MsmEngine& E, const void* d_raw, void* d_mont, uint32_t npt
 
 template <class F>
 int emit_infinity_t(MsmEngine& E) {
-    hipLaunchKernelGGL(k_emit_infinity<F>, dim3(1), dim3(64), 0, E.stream, E.result.as<uint32_t>());
+    hipLaunchKernelGGL(k_emit_infinity<F>, dim3(1), dim3(64), 0, E.stream, E.slot_result(E.cur));
     BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
     return BLZ_OK;
 }
@@ -318,21 +318,22 @@ int emit_infinity_t(MsmEngine& E) {
 template <class F>
 int run_tail_t(MsmEngine& E, const void* d_pts, uint32_t U, uint32_t maxcount) {
     hipStream_t st = E.stream;
+    MsmSlot& S = E.slots[E.cur];
     const MsmPlan& P = E.last_plan;
     const uint64_t G = P.G;
     BLZ_TRY(E.unit_bucket.reserve(((size_t)U + 1) * 4));
     BLZ_TRY(E.partial.reserve(((size_t)U + 1) * 16 * F::N));
-    BLZ_HIP(hipEventRecord(E.ev[1], st), BLZ_ERR_UNKNOWN);
+    BLZ_HIP(hipEventRecord(S.ev[1], st), BLZ_ERR_UNKNOWN);
 
     // ---- phase 1
-    E.accum_timed = U != 0;
+    S.accum_timed = U != 0;
     if (U) {
         BLZ_TRY(launch_fill_units(E, U));
-        BLZ_HIP(hipEventRecord(E.ev[5], st), BLZ_ERR_UNKNOWN);  // ev5..ev6 bracket the dominant kernel alone
+        BLZ_HIP(hipEventRecord(S.ev[5], st), BLZ_ERR_UNKNOWN);  // ev5..ev6 bracket the dominant kernel alone
         hipLaunchKernelGGL(k_accumulate<F>, dim3((U + 127) / 128), dim3(128), 0, st, (const uint32_t*)d_pts,
                            E.entries.as<uint32_t>(), E.off.as<uint32_t>(), E.unit_off.as<uint32_t>(),
                            E.unit_bucket.as<uint32_t>(), E.unit_order.as<uint32_t>(), U, P.L, E.partial.as<uint32_t>());
-        BLZ_HIP(hipEventRecord(E.ev[6], st), BLZ_ERR_UNKNOWN);
+        BLZ_HIP(hipEventRecord(S.ev[6], st), BLZ_ERR_UNKNOWN);
         uint32_t maxunits = (maxcount + P.L - 1) / P.L;
         uint64_t full_bound = (uint64_t)P.npts * P.W / P.L + 1;  // units of length L: at most entries / L
         if (full_bound > U) full_bound = U;
@@ -342,7 +343,7 @@ int run_tail_t(MsmEngine& E, const void* d_pts, uint32_t U, uint32_t maxcount) {
                                E.lenhist.as<uint32_t>() + P.L, stride, E.partial.as<uint32_t>());
         BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
     }
-    BLZ_HIP(hipEventRecord(E.ev[2], st), BLZ_ERR_UNKNOWN);
+    BLZ_HIP(hipEventRecord(S.ev[2], st), BLZ_ERR_UNKNOWN);
 
     // ---- phase 2
     // level 0 is throughput-bound (2 adds per bucket): long segments; the upper levels have few
@@ -363,17 +364,23 @@ int run_tail_t(MsmEngine& E, const void* d_pts, uint32_t U, uint32_t maxcount) {
         int seglog = 0;
         while ((1u << seglog) < SEG) ++seglog;
         uint32_t T = (M + SEG - 1) / SEG;
-        DevBuf& oA = E.lvlA[level & 1];
-        DevBuf& oC = E.lvlC[level & 1];
+        DevBuf& oA = S.lvlA[level & 1];
+        DevBuf& oC = S.lvlC[level & 1];
         BLZ_TRY(oA.reserve((size_t)T * P.W * 16 * F::N));
         BLZ_TRY(oC.reserve((size_t)T * P.W * 16 * F::N));
         uint32_t nthreads = T * (uint32_t)P.W;
-        if (level == 0)
+        if (level == 0) {
             hipLaunchKernelGGL((k_reduce_level<F, true>), dim3((nthreads + 63) / 64), dim3(64), 0, st, curA, curC,
                                E.unit_off.as<uint32_t>(), M, SEG, T, P.W, shift, oA.as<uint32_t>(), oC.as<uint32_t>());
-        else
+            // the rest is a few lanes of sequential work: hand it to the tail stream, so this stream can
+            // start the next task's sort while it runs
+            BLZ_HIP(hipEventRecord(S.ev_l0, st), BLZ_ERR_UNKNOWN);
+            st = E.tail_stream;
+            BLZ_HIP(hipStreamWaitEvent(st, S.ev_l0, 0), BLZ_ERR_UNKNOWN);
+        } else {
             hipLaunchKernelGGL((k_reduce_level<F, false>), dim3((nthreads * 4 + 63) / 64), dim3(64), 0, st, curA, curC,
                                E.unit_off.as<uint32_t>(), M, SEG, T, P.W, shift, oA.as<uint32_t>(), oC.as<uint32_t>());
+        }
         curA = oA.as<uint32_t>();
         curC = oC.as<uint32_t>();
         shift += seglog;
@@ -382,31 +389,35 @@ int run_tail_t(MsmEngine& E, const void* d_pts, uint32_t U, uint32_t maxcount) {
         if (T == 1) break;
     }
     BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
-    BLZ_HIP(hipEventRecord(E.ev[3], st), BLZ_ERR_UNKNOWN);
+    BLZ_HIP(hipEventRecord(S.ev[3], st), BLZ_ERR_UNKNOWN);
 
     // ---- phase 3
-    hipLaunchKernelGGL(k_finish<F>, dim3(1), dim3(64), 0, st, curC, P.W, P.c, E.result.as<uint32_t>());
+    hipLaunchKernelGGL(k_finish<F>, dim3(1), dim3(64), 0, st, curC, P.W, P.c, E.slot_result(E.cur));
     BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
-    BLZ_HIP(hipEventRecord(E.ev[4], st), BLZ_ERR_UNKNOWN);
+    BLZ_HIP(hipEventRecord(S.ev[4], st), BLZ_ERR_UNKNOWN);
+    BLZ_HIP(hipMemcpyAsync(S.result_h, E.slot_result(E.cur), 12 * F::N, hipMemcpyDeviceToHost, st), BLZ_ERR_READ);
+    BLZ_HIP(hipEventRecord(S.ev_done, st), BLZ_ERR_UNKNOWN);
     return BLZ_OK;
 }
 
 template <class F>
 int combine_t(MsmEngine& E, const uint8_t* partials, size_t count, uint8_t* out) {
+    // own stream: it must not queue behind a task in flight (its tail waits for its accumulation)
+    hipStream_t st = E.aux_stream;
     size_t rs = 3 * F::N * 4;
     DevBuf tmp;
+    uint32_t* d_out = E.result.as<uint32_t>() + 128;
     uint32_t* d_in = E.result.as<uint32_t>() + 256;  // 15 KiB of the result buffer: up to 100 partials without an allocation
     if (rs * count > 15 * 1024) {
         BLZ_TRY(tmp.reserve(rs * count));
         d_in = tmp.as<uint32_t>();
     }
-    if (count) BLZ_HIP(hipMemcpyAsync(d_in, partials, rs * count, hipMemcpyHostToDevice, E.stream), BLZ_ERR_WRITE);
-    hipLaunchKernelGGL(k_combine_partials<F>, dim3(1), dim3(64), 0, E.stream, d_in, (uint32_t)count,
-                       E.result.as<uint32_t>() + 64);
+    if (count) BLZ_HIP(hipMemcpyAsync(d_in, partials, rs * count, hipMemcpyHostToDevice, st), BLZ_ERR_WRITE);
+    hipLaunchKernelGGL(k_combine_partials<F>, dim3(1), dim3(64), 0, st, d_in, (uint32_t)count, d_out);
     BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
-    BLZ_HIP(hipMemcpyAsync(E.result_h, E.result.as<uint32_t>() + 64, rs, hipMemcpyDeviceToHost, E.stream), BLZ_ERR_READ);
-    BLZ_HIP(hipStreamSynchronize(E.stream), BLZ_ERR_UNKNOWN);
-    memcpy(out, E.result_h, rs);
+    BLZ_HIP(hipMemcpyAsync(E.combine_h, d_out, rs, hipMemcpyDeviceToHost, st), BLZ_ERR_READ);
+    BLZ_HIP(hipStreamSynchronize(st), BLZ_ERR_UNKNOWN);
+    memcpy(out, E.combine_h, rs);
     tmp.release();
     return BLZ_OK;
 }

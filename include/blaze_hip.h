@@ -69,7 +69,13 @@ int blz_msm_loaded_binary_parameters(blz_msm* h, uint32_t out[2]);
  * (unwrap at msm_api.rs:84) -> BLZ_ERR_INVALID_PARAM here. */
 int blz_msm_initialize(blz_msm* h, uint32_t nof_elements, int has_hbm, uint64_t hbm_addr, uint64_t hbm_off);
 
-/* MSMClient::start_process (msm_api.rs:113-120): push the configured task to the task queue. */
+/* MSMClient::start_process (msm_api.rs:113-120): push the configured task to the task queue.
+ * The device has a task queue and a result queue (msm_hw_code.rs:19-25): up to TWO tasks may be in
+ * flight (initialize / start_process / set_data twice before the first wait_result).  Results are
+ * returned in submission order with their labels.  The few-lane tail of a task (upper bucket-reduce
+ * levels, Horner, inversion) overlaps the sort + accumulation of the next one, so a stream of MSMs
+ * should keep two in flight.  A third submission returns BLZ_ERR_INVALID_PARAM until a result was
+ * collected with wait_result; blz_msm_is_engine_ready reports whether a task can be accepted. */
 int blz_msm_start_process(blz_msm* h);
 
 /* MSMClient::set_data(MSMInput{points, scalars, params}) (msm_api.rs:155-220).
@@ -90,7 +96,7 @@ int blz_msm_set_data_device(blz_msm* h, const void* d_points, size_t points_len,
                             size_t scalars_len, uint32_t nof_elements, int has_hbm, uint64_t hbm_addr,
                             uint64_t hbm_off);
 
-/* MSMClient::wait_result (msm_api.rs:222-238): block until the armed task's result is valid.
+/* MSMClient::wait_result (msm_api.rs:222-238): block until the OLDEST task's result is valid.
  * The reference spins forever when nothing is armed; here that is BLZ_ERR_INVALID_PARAM. */
 int blz_msm_wait_result(blz_msm* h);
 

@@ -353,3 +353,71 @@ def test_randomised_small_cases(gpu, orc):
         assert got == exp, f"case {case}: {curve} pf={pf} n={n} {pattern}"
     for c in clients.values():
         c.close()
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_task_queue_two_in_flight(gpu, orc, curve):
+    """The device has a task queue and a result queue (msm_hw_code.rs:19-25): two tasks may be submitted
+    before the first result is popped; results come back in submission order with their labels, and a
+    third submission is refused until a result has been collected."""
+    cl = msm_client(curve, 1)
+    jobs = [orc.input_generator(curve, n, 1, 500 + n) for n in (700, 5000, 1300, 64)]
+    def submit(j):
+        pts, sc, _ = jobs[j]
+        n = len(sc) // 32
+        params = MSMParams(n, None)
+        cl.initialize(params)
+        cl.start_process()
+        cl.set_data(MSMInput(pts, sc, params))
+    submit(0)
+    submit(1)
+    assert cl.is_msm_engine_ready() == 0
+    with pytest.raises(DriverClientError) as ei:
+        submit(2)
+    assert ei.value.variant == "InvalidPrimitiveParam"
+    cl.reset()
+    submit(0)
+    submit(1)
+    cl.wait_result()
+    r0 = cl.result()
+    assert r0.result == jobs[0][2]
+    submit(2)                      # slot of task 0 is free again while task 1 may still be running
+    cl.wait_result()
+    r1 = cl.result()
+    assert r1.result == jobs[1][2] and r1.result_label == r0.result_label + 1
+    submit(3)
+    cl.wait_result()
+    cl.wait_result()
+    r2, r3 = cl.result(), cl.result()
+    assert r2.result == jobs[2][2] and r3.result == jobs[3][2]
+    assert r3.result_label == r2.result_label + 1 == r1.result_label + 2
+    cl.close()
+
+
+def test_task_queue_overlap_large(gpu, orc):
+    """Back-to-back 2^22 tasks with two in flight: same bytes as one at a time."""
+    curve, n = "BLS381", 1 << 22
+    dp, ds0 = synth(curve, n, seed=3)
+    _, ds1 = synth(curve, 16, seed=4)
+    ds1.free()
+    ds1 = DeviceBuffer(0, n * 32)
+    blaze_amd._lib.check(blaze_amd.lib().blz_synth_scalars(0, 1, ds1.ptr, n, 4))
+    cl = msm_client(curve, 1)
+    ref = [run_msm(cl, dp, d, n) for d in (ds0, ds1)]
+    assert ref[0] != ref[1]
+    params = MSMParams(n, None)
+    got = []
+    order = [ds0, ds1, ds1, ds0, ds0]
+    for k, d in enumerate(order):
+        cl.initialize(params)
+        cl.start_process()
+        cl.set_data(MSMInput(dp, d, params))
+        if k >= 1:
+            cl.wait_result()
+            got.append(cl.result().result)
+    cl.wait_result()
+    got.append(cl.result().result)
+    assert got == [ref[0], ref[1], ref[1], ref[0], ref[0]]
+    cl.close()
+    for b in (dp, ds0, ds1):
+        b.free()
