@@ -1,6 +1,7 @@
 // G1 group law on y^2 = x^3 + b (a = 0) in extended-Jacobian XYZZ coordinates:
 //   x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2;  infinity <=> ZZ == 0 (literal zero limbs).
-// Mixed add 8M+2S, full add 12M+2S, doubling 6M+3S (EFD "madd-2008-s", "add-2008-s", "dbl-2008-s-1").
+// Mixed add 8M+2S, full add 12M+2S, doubling 6M+3S (EFD "madd-2008-s", "add-2008-s", "dbl-2008-s-1");
+// the closing Y3 = u v - w z of each is one sum-of-products with a single reduction (fp_mulsub2).
 // Every routine is complete: infinity, P+P and P+(-P) are handled, because the reference harness
 // repeats a 256-element tile (tests/msm/mod.rs:337-354) so equal / opposite operands meet in the
 // same bucket constantly.
@@ -63,9 +64,7 @@ __device__ __noinline__ void pt_mdbl(XYZZ<F>& r, const Affine<F>& a) {
     fp_sub(r.x, r.x, S);
     fp_sub(r.x, r.x, S);
     fp_sub(t, S, r.x);
-    fp_mul(t, M, t);
-    fp_mul(U, W, a.y);
-    fp_sub(r.y, t, U);
+    fp_mulsub2(r.y, M, t, W, a.y);   // M (S - X3) - W Y1, one reduction
     r.zz = V;
     r.zzz = W;
 }
@@ -93,9 +92,8 @@ __device__ __noinline__ void pt_dbl(XYZZ<F>& r, const XYZZ<F>& p) {
     fp_sub(x3, x3, S);
     fp_sub(x3, x3, S);
     fp_sub(t, S, x3);
-    fp_mul(t, M, t);
-    fp_mul(U, W, p.y);
-    fp_sub(r.y, t, U);
+    fp_mulsub2(U, M, t, W, p.y);     // M (S - X3) - W Y1, one reduction (r may alias p)
+    r.y = U;
     r.x = x3;
     fp_mul(r.zz, V, p.zz);
     fp_mul(r.zzz, W, p.zzz);
@@ -132,15 +130,13 @@ BLZ_DEV void pt_madd(XYZZ<F>& acc, const Affine<F>& q) {
     fp_mul(PPP, P, PP);
     fp_mul(acc.zzz, acc.zzz, PPP); // ZZZ3
     fp_mul(Q, acc.x, PP);
-    fp_mul(PP, acc.y, PPP);        // Y1 * PPP
     fp_sqr(t, R);
     fp_sub(t, t, PPP);
     fp_sub(t, t, Q);
     fp_sub(t, t, Q);               // X3
     acc.x = t;
     fp_sub(Q, Q, t);
-    fp_mul(Q, R, Q);
-    fp_sub(acc.y, Q, PP);
+    fp_mulsub2(acc.y, R, Q, acc.y, PPP);   // R (Q - X3) - Y1 PPP with one reduction
 }
 
 template <class F>
@@ -177,10 +173,8 @@ BLZ_DEV void pt_add_inl(XYZZ<F>& acc, const XYZZ<F>& q) {
     fp_sub(t, t, Q);
     fp_sub(t, t, Q);  // X3
     fp_sub(Q, Q, t);
-    fp_mul(Q, R, Q);
-    fp_mul(S1, S1, PPP);
     acc.x = t;
-    fp_sub(acc.y, Q, S1);
+    fp_mulsub2(acc.y, R, Q, S1, PPP);      // R (Q - X3) - S1 PPP with one reduction
     fp_mul(t, acc.zz, q.zz);
     fp_mul(acc.zz, t, PP);
     fp_mul(t, acc.zzz, q.zzz);
@@ -214,10 +208,8 @@ __device__ __noinline__ void pt_add(XYZZ<F>& acc, const XYZZ<F>& q) {
     fp_sub(t, t, Q);
     fp_sub(t, t, Q);  // X3
     fp_sub(Q, Q, t);
-    fp_mul(Q, R, Q);
-    fp_mul(S1, S1, PPP);
     acc.x = t;
-    fp_sub(acc.y, Q, S1);
+    fp_mulsub2(acc.y, R, Q, S1, PPP);      // R (Q - X3) - S1 PPP with one reduction
     fp_mul(t, acc.zz, q.zz);
     fp_mul(acc.zz, t, PP);
     fp_mul(t, acc.zzz, q.zzz);

@@ -285,6 +285,109 @@ BLZ_DEV void fp_mul_ps(Fp<P>& r, const Fp<P>& a, const Fp<P>& b) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Sum of two products with ONE Montgomery reduction:  r = (a b + c d) R^-1  (mod m).
+// Column K accumulates a_i b_j + c_i d_j + q_i m_j; everything else is the scan above.  The group law
+// ends in such a sum (Y3 = R (Q - X3) - Y1 PPP), so each point addition saves one reduction: N^2 of the
+// 2 N^2 multiply-adds of a field multiplication.
+// Range: inputs in [0, 2m] give (a b + c d + q m) / R < 8 m^2 / R + m, which is < 2m when 8 m <= R
+// (both BLS fields); BN254's q is 254 of 256 bits (8 m^2 / R < 1.52 m), so one conditional subtraction
+// of 2m brings the result back into the lazy range.
+// ------------------------------------------------------------------------------------------------
+template <class P, int K, int I0, int NP, bool FIRST, bool EXTRA>
+BLZ_DEV void ps2_chunk(const Fp<P>& a, const Fp<P>& b, const Fp<P>& c, const Fp<P>& d, const uint32_t (&q)[P::N],
+                       uint64_t& alo, uint32_t& ahi) {
+#define BLZ_PA(e) a.v[I0 + e], b.v[K - I0 - e], c.v[I0 + e], d.v[K - I0 - e], q[I0 + e], P::MOD[K - I0 - e]
+#define BLZ_DISPATCH(NPV, ...)                                                                               \
+    if constexpr (NP == NPV) {                                                                               \
+        if constexpr (FIRST && EXTRA) mac2_p##NPV##fx(alo, ahi, __VA_ARGS__, a.v[K], b.v[0], c.v[K], d.v[0]); \
+        else if constexpr (FIRST) mac2_p##NPV##f(alo, ahi, __VA_ARGS__);                                     \
+        else if constexpr (EXTRA) mac2_p##NPV##x(alo, ahi, __VA_ARGS__, a.v[K], b.v[0], c.v[K], d.v[0]);      \
+        else mac2_p##NPV(alo, ahi, __VA_ARGS__);                                                             \
+    }
+    if constexpr (NP == 0) {
+        static_assert(NP != 0 || EXTRA, "empty chunk");
+        if constexpr (FIRST) mac2_p0fx(alo, ahi, a.v[K], b.v[0], c.v[K], d.v[0]);
+        else mac2_p0x(alo, ahi, a.v[K], b.v[0], c.v[K], d.v[0]);
+    }
+    BLZ_DISPATCH(1, BLZ_PA(0))
+    BLZ_DISPATCH(2, BLZ_PA(0), BLZ_PA(1))
+    BLZ_DISPATCH(3, BLZ_PA(0), BLZ_PA(1), BLZ_PA(2))
+#undef BLZ_DISPATCH
+#undef BLZ_PA
+}
+
+template <class P, int K, int I0, int LEFT, bool FIRST, bool EXTRA>
+BLZ_DEV void ps2_chunks(const Fp<P>& a, const Fp<P>& b, const Fp<P>& c, const Fp<P>& d, const uint32_t (&q)[P::N],
+                        uint64_t& alo, uint32_t& ahi) {
+    if constexpr (LEFT > 3) {
+        ps2_chunk<P, K, I0, 3, FIRST, false>(a, b, c, d, q, alo, ahi);
+        ps2_chunks<P, K, I0 + 3, LEFT - 3, false, EXTRA>(a, b, c, d, q, alo, ahi);
+    } else if constexpr (LEFT > 0 || EXTRA) {
+        ps2_chunk<P, K, I0, LEFT, FIRST, EXTRA>(a, b, c, d, q, alo, ahi);
+    }
+}
+
+template <class P, int K>
+BLZ_DEV void ps2_column(const Fp<P>& a, const Fp<P>& b, const Fp<P>& c, const Fp<P>& d, uint32_t (&q)[P::N],
+                        uint32_t (&t)[P::N], uint64_t& alo) {
+    constexpr int N = P::N;
+    constexpr int ilo = K < N ? 0 : K - N + 1;
+    constexpr int ihq = K < N ? K - 1 : N - 1;
+    constexpr int npair = ihq - ilo + 1 > 0 ? ihq - ilo + 1 : 0;
+    constexpr bool extra = K < N;
+    if constexpr (npair == 0 && !extra) {
+        t[K - N] = (uint32_t)alo;
+        alo >>= 32;
+    } else {
+        uint32_t ahi;
+        ps2_chunks<P, K, ilo, npair, true, extra>(a, b, c, d, q, alo, ahi);
+        if constexpr (K < N) {
+            q[K] = (uint32_t)alo * P::N0;
+            mac_vs(alo, ahi, q[K], P::MOD[0]);
+        } else {
+            t[K - N] = (uint32_t)alo;
+        }
+        alo = (alo >> 32) | ((uint64_t)ahi << 32);
+    }
+}
+
+template <class P, int... Ks>
+BLZ_DEV void ps2_columns(const Fp<P>& a, const Fp<P>& b, const Fp<P>& c, const Fp<P>& d, uint32_t (&q)[P::N],
+                         uint32_t (&t)[P::N], uint64_t& alo, std::integer_sequence<int, Ks...>) {
+    (ps2_column<P, Ks>(a, b, c, d, q, t, alo), ...);
+}
+
+// r = a b + c d   (lazy fields only: the group law's base fields)
+template <class P>
+BLZ_DEV void fp_mul2(Fp<P>& r, const Fp<P>& a, const Fp<P>& b, const Fp<P>& c, const Fp<P>& d) {
+    static_assert(P::LAZY, "fp_mul2 needs the lazy [0, 2m] representation");
+    constexpr int N = P::N;
+    uint32_t q[N];
+    uint32_t t[N];
+    uint64_t alo = 0;
+    ps2_columns<P>(a, b, c, d, q, t, alo, std::make_integer_sequence<int, 2 * N>{});
+#pragma unroll
+    for (int j = 0; j < N; ++j) r.v[j] = t[j];
+    if constexpr (P::MOD[N - 1] >= (1u << 29)) {  // 8 m > R: the sum can reach 2.52 m (BN254)
+        uint32_t u[N];
+        uint32_t br = 0;
+#pragma unroll
+        for (int j = 0; j < N; ++j) u[j] = sub_bb(t[j], P::MOD2[j], br);
+#pragma unroll
+        for (int j = 0; j < N; ++j) r.v[j] = br ? t[j] : u[j];
+    }
+}
+// r = a b - c d
+template <class P>
+BLZ_DEV void fp_mulsub2(Fp<P>& r, const Fp<P>& a, const Fp<P>& b, const Fp<P>& c, const Fp<P>& d) {
+    Fp<P> nc;
+    uint32_t br = 0;
+#pragma unroll
+    for (int j = 0; j < P::N; ++j) nc.v[j] = sub_bb(P::MOD2[j], c.v[j], br);  // 2m - c in [0, 2m]
+    fp_mul2(r, a, b, nc, d);
+}
+
 #ifndef BLZ_MUL_VARIANT
 #define BLZ_MUL_VARIANT 1
 #endif

@@ -19,6 +19,18 @@ __global__ __launch_bounds__(64) void k_test_field(int op, const uint32_t* a, co
         case 1: fp_add(r, x, y); break;
         case 2: fp_sub(r, x, y); break;
         case 3: fp_inv(r, x); break;
+        case 5:  // x y + (x + y)(x - y), unreduced sums as operands
+        case 6:  // x y - (x + y)(x - y)
+            if constexpr (P::LAZY) {
+                Fp<P> s, d;
+                fp_add(s, x, y);
+                fp_sub(d, x, y);
+                if (op == 5) fp_mul2(r, x, y, s, d);
+                else fp_mulsub2(r, x, y, s, d);
+            } else {
+                fp_zero(r);
+            }
+            break;
         default: fp_sqr(r, x); break;
     }
     fp_from_mont(r, r);
