@@ -61,6 +61,7 @@ _SIGS = {
     "blz_msm_combine_partials": (C.c_int, [C.c_void_p, _u8p, C.c_size_t, _u8p, C.c_size_t]),
     "blz_ntt_new": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "blz_ntt_new_ex": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "blz_ntt_new_field": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "blz_ntt_free": (None, [C.c_void_p]),
     "blz_ntt_initialize": (C.c_int, [C.c_void_p]),
     "blz_ntt_set_data": (C.c_int, [C.c_void_p, C.c_size_t, _u8p, C.c_size_t]),

@@ -1,4 +1,4 @@
-// Radix-2^k NTT over the BLS12-381 scalar field for gfx950 (device task of SURVEY.md a16: what the
+// Radix-2^k NTT over a scalar field (BLS12-381 Fr by default; BLS12-377 / BN254 Fr on request) for gfx950 (device task of SURVEY.md a16: what the
 // bitstream behind src/ingo_ntt/ntt_hw_code.rs:6-83 computes on one 2^27 x 32 B buffer).
 //
 //   X[k] = sum_i x[i] w^(ik),  natural order in and out,  w = 7^((r-1)/2^log_size)
@@ -12,51 +12,10 @@
 // Data stay in plain canonical form; only twiddles are in Montgomery form (mont_mul(x, tR) = x t),
 // so there is no conversion pass.  Algorithmic traffic 2 x 4 GiB; this 3-pass form moves 3x that.
 #include "common.hpp"
-#include "field.cuh"
+#include "ntt_engine.hpp"
 
 namespace blz {
 
-using Fr = Fr_BLS381;
-using E = Fp<Fr>;
-
-struct NttTables {  // all Montgomery form, device memory
-    uint32_t* wpass[3];  // wpass[p][j] = root_p^j, j < radix_p       (root_p = primitive radix_p-th root)
-    uint32_t* t0;        // w^j            j < 512
-    uint32_t* t1;        // w^(512 j)      j < 512
-    uint32_t* t2;        // w^(2^18 j)     j < 512
-    uint32_t* ninv;      // n^-1 (Montgomery) for the inverse transform, else nullptr
-};
-
-// out[j] = base^(j * mult) where base = ROOT^(2^(TWO_ADICITY - logn))
-__global__ void k_ntt_table(uint32_t* out, int count, int logn, uint64_t mult, int inverse) {
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= count) return;
-    E w;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) w.v[i] = inverse ? Fr::ROOT_INV[i] : Fr::ROOT[i];
-    for (int i = 0; i < Fr::TWO_ADICITY - logn; ++i) fp_sqr(w, w);
-    uint64_t e = (uint64_t)j * mult;
-    E acc;
-    fp_one(acc);
-    for (int b = 63; b >= 0; --b) {
-        fp_sqr(acc, acc);
-        if ((e >> b) & 1) fp_mul(acc, acc, w);
-    }
-    fp_store(out + (size_t)j * 8, acc);
-}
-
-// out = (2^logn)^-1 in Montgomery form
-__global__ void k_ntt_ninv(uint32_t* out, int logn) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    E two, acc;
-    fp_one(two);
-    fp_add(two, two, two);
-    fp_one(acc);
-    for (int i = 0; i < logn; ++i) fp_mul(acc, acc, two);
-    E inv;
-    fp_inv(inv, acc);
-    fp_store(out, inv);
-}
 
 // NTTBanks::preprocess / postprocess (src/ingo_ntt/ntt_data.rs:80-156) as device permutations of
 // 32-byte elements, from the closed forms of the reference loops:
@@ -84,319 +43,14 @@ __global__ __launch_bounds__(256) void k_ntt_banks_post(const uint4* __restrict_
     out[2 * a + 1] = banks[2 * src + 1];
 }
 
-BLZ_DEV void lds_load(E& r, const uint32_t* lds, uint32_t dw) {  // dw: dword offset, multiple of 8
-    const uint4* q = reinterpret_cast<const uint4*>(lds + dw);
-    uint4 a = q[0], b = q[1];
-    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
-}
-BLZ_DEV void lds_store(uint32_t* lds, uint32_t dw, const E& r) {
-    uint4* q = reinterpret_cast<uint4*>(lds + dw);
-    q[0] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
-    q[1] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
-}
-
-// w^e for e < 2^27 from the three 512-entry tables
-BLZ_DEV void tw_pow(E& r, const NttTables& T, uint32_t e) {
-    E a, b;
-    fp_load(r, T.t0 + (size_t)(e & 511u) * 8);
-    uint32_t e1 = (e >> 9) & 511u, e2 = e >> 18;
-    if (e1) { fp_load(a, T.t1 + (size_t)e1 * 8); fp_mul(r, r, a); }
-    if (e2) { fp_load(b, T.t2 + (size_t)e2 * 8); fp_mul(r, r, b); }
-}
-
-struct NttGeom {
-    int logA, logB, logC, logn;
-};
-
-constexpr int NTT_THREADS = 1024;  // 4 waves per SIMD: the 128-147 KiB tile allows one block per CU
-
-// LDS tile: element (row, col) at dword offset row * RS + col * 8 with RS = COLS * 8 + 8: the one
-// element of padding per row spreads rows over the banks (a power-of-two row stride puts every row
-// of a column on the same banks, and the bit-reversed row order of the load makes that the norm).
-BLZ_DEV uint32_t ntt_rs(uint32_t cols) { return cols * 8u + 8u; }
-
-// PASS 1..3 as in the header comment.  Tile = COLS columns x (1 << lr) rows.
-// Inter-pass twiddles (the w^(i0 k2) factor of pass 2 is applied in pass 1: it does not depend on
-// the index pass 2 transforms over):
-//   after pass 1: x(i0, i1, k2) *= w^(k2 (i0 + A i1))      step along i0: w^k2
-//   after pass 2: x(i0, k1, k2) *= w^(C i0 k1)             step along i0: w^(C k1)
-// so a lane that owns a few adjacent columns of one row derives its twiddles by repeated
-// multiplication from one table look-up.
-template <int PASS>
-__global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
-                                                          NttGeom g, NttTables T, int cols_log) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const int lr = PASS == 1 ? g.logC : PASS == 2 ? g.logB : g.logA;  // log radix of this pass
-    const uint32_t radix = 1u << lr;
-    const uint32_t COLS = 1u << cols_log;
-    const uint32_t RS = ntt_rs(COLS);
-    const uint32_t A = 1u << g.logA, B = 1u << g.logB, C = 1u << g.logC;
-    uint64_t col_base, fixed, in_base, in_rstride, in_cstride;
-    const uint64_t tile = blockIdx.x;
-    if (PASS == 1) {  // rows i2 (stride AB), cols i0 (stride 1), fixed i1
-        uint64_t tiles_per = A >> cols_log;
-        fixed = tile / tiles_per;
-        col_base = (tile % tiles_per) << cols_log;
-        in_base = col_base + (uint64_t)A * fixed;
-        in_rstride = (uint64_t)A * B;
-        in_cstride = 1;
-    } else if (PASS == 2) {  // rows i1 (stride A), cols i0, fixed k2
-        uint64_t tiles_per = A >> cols_log;
-        fixed = tile / tiles_per;
-        col_base = (tile % tiles_per) << cols_log;
-        in_base = col_base + (uint64_t)A * B * fixed;
-        in_rstride = A;
-        in_cstride = 1;
-    } else {  // rows i0 (stride 1), cols k2 (stride AB), fixed k1
-        uint64_t tiles_per = C >> cols_log;
-        fixed = tile / tiles_per;
-        col_base = (tile % tiles_per) << cols_log;
-        in_base = (uint64_t)A * fixed + (uint64_t)A * B * col_base;
-        in_rstride = 1;
-        in_cstride = (uint64_t)A * B;
-    }
-    const uint32_t total = radix << cols_log;
-    // ---- load, rows bit-reversed (decimation in time)
-    for (uint32_t e = threadIdx.x; e < total; e += NTT_THREADS) {
-        uint32_t row, col;
-        if (PASS == 3) { row = e & (radix - 1); col = e >> lr; }   // contiguous along rows
-        else { col = e & (COLS - 1); row = e >> cols_log; }         // contiguous along cols
-        E x;
-        fp_load(x, in + (in_base + row * in_rstride + col * in_cstride) * 8);
-        uint32_t rrow = lr ? (__brev(row) >> (32 - lr)) : 0;
-        lds_store(lds, rrow * RS + col * 8, x);
-    }
-    __syncthreads();
-    // ---- radix-2 stages
-    const uint32_t* wp = T.wpass[PASS - 1];
-    const uint32_t nbf = (radix >> 1) << cols_log;
-    for (int s = 1; s <= lr; ++s) {
-        const uint32_t half = 1u << (s - 1);
-        for (uint32_t e = threadIdx.x; e < nbf; e += NTT_THREADS) {
-            uint32_t col = e & (COLS - 1), b = e >> cols_log;
-            uint32_t blk = b >> (s - 1), k = b & (half - 1);
-            uint32_t u = (blk << s) + k, v = u + half;
-            E xu, xv;
-            lds_load(xu, lds, u * RS + col * 8);
-            lds_load(xv, lds, v * RS + col * 8);
-            uint32_t tw = k << (lr - s);
-            if (tw) {
-                E w;
-                fp_load(w, wp + (size_t)tw * 8);
-                fp_mul(xv, xv, w);
-            }
-            E sum, dif;
-            fp_add(sum, xu, xv);
-            fp_sub(dif, xu, xv);
-            lds_store(lds, u * RS + col * 8, sum);
-            lds_store(lds, v * RS + col * 8, dif);
-        }
-        __syncthreads();
-    }
-    // ---- inter-pass twiddle + store: one lane owns CG adjacent columns of one row
-    const uint32_t cg_log = cols_log < 2 ? cols_log : 2;
-    const uint32_t CG = 1u << cg_log;
-    const uint32_t ntask = total >> cg_log;
-    for (uint32_t t = threadIdx.x; t < ntask; t += NTT_THREADS) {
-        const uint32_t grp = t & ((COLS >> cg_log) - 1), row = t >> (cols_log - cg_log);
-        const uint32_t col0 = grp << cg_log;
-        E w, step;
-        bool tw = false;
-        if (PASS == 1) {
-            // k2 = row, i1 = fixed, i0 = col_base + col0 + j
-            uint32_t ex = (uint32_t)((uint64_t)row * (col_base + col0 + ((uint64_t)fixed << g.logA)));
-            tw = row != 0;
-            if (tw) { tw_pow(w, T, ex); fp_load(step, T.t0 + (size_t)row * 8); }
-        } else if (PASS == 2) {
-            // k1 = row, i0 = col_base + col0 + j
-            uint32_t ex = (uint32_t)(((uint64_t)row * (col_base + col0)) << g.logC);
-            tw = row != 0;
-            if (tw) { tw_pow(w, T, ex); tw_pow(step, T, row << g.logC); }
-        }
-#pragma unroll 4
-        for (uint32_t j = 0; j < CG; ++j) {
-            E x;
-            lds_load(x, lds, row * RS + (col0 + j) * 8);
-            uint64_t oaddr;
-            if (PASS == 3) {
-                // element (k0 = row, k1 = fixed, k2 = col_base + col) -> natural address k2 + C k1 + CB k0
-                if (T.ninv) { E s; fp_load(s, T.ninv); fp_mul(x, x, s); }  // inverse transform: * n^-1
-                oaddr = (col_base + col0 + j) + (uint64_t)C * fixed + (uint64_t)C * B * row;
-            } else {
-                if (tw) {
-                    fp_mul(x, x, w);
-                    if (j + 1 < CG) fp_mul(w, w, step);
-                }
-                oaddr = in_base + row * in_rstride + col0 + j;
-            }
-            fp_store(out + oaddr * 8, x);
-        }
-    }
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// 512-point passes, register resident: 512 = 8 * 8 * 8.  A lane holds 8 elements (64 VGPRs) and runs
-// a whole 8-point DFT (three radix-2 stages, 5 non-trivial twiddles) in registers; the tile goes
-// through LDS only twice (between the three radix-8 steps) instead of once per radix-2 stage, the
-// loads come straight from global memory and the last step stores straight to it with the
-// inter-pass twiddle applied by stepping along the lane's own 8 outputs.  PMC counters of the
-// radix-2-in-LDS kernel: VALU busy 22 %, 44 % of wave cycles parked on barriers / waitcnt, 58 % of
-// LDS cycles bank conflicts.  COLS = 4 columns x 512 rows per 256-lane block (80 KiB of LDS), two
-// blocks per CU so one block's global traffic overlaps the other's arithmetic.
-// ------------------------------------------------------------------------------------------------
-constexpr int N8_COLS_LOG = 2;
-constexpr int N8_COLS = 1 << N8_COLS_LOG;
-constexpr int N8_THREADS = 64 * N8_COLS;
-constexpr uint32_t N8_RS = N8_COLS * 8 + 8;  // padded row stride in dwords
-
-// in-register 8-point DFT, decimation in time: a[] must hold x[0],x[4],x[2],x[6],x[1],x[5],x[3],x[7];
-// output natural order.  w1,w2,w3 = w8, w8^2, w8^3 (Montgomery).
-BLZ_DEV void bfly(E& u, E& v) {
-    E s, d;
-    fp_add(s, u, v);
-    fp_sub(d, u, v);
-    u = s;
-    v = d;
-}
-BLZ_DEV void dft8(E (&a)[8], const E& w1, const E& w2, const E& w3) {
-    bfly(a[0], a[1]); bfly(a[2], a[3]); bfly(a[4], a[5]); bfly(a[6], a[7]);
-    fp_mul(a[3], a[3], w2);
-    fp_mul(a[7], a[7], w2);
-    bfly(a[0], a[2]); bfly(a[1], a[3]); bfly(a[4], a[6]); bfly(a[5], a[7]);
-    fp_mul(a[5], a[5], w1);
-    fp_mul(a[6], a[6], w2);
-    fp_mul(a[7], a[7], w3);
-    bfly(a[0], a[4]); bfly(a[1], a[5]); bfly(a[2], a[6]); bfly(a[3], a[7]);
-}
-// order in which a DIT 8-point DFT wants its inputs
-__device__ constexpr int BR8[8] = {0, 4, 2, 6, 1, 5, 3, 7};
-
-template <int PASS>
-__global__ __launch_bounds__(N8_THREADS, 2) void k_ntt512(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
-                                                         NttGeom g, NttTables T) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const uint32_t A = 1u << g.logA, B = 1u << g.logB, C = 1u << g.logC;
-    uint64_t col_base, fixed, in_base, in_rstride, in_cstride;
-    const uint64_t tile = blockIdx.x;
-    uint32_t col, n2;  // this lane's column and its index in [0,64)
-    if (PASS == 1) {   // rows i2 (stride AB), cols i0 (stride 1), fixed i1
-        uint64_t tiles_per = A >> N8_COLS_LOG;
-        fixed = tile / tiles_per;
-        col_base = (tile % tiles_per) << N8_COLS_LOG;
-        in_base = col_base + (uint64_t)A * fixed;
-        in_rstride = (uint64_t)A * B;
-        in_cstride = 1;
-        col = threadIdx.x & (N8_COLS - 1);
-        n2 = threadIdx.x >> N8_COLS_LOG;
-    } else if (PASS == 2) {  // rows i1 (stride A), cols i0, fixed k2
-        uint64_t tiles_per = A >> N8_COLS_LOG;
-        fixed = tile / tiles_per;
-        col_base = (tile % tiles_per) << N8_COLS_LOG;
-        in_base = col_base + (uint64_t)A * B * fixed;
-        in_rstride = A;
-        in_cstride = 1;
-        col = threadIdx.x & (N8_COLS - 1);
-        n2 = threadIdx.x >> N8_COLS_LOG;
-    } else {  // rows i0 (stride 1, contiguous), cols k2 (stride AB), fixed k1
-        uint64_t tiles_per = C >> N8_COLS_LOG;
-        fixed = tile / tiles_per;
-        col_base = (tile % tiles_per) << N8_COLS_LOG;
-        in_base = (uint64_t)A * fixed + (uint64_t)A * B * col_base;
-        in_rstride = 1;
-        in_cstride = (uint64_t)A * B;
-        n2 = threadIdx.x & 63u;   // consecutive lanes read consecutive rows
-        col = threadIdx.x >> 6;
-    }
-    const uint32_t* wp = T.wpass[PASS - 1];  // w512^j, j < 512
-    E w1, w2, w3;
-    fp_load(w1, wp + 64 * 8);
-    fp_load(w2, wp + 128 * 8);
-    fp_load(w3, wp + 192 * 8);
-    E a[8];
-    // ---- step 1: 8-point DFTs over n1 (rows 64 n1 + n2), straight from global memory
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        uint32_t row = 64u * BR8[j] + n2;
-        fp_load(a[j], in + (in_base + row * in_rstride + col * in_cstride) * 8);
-    }
-    dft8(a, w1, w2, w3);
-#pragma unroll
-    for (int k1 = 0; k1 < 8; ++k1) {
-        if (k1 != 0 && n2 != 0) {  // * w512^(n2 k1)
-            E w;
-            fp_load(w, wp + (size_t)(n2 * k1) * 8);
-            fp_mul(a[k1], a[k1], w);
-        }
-        lds_store(lds, (64u * k1 + n2) * N8_RS + col * 8, a[k1]);
-    }
-    __syncthreads();
-    // ---- step 2a: lane (k1, n2', col): 8-point DFTs over n1' (rows 64 k1 + 8 n1' + n2')
-    {
-        const uint32_t k1 = n2 >> 3, n2p = n2 & 7u;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) lds_load(a[j], lds, (64u * k1 + 8u * BR8[j] + n2p) * N8_RS + col * 8);
-        dft8(a, w1, w2, w3);
-        __syncthreads();
-#pragma unroll
-        for (int k1p = 0; k1p < 8; ++k1p) {
-            if (k1p != 0 && n2p != 0) {  // * w64^(n2' k1') = w512^(8 n2' k1')
-                E w;
-                fp_load(w, wp + (size_t)(8u * n2p * k1p) * 8);
-                fp_mul(a[k1p], a[k1p], w);
-            }
-            lds_store(lds, (64u * k1 + 8u * k1p + n2p) * N8_RS + col * 8, a[k1p]);
-        }
-    }
-    __syncthreads();
-    // ---- step 2b: lane (k1, k1', col): 8-point DFTs over n2' (rows 64 k1 + 8 k1' + n2'), outputs
-    // k = k1 + 8 k1' + 64 k2' go to global memory with the inter-pass twiddle
-    {
-        const uint32_t k1 = n2 >> 3, k1p = n2 & 7u;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) lds_load(a[j], lds, (64u * k1 + 8u * k1p + BR8[j]) * N8_RS + col * 8);
-        dft8(a, w1, w2, w3);
-        const uint32_t kb = k1 + 8u * k1p;  // output row of a[k2'] is kb + 64 k2'
-        E w, step;
-        bool tw = false;
-        if (PASS == 1) {
-            // x(i0, i1, k2 = row) *= w^(row * (i0 + A i1)),  m = i0 + A i1 < 2^18
-            const uint64_t m = col_base + col + ((uint64_t)fixed << g.logA);
-            tw = m != 0;
-            if (tw) { tw_pow(w, T, (uint32_t)(kb * m)); tw_pow(step, T, (uint32_t)(64u * m)); }
-        } else if (PASS == 2) {
-            // x(i0, k1 = row, k2) *= w^(C i0 row)
-            const uint64_t m = (col_base + col) << g.logC;
-            tw = m != 0;
-            if (tw) { tw_pow(w, T, (uint32_t)(kb * m)); tw_pow(step, T, (uint32_t)(64u * m)); }
-        }
-        E sc;
-        if (PASS == 3 && T.ninv) fp_load(sc, T.ninv);
-#pragma unroll
-        for (int k2p = 0; k2p < 8; ++k2p) {
-            const uint32_t row = kb + 64u * k2p;
-            uint64_t oaddr;
-            if (PASS == 3) {
-                if (T.ninv) fp_mul(a[k2p], a[k2p], sc);  // inverse transform: * n^-1
-                oaddr = (col_base + col) + (uint64_t)C * fixed + (uint64_t)C * B * row;
-            } else {
-                if (tw) {
-                    if (k2p != 0 || kb != 0) fp_mul(a[k2p], a[k2p], w);
-                    if (k2p != 7) fp_mul(w, w, step);
-                }
-                oaddr = in_base + row * in_rstride + col;
-            }
-            fp_store(out + oaddr * 8, a[k2p]);
-        }
-    }
-}
-
 }  // namespace blz
 
 using namespace blz;
 
 struct blz_ntt {
     int device = 0;
+    int field = BLZ_BLS381;  // scalar field of this curve (enum blz_curve)
+    const NttFieldOps* ops = nullptr;
     int logn = 27;
     int inverse = 0;
     bool force_generic = false;  // BLAZE_NTT_GENERIC=1: radix-2-in-LDS kernel for every pass (A/B runs)
@@ -415,6 +69,15 @@ struct blz_ntt {
 namespace {
 
 size_t ntt_bytes(const blz_ntt* h) { return (size_t)32 << h->logn; }
+
+const NttFieldOps* ntt_ops_for(int field) {
+    switch (field) {
+        case BLZ_BLS377: return &ntt_ops_bls377();
+        case BLZ_BLS381: return &ntt_ops_bls381();
+        case BLZ_BN254: return &ntt_ops_bn254();
+    }
+    return nullptr;
+}
 
 int ntt_setup(blz_ntt* h) {
     // split logn into three radices, largest last-pass first so the contiguous pass is wide
@@ -442,57 +105,14 @@ int ntt_setup(blz_ntt* h) {
     h->T.t0 = p; p += 512 * 8;
     h->T.t1 = p; p += 512 * 8;
     h->T.t2 = p; p += 512 * 8;
-    h->T.ninv = nullptr;
-    if (h->inverse) {
-        h->T.ninv = p;
-        hipLaunchKernelGGL(k_ntt_ninv, dim3(1), dim3(64), 0, h->stream, p, l);
-    }
-    const uint64_t n = 1ull << l;
-    int lrs[3] = {lc, lb, la};
-    for (int i = 0; i < 3; ++i) {
-        int cnt = lrs[i] ? (1 << lrs[i]) : 1;  // the whole circle: the radix-8 kernel indexes exponents up to radix-1
-        hipLaunchKernelGGL(k_ntt_table, dim3(2), dim3(256), 0, h->stream, h->T.wpass[i], cnt, l, n >> lrs[i], h->inverse);
-    }
-    hipLaunchKernelGGL(k_ntt_table, dim3(2), dim3(256), 0, h->stream, h->T.t0, 512, l, (uint64_t)1, h->inverse);
-    hipLaunchKernelGGL(k_ntt_table, dim3(2), dim3(256), 0, h->stream, h->T.t1, 512, l, (uint64_t)512, h->inverse);
-    hipLaunchKernelGGL(k_ntt_table, dim3(2), dim3(256), 0, h->stream, h->T.t2, 512, l, (uint64_t)1 << 18, h->inverse);
-    BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
+    h->T.ninv = h->inverse ? p : nullptr;
+    BLZ_TRY(h->ops->setup(h->stream, h->T, h->geom, h->inverse));
     BLZ_HIP(hipStreamSynchronize(h->stream), BLZ_ERR_UNKNOWN);
     return BLZ_OK;
 }
 
-template <int PASS>
-int launch_pass(blz_ntt* h, const void* in, void* out) {
-    const NttGeom& g = h->geom;
-    int lr = PASS == 1 ? g.logC : PASS == 2 ? g.logB : g.logA;
-    const int cols_avail = PASS == 3 ? g.logC : g.logA;  // extent of the tile's column index
-    if (lr == 9 && cols_avail >= N8_COLS_LOG && !h->force_generic) {
-        static bool attr8 = false;
-        if (!attr8) {
-            BLZ_HIP(hipFuncSetAttribute((const void*)k_ntt512<PASS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
-                    BLZ_ERR_UNKNOWN);
-            attr8 = true;
-        }
-        size_t lds8 = (size_t)512 * N8_RS * 4;
-        uint64_t tiles8 = (1ull << g.logn) >> (9 + N8_COLS_LOG);
-        hipLaunchKernelGGL(k_ntt512<PASS>, dim3((unsigned)tiles8), dim3(N8_THREADS), lds8, h->stream, (const uint32_t*)in,
-                           (uint32_t*)out, g, h->T);
-        BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
-        return BLZ_OK;
-    }
-    int cl = h->cols_log[PASS - 1];
-    size_t lds = ((size_t)4 << lr) * (((size_t)8 << cl) + 8);  // rows x (COLS*8 + 8) dwords
-    uint64_t tiles = (1ull << g.logn) >> (lr + cl);
-    static bool attr_set = false;
-    if (!attr_set) {
-        BLZ_HIP(hipFuncSetAttribute((const void*)k_ntt_pass<PASS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
-                BLZ_ERR_UNKNOWN);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(k_ntt_pass<PASS>, dim3((unsigned)tiles), dim3(NTT_THREADS), lds, h->stream, (const uint32_t*)in,
-                       (uint32_t*)out, g, h->T, cl);
-    BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
-    return BLZ_OK;
+int launch_pass(blz_ntt* h, int pass, const void* in, void* out) {
+    return h->ops->pass(pass, h->stream, in, out, h->geom, h->T, h->cols_log[pass - 1], h->force_generic);
 }
 
 }  // namespace
@@ -502,12 +122,22 @@ extern "C" {
 int blz_ntt_new(int device_id, int log_size, blz_ntt** out) { return blz_ntt_new_ex(device_id, log_size, 0, out); }
 
 int blz_ntt_new_ex(int device_id, int log_size, int inverse, blz_ntt** out) {
+    return blz_ntt_new_field(device_id, BLZ_BLS381, log_size, inverse, out);
+}
+
+int blz_ntt_new_field(int device_id, int field, int log_size, int inverse, blz_ntt** out) {
     if (!out) return fail(BLZ_ERR_INVALID_PARAM, "null out");
     *out = nullptr;
+    const NttFieldOps* ops = ntt_ops_for(field);
+    if (!ops) return fail(BLZ_ERR_INVALID_PARAM, "unknown field %d", field);
     if (log_size < 1 || log_size > 27) return fail(BLZ_ERR_INVALID_PARAM, "log_size %d out of range [1,27]", log_size);
+    if (log_size > ops->two_adicity)
+        return fail(BLZ_ERR_INVALID_PARAM, "log_size %d exceeds the two-adicity %d of the field", log_size, ops->two_adicity);
     BLZ_TRY(use_device(device_id));
     blz_ntt* h = new blz_ntt();
     h->device = device_id;
+    h->field = field;
+    h->ops = ops;
     h->logn = log_size;
     h->inverse = inverse ? 1 : 0;
     { const char* e = getenv("BLAZE_NTT_GENERIC"); h->force_generic = e && *e == '1'; }
@@ -575,13 +205,13 @@ int blz_ntt_start_process(blz_ntt* h, size_t buf_kernel) {
     void* s = h->scratch.p;
     BLZ_HIP(hipEventRecord(h->ev0, h->stream), BLZ_ERR_UNKNOWN);
     const void* cur = b;
-    if (h->geom.logC) { BLZ_TRY(launch_pass<1>(h, cur, s)); cur = s; }
-    if (h->geom.logB) { BLZ_TRY(launch_pass<2>(h, cur, s)); cur = s; }
+    if (h->geom.logC) { BLZ_TRY(launch_pass(h, 1, cur, s)); cur = s; }
+    if (h->geom.logB) { BLZ_TRY(launch_pass(h, 2, cur, s)); cur = s; }
     if (cur == b) {  // single pass: keep it out of place through the scratch
         BLZ_HIP(hipMemcpyAsync(s, b, ntt_bytes(h), hipMemcpyDeviceToDevice, h->stream), BLZ_ERR_UNKNOWN);
         cur = s;
     }
-    BLZ_TRY(launch_pass<3>(h, cur, b));
+    BLZ_TRY(launch_pass(h, 3, cur, b));
     BLZ_HIP(hipEventRecord(h->ev1, h->stream), BLZ_ERR_UNKNOWN);
     h->in_flight = true;
     return BLZ_OK;

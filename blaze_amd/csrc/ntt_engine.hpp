@@ -1,0 +1,32 @@
+// Host-side interface of the NTT device passes (per-field translation units: ntt_<field>.hip).
+#pragma once
+#include "common.hpp"
+
+namespace blz {
+
+struct NttTables {  // all Montgomery form, device memory
+    uint32_t* wpass[3];  // wpass[p][j] = root_p^j, j < radix_p       (root_p = primitive radix_p-th root)
+    uint32_t* t0;        // w^j            j < 512
+    uint32_t* t1;        // w^(512 j)      j < 512
+    uint32_t* t2;        // w^(2^18 j)     j < 512
+    uint32_t* ninv;      // n^-1 (Montgomery) for the inverse transform, else nullptr
+};
+
+struct NttGeom {
+    int logA, logB, logC, logn;
+};
+
+// per-field entry points.  Field ids follow enum blz_curve: the scalar field Fr of that curve.
+struct NttFieldOps {
+    int two_adicity;
+    // fill the twiddle tables (device memory already carved into T) for a 2^logn transform
+    int (*setup)(hipStream_t st, NttTables& T, const NttGeom& g, int inverse);
+    // one of the three passes; cols_log is the tile width of the radix-2-in-LDS kernel
+    int (*pass)(int pass, hipStream_t st, const void* in, void* out, const NttGeom& g, const NttTables& T, int cols_log,
+                bool force_generic);
+};
+const NttFieldOps& ntt_ops_bls377();
+const NttFieldOps& ntt_ops_bls381();
+const NttFieldOps& ntt_ops_bn254();
+
+}  // namespace blz

@@ -30,15 +30,20 @@ class NTTInput:  # ntt_api.rs:19-23
 
 class NTTClient(DriverPrimitive[NTT, NttInit, NTTInput, bytes]):
     """ntt_api.rs:12-15, 25-125.  `log_size` defaults to the reference's fixed 2^27; smaller
-    transforms exist for tests (the reference has no such knob)."""
+    transforms exist for tests (the reference has no such knob).  `field` names the curve whose
+    scalar field the transform is over ("BLS381" by default, "BLS377", "BN254")."""
 
-    def __init__(self, _ptype: NTT, dclient: DriverClient, log_size: int = NTT_LOG_SIZE, inverse: bool = False):
+    _FIELDS = {"BLS377": 0, "BLS381": 1, "BN254": 2}  # enum blz_curve
+
+    def __init__(self, _ptype: NTT, dclient: DriverClient, log_size: int = NTT_LOG_SIZE, inverse: bool = False,
+                 field: str = "BLS381"):
         self.driver_client = dclient
         self.log_size = log_size
         self.inverse = inverse
+        self.field = field
         self.nbytes = NTT_WORD_SIZE << log_size
         h = C.c_void_p()
-        check(lib().blz_ntt_new_ex(dclient.id, log_size, int(inverse), C.byref(h)))
+        check(lib().blz_ntt_new_field(dclient.id, self._FIELDS[field], log_size, int(inverse), C.byref(h)))
         self._h = h
 
     def close(self):

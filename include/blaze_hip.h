@@ -148,6 +148,10 @@ int blz_ntt_new(int device_id, int log_size, blz_ntt** out);
 /* same, with the transform direction: inverse != 0 gives x[i] = n^-1 sum_k X[k] omega^(-ik) (natural order;
  * the reference has no such knob: SURVEY.md 8(f) rank 3) */
 int blz_ntt_new_ex(int device_id, int log_size, int inverse, blz_ntt** out);
+/* same over the scalar field of another curve (field = enum blz_curve: BLS12-377 Fr, generator 22,
+ * two-adicity 47; BN254 Fr, generator 5, two-adicity 28).  The bitstream the
+ * reference drives is built for one field; here the kernels are instantiated per field. */
+int blz_ntt_new_field(int device_id, int field, int log_size, int inverse, blz_ntt** out);
 void blz_ntt_free(blz_ntt* h);
 /* NTTClient::initialize(NttInit{}) (ntt_api.rs:37-56) */
 int blz_ntt_initialize(blz_ntt* h);

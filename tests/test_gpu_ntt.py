@@ -168,3 +168,44 @@ def test_bank_wire_permutation(gpu, orc, logn):
     cl.close()
     for b in (d_in, d_banks, d_out):
         b.free()
+
+
+@pytest.mark.parametrize("field", ["BLS377", "BN254"])
+@pytest.mark.parametrize("logn", [3, 9, 12, 18, 20])
+def test_other_scalar_fields(gpu, orc, field, logn):
+    """the same passes over BLS12-377 Fr and BN254 Fr (lazy-range fields on the
+    device, canonical on the wire), forward against the oracle and inverse(forward(x)) == x."""
+    r = pyref.CURVES[field]["r"]
+    rng = random.Random(1000 + logn)
+    n = 1 << logn
+    base = [rng.randrange(r) for _ in range(min(n, 2048))] + [0, 1, r - 1, r - 2]
+    data = b"".join(base[(i * 7 + i // 2048) % len(base)].to_bytes(32, "little") for i in range(n))
+    cl = NTTClient(NTT.Ntt, DriverClient(0), log_size=logn, field=field)
+    got = _ntt(cl, data)
+    assert got == bytes(orc.ntt(field, data, logn, threads=16))
+    inv = NTTClient(NTT.Ntt, DriverClient(0), log_size=logn, inverse=True, field=field)
+    assert _ntt(inv, got) == data
+    cl.close()
+    inv.close()
+
+
+def test_other_fields_large_and_limits(gpu, orc):
+    """2^24 over BN254 Fr by properties + spot coefficients; BN254's two-adicity is 28, so 2^27 exists;
+    sizes beyond a field's two-adicity are refused."""
+    import numpy as np
+    field, logn = "BN254", 24
+    r = pyref.CURVES[field]["r"]
+    n = 1 << logn
+    rng = np.random.default_rng(3)
+    x = rng.integers(0, 256, size=32 * n, dtype=np.uint8)
+    x[31::32] &= 0x1F          # < 2^253 < r: canonical
+    cl = NTTClient(NTT.Ntt, DriverClient(0), log_size=logn, field=field)
+    y = np.frombuffer(_ntt(cl, x.tobytes()), dtype=np.uint8)
+    for k in (0, 1, 54321, n - 1):
+        got = int.from_bytes(y[32 * k: 32 * k + 32].tobytes(), "little")
+        assert got == orc.ntt_eval_at(field, x, logn, k), k
+        assert got < r
+    cl.close()
+    with pytest.raises(DriverClientError) as ei:
+        NTTClient(NTT.Ntt, DriverClient(0), log_size=28, field="BN254")   # > 27: shape limit of the 3-pass plan
+    assert ei.value.variant == "InvalidPrimitiveParam"
