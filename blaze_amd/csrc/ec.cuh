@@ -139,15 +139,34 @@ BLZ_DEV void pt_madd(XYZZ<F>& acc, const Affine<F>& q) {
     fp_mulsub2(acc.y, R, Q, acc.y, PPP);   // R (Q - X3) - Y1 PPP with one reduction
 }
 
-template <class F>
+// TAG: a kernel with its own register budget instantiates its own copy of the out-of-line doubling
+// (a shared callee is compiled for the most generous of its callers, and that then becomes the
+// register count of every kernel that can reach it)
+template <class F, int TAG = 0>
 __device__ __noinline__ XYZZ<F> pt_dbl_val(XYZZ<F> p) {
     XYZZ<F> r;
-    pt_dbl(r, p);
+    if (pt_is_inf(p)) { pt_set_inf(r); return r; }
+    Fp<F> U, V, W, S, M, t, x3;
+    fp_dbl(U, p.y);
+    fp_sqr(V, U);
+    fp_mul(W, U, V);
+    fp_mul(S, p.x, V);
+    fp_sqr(t, p.x);
+    fp_dbl(M, t);
+    fp_add(M, M, t);
+    fp_sqr(x3, M);
+    fp_sub(x3, x3, S);
+    fp_sub(x3, x3, S);
+    fp_sub(t, S, x3);
+    fp_mulsub2(r.y, M, t, W, p.y);
+    r.x = x3;
+    fp_mul(r.zz, V, p.zz);
+    fp_mul(r.zzz, W, p.zzz);
     return r;
 }
 
 // acc += q   (both XYZZ), inlined form for throughput-bound kernels (operands stay in registers)
-template <class F>
+template <class F, int TAG = 0>
 BLZ_DEV void pt_add_inl(XYZZ<F>& acc, const XYZZ<F>& q) {
     if (pt_is_inf(q)) return;
     if (pt_is_inf(acc)) { acc = q; return; }
@@ -160,7 +179,7 @@ BLZ_DEV void pt_add_inl(XYZZ<F>& acc, const XYZZ<F>& q) {
     fp_sub(R, R, S1);
     if (__builtin_expect(fp_maybe_zero(P), 0)) {
         if (fp_is_zero(P)) {
-            if (fp_is_zero(R)) acc = pt_dbl_val(q);
+            if (fp_is_zero(R)) acc = pt_dbl_val<F, TAG>(q);
             else pt_set_inf(acc);
             return;
         }

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(128, 3) void k_combine_units(const uint32_t* __rest
 // outA[t] = r_t (weights t at the next level, woff = 0), outC[t] = Sum C_in + 2^shift * s_t.
 // ------------------------------------------------------------------------------------------------
 template <class F, bool FIRST>
-__global__ __launch_bounds__(64, 3) void k_reduce_level(const uint32_t* __restrict__ inA, const uint32_t* __restrict__ inC,
+__global__ __launch_bounds__(64, FIRST ? 2 : 3) void k_reduce_level(const uint32_t* __restrict__ inA, const uint32_t* __restrict__ inC,
                                                      const uint32_t* __restrict__ unit_off, uint32_t M, uint32_t SEG,
                                                      uint32_t T, int W, int shift, uint32_t* __restrict__ outA,
                                                      uint32_t* __restrict__ outC) {
@@ -168,8 +168,8 @@ __global__ __launch_bounds__(64, 3) void k_reduce_level(const uint32_t* __restri
             uint32_t u0 = unit_off[idx], u1 = unit_off[idx + 1];
             if (u1 > u0) load_xyzz(a, inA, u0);
             else pt_set_inf(a);
-            pt_add_inl(run, a);
-            pt_add_inl(s, run);  // weights i + 1 at the first level
+            pt_add_inl<F, 1>(run, a);
+            pt_add_inl<F, 1>(s, run);  // weights i + 1 at the first level
         } else {
             load_xyzz(a, inA, idx);
             XYZZ<F> cc;
@@ -180,8 +180,8 @@ __global__ __launch_bounds__(64, 3) void k_reduce_level(const uint32_t* __restri
         }
     }
     if constexpr (FIRST) {
-        for (int d = 0; d < shift; ++d) { XYZZ<F> t2; pt_dbl(t2, s); s = t2; }
-        pt_add(cs, s);
+        cs = s;  // level 0: shift = 0 and no incoming C (and no call into the shared out-of-line group law:
+                 // this kernel has its own register budget, see pt_dbl_val's TAG)
     } else {
         for (int d = 0; d < shift; ++d) quad_dbl(s, ql);
         quad_add(cs, s, ql);
