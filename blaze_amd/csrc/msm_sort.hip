@@ -165,6 +165,106 @@ __global__ __launch_bounds__(SORT_THREADS) void k_coarse_scatter(const uint32_t*
     }
 }
 
+// Coarse scatter, window at a time, LDS-staged.  The kernel above issues one 8-byte store per entry to
+// W * 2^ch scattered cursors, and the L2 takes ~100 G such requests per second whatever their size:
+// 8.2 of its 9.6 ms at 2^26 (with the stores removed it runs in 1.4 ms).  Here a block keeps CS_T
+// scalars per lane in registers and walks the windows: per window its entries are ranked with an LDS
+// histogram over the window's 2^ch bins, laid out bin-major in an LDS stage, and copied out slot-major,
+// so consecutive lanes write consecutive addresses of a bin's run (8 entries = 64 B on average).
+constexpr int CS_THREADS = 512;
+constexpr int CS_T = 16;
+constexpr int CS_PTS = CS_THREADS * CS_T;  // 8192 points per block: 64 KiB of staging
+
+template <int SW>
+__global__ __launch_bounds__(CS_THREADS) void k_coarse_scatter_staged(const uint32_t* __restrict__ scalars, uint32_t npts,
+                                                                      SortGeom g, uint32_t* __restrict__ coarse_cursor,
+                                                                      uint2* __restrict__ inter) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t sh[];
+    const uint32_t nb = 1u << g.ch;
+    uint32_t* hist = sh;              // [nb] counts of this window
+    uint32_t* lstart = sh + nb;       // [nb] first stage slot of the bin
+    uint32_t* gbase = sh + 2 * nb;    // [nb] reserved global position of the bin's run
+    uint2* stage = reinterpret_cast<uint2*>(sh + 3 * nb);  // [CS_PTS]
+    __shared__ uint32_t wave_tot[CS_THREADS / 64];
+    __shared__ uint32_t total_sh;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t base = blockIdx.x * (uint32_t)CS_PTS;
+    const uint32_t mask = (1u << g.c) - 1u, half = 1u << (g.c - 1), fmask = (1u << g.cl) - 1u;
+    ScalarWords<SW> sw[CS_T];
+    uint32_t carry[CS_T];
+#pragma unroll
+    for (int u = 0; u < CS_T; ++u) {
+        uint32_t p = base + u * CS_THREADS + tid;
+        sw[u].load(scalars, p < npts ? p : 0u);
+        carry[u] = 0;
+    }
+    const uint32_t per = nb > (uint32_t)CS_THREADS ? nb / CS_THREADS : 1u;  // bins per lane in the scan
+    for (int w = 0; w < g.W; ++w) {
+        for (uint32_t i = tid; i < nb; i += CS_THREADS) hist[i] = 0;
+        __syncthreads();
+        uint32_t key[CS_T], rk[CS_T];  // key = fine | bin << 12 | sign << 31;  rk = rank in the bin, ~0 = no entry
+#pragma unroll
+        for (int u = 0; u < CS_T; ++u) {
+            int d = sw[u].next(g.c, mask, half, carry[u]);
+            rk[u] = ~0u;
+            key[u] = 0;
+            if (d != 0 && base + u * CS_THREADS + tid < npts) {
+                uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1u;
+                uint32_t bin = b >> g.cl;
+                key[u] = (b & fmask) | (bin << 12) | (d < 0 ? 0x80000000u : 0u);
+                rk[u] = atomicAdd(&hist[bin], 1u);
+            }
+        }
+        __syncthreads();
+        {   // exclusive scan of hist + one global reservation per non-empty bin
+            const uint32_t b0 = tid * per;
+            uint32_t loc[4];
+            uint32_t sum = 0;
+            for (uint32_t q = 0; q < per; ++q) {
+                uint32_t v = (b0 + q) < nb ? hist[b0 + q] : 0u;
+                loc[q] = v;
+                sum += v;
+            }
+            uint32_t incl = sum;
+            for (int o = 1; o < 64; o <<= 1) {
+                uint32_t t2 = __shfl_up(incl, o, 64);
+                if ((tid & 63u) >= (uint32_t)o) incl += t2;
+            }
+            if ((tid & 63u) == 63u) wave_tot[tid >> 6] = incl;
+            __syncthreads();
+            uint32_t wbase = 0;
+            for (uint32_t q = 0; q < (tid >> 6); ++q) wbase += wave_tot[q];
+            uint32_t run = wbase + incl - sum;
+            for (uint32_t q = 0; q < per; ++q) {
+                if ((b0 + q) < nb) {
+                    uint32_t v = loc[q];
+                    lstart[b0 + q] = run;
+                    gbase[b0 + q] = v ? atomicAdd(&coarse_cursor[((uint32_t)w << g.ch) + b0 + q], v) : 0u;
+                    run += v;
+                }
+            }
+            if (tid == CS_THREADS - 1) total_sh = wbase + incl;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < CS_T; ++u) {
+            if (rk[u] != ~0u) {
+                uint32_t bin = (key[u] >> 12) & 0x7ffffu;
+                uint32_t p = base + u * CS_THREADS + tid;
+                stage[lstart[bin] + rk[u]] = make_uint2(p | (key[u] & 0x80000000u), (key[u] & 0xfffu) | (bin << 16));
+            }
+        }
+        __syncthreads();
+        const uint32_t total = total_sh;
+        for (uint32_t slot = tid; slot < total; slot += CS_THREADS) {
+            uint2 e = stage[slot];
+            uint32_t bin = e.y >> 16;
+            inter[gbase[bin] + (slot - lstart[bin])] = make_uint2(e.x, e.y & 0xffffu);
+        }
+        __syncthreads();
+    }
+}
+
 // Work list of the fine passes: coarse bin k is cut into ceil(size_k / SLICE) slices, so a bin that
 // holds far more than the mean (the short top window puts 1/W of all entries into a handful of bins;
 // the reference harness's repeated tile does the same everywhere) is spread over many blocks.  Built on
@@ -245,14 +345,14 @@ __global__ __launch_bounds__(FINE_THREADS) void k_fine_count(const uint2* __rest
 }
 
 // Final scatter, LDS-staged: a block takes its slice in rounds of up to FS_ROUND entries held in
-// registers; ranks come from an LDS histogram, the round is laid out bucket-major in an LDS staging
-// buffer, and ONE lane per bucket copies that bucket's run to its reserved global range - so HBM sees
-// contiguous runs instead of one 4-byte write per entry (the unstaged version wrote 17.6 GB for
-// 3.2 GB of entries in the WRITE_SIZE counter).
+// registers; ranks come from an LDS histogram, the round is laid out bucket-major in an LDS stage
+// (payload + 16-bit bucket id per slot) and copied out slot-major: consecutive lanes write consecutive
+// entries of a bucket's run, and neighbouring buckets' runs are neighbours in memory too, so a store
+// instruction touches a handful of lines instead of 64 (one-lane-per-bucket copy-out: 5.0 ms; the
+// unstaged version wrote 17.6 GB for 3.2 GB of entries in the WRITE_SIZE counter).
 constexpr int FS_THREADS = 1024;
-constexpr int FS_PER_THREAD = 32;
-constexpr int FS_ROUND = FS_THREADS * FS_PER_THREAD;  // 32768 entries = 128 KiB of staging
-constexpr uint32_t FS_BIG_RUN = 128;
+constexpr int FS_PER_THREAD = 24;
+constexpr int FS_ROUND = FS_THREADS * FS_PER_THREAD;  // up to 24576 entries: 6 bytes of staging each
 
 __global__ __launch_bounds__(FS_THREADS) void k_fine_scatter(const uint2* __restrict__ inter, const uint32_t* __restrict__ coarse_off,
                                                              const uint2* __restrict__ slice_map, const uint32_t* __restrict__ nslices,
@@ -260,18 +360,15 @@ __global__ __launch_bounds__(FS_THREADS) void k_fine_scatter(const uint2* __rest
                                                              uint32_t* __restrict__ cursor, uint32_t* __restrict__ entries) {
     extern __shared__ __attribute__((aligned(16))) uint32_t sh[];
     const uint32_t nf = 1u << cl;
-    uint32_t* hist = sh;             // [nf]  counts, then exclusive local base
-    uint32_t* gbase = sh + nf;       // [nf]  reserved global base per bucket
-    uint32_t* cnt = sh + 2 * nf;     // [nf]  counts of this round
-    uint32_t* stage = sh + 3 * nf;   // [FS_ROUND]
+    uint32_t* hist = sh;             // [nf]  counts, then first stage slot of the bucket
+    uint32_t* gbase = sh + nf;       // [nf]  reserved global position of the bucket's run
+    uint32_t* stage = sh + 2 * nf;   // [round_cap] payloads
+    uint16_t* ids = reinterpret_cast<uint16_t*>(stage + round_cap);  // [round_cap] bucket of each slot
     __shared__ uint32_t wave_tot[FS_THREADS / 64];
-    __shared__ uint32_t big[FS_ROUND / FS_BIG_RUN];  // runs longer than FS_BIG_RUN in one round
-    __shared__ uint32_t nbig;
     uint32_t k, lo, hi;
     bool multi;
     if (!slice_range(coarse_off, slice_map, nslices, blockIdx.x, k, lo, hi, multi)) return;
     uint32_t* cur = cursor + ((size_t)k << cl);
-    uint32_t* dst = entries;
     const uint32_t per_thr_bins = (nf + FS_THREADS - 1) / FS_THREADS;
     for (uint32_t r0 = lo; r0 < hi; r0 += round_cap) {
         const uint32_t rn = (hi - r0) < round_cap ? (hi - r0) : round_cap;
@@ -312,7 +409,6 @@ __global__ __launch_bounds__(FS_THREADS) void k_fine_scatter(const uint2* __rest
             for (uint32_t q = 0; q < per_thr_bins; ++q) {
                 if ((b0 + q) < nf) {
                     uint32_t v = loc[q];
-                    cnt[b0 + q] = v;
                     hist[b0 + q] = run;
                     gbase[b0 + q] = v ? atomicAdd(&cur[b0 + q], v) : 0u;
                     run += v;
@@ -323,28 +419,16 @@ __global__ __launch_bounds__(FS_THREADS) void k_fine_scatter(const uint2* __rest
 #pragma unroll
         for (int t = 0; t < FS_PER_THREAD; ++t) {
             uint32_t j = t * FS_THREADS + threadIdx.x;
-            if (j < rn) stage[hist[ey[t] & 0xfffu] + (ey[t] >> 12)] = ex[t];
-        }
-        __syncthreads();
-        // one lane copies one bucket's run (a slot-major copy with a binary search for the bucket
-        // measured slower: 27.7 vs 23.5 ms for the whole sort)
-        // ... except for long runs (a hot bucket: short top window, repeated scalars), which would
-        // serialise the block behind one lane: those are queued and copied a wave per run
-        if (threadIdx.x == 0) nbig = 0;
-        __syncthreads();
-        for (uint32_t f = threadIdx.x; f < nf; f += FS_THREADS) {
-            uint32_t n = cnt[f], src = hist[f], g0 = gbase[f];
-            if (n > FS_BIG_RUN) {
-                big[atomicAdd(&nbig, 1u)] = f;
-                continue;
+            if (j < rn) {
+                uint32_t f = ey[t] & 0xfffu, slot = hist[f] + (ey[t] >> 12);
+                stage[slot] = ex[t];
+                ids[slot] = (uint16_t)f;
             }
-            for (uint32_t q = 0; q < n; ++q) dst[g0 + q] = stage[src + q];
         }
         __syncthreads();
-        for (uint32_t b = threadIdx.x >> 6; b < nbig; b += FS_THREADS / 64) {
-            uint32_t f = big[b];
-            uint32_t n = cnt[f], src = hist[f], g0 = gbase[f];
-            for (uint32_t q = threadIdx.x & 63u; q < n; q += 64) dst[g0 + q] = stage[src + q];
+        for (uint32_t slot = threadIdx.x; slot < rn; slot += FS_THREADS) {
+            uint32_t f = ids[slot];
+            entries[gbase[f] + (slot - hist[f])] = stage[slot];
         }
         __syncthreads();
     }
@@ -399,7 +483,21 @@ int msm_sort_lds(MsmEngine& E, const void* d_scalars, uint32_t npts, int sbits) 
     if (sbits == 256) hipLaunchKernelGGL(k_coarse_count<8>, dim3(nblk), dim3(SORT_THREADS), lds, st, sc, npts, g, coarse_count);
     else hipLaunchKernelGGL(k_coarse_count<1>, dim3(nblk), dim3(SORT_THREADS), lds, st, sc, npts, g, coarse_count);
     hipLaunchKernelGGL(k_coarse_scan, dim3(1), dim3(1024), 0, st, coarse_count, g.NC, coarse_off);
-    if (sbits == 256)
+    // BLAZE_SORT_STAGED=0 selects the unstaged coarse scatter (kept for A/B measurements)
+    if (msm_env_int("BLAZE_SORT_STAGED", 1) != 0 && g.ch <= 11 && g.cl <= 12) {
+        static bool attr_cs = false;
+        if (!attr_cs) {
+            BLZ_HIP(hipFuncSetAttribute((const void*)k_coarse_scatter_staged<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024), BLZ_ERR_UNKNOWN);
+            BLZ_HIP(hipFuncSetAttribute((const void*)k_coarse_scatter_staged<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024), BLZ_ERR_UNKNOWN);
+            attr_cs = true;
+        }
+        const size_t lds_cs = ((size_t)3 << g.ch) * 4 + (size_t)CS_PTS * 8;
+        const uint32_t nblk_cs = (npts + CS_PTS - 1) / CS_PTS;
+        if (sbits == 256)
+            hipLaunchKernelGGL(k_coarse_scatter_staged<8>, dim3(nblk_cs), dim3(CS_THREADS), lds_cs, st, sc, npts, g, coarse_count, E.inter.as<uint2>());
+        else
+            hipLaunchKernelGGL(k_coarse_scatter_staged<1>, dim3(nblk_cs), dim3(CS_THREADS), lds_cs, st, sc, npts, g, coarse_count, E.inter.as<uint2>());
+    } else if (sbits == 256)
         hipLaunchKernelGGL(k_coarse_scatter<8>, dim3(nblk), dim3(SORT_THREADS), lds, st, sc, npts, g, coarse_count, E.inter.as<uint2>());
     else
         hipLaunchKernelGGL(k_coarse_scatter<1>, dim3(nblk), dim3(SORT_THREADS), lds, st, sc, npts, g, coarse_count, E.inter.as<uint2>());
@@ -426,12 +524,12 @@ int msm_sort_lds_scatter(MsmEngine& E) {
         BLZ_HIP(hipFuncSetAttribute((const void*)k_fine_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024), BLZ_ERR_UNKNOWN);
         attr_done = true;
     }
-    // staging entries per round: what is left of the LDS after the three per-bucket arrays
-    size_t budget = (size_t)157 * 1024 - ((size_t)3 << E.sort_cl) * 4;
-    uint32_t round_cap = (uint32_t)(budget / 4);
+    // staging entries per round (6 bytes each): what is left of the LDS after the two per-bucket arrays
+    size_t budget = (size_t)157 * 1024 - ((size_t)2 << E.sort_cl) * 4;
+    uint32_t round_cap = (uint32_t)(budget / 6);
     if (round_cap > (uint32_t)FS_ROUND) round_cap = FS_ROUND;
     round_cap &= ~1023u;
-    const size_t lds = ((size_t)3 << E.sort_cl) * 4 + (size_t)round_cap * 4;
+    const size_t lds = ((size_t)2 << E.sort_cl) * 4 + (size_t)round_cap * 6;
     hipLaunchKernelGGL(k_fine_scatter, dim3(E.sort_slices), dim3(FS_THREADS), lds, st, E.inter.as<uint2>(), coarse_off,
                        E.slice_map.as<uint2>() + 1, E.slice_map.as<uint32_t>(), E.sort_cl, round_cap, E.count.as<uint32_t>(),
                        E.entries.as<uint32_t>());
