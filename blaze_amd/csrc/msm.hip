@@ -152,7 +152,8 @@ __global__ __launch_bounds__(256) void k_scan_reduce(const uint32_t* __restrict_
     }
     uint64_t tot = block_sum_u64(acc, sh);
     for (int o = 32; o > 0; o >>= 1) { uint32_t t = __shfl_down(mx, o, 64); mx = t > mx ? t : mx; }
-    if ((threadIdx.x & 63) == 0 && mx) atomicMax(&stats[1], mx);
+    // (guarded: 5 x 10^4 unconditional atomics on one address cost 0.5 ms; the value only grows)
+    if ((threadIdx.x & 63) == 0 && mx > *(volatile uint32_t*)&stats[1]) atomicMax(&stats[1], mx);
     if (threadIdx.x == 0) blocksums[blockIdx.x] = tot;
 }
 
@@ -232,32 +233,40 @@ __global__ __launch_bounds__(256) void k_scan_final(uint32_t* __restrict__ count
 constexpr int MAX_L = 1024;
 constexpr uint32_t UNITS_INLINE = 8;   // buckets with more units than this are filled by the whole block
 
-// unit -> bucket map + histogram of unit lengths
+// unit -> bucket map + histogram of unit lengths.  Grid-stride over chunks of 256 buckets: the LDS
+// histogram is flushed once per block (one block per chunk meant 10^5 blocks x 257 global atomics on
+// the same 257 addresses: 1.3 ms at 2^26, all of it atomic serialisation).
+constexpr uint32_t UNIT_GRID = 2048;
+
 __global__ __launch_bounds__(256) void k_fill_units(const uint32_t* __restrict__ off, const uint32_t* __restrict__ unit_off,
                                                     uint64_t G, uint32_t L, uint32_t* __restrict__ unit_bucket,
                                                     uint32_t* __restrict__ hist) {
     __shared__ uint32_t sh[MAX_L + 1];
     __shared__ uint32_t big[256], nbig;
     for (uint32_t i = threadIdx.x; i <= L; i += 256) sh[i] = 0;
-    if (threadIdx.x == 0) nbig = 0;
-    __syncthreads();
-    // a bucket of cnt entries has cnt / L full units and one unit of cnt % L entries
-    const uint64_t g0 = (uint64_t)blockIdx.x * 256;
-    uint64_t g = g0 + threadIdx.x;
-    if (g < G) {
-        uint32_t u0 = unit_off[g], u1 = unit_off[g + 1];
-        uint32_t cnt = off[g + 1] - off[g];
-        uint32_t nfull = cnt / L, rem = cnt - nfull * L;
-        if (nfull) atomicAdd(&sh[L], nfull);
-        if (rem) atomicAdd(&sh[rem], 1u);
-        if (u1 - u0 > UNITS_INLINE) big[atomicAdd(&nbig, 1u)] = threadIdx.x;   // hot bucket: the block fills it together
-        else for (uint32_t u = u0; u < u1; ++u) unit_bucket[u] = (uint32_t)g;
-    }
-    __syncthreads();
-    for (uint32_t b = 0; b < nbig; ++b) {
-        uint64_t gb = g0 + big[b];
-        uint32_t u0 = unit_off[gb], u1 = unit_off[gb + 1];
-        for (uint32_t u = u0 + threadIdx.x; u < u1; u += 256) unit_bucket[u] = (uint32_t)gb;
+    const uint64_t nchunks = (G + 255) / 256;
+    for (uint64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        if (threadIdx.x == 0) nbig = 0;
+        __syncthreads();
+        // a bucket of cnt entries has cnt / L full units and one unit of cnt % L entries
+        const uint64_t g0 = chunk * 256;
+        uint64_t g = g0 + threadIdx.x;
+        if (g < G) {
+            uint32_t u0 = unit_off[g], u1 = unit_off[g + 1];
+            uint32_t cnt = off[g + 1] - off[g];
+            uint32_t nfull = cnt / L, rem = cnt - nfull * L;
+            if (nfull) atomicAdd(&sh[L], nfull);
+            if (rem) atomicAdd(&sh[rem], 1u);
+            if (u1 - u0 > UNITS_INLINE) big[atomicAdd(&nbig, 1u)] = threadIdx.x;   // hot bucket: the block fills it together
+            else for (uint32_t u = u0; u < u1; ++u) unit_bucket[u] = (uint32_t)g;
+        }
+        __syncthreads();
+        for (uint32_t b = 0; b < nbig; ++b) {
+            uint64_t gb = g0 + big[b];
+            uint32_t u0 = unit_off[gb], u1 = unit_off[gb + 1];
+            for (uint32_t u = u0 + threadIdx.x; u < u1; u += 256) unit_bucket[u] = (uint32_t)gb;
+        }
+        __syncthreads();
     }
     for (uint32_t i = threadIdx.x; i <= L; i += 256)
         if (sh[i]) atomicAdd(&hist[i], sh[i]);
@@ -281,18 +290,17 @@ __global__ __launch_bounds__(256) void k_unit_order(const uint32_t* __restrict__
     __shared__ uint32_t sh_base[MAX_L + 1];
     __shared__ uint32_t big[256], big_pos[256], nbig;
     for (uint32_t i = threadIdx.x; i <= L; i += 256) sh_cnt[i] = 0;
-    if (threadIdx.x == 0) nbig = 0;
     __syncthreads();
-    const uint64_t g0 = (uint64_t)blockIdx.x * 256;
-    uint64_t g = g0 + threadIdx.x;
-    uint32_t u0 = 0, nfull = 0, rem = 0;
-    if (g < G) {
-        u0 = unit_off[g];
-        uint32_t cnt = off[g + 1] - off[g];
-        nfull = cnt / L;
-        rem = cnt - nfull * L;
-        if (nfull) atomicAdd(&sh_cnt[L], nfull);
-        if (rem) atomicAdd(&sh_cnt[rem], 1u);
+    const uint64_t nchunks = (G + 255) / 256;
+    // pass 1 over this block's chunks: how many units of each length
+    for (uint64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        uint64_t g = chunk * 256 + threadIdx.x;
+        if (g < G) {
+            uint32_t cnt = off[g + 1] - off[g];
+            uint32_t nfull = cnt / L, rem = cnt - nfull * L;
+            if (nfull) atomicAdd(&sh_cnt[L], nfull);
+            if (rem) atomicAdd(&sh_cnt[rem], 1u);
+        }
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i <= L; i += 256) {
@@ -300,24 +308,36 @@ __global__ __launch_bounds__(256) void k_unit_order(const uint32_t* __restrict__
         sh_base[i] = v ? atomicAdd(&cursor[i], v) : 0u;
         sh_cnt[i] = 0;
     }
-    __syncthreads();
-    if (nfull) {
-        uint32_t pos = sh_base[L] + atomicAdd(&sh_cnt[L], nfull);
-        if (nfull > UNITS_INLINE) {
-            uint32_t q = atomicAdd(&nbig, 1u);
-            big[q] = threadIdx.x;
-            big_pos[q] = pos;
-        } else {
-            for (uint32_t k = 0; k < nfull; ++k) unit_order[pos + k] = u0 + k;
+    // pass 2: place
+    for (uint64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        if (threadIdx.x == 0) nbig = 0;
+        __syncthreads();
+        const uint64_t g0 = chunk * 256;
+        uint64_t g = g0 + threadIdx.x;
+        if (g < G) {
+            uint32_t u0 = unit_off[g];
+            uint32_t cnt = off[g + 1] - off[g];
+            uint32_t nfull = cnt / L, rem = cnt - nfull * L;
+            if (nfull) {
+                uint32_t pos = sh_base[L] + atomicAdd(&sh_cnt[L], nfull);
+                if (nfull > UNITS_INLINE) {
+                    uint32_t q = atomicAdd(&nbig, 1u);
+                    big[q] = threadIdx.x;
+                    big_pos[q] = pos;
+                } else {
+                    for (uint32_t k = 0; k < nfull; ++k) unit_order[pos + k] = u0 + k;
+                }
+            }
+            if (rem) unit_order[sh_base[rem] + atomicAdd(&sh_cnt[rem], 1u)] = u0 + nfull;
         }
-    }
-    if (rem) unit_order[sh_base[rem] + atomicAdd(&sh_cnt[rem], 1u)] = u0 + nfull;
-    __syncthreads();
-    for (uint32_t b = 0; b < nbig; ++b) {
-        uint64_t gb = g0 + big[b];
-        uint32_t ub = unit_off[gb];
-        uint32_t nf = (off[gb + 1] - off[gb]) / L, pos = big_pos[b];
-        for (uint32_t k = threadIdx.x; k < nf; k += 256) unit_order[pos + k] = ub + k;
+        __syncthreads();
+        for (uint32_t b = 0; b < nbig; ++b) {
+            uint64_t gb = g0 + big[b];
+            uint32_t ub = unit_off[gb];
+            uint32_t nf = (off[gb + 1] - off[gb]) / L, pos = big_pos[b];
+            for (uint32_t k = threadIdx.x; k < nf; k += 256) unit_order[pos + k] = ub + k;
+        }
+        __syncthreads();
     }
 }
 
@@ -347,7 +367,8 @@ int launch_fill_units(MsmEngine& E, uint32_t U) {
     uint32_t* hist = E.lenhist.as<uint32_t>();
     uint32_t* cursor = hist + (MAX_L + 1);
     BLZ_HIP(hipMemsetAsync(hist, 0, 2 * (MAX_L + 1) * 4, st), BLZ_ERR_UNKNOWN);
-    dim3 gg((uint32_t)((G + 255) / 256)), b(256);
+    uint64_t nchunks = (G + 255) / 256;
+    dim3 gg((uint32_t)(nchunks < UNIT_GRID ? nchunks : UNIT_GRID)), b(256);
     hipLaunchKernelGGL(k_fill_units, gg, b, 0, st, E.off.as<uint32_t>(), E.unit_off.as<uint32_t>(), G, L,
                        E.unit_bucket.as<uint32_t>(), hist);
     hipLaunchKernelGGL(k_unit_len_scan, dim3(1), b, 0, st, hist, L, cursor);
