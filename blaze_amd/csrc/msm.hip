@@ -11,7 +11,7 @@
 //   k_reduce_level Sum_b b*S_b per window by segmented running sums, a few levels  [phase 2]
 //   k_finish       Horner over windows, single inversion, canonical Z=1|y|x        [phase 3]
 //
-// HBM layout: points AoS Montgomery (2N dwords each, 16-B aligned), scalars raw 32 B LE, entries
+// HBM layout: points AoS Montgomery (one 128-B line per BLS point, 64 B per BN254 point), scalars raw 32 B LE, entries
 // u32, bucket partials AoS XYZZ (4N dwords).  The gathers are 96-B (64-B) contiguous per lane;
 // the arithmetic (v_mad_u64_u32) bounds every kernel here, not HBM.
 #include "msm_engine.hpp"
@@ -21,6 +21,7 @@
 namespace blz {
 
 size_t fq_bytes(int curve) { return curve == BLZ_BN254 ? 32 : 48; }
+size_t mont_point_bytes(int curve) { return curve == BLZ_BN254 ? 64 : 128; }
 
 // ------------------------------------------------------------------------------------------------
 // plan

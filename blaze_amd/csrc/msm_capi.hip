@@ -46,15 +46,18 @@ int arena_points_mont(blz_msm* h, uint64_t pos, uint32_t npts, const void** out)
     if (!e)
         return fail(BLZ_ERR_INVALID_PARAM, "HBM bases: no loaded extent covers [%llu, +%zu) on device %d",
                     (unsigned long long)pos, len, h->device);
-    if ((pos - e->start) % 16 != 0) return fail(BLZ_ERR_INVALID_PARAM, "HBM point address must be 16-byte aligned");
+    // the shadow holds the Montgomery form of the extent's whole points, one per mont_point_bytes()
+    if ((pos - e->start) % point_size(h) != 0)
+        return fail(BLZ_ERR_INVALID_PARAM, "HBM point address must be a whole number of points into its loaded extent");
+    const size_t mp = mont_point_bytes(h->curve);
     if (e->mont_curve != h->curve) {
-        if (!e->mont) BLZ_HIP(hipMalloc(&e->mont, e->len), BLZ_ERR_UNKNOWN);
-        // shadow holds the Montgomery form of whole points; extents are loaded point-aligned
         uint32_t ext_pts = (uint32_t)(e->len / point_size(h));
+        if (e->mont) { (void)hipFree(e->mont); e->mont = nullptr; }   // stride differs between curves
+        BLZ_HIP(hipMalloc(&e->mont, (size_t)ext_pts * mp + 16), BLZ_ERR_UNKNOWN);
         BLZ_TRY(h->eng.points_to_mont(e->raw, e->mont, ext_pts));
         e->mont_curve = h->curve;
     }
-    *out = (const char*)e->mont + (pos - e->start);
+    *out = (const char*)e->mont + (pos - e->start) / point_size(h) * mp;
     return BLZ_OK;
 }
 
@@ -102,17 +105,17 @@ int stage_common(blz_msm* h, bool have_points, const void* points, size_t points
         // (msm_api.rs:312); both tests use offset 0.  Here the task reads where the load wrote.
         BLZ_TRY(arena_points_mont(h, hbm_addr + hbm_off, npts, &h->d_points_mont));
     } else {
+        const size_t want_mont = (size_t)npts * mont_point_bytes(h->curve);
+        BLZ_TRY(h->points_mont.reserve(want_mont ? want_mont : 16));
         if (on_device) {
             if (((uintptr_t)points) % 16) return fail(BLZ_ERR_INVALID_PARAM, "device points must be 16-byte aligned");
-            BLZ_TRY(h->points_mont.reserve(want_pts ? want_pts : 16));
             BLZ_TRY(h->eng.points_to_mont(points, h->points_mont.p, npts));
         } else {
             BLZ_TRY(h->points_raw.reserve(want_pts ? want_pts : 16));
             if (want_pts) BLZ_HIP(hipMemcpyAsync(h->points_raw.p, points, want_pts, hipMemcpyHostToDevice, st), BLZ_ERR_WRITE);
-            BLZ_TRY(h->eng.points_to_mont(h->points_raw.p, h->points_raw.p, npts));  // in place
-            h->d_points_mont = h->points_raw.p;
+            BLZ_TRY(h->eng.points_to_mont(h->points_raw.p, h->points_mont.p, npts));
         }
-        if (on_device) h->d_points_mont = h->points_mont.p;
+        h->d_points_mont = h->points_mont.p;
     }
     if (on_device) {
         if (((uintptr_t)scalars) % 16) return fail(BLZ_ERR_INVALID_PARAM, "device scalars must be 16-byte aligned");

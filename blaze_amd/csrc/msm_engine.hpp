@@ -53,7 +53,7 @@ struct MsmEngine {
     // device result bytes of slot s / scratch of combine_partials inside `result`
     uint32_t* slot_result(int s) { return result.as<uint32_t>() + (size_t)s * 64; }
     bool can_accept() const;
-    // raw wire-format points (x||y canonical LE) -> Montgomery AoS, npts points
+    // raw wire-format points (x||y canonical LE) -> Montgomery AoS at mont_point_bytes() stride (never in place)
     int points_to_mont(const void* d_raw, void* d_mont, uint32_t npts);
     // enqueue the whole pipeline; *slot identifies the task for finish().  Fails when both slots are busy.
     int run(const void* d_points_mont, const void* d_scalars, uint32_t npts, int sbits, int* slot);
@@ -65,6 +65,7 @@ struct MsmEngine {
 };
 
 size_t fq_bytes(int curve);
+size_t mont_point_bytes(int curve);  // stride of the Montgomery point array the pipeline reads (msm_impl.cuh MONT_STRIDE)
 int msm_env_int(const char* name, int dflt);
 // two-level LDS-privatised digit sort (msm_sort.hip): fills count[], then (after the scan) entries[]
 int msm_sort_lds(MsmEngine& E, const void* d_scalars, uint32_t npts, int sbits);

@@ -13,10 +13,15 @@
 namespace blz {
 
 // ------------------------------------------------------------------------------------------------
-// points: wire format -> Montgomery AoS
+// points: wire format -> Montgomery AoS.  A 96-byte point at a 96-byte stride straddles two 128-byte
+// lines half of the time, and every bucket add gathers one point: the Montgomery copy of a BLS point is
+// therefore padded to one 128-byte line (BN254: 64 bytes, two per line).
 // ------------------------------------------------------------------------------------------------
 template <class F>
-__global__ __launch_bounds__(256) void k_points_to_mont(const uint32_t* raw, uint32_t* mont,  // may alias (in place)
+constexpr int MONT_STRIDE = 2 * F::N > 16 ? 32 : 2 * F::N;  // dwords per Montgomery point
+
+template <class F>
+__global__ __launch_bounds__(256) void k_points_to_mont(const uint32_t* __restrict__ raw, uint32_t* __restrict__ mont,
                                                         uint32_t npts) {
     uint32_t p = blockIdx.x * 256u + threadIdx.x;
     if (p >= npts) return;
@@ -25,13 +30,13 @@ __global__ __launch_bounds__(256) void k_points_to_mont(const uint32_t* raw, uin
     fp_load(y, raw + (size_t)p * 2 * F::N + F::N);
     fp_to_mont(x, x);
     fp_to_mont(y, y);
-    fp_store(mont + (size_t)p * 2 * F::N, x);
-    fp_store(mont + (size_t)p * 2 * F::N + F::N, y);
+    fp_store(mont + (size_t)p * MONT_STRIDE<F>, x);
+    fp_store(mont + (size_t)p * MONT_STRIDE<F> + F::N, y);
 }
 
 template <class F>
 BLZ_DEV void load_affine(Affine<F>& a, const uint32_t* pts, uint32_t idx) {
-    const uint32_t* q = pts + (size_t)idx * 2 * F::N;
+    const uint32_t* q = pts + (size_t)idx * MONT_STRIDE<F>;
     fp_load(a.x, q);
     fp_load(a.y, q + F::N);
 }
