@@ -122,24 +122,41 @@ __global__ __launch_bounds__(128, 3) void k_combine_units(const uint32_t* __rest
                                                        const uint32_t* __restrict__ unit_order,
                                                        const uint32_t* __restrict__ nfull_ptr,
                                                        uint32_t stride, uint32_t* __restrict__ partial) {
-    uint32_t t0 = blockIdx.x * 128u + threadIdx.x;
-    if (t0 >= *nfull_ptr) return;
-    uint32_t u = unit_order[t0];
-    uint32_t g = unit_bucket[u];
-    uint32_t u0 = unit_off[g], u1 = unit_off[g + 1];
-    uint32_t k = u - u0;
-    if (u1 - u0 <= stride) return;
-    if (k % (16u * stride) != 0) return;
-    XYZZ<F> acc;
-    load_xyzz(acc, partial, u);
-    for (uint32_t j = 1; j < 16; ++j) {
-        uint32_t v = u + j * stride;
-        if (v >= u1) break;
-        XYZZ<F> t;
-        load_xyzz(t, partial, v);
-        pt_add(acc, t);
+    // One DPP quad per 16 consecutive entries of the full-unit list (ec_quad.cuh): it scans them for
+    // group leaders (at most two: a bucket's full units are contiguous in the list) and folds each
+    // leader's group.  The chain of up to 15 additions is sequential and only hot buckets have any, so
+    // latency is what counts: 4 dependent product rounds per add instead of 14, and every lane of a wave
+    // busy (one lane per list entry left 1 quad in 16 working: 1.4 ms for 16 K groups).
+    const uint32_t gt = blockIdx.x * 128u + threadIdx.x;
+    const uint32_t q = gt >> 2, ql = gt & 3u;
+    const uint32_t nfull = *nfull_ptr;
+    // scan first, fold afterwards: the quads of a wave find their leaders at different positions, and a
+    // chain started inside the scan loop would run once per distinct position (measured: 4x the work)
+    uint32_t leaders = 0;
+    for (uint32_t i = 0; i < 16; ++i) {
+        const uint32_t t0 = q * 16u + i;
+        if (t0 >= nfull) break;
+        uint32_t u = unit_order[t0];
+        uint32_t g = unit_bucket[u];
+        uint32_t u0 = unit_off[g], u1 = unit_off[g + 1];
+        if (u1 - u0 > stride && (u - u0) % (16u * stride) == 0) leaders |= 1u << i;
     }
-    store_xyzz(partial, u, acc);
+    while (leaders) {
+        const uint32_t i = (uint32_t)__builtin_ctz(leaders);
+        leaders &= leaders - 1u;
+        const uint32_t u = unit_order[q * 16u + i];
+        const uint32_t u1 = unit_off[unit_bucket[u] + 1];
+        XYZZ<F> acc;
+        load_xyzz(acc, partial, u);
+        for (uint32_t j = 1; j < 16; ++j) {
+            uint32_t v = u + j * stride;
+            if (v >= u1) break;
+            XYZZ<F> t;
+            load_xyzz(t, partial, v);
+            quad_add(acc, t, ql);
+        }
+        if (ql == 0) store_xyzz(partial, u, acc);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -343,7 +360,7 @@ int run_tail_t(MsmEngine& E, const void* d_pts, uint32_t U, uint32_t maxcount) {
         uint64_t full_bound = (uint64_t)P.npts * P.W / P.L + 1;  // units of length L: at most entries / L
         if (full_bound > U) full_bound = U;
         for (uint32_t stride = 1; stride < maxunits; stride *= 16)
-            hipLaunchKernelGGL(k_combine_units<F>, dim3((uint32_t)((full_bound + 127) / 128)), dim3(128), 0, st,
+            hipLaunchKernelGGL(k_combine_units<F>, dim3((uint32_t)((full_bound / 16 + 1) * 4 / 128 + 1)), dim3(128), 0, st,
                                E.unit_off.as<uint32_t>(), E.unit_bucket.as<uint32_t>(), E.unit_order.as<uint32_t>(),
                                E.lenhist.as<uint32_t>() + P.L, stride, E.partial.as<uint32_t>());
         BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
