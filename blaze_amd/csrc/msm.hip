@@ -27,19 +27,20 @@ size_t mont_point_bytes(int curve) { return curve == BLZ_BN254 ? 64 : 128; }
 // plan
 // ------------------------------------------------------------------------------------------------
 // Window choice by a cost model fitted to MI355X measurements (tools/sweep_c.py, 2^16..2^26 points):
-//   0.18 ns per entry (digit sort + one mixed add), 0.71 ns per occupied bucket (two full adds in the
-//   bucket reduce, unit bookkeeping), 0.05 ns per empty bucket.
+//   0.163 ns per entry (digit sort + one mixed add), 0.62 ns per occupied bucket (two full adds in the
+//   bucket reduce, unit bookkeeping), 0.03 ns per empty bucket.
 // `ebits` is the expected significant width of the scalars (bit length of r: 255 / 253 / 254; 32 for a
 // pf = 8 chunk).  It only steers the choice - W always covers sbits + 1 bits, so scalars above 2^ebits
-// are still summed correctly - but it matters: the top window holds ebits - (W-1) c real bits, and when
-// that is 0..3 bits every entry of the window lands in 1..8 buckets (c = 17 on 255-bit scalars: a
-// carry-only window with n/2 entries in ONE bucket), which the run-splitting units and the slice sort
-// handle correctly but at a measured 0.1 - 0.4 ns per entry extra.
+// are still summed correctly - but it matters: the top window holds ebits - (W-1) c real bits, i.e.
+// fewer occupied buckets than 2^(c-1), or (c = 17 on 255-bit scalars) nothing but the carry of the
+// window below.  A window whose entries fall into a handful of buckets used to cost 0.1 - 0.4 ns per
+// entry extra; with the run-splitting units, the cooperative fills and the quad-folded combine it is
+// within noise (t_hot), so odd c are no longer avoided.
 MsmPlan make_plan(uint32_t npts, int sbits, int ebits, int force_c) {
     MsmPlan best;
     double best_cost = 1e300;
     if (ebits <= 0 || ebits > sbits) ebits = sbits;
-    const double t_entry = 0.181, t_bucket = 0.71, t_empty = 0.05, t_hot = 0.15;
+    const double t_entry = 0.163, t_bucket = 0.62, t_empty = 0.03, t_hot = 0.01;
     for (int c = 3; c <= 23; ++c) {
         if (force_c > 0 && c != force_c) continue;
         int W = (sbits + 1 + c - 1) / c;

@@ -26,6 +26,7 @@ struct blz_msm {
     std::deque<Res> results;
     // staged input
     DevBuf scalars_buf, points_raw, points_mont;
+    hipStream_t copy_stream = nullptr;  // host -> device staging: runs under the previous task's accumulation
     const void* d_scalars = nullptr;
     const void* d_points_mont = nullptr;
     uint32_t staged_n = 0;
@@ -91,6 +92,11 @@ int stage_common(blz_msm* h, bool have_points, const void* points, size_t points
     if (!h->eng.can_accept())
         return fail(BLZ_ERR_INVALID_PARAM, "task queue full (%d in flight); call wait_result first", MSM_QUEUE_DEPTH);
     hipStream_t st = h->eng.stream;
+    // Host buffers are staged on their own stream, so the PCIe transfer of this task overlaps the
+    // accumulation of the task in flight (the reference's DMA writes overlap device compute the same
+    // way).  The staging buffers are free: everything that read them (to-Montgomery,
+    // digit sort) had completed when the previous set_data returned.
+    hipStream_t cst = h->copy_stream;
     uint32_t npts = n * h->pf;
 
     if (have_points && has_hbm) {
@@ -112,7 +118,8 @@ int stage_common(blz_msm* h, bool have_points, const void* points, size_t points
             BLZ_TRY(h->eng.points_to_mont(points, h->points_mont.p, npts));
         } else {
             BLZ_TRY(h->points_raw.reserve(want_pts ? want_pts : 16));
-            if (want_pts) BLZ_HIP(hipMemcpyAsync(h->points_raw.p, points, want_pts, hipMemcpyHostToDevice, st), BLZ_ERR_WRITE);
+            if (want_pts) BLZ_HIP(hipMemcpyAsync(h->points_raw.p, points, want_pts, hipMemcpyHostToDevice, cst), BLZ_ERR_WRITE);
+            BLZ_HIP(hipStreamSynchronize(cst), BLZ_ERR_WRITE);
             BLZ_TRY(h->eng.points_to_mont(h->points_raw.p, h->points_mont.p, npts));
         }
         h->d_points_mont = h->points_mont.p;
@@ -122,10 +129,10 @@ int stage_common(blz_msm* h, bool have_points, const void* points, size_t points
         h->d_scalars = scalars;
     } else {
         BLZ_TRY(h->scalars_buf.reserve(scalars_len ? scalars_len : 16));
-        if (scalars_len) BLZ_HIP(hipMemcpyAsync(h->scalars_buf.p, scalars, scalars_len, hipMemcpyHostToDevice, st), BLZ_ERR_WRITE);
+        if (scalars_len) BLZ_HIP(hipMemcpyAsync(h->scalars_buf.p, scalars, scalars_len, hipMemcpyHostToDevice, cst), BLZ_ERR_WRITE);
         h->d_scalars = h->scalars_buf.p;
         // the caller may drop its buffers as soon as we return (set_data is synchronous: utils.rs:71)
-        BLZ_HIP(hipStreamSynchronize(st), BLZ_ERR_WRITE);
+        BLZ_HIP(hipStreamSynchronize(cst), BLZ_ERR_WRITE);
     }
     h->staged_n = n;
     h->data_ready = true;
@@ -148,7 +155,10 @@ int blz_msm_new(int device_id, int mem_type, int is_precompute, int curve, blz_m
     h->pf = is_precompute ? BLZ_PRECOMPUTE_FACTOR : BLZ_PRECOMPUTE_FACTOR_BASE;
     h->curve = curve;
     int rc = h->eng.init(device_id, curve);
+    if (rc == BLZ_OK && hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess)
+        rc = fail(BLZ_ERR_UNKNOWN, "copy stream creation failed");
     if (rc != BLZ_OK) {
+        h->eng.destroy();
         delete h;
         return rc;
     }
@@ -160,6 +170,7 @@ void blz_msm_free(blz_msm* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     h->eng.destroy();
+    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     h->scalars_buf.release();
     h->points_raw.release();
     h->points_mont.release();
