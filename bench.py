@@ -208,7 +208,7 @@ def main():
         ns = min(1 << ls, n_loc)
         pts = d_pts.download(ns * 96)
         sc = d_sc.download(ns * 32)
-        cores = os.cpu_count() or 1
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         cbits = 13
         threads = min(cores, (257 + cbits - 1) // cbits)  # the oracle parallelises over windows
         t1 = time.perf_counter()
@@ -216,7 +216,7 @@ def main():
         tc = time.perf_counter() - t1
         cpu = {"value": round((ns / n) / tc, 6), "unit": "MSM/s", "cores": threads, "kind": "port",
                "sample": f"first 2^{ls} of the 2^{LOG_N} elements: {tc:.2f} s wall on {threads} threads "
-                         f"(host has {cores}); value scaled linearly to 2^{LOG_N}"}
+                         f"(host offers {cores} hardware threads); value scaled linearly to 2^{LOG_N}"}
 
     if rank == 0:
         line = {
