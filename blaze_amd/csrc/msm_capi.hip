@@ -321,6 +321,22 @@ int blz_msm_last_timings(blz_msm* h, float out[8]) {
     return BLZ_OK;
 }
 
+int blz_msm_plan(int curve, uint32_t nof_elements, int is_precompute, uint32_t out[4]) {
+    if (!out) return fail(BLZ_ERR_INVALID_PARAM, "null argument");
+    if (curve < 0 || curve > 2) return fail(BLZ_ERR_INVALID_PARAM, "unknown curve %d", curve);
+    static const int r_bits[3] = {253, 255, 254};
+    const uint64_t npts = (uint64_t)nof_elements * (is_precompute ? BLZ_PRECOMPUTE_FACTOR : BLZ_PRECOMPUTE_FACTOR_BASE);
+    if (npts == 0 || npts >= (1ull << 31)) return fail(BLZ_ERR_INVALID_PARAM, "nof_elements out of range");
+    const int sbits = is_precompute ? 32 : 256;
+    MsmPlan P = make_plan((uint32_t)npts, sbits, is_precompute ? 32 : r_bits[curve], 0);
+    if (P.c == 0) return fail(BLZ_ERR_INVALID_PARAM, "no window plan");
+    out[0] = (uint32_t)P.c;
+    out[1] = (uint32_t)P.W;
+    out[2] = P.L;
+    out[3] = P.Bw;
+    return BLZ_OK;
+}
+
 int blz_msm_combine_partials(blz_msm* h, const uint8_t* partials, size_t count, uint8_t* out, size_t out_cap) {
     if (!h || !out || (!partials && count)) return fail(BLZ_ERR_INVALID_PARAM, "null argument");
     if (out_cap < result_size(h)) return fail(BLZ_ERR_INVALID_PARAM, "result buffer too small");

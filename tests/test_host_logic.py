@@ -38,3 +38,34 @@ def test_msm_config_sizes():
     assert MSMConfig.msm_cfg(Curve.BLS381, PointMemoryType.DMA) == MSMConfig(144, 96, 32)
     assert MSMConfig.msm_cfg(Curve.BN254, PointMemoryType.HBM) == MSMConfig(96, 64, 32)
     assert DriverConfig.driver_client_cfg(CardType.MI355X).card is CardType.MI355X
+
+
+def test_window_plan_invariants():
+    """make_plan through the C ABI (host code, no device): the windows cover the scalar width + 1 for
+    signed digits, the workspace bounds hold, and the choice grows with the input."""
+    import ctypes as C
+    import blaze_amd
+    L = blaze_amd.lib()
+    prev_c = {}
+    for curve in (0, 1, 2):
+        for pf in (0, 1):
+            for logn in range(0, 27):
+                n = 1 << logn
+                if pf and n * 8 >= 1 << 31:
+                    continue
+                out = (C.c_uint32 * 4)()
+                assert L.blz_msm_plan(curve, n, pf, out) == 0, L.blz_last_error_message()
+                c, W, unit, Bw = list(out)
+                sbits = 32 if pf else 256
+                assert 3 <= c <= 23 and W * c >= sbits + 1 and (W - 1) * c < sbits + 1
+                assert Bw == 1 << (c - 1) and W * Bw <= 1 << 26
+                assert 16 <= unit <= 256 and unit & (unit - 1) == 0
+                assert n * (8 if pf else 1) * W < 1 << 32
+                key = (curve, pf)
+                if logn >= 8:
+                    assert c + 1 >= prev_c.get(key, 0)       # grows with n (a dip of one bit between W steps is fine)
+                    prev_c[key] = max(prev_c.get(key, 0), c)
+    out = (C.c_uint32 * 4)()
+    assert L.blz_msm_plan(1, 1 << 26, 0, out) == 0 and out[0] in (20, 21, 22)
+    assert L.blz_msm_plan(7, 10, 0, out) != 0
+    assert L.blz_msm_plan(1, 0, 0, out) != 0
