@@ -36,34 +36,74 @@ size_t mont_point_bytes(int curve) { return curve == BLZ_BN254 ? 64 : 128; }
 // window below.  A window whose entries fall into a handful of buckets used to cost 0.1 - 0.4 ns per
 // entry extra; with the run-splitting units, the cooperative fills and the quad-folded combine it is
 // within noise (t_hot), so odd c are no longer avoided.
+//
+// Layouts searched: W windows, the lowest k of width cmin+1, the next W-1-k of width cmin, and a top
+// window of max(cmin, what is left of sbits+1) bits (its upper bits are zero for canonical scalars, so
+// its signed digits never go negative; only 2^(real bits) of its buckets are occupied).  k = 0 with a
+// top window of cmin bits is the uniform plan; BLAZE_MSM_C forces that one.
 MsmPlan make_plan(uint32_t npts, int sbits, int ebits, int force_c) {
     MsmPlan best;
     double best_cost = 1e300;
     if (ebits <= 0 || ebits > sbits) ebits = sbits;
     const double t_entry = 0.163, t_bucket = 0.62, t_empty = 0.03, t_hot = 0.01;
-    for (int c = 3; c <= 23; ++c) {
-        if (force_c > 0 && c != force_c) continue;
-        int W = (sbits + 1 + c - 1) / c;
-        uint64_t Bw = 1ull << (c - 1);
-        uint64_t G = (uint64_t)W * Bw;
-        if (G > (1ull << 26)) continue;                       // workspace bound (partials: 192 B each)
-        if ((uint64_t)npts * W >= (1ull << 32)) continue;      // entries are indexed with u32
-        double cost = 0;
-        for (int w = 0; w < W; ++w) {
-            int t = ebits - w * c;                              // real scalar bits in this window
-            if (t > c) t = c;
-            double entries, active;
-            if (t >= c) { entries = npts; active = (double)Bw; }
-            else if (t > 0) { entries = npts; active = (double)(1ull << t) + 1; if (active > (double)Bw) active = (double)Bw; }
-            else if (t == 0) { entries = 0.5 * npts; active = 1; }   // carry of a full window below
-            else { entries = 0; active = 0; }
-            if (active > entries) active = entries;
-            cost += entries * t_entry + active * t_bucket + ((double)Bw - active) * t_empty;
-            if (active > 0 && entries / active > 8192.0) cost += entries * t_hot;
-        }
-        if (cost < best_cost) {
-            best_cost = cost;
-            best.npts = npts; best.sbits = sbits; best.c = c; best.W = W; best.Bw = (uint32_t)Bw; best.G = G;
+    const int need = sbits + 1;
+    const double t_split = (double)msm_env_int("BLAZE_MSM_SPLIT_NS", 6000);  // tests set 0: mixed widths at any size
+    for (int cmin = 3; cmin <= 23; ++cmin) {
+        if (force_c > 0 && cmin != force_c) continue;
+        for (int W = 1; W <= MSM_MAX_W; ++W) {
+            if ((uint64_t)npts * W >= (1ull << 32)) break;     // entries are indexed with u32
+            const int lower = W - 1;
+            for (int k = 0; k <= lower; ++k) {
+                if (force_c > 0 && k != 0) break;
+                if (k > 0 && cmin + 1 > 23) break;
+                const int low_bits = lower * cmin + k;
+                if (low_bits >= need + cmin) break;            // a window too many
+                int top = need - low_bits;
+                if (top < cmin) top = cmin;
+                if (top > 23) continue;
+                if (force_c > 0 && top != cmin) continue;
+                // cost over the windows
+                double cost = 0;
+                uint64_t G = 0;
+                int off = 0;
+                for (int w = 0; w < W; ++w) {
+                    const int cw = w == lower ? top : (w < k ? cmin + 1 : cmin);
+                    const double Bw = (double)(1ull << (cw - 1));
+                    int t = ebits - off;                        // real scalar bits in this window
+                    if (t > cw) t = cw;
+                    double entries, active;
+                    if (t >= cw) { entries = npts; active = Bw; }
+                    else if (t > 0) { entries = npts; active = (double)(1ull << t) + 1; if (active > Bw) active = Bw; }
+                    else if (t == 0) { entries = 0.5 * npts; active = 1; }   // carry of a full window below
+                    else { entries = 0; active = 0; }
+                    if (active > entries) active = entries;
+                    cost += entries * t_entry + active * t_bucket + (Bw - active) * t_empty;
+                    if (active > 0 && entries / active > 8192.0) cost += entries * t_hot;
+                    G += 1ull << (cw - 1);
+                    off += cw;
+                    // a window of m > 1 virtual windows costs k_finish 2 (m - 1) + 1 more quad additions
+                    // (~6 us each, sequential): irrelevant at 2^26, decisive below 2^21
+                    const int m = 1 << (cw - cmin);
+                    if (m > 1) cost += (2.0 * (m - 1) + 1.0) * t_split;
+                }
+                if (G > (1ull << 26)) continue;                 // workspace bound (partials: 192 B each)
+                if (cost < best_cost) {
+                    best_cost = cost;
+                    best = MsmPlan();
+                    best.npts = npts; best.sbits = sbits; best.W = W; best.G = G;
+                    best.c = k > 0 ? cmin + 1 : cmin;
+                    best.Bw = 1u << (cmin - 1);
+                    uint32_t b = 0;
+                    for (int w = 0; w < W; ++w) {
+                        const int cw = w == lower ? top : (w < k ? cmin + 1 : cmin);
+                        best.width[w] = (uint8_t)cw;
+                        best.boff[w] = b;
+                        b += 1u << (cw - 1);
+                    }
+                    best.boff[W] = b;
+                    best.Wv = (int)(G >> (cmin - 1));
+                }
+            }
         }
     }
     // Unit length: a unit is one lane's sequential chain (L mixed adds of ~15 us each when the SIMD has
@@ -471,7 +511,12 @@ int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int 
         return BLZ_OK;
     }
     static const int r_bits[3] = {253, 255, 254};  // bit length of the scalar field modulus (BLS12-377 / 381 / BN254)
-    MsmPlan P = make_plan(npts, sbits, sbits == 256 ? r_bits[curve] : sbits, msm_env_int("BLAZE_MSM_C", 0));
+    // BLAZE_MSM_SORT=0 selects the one-global-atomic-per-entry path (kept for A/B measurements; it only
+    // knows uniform windows)
+    const bool lds_sort = msm_env_int("BLAZE_MSM_SORT", 1) != 0;
+    const int ebits = sbits == 256 ? r_bits[curve] : sbits;
+    MsmPlan P = make_plan(npts, sbits, ebits, msm_env_int("BLAZE_MSM_C", 0));
+    if (!lds_sort && P.c) P = make_plan(npts, sbits, ebits, P.width[0]);
     if (P.c == 0) return fail(BLZ_ERR_INVALID_PARAM, "no window plan for npts=%u sbits=%d", npts, sbits);
     P.L = (uint32_t)msm_env_int("BLAZE_MSM_L", (int)P.L);
     if (P.L < 1) P.L = 1;
@@ -493,13 +538,11 @@ int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int 
     BLZ_HIP(hipMemsetAsync(stats.p, 0, 64, st), BLZ_ERR_UNKNOWN);
     const uint32_t* sc = (const uint32_t*)d_scalars;
     dim3 gp((npts + 255) / 256), b256(256);
-    // BLAZE_MSM_SORT=0 selects the one-global-atomic-per-entry path (kept for A/B measurements)
-    const bool lds_sort = msm_env_int("BLAZE_MSM_SORT", 1) != 0;
     if (lds_sort) {
         BLZ_TRY(msm_sort_lds(E, d_scalars, npts, sbits));
     } else {
-        if (sbits == 256) hipLaunchKernelGGL(k_count<8>, gp, b256, 0, st, sc, npts, P.c, P.W, P.Bw, count.as<uint32_t>());
-        else hipLaunchKernelGGL(k_count<1>, gp, b256, 0, st, sc, npts, P.c, P.W, P.Bw, count.as<uint32_t>());
+        if (sbits == 256) hipLaunchKernelGGL(k_count<8>, gp, b256, 0, st, sc, npts, (int)P.width[0], P.W, P.Bw, count.as<uint32_t>());
+        else hipLaunchKernelGGL(k_count<1>, gp, b256, 0, st, sc, npts, (int)P.width[0], P.W, P.Bw, count.as<uint32_t>());
     }
     hipLaunchKernelGGL(k_scan_reduce, dim3(nscan), b256, 0, st, count.as<uint32_t>(), G, P.L, blocksums.as<uint64_t>(),
                        stats.as<uint32_t>());
@@ -509,9 +552,9 @@ int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int 
     if (lds_sort) {
         BLZ_TRY(msm_sort_lds_scatter(E));
     } else if (sbits == 256) {
-        hipLaunchKernelGGL(k_scatter<8>, gp, b256, 0, st, sc, npts, P.c, P.W, P.Bw, count.as<uint32_t>(), entries.as<uint32_t>());
+        hipLaunchKernelGGL(k_scatter<8>, gp, b256, 0, st, sc, npts, (int)P.width[0], P.W, P.Bw, count.as<uint32_t>(), entries.as<uint32_t>());
     } else {
-        hipLaunchKernelGGL(k_scatter<1>, gp, b256, 0, st, sc, npts, P.c, P.W, P.Bw, count.as<uint32_t>(), entries.as<uint32_t>());
+        hipLaunchKernelGGL(k_scatter<1>, gp, b256, 0, st, sc, npts, (int)P.width[0], P.W, P.Bw, count.as<uint32_t>(), entries.as<uint32_t>());
     }
     BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
     // unit totals are needed on the host to size the accumulate launch

@@ -321,7 +321,7 @@ int blz_msm_last_timings(blz_msm* h, float out[8]) {
     return BLZ_OK;
 }
 
-int blz_msm_plan(int curve, uint32_t nof_elements, int is_precompute, uint32_t out[4]) {
+int blz_msm_plan(int curve, uint32_t nof_elements, int is_precompute, uint32_t out[4], uint8_t* widths) {
     if (!out) return fail(BLZ_ERR_INVALID_PARAM, "null argument");
     if (curve < 0 || curve > 2) return fail(BLZ_ERR_INVALID_PARAM, "unknown curve %d", curve);
     static const int r_bits[3] = {253, 255, 254};
@@ -333,7 +333,9 @@ int blz_msm_plan(int curve, uint32_t nof_elements, int is_precompute, uint32_t o
     out[0] = (uint32_t)P.c;
     out[1] = (uint32_t)P.W;
     out[2] = P.L;
-    out[3] = P.Bw;
+    out[3] = (uint32_t)P.G;
+    if (widths)
+        for (int w = 0; w < P.W; ++w) widths[w] = P.width[w];
     return BLZ_OK;
 }
 

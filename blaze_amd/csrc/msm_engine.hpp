@@ -4,13 +4,23 @@
 
 namespace blz {
 
+// Window layout.  Windows may have two widths (cmin and cmin+1 bits, signed digits) plus a top window
+// that takes the rest: with W fixed by the scalar width, the bucket count is what the widths can still
+// trade (12 windows over 257 bits: 3 x 22 + 8 x 21 + 23 bits hold 18.9 M bucket slots, 12 x 22 hold
+// 25.2 M).  Bucket g of window w is boff[w] + (|digit| - 1).  Downstream of the sort the bucket space is
+// flat; the bucket reduce walks it as Wv "virtual windows" of V = 2^(cmin-1) buckets each (every
+// window's bucket count is a multiple of V) and k_finish stitches them (msm_impl.cuh).
+constexpr int MSM_MAX_W = 96;
 struct MsmPlan {
     uint32_t npts = 0;   // points in the sum (n * precompute_factor)
     int sbits = 256;     // scalar width per point: 256 (pf=1) or 32 (pf=8 chunk)
-    int c = 0;           // window bits
-    int W = 0;           // windows, W*c >= sbits+1
-    uint32_t Bw = 0;     // buckets per window = 2^(c-1) (signed digits)
-    uint64_t G = 0;      // W * Bw
+    int c = 0;           // widest lower window (reported as window_bits)
+    int W = 0;           // windows; their widths sum to >= sbits+1 (signed digits carry into the top one)
+    uint8_t width[MSM_MAX_W] = {};     // bits of window w, low to high
+    uint32_t boff[MSM_MAX_W + 1] = {}; // first bucket of window w; boff[W] = G
+    uint32_t Bw = 0;     // V: buckets per virtual window = 2^(cmin-1)
+    int Wv = 0;          // G / V
+    uint64_t G = 0;      // bucket slots
     uint32_t L = 0;      // max run length handled by one accumulate unit
 };
 MsmPlan make_plan(uint32_t npts, int sbits, int ebits, int force_c);

@@ -237,18 +237,57 @@ __device__ void emit_result(uint32_t* out, const XYZZ<F>& p) {
     fp_store(out + 2 * F::N, x);
 }
 
+// window table of k_finish: window w owns virtual windows v0 .. v0 + m - 1 and starts at scalar bit `off`
+struct FinishPlan {
+    int W, logV;
+    uint16_t v0[MSM_MAX_W], off[MSM_MAX_W];
+    uint8_t m[MSM_MAX_W];
+};
+
+// The bucket reduce leaves, per virtual window v (V buckets), A_v = sum of its buckets and
+// C_v = sum_b (b + 1) B_b.  A window made of m virtual windows has
+//   S_w = sum_j C_(v0+j) + V * sum_j j * A_(v0+j),
+// so the result is a Horner evaluation over the terms (off_w + log2 V, sum_j j A_j) and (off_w, sum_j C_j)
+// in descending bit offset (off_(w+1) >= off_w + log2 V + 1, so the order is strict).
 template <class F>
-__global__ __launch_bounds__(64, 3) void k_finish(const uint32_t* __restrict__ winsum, int W, int c, uint32_t* __restrict__ out) {
-    // one wave; every DPP quad runs the same Horner chain cooperatively (ec_quad.cuh), lane 0 emits
+__global__ __launch_bounds__(64, 3) void k_finish(const uint32_t* __restrict__ vsumA, const uint32_t* __restrict__ vsumC,
+                                                  FinishPlan fp, uint32_t* __restrict__ out) {
+    // one wave; every DPP quad runs the same chain cooperatively (ec_quad.cuh), lane 0 emits
     if (blockIdx.x != 0) return;
     const uint32_t ql = threadIdx.x & 3u;
     XYZZ<F> acc;
     pt_set_inf(acc);
-    for (int w = W - 1; w >= 0; --w) {
-        for (int d = 0; d < c; ++d) quad_dbl(acc, ql);
-        XYZZ<F> tw;
-        load_xyzz(tw, winsum, (size_t)w);
-        quad_add(acc, tw, ql);
+    int pos = 0;
+    bool started = false;
+    for (int w = fp.W - 1; w >= 0; --w) {
+        const int v0 = fp.v0[w], m = fp.m[w], off = fp.off[w];
+        if (m > 1) {
+            XYZZ<F> t, u;
+            pt_set_inf(t);
+            pt_set_inf(u);
+            for (int j = m - 1; j >= 1; --j) {
+                XYZZ<F> a;
+                load_xyzz(a, vsumA, (size_t)(v0 + j));
+                quad_add(t, a, ql);
+                quad_add(u, t, ql);
+            }
+            const int o2 = off + fp.logV;
+            if (started) for (int d = 0; d < pos - o2; ++d) quad_dbl(acc, ql);
+            quad_add(acc, u, ql);
+            pos = o2;
+            started = true;
+        }
+        XYZZ<F> cs;
+        load_xyzz(cs, vsumC, (size_t)v0);
+        for (int j = 1; j < m; ++j) {
+            XYZZ<F> a;
+            load_xyzz(a, vsumC, (size_t)(v0 + j));
+            quad_add(cs, a, ql);
+        }
+        if (started) for (int d = 0; d < pos - off; ++d) quad_dbl(acc, ql);
+        quad_add(acc, cs, ql);
+        pos = off;
+        started = true;
     }
     if (threadIdx.x == 0) emit_result(out, acc);
 }
@@ -388,12 +427,12 @@ int run_tail_t(MsmEngine& E, const void* d_pts, uint32_t U, uint32_t maxcount) {
         uint32_t T = (M + SEG - 1) / SEG;
         DevBuf& oA = S.lvlA[level & 1];
         DevBuf& oC = S.lvlC[level & 1];
-        BLZ_TRY(oA.reserve((size_t)T * P.W * 16 * F::N));
-        BLZ_TRY(oC.reserve((size_t)T * P.W * 16 * F::N));
-        uint32_t nthreads = T * (uint32_t)P.W;
+        BLZ_TRY(oA.reserve((size_t)T * P.Wv * 16 * F::N));
+        BLZ_TRY(oC.reserve((size_t)T * P.Wv * 16 * F::N));
+        uint32_t nthreads = T * (uint32_t)P.Wv;
         if (level == 0) {
             hipLaunchKernelGGL((k_reduce_level<F, true>), dim3((nthreads + 63) / 64), dim3(64), 0, st, curA, curC,
-                               E.unit_off.as<uint32_t>(), M, SEG, T, P.W, shift, oA.as<uint32_t>(), oC.as<uint32_t>());
+                               E.unit_off.as<uint32_t>(), M, SEG, T, P.Wv, shift, oA.as<uint32_t>(), oC.as<uint32_t>());
             // the rest is a few lanes of sequential work: hand it to the tail stream, so this stream can
             // start the next task's sort while it runs
             BLZ_HIP(hipEventRecord(S.ev_l0, st), BLZ_ERR_UNKNOWN);
@@ -401,7 +440,7 @@ int run_tail_t(MsmEngine& E, const void* d_pts, uint32_t U, uint32_t maxcount) {
             BLZ_HIP(hipStreamWaitEvent(st, S.ev_l0, 0), BLZ_ERR_UNKNOWN);
         } else {
             hipLaunchKernelGGL((k_reduce_level<F, false>), dim3((nthreads * 4 + 63) / 64), dim3(64), 0, st, curA, curC,
-                               E.unit_off.as<uint32_t>(), M, SEG, T, P.W, shift, oA.as<uint32_t>(), oC.as<uint32_t>());
+                               E.unit_off.as<uint32_t>(), M, SEG, T, P.Wv, shift, oA.as<uint32_t>(), oC.as<uint32_t>());
         }
         curA = oA.as<uint32_t>();
         curC = oC.as<uint32_t>();
@@ -414,7 +453,20 @@ int run_tail_t(MsmEngine& E, const void* d_pts, uint32_t U, uint32_t maxcount) {
     BLZ_HIP(hipEventRecord(S.ev[3], st), BLZ_ERR_UNKNOWN);
 
     // ---- phase 3
-    hipLaunchKernelGGL(k_finish<F>, dim3(1), dim3(64), 0, st, curC, P.W, P.c, E.slot_result(E.cur));
+    FinishPlan fp;
+    fp.W = P.W;
+    fp.logV = 0;
+    while ((1u << fp.logV) < P.Bw) ++fp.logV;
+    {
+        int off = 0;
+        for (int w = 0; w < P.W; ++w) {
+            fp.v0[w] = (uint16_t)(P.boff[w] >> fp.logV);
+            fp.m[w] = (uint8_t)((P.boff[w + 1] - P.boff[w]) >> fp.logV);
+            fp.off[w] = (uint16_t)off;
+            off += P.width[w];
+        }
+    }
+    hipLaunchKernelGGL(k_finish<F>, dim3(1), dim3(64), 0, st, curA, curC, fp, E.slot_result(E.cur));
     BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
     BLZ_HIP(hipEventRecord(S.ev[4], st), BLZ_ERR_UNKNOWN);
     BLZ_HIP(hipMemcpyAsync(S.result_h, E.slot_result(E.cur), 12 * F::N, hipMemcpyDeviceToHost, st), BLZ_ERR_READ);

@@ -25,11 +25,20 @@ constexpr int FINE_THREADS = 512;
 constexpr int SORT_UNROLL = 4;
 
 struct SortGeom {
-    int c, W, ch, cl;      // window bits, windows, coarse / fine bits of the bucket index
-    uint32_t Bw;           // buckets per window
-    uint32_t NC;           // W << ch coarse bins
+    int W, cl;                      // windows; fine bits of the bucket index (the same for every window)
+    int chmax;                      // log2 of the largest window's coarse-bin count
+    uint32_t NC;                    // total coarse bins = G >> cl
     uint32_t pts_per_block;
+    uint8_t width[MSM_MAX_W];       // window widths (MsmPlan)
+    uint32_t binoff[MSM_MAX_W + 1]; // first coarse bin of window w
 };
+
+// signed digit of window w (pops width[w] bits); carry runs through the windows of one scalar
+template <int SW>
+__device__ __forceinline__ int next_digit(ScalarWords<SW>& sw, const SortGeom& g, int w, uint32_t& carry) {
+    const int cw = g.width[w];
+    return sw.next(cw, (1u << cw) - 1u, 1u << (cw - 1), carry);
+}
 
 template <int SW>
 __global__ __launch_bounds__(SORT_THREADS) void k_coarse_count(const uint32_t* __restrict__ scalars, uint32_t npts, SortGeom g,
@@ -40,7 +49,6 @@ __global__ __launch_bounds__(SORT_THREADS) void k_coarse_count(const uint32_t* _
     const uint32_t base = blockIdx.x * g.pts_per_block;
     uint32_t end = base + g.pts_per_block;
     if (end > npts) end = npts;
-    const uint32_t mask = (1u << g.c) - 1u, half = 1u << (g.c - 1);
     // SORT_UNROLL scalars in flight per lane before their digits are consumed (latency, not bandwidth,
     // bounds the one-scalar-per-iteration form)
     for (uint32_t p0 = base + threadIdx.x; p0 < end; p0 += SORT_UNROLL * SORT_THREADS) {
@@ -55,10 +63,10 @@ __global__ __launch_bounds__(SORT_THREADS) void k_coarse_count(const uint32_t* _
             if (p0 + u * SORT_THREADS >= end) break;
             uint32_t carry = 0;
             for (int w = 0; w < g.W; ++w) {
-                int d = sw[u].next(g.c, mask, half, carry);
+                int d = next_digit(sw[u], g, w, carry);
                 if (d != 0) {
                     uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1u;
-                    atomicAdd(&sh[((uint32_t)w << g.ch) + (b >> g.cl)], 1u);
+                    atomicAdd(&sh[g.binoff[w] + (b >> g.cl)], 1u);
                 }
             }
         }
@@ -110,7 +118,6 @@ __global__ __launch_bounds__(SORT_THREADS) void k_coarse_scatter(const uint32_t*
     const uint32_t base = blockIdx.x * g.pts_per_block;
     uint32_t end = base + g.pts_per_block;
     if (end > npts) end = npts;
-    const uint32_t mask = (1u << g.c) - 1u, half = 1u << (g.c - 1);
     // SORT_UNROLL scalars in flight per lane before their digits are consumed (latency, not bandwidth,
     // bounds the one-scalar-per-iteration form)
     for (uint32_t p0 = base + threadIdx.x; p0 < end; p0 += SORT_UNROLL * SORT_THREADS) {
@@ -125,10 +132,10 @@ __global__ __launch_bounds__(SORT_THREADS) void k_coarse_scatter(const uint32_t*
             if (p0 + u * SORT_THREADS >= end) break;
             uint32_t carry = 0;
             for (int w = 0; w < g.W; ++w) {
-                int d = sw[u].next(g.c, mask, half, carry);
+                int d = next_digit(sw[u], g, w, carry);
                 if (d != 0) {
                     uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1u;
-                    atomicAdd(&sh[((uint32_t)w << g.ch) + (b >> g.cl)], 1u);
+                    atomicAdd(&sh[g.binoff[w] + (b >> g.cl)], 1u);
                 }
             }
         }
@@ -154,10 +161,10 @@ __global__ __launch_bounds__(SORT_THREADS) void k_coarse_scatter(const uint32_t*
             if (p >= end) break;
             uint32_t carry = 0;
             for (int w = 0; w < g.W; ++w) {
-                int d = sw[u].next(g.c, mask, half, carry);
+                int d = next_digit(sw[u], g, w, carry);
                 if (d != 0) {
                     uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1u;
-                    uint32_t pos = atomicAdd(&sh[((uint32_t)w << g.ch) + (b >> g.cl)], 1u);
+                    uint32_t pos = atomicAdd(&sh[g.binoff[w] + (b >> g.cl)], 1u);
                     inter[pos] = make_uint2(p | (d < 0 ? 0x80000000u : 0u), b & fmask);
                 }
             }
@@ -180,16 +187,16 @@ __global__ __launch_bounds__(CS_THREADS) void k_coarse_scatter_staged(const uint
                                                                       SortGeom g, uint32_t* __restrict__ coarse_cursor,
                                                                       uint2* __restrict__ inter) {
     extern __shared__ __attribute__((aligned(16))) uint32_t sh[];
-    const uint32_t nb = 1u << g.ch;
+    const uint32_t nbmax = 1u << g.chmax;
     uint32_t* hist = sh;              // [nb] counts of this window
-    uint32_t* lstart = sh + nb;       // [nb] first stage slot of the bin
-    uint32_t* gbase = sh + 2 * nb;    // [nb] reserved global position of the bin's run
-    uint2* stage = reinterpret_cast<uint2*>(sh + 3 * nb);  // [CS_PTS]
+    uint32_t* lstart = sh + nbmax;       // [nb] first stage slot of the bin
+    uint32_t* gbase = sh + 2 * nbmax;    // [nb] reserved global position of the bin's run
+    uint2* stage = reinterpret_cast<uint2*>(sh + 3 * nbmax);  // [CS_PTS]
     __shared__ uint32_t wave_tot[CS_THREADS / 64];
     __shared__ uint32_t total_sh;
     const uint32_t tid = threadIdx.x;
     const uint32_t base = blockIdx.x * (uint32_t)CS_PTS;
-    const uint32_t mask = (1u << g.c) - 1u, half = 1u << (g.c - 1), fmask = (1u << g.cl) - 1u;
+    const uint32_t fmask = (1u << g.cl) - 1u;
     ScalarWords<SW> sw[CS_T];
     uint32_t carry[CS_T];
 #pragma unroll
@@ -198,14 +205,15 @@ __global__ __launch_bounds__(CS_THREADS) void k_coarse_scatter_staged(const uint
         sw[u].load(scalars, p < npts ? p : 0u);
         carry[u] = 0;
     }
-    const uint32_t per = nb > (uint32_t)CS_THREADS ? nb / CS_THREADS : 1u;  // bins per lane in the scan
     for (int w = 0; w < g.W; ++w) {
+        const uint32_t nb = g.binoff[w + 1] - g.binoff[w];                     // bins of this window (a power of two)
+        const uint32_t per = nb > (uint32_t)CS_THREADS ? nb / CS_THREADS : 1u;  // bins per lane in the scan
         for (uint32_t i = tid; i < nb; i += CS_THREADS) hist[i] = 0;
         __syncthreads();
         uint32_t key[CS_T], rk[CS_T];  // key = fine | bin << 12 | sign << 31;  rk = rank in the bin, ~0 = no entry
 #pragma unroll
         for (int u = 0; u < CS_T; ++u) {
-            int d = sw[u].next(g.c, mask, half, carry[u]);
+            int d = next_digit(sw[u], g, w, carry[u]);
             rk[u] = ~0u;
             key[u] = 0;
             if (d != 0 && base + u * CS_THREADS + tid < npts) {
@@ -239,7 +247,7 @@ __global__ __launch_bounds__(CS_THREADS) void k_coarse_scatter_staged(const uint
                 if ((b0 + q) < nb) {
                     uint32_t v = loc[q];
                     lstart[b0 + q] = run;
-                    gbase[b0 + q] = v ? atomicAdd(&coarse_cursor[((uint32_t)w << g.ch) + b0 + q], v) : 0u;
+                    gbase[b0 + q] = v ? atomicAdd(&coarse_cursor[g.binoff[w] + b0 + q], v) : 0u;
                     run += v;
                 }
             }
@@ -437,17 +445,20 @@ __global__ __launch_bounds__(FS_THREADS) void k_fine_scatter(const uint2* __rest
 // coarse / fine split of the bucket index
 static SortGeom make_geom(const MsmPlan& P) {
     SortGeom g;
-    g.c = P.c;
     g.W = P.W;
-    g.Bw = P.Bw;
-    int cb = P.c - 1;
+    int cmin = 32, cmax = 0;
+    for (int w = 0; w < P.W; ++w) {
+        cmin = P.width[w] < cmin ? P.width[w] : cmin;
+        cmax = P.width[w] > cmax ? P.width[w] : cmax;
+    }
     const int cl_pref = msm_env_int("BLAZE_SORT_CL", 11);
-    int cl = cb < cl_pref ? cb : cl_pref;
-    int ch = cb - cl;
-    while (((uint32_t)P.W << ch) > 24576u && ch > 0) { --ch; ++cl; }
-    g.ch = ch;
+    int cl = cmin - 1 < cl_pref ? cmin - 1 : cl_pref;    // every window needs >= 1 coarse bin
+    while ((P.G >> cl) > 24576u && cl < cmin - 1) ++cl;
     g.cl = cl;
-    g.NC = (uint32_t)P.W << ch;
+    g.chmax = cmax - 1 - cl;
+    g.NC = (uint32_t)(P.G >> cl);
+    for (int w = 0; w <= P.W; ++w) g.binoff[w] = P.boff[w] >> cl;
+    for (int w = 0; w < P.W; ++w) g.width[w] = P.width[w];
     g.pts_per_block = 0;
     return g;
 }
@@ -484,14 +495,14 @@ int msm_sort_lds(MsmEngine& E, const void* d_scalars, uint32_t npts, int sbits) 
     else hipLaunchKernelGGL(k_coarse_count<1>, dim3(nblk), dim3(SORT_THREADS), lds, st, sc, npts, g, coarse_count);
     hipLaunchKernelGGL(k_coarse_scan, dim3(1), dim3(1024), 0, st, coarse_count, g.NC, coarse_off);
     // BLAZE_SORT_STAGED=0 selects the unstaged coarse scatter (kept for A/B measurements)
-    if (msm_env_int("BLAZE_SORT_STAGED", 1) != 0 && g.ch <= 11 && g.cl <= 12) {
+    if (msm_env_int("BLAZE_SORT_STAGED", 1) != 0 && g.chmax <= 11 && g.cl <= 12) {
         static bool attr_cs = false;
         if (!attr_cs) {
             BLZ_HIP(hipFuncSetAttribute((const void*)k_coarse_scatter_staged<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024), BLZ_ERR_UNKNOWN);
             BLZ_HIP(hipFuncSetAttribute((const void*)k_coarse_scatter_staged<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024), BLZ_ERR_UNKNOWN);
             attr_cs = true;
         }
-        const size_t lds_cs = ((size_t)3 << g.ch) * 4 + (size_t)CS_PTS * 8;
+        const size_t lds_cs = ((size_t)3 << g.chmax) * 4 + (size_t)CS_PTS * 8;
         const uint32_t nblk_cs = (npts + CS_PTS - 1) / CS_PTS;
         if (sbits == 256)
             hipLaunchKernelGGL(k_coarse_scatter_staged<8>, dim3(nblk_cs), dim3(CS_THREADS), lds_cs, st, sc, npts, g, coarse_count, E.inter.as<uint2>());

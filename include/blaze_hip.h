@@ -133,10 +133,11 @@ int blz_msm_last_timings(blz_msm* h, float out[8]);
  * The reference builds this table on the host before set_data / load_data_to_hbm. */
 int blz_msm_precompute_bases_device(int device_id, int curve, const void* d_points, void* d_out, uint64_t n);
 
-/* The window plan the pipeline would use for this input size (no device needed): out = {window bits c,
- * windows W, unit length L, buckets per window 2^(c-1)}.  Diagnostic; W * c always covers the scalar
- * width + 1 (signed digits).  No reference counterpart (the bitstream's plan is fixed). */
-int blz_msm_plan(int curve, uint32_t nof_elements, int is_precompute, uint32_t out[4]);
+/* The window plan the pipeline would use for this input size (no device needed): out = {widest lower
+ * window in bits, windows W, unit length L, bucket slots G}; widths (nullable, room for 96 bytes)
+ * receives the W window widths, low to high.  The widths always sum to at least the scalar width + 1
+ * (signed digits).  Diagnostic; no reference counterpart (the bitstream's plan is fixed). */
+int blz_msm_plan(int curve, uint32_t nof_elements, int is_precompute, uint32_t out[4], uint8_t* widths);
 
 /* Multi-GPU: add G partial results (each result_size bytes, as returned by blz_msm_result on each
  * rank, in rank order) on this handle's device and emit the normalised sum.  The exchange itself

@@ -356,6 +356,27 @@ def test_randomised_small_cases(gpu, orc):
 
 
 @pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("pf", [1, 8])
+def test_mixed_window_widths_small(gpu, orc, curve, pf, monkeypatch):
+    """Two window widths + a top window (the plan large inputs get) forced at small sizes, where the
+    oracle can check every byte: BLAZE_MSM_SPLIT_NS=0 removes the model's charge for stitching virtual
+    windows in k_finish."""
+    import ctypes as C
+    monkeypatch.setenv("BLAZE_MSM_SPLIT_NS", "0")
+    mixed = 0
+    for n in (700, 5000, 40000):
+        out, wd = (C.c_uint32 * 4)(), (C.c_uint8 * 96)()
+        assert gpu.blz_msm_plan(pyref.CURVES[curve]["id"], n, int(pf == 8), out, wd) == 0
+        widths = list(wd)[:out[1]]
+        mixed += len(set(widths)) > 1
+        pts, sc, exp = orc.input_generator(curve, n, pf, 900 + n)
+        cl = msm_client(curve, pf)
+        assert run_msm(cl, pts, sc, n) == exp, f"{curve} pf={pf} n={n} widths={widths}"
+        cl.close()
+    assert mixed >= 1
+
+
+@pytest.mark.parametrize("curve", CURVES)
 def test_task_queue_two_in_flight(gpu, orc, curve):
     """The device has a task queue and a result queue (msm_hw_code.rs:19-25): two tasks may be submitted
     before the first result is popped; results come back in submission order with their labels, and a

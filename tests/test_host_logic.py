@@ -41,8 +41,9 @@ def test_msm_config_sizes():
 
 
 def test_window_plan_invariants():
-    """make_plan through the C ABI (host code, no device): the windows cover the scalar width + 1 for
-    signed digits, the workspace bounds hold, and the choice grows with the input."""
+    """make_plan through the C ABI (host code, no device): the window widths cover the scalar width + 1
+    for signed digits, use at most two adjacent widths below the top window, the workspace bounds hold
+    and the choice grows with the input."""
     import ctypes as C
     import blaze_amd
     L = blaze_amd.lib()
@@ -54,11 +55,19 @@ def test_window_plan_invariants():
                 if pf and n * 8 >= 1 << 31:
                     continue
                 out = (C.c_uint32 * 4)()
-                assert L.blz_msm_plan(curve, n, pf, out) == 0, L.blz_last_error_message()
-                c, W, unit, Bw = list(out)
+                wd = (C.c_uint8 * 96)()
+                assert L.blz_msm_plan(curve, n, pf, out, wd) == 0, L.blz_last_error_message()
+                c, W, unit, G = list(out)
+                widths = list(wd)[:W]
                 sbits = 32 if pf else 256
-                assert 3 <= c <= 23 and W * c >= sbits + 1 and (W - 1) * c < sbits + 1
-                assert Bw == 1 << (c - 1) and W * Bw <= 1 << 26
+                assert all(3 <= x <= 23 for x in widths) and max(widths[:-1] or widths) == c
+                assert sum(widths) >= sbits + 1
+                assert sum(widths[:-1]) < sbits + 1 + min(widths)          # no window beyond the carry
+                lower = widths[:-1]
+                assert not lower or max(lower) - min(lower) <= 1            # two adjacent widths
+                assert lower == sorted(lower, reverse=True) and widths[-1] >= min(widths)
+                assert G == sum(1 << (x - 1) for x in widths) and G <= 1 << 26
+                assert G % (1 << (min(widths) - 1)) == 0                    # whole virtual windows
                 assert 16 <= unit <= 256 and unit & (unit - 1) == 0
                 assert n * (8 if pf else 1) * W < 1 << 32
                 key = (curve, pf)
@@ -66,6 +75,6 @@ def test_window_plan_invariants():
                     assert c + 1 >= prev_c.get(key, 0)       # grows with n (a dip of one bit between W steps is fine)
                     prev_c[key] = max(prev_c.get(key, 0), c)
     out = (C.c_uint32 * 4)()
-    assert L.blz_msm_plan(1, 1 << 26, 0, out) == 0 and out[0] in (20, 21, 22)
-    assert L.blz_msm_plan(7, 10, 0, out) != 0
-    assert L.blz_msm_plan(1, 0, 0, out) != 0
+    assert L.blz_msm_plan(1, 1 << 26, 0, out, None) == 0 and out[0] in (20, 21, 22)
+    assert L.blz_msm_plan(7, 10, 0, out, None) != 0
+    assert L.blz_msm_plan(1, 0, 0, out, None) != 0
