@@ -442,3 +442,30 @@ def test_task_queue_overlap_large(gpu, orc):
     cl.close()
     for b in (dp, ds0, ds1):
         b.free()
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_non_canonical_scalars(gpu, orc, curve, monkeypatch):
+    """The wire format says scalars are < r (tests/msm/mod.rs:331-332); the windows nevertheless cover
+    all 256 bits + the digit carry, so values >= r (up to 2^256 - 1) are summed as the integers they
+    are.  Checked against the oracle's double-and-add, under the uniform and the mixed window plan."""
+    import random
+    rng = random.Random(77)
+    n = 600
+    pts, sc, _ = orc.input_generator(curve, n, 1, 4242)
+    sc = bytearray(sc)
+    special = [(1 << 256) - 1, (1 << 256) - 2, 1 << 255, (1 << 255) - 1, pyref.CURVES[curve]["r"], pyref.CURVES[curve]["r"] + 1]
+    for i in range(n):
+        if i < len(special):
+            v = special[i]
+        elif i % 3 == 0:
+            v = rng.getrandbits(256)
+        else:
+            continue
+        sc[32 * i: 32 * i + 32] = v.to_bytes(32, "little")
+    exp = orc.msm_naive(curve, pts, bytes(sc), n, 1)
+    for split in ("6000", "0"):
+        monkeypatch.setenv("BLAZE_MSM_SPLIT_NS", split)
+        cl = msm_client(curve, 1)
+        assert run_msm(cl, pts, bytes(sc), n) == exp, f"{curve} split={split}"
+        cl.close()
