@@ -388,6 +388,61 @@ BLZ_DEV void fp_mulsub2(Fp<P>& r, const Fp<P>& a, const Fp<P>& b, const Fp<P>& c
     fp_mul2(r, a, b, nc, d);
 }
 
+// ------------------------------------------------------------------------------------------------
+// "Wide lazy" arithmetic for a field whose modulus is too large for the [0, 2m] representation to leave
+// head-room (BLS12-381 Fr: 4m > R = 2^256, so P::LAZY is false), used by the NTT where every product is
+// data x canonical twiddle:  x < 2^(32N) arbitrary, w < m  =>  (x w + q m) / R < m (1 + x/R) < 2m, so the
+// product needs NO final subtraction if the data are allowed to live in [0, 2m).  Sums of two such values
+// can exceed 2^(32N) (2m is most of the word), so add / sub carry one extra bit through the comparison.
+// ------------------------------------------------------------------------------------------------
+template <class P>
+BLZ_DEV void fp_mul_nr(Fp<P>& r, const Fp<P>& x, const Fp<P>& w_canonical) {
+    constexpr int N = P::N;
+    uint32_t q[N];
+    uint32_t t[N];
+    uint64_t alo = 0;
+    ps_columns<P>(x, w_canonical, q, t, alo, std::make_integer_sequence<int, 2 * N>{});
+#pragma unroll
+    for (int j = 0; j < N; ++j) r.v[j] = t[j];   // < 2m < 2^(32N): the word above (alo) is zero
+}
+// r = a + b mod-ish: a, b in [0, 2m) -> r in [0, 2m)
+template <class P>
+BLZ_DEV void fp_add_wide(Fp<P>& r, const Fp<P>& a, const Fp<P>& b) {
+    uint32_t c = 0;
+    uint32_t t[P::N];
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) t[i] = add_cc(a.v[i], b.v[i], c);
+    uint32_t u[P::N];
+    uint32_t br = 0;
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) u[i] = sub_bb(t[i], P::MOD2[i], br);
+    const bool keep = (c == 0) & (br != 0);   // a + b < 2m: no carry out and the subtraction borrowed
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) r.v[i] = keep ? t[i] : u[i];
+}
+// r = a - b: a, b in [0, 2m) -> r in [0, 2m)
+template <class P>
+BLZ_DEV void fp_sub_wide(Fp<P>& r, const Fp<P>& a, const Fp<P>& b) {
+    uint32_t br = 0;
+    uint32_t t[P::N];
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) t[i] = sub_bb(a.v[i], b.v[i], br);
+    uint32_t c = 0;
+    uint32_t mask = 0u - br;
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) r.v[i] = add_cc(t[i], P::MOD2[i] & mask, c);   // + 2m if it went negative
+}
+// [0, 2m) -> [0, m)
+template <class P>
+BLZ_DEV void fp_canon_wide(Fp<P>& a) {
+    uint32_t u[P::N];
+    uint32_t br = 0;
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) u[i] = sub_bb(a.v[i], P::MOD[i], br);
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) a.v[i] = br ? a.v[i] : u[i];
+}
+
 #ifndef BLZ_MUL_VARIANT
 #define BLZ_MUL_VARIANT 1
 #endif

@@ -64,6 +64,27 @@ BLZ_DEV void tw_pow(E& r, const NttTables& T, uint32_t e) {
     if (e2) { fp_load(b, T.t2 + (size_t)e2 * 8); fp_mul(r, r, b); }
 }
 
+// Data arithmetic of the transform.  Fields with head-room (P::LAZY: BLS12-377 / BN254 Fr) already
+// multiply without a final subtraction; BLS12-381 Fr gets the wide-lazy forms of field.cuh: data live
+// in [0, 2m), twiddles stay canonical, only the last pass reduces to the wire format.
+template <class E> struct NttOps;
+template <class Fr>
+struct NttOps<Fp<Fr>> {
+    using E = Fp<Fr>;
+    static BLZ_DEV void mul(E& r, const E& x, const E& w) {
+        if constexpr (Fr::LAZY) fp_mul(r, x, w); else fp_mul_nr(r, x, w);
+    }
+    static BLZ_DEV void add(E& r, const E& a, const E& b) {
+        if constexpr (Fr::LAZY) fp_add(r, a, b); else fp_add_wide(r, a, b);
+    }
+    static BLZ_DEV void sub(E& r, const E& a, const E& b) {
+        if constexpr (Fr::LAZY) fp_sub(r, a, b); else fp_sub_wide(r, a, b);
+    }
+    static BLZ_DEV void canon(E& a) {
+        if constexpr (Fr::LAZY) fp_reduce(a); else fp_canon_wide(a);
+    }
+};
+
 constexpr int NTT_THREADS = 1024;  // 4 waves per SIMD: the 128-147 KiB tile allows one block per CU
 
 // LDS tile: element (row, col) at dword offset row * RS + col * 8 with RS = COLS * 8 + 8: the one
@@ -140,11 +161,11 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const uint32_t* __rest
             if (tw) {
                 E w;
                 fp_load(w, wp + (size_t)tw * 8);
-                fp_mul(xv, xv, w);
+                NttOps<E>::mul(xv, xv, w);
             }
             E sum, dif;
-            fp_add(sum, xu, xv);
-            fp_sub(dif, xu, xv);
+            NttOps<E>::add(sum, xu, xv);
+            NttOps<E>::sub(dif, xu, xv);
             lds_store(lds, u * RS + col * 8, sum);
             lds_store(lds, v * RS + col * 8, dif);
         }
@@ -177,13 +198,13 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const uint32_t* __rest
             uint64_t oaddr;
             if (PASS == 3) {
                 // element (k0 = row, k1 = fixed, k2 = col_base + col) -> natural address k2 + C k1 + CB k0
-                if (T.ninv) { E s; fp_load(s, T.ninv); fp_mul(x, x, s); }  // inverse transform: * n^-1
-                if constexpr (Fr::LAZY) fp_reduce(x);                        // the wire format is canonical
+                if (T.ninv) { E s; fp_load(s, T.ninv); NttOps<E>::mul(x, x, s); }  // inverse transform: * n^-1
+                NttOps<E>::canon(x);                                               // the wire format is canonical
                 oaddr = (col_base + col0 + j) + (uint64_t)C * fixed + (uint64_t)C * B * row;
             } else {
                 if (tw) {
-                    fp_mul(x, x, w);
-                    if (j + 1 < CG) fp_mul(w, w, step);
+                    NttOps<E>::mul(x, x, w);
+                    if (j + 1 < CG) fp_mul(w, w, step);   // twiddle x twiddle: stays canonical
                 }
                 oaddr = in_base + row * in_rstride + col0 + j;
             }
@@ -213,20 +234,20 @@ constexpr uint32_t N8_RS = N8_COLS * 8 + 8;  // padded row stride in dwords
 template <class E>
 BLZ_DEV void bfly(E& u, E& v) {
     E s, d;
-    fp_add(s, u, v);
-    fp_sub(d, u, v);
+    NttOps<E>::add(s, u, v);
+    NttOps<E>::sub(d, u, v);
     u = s;
     v = d;
 }
 template <class E>
 BLZ_DEV void dft8(E (&a)[8], const E& w1, const E& w2, const E& w3) {
     bfly(a[0], a[1]); bfly(a[2], a[3]); bfly(a[4], a[5]); bfly(a[6], a[7]);
-    fp_mul(a[3], a[3], w2);
-    fp_mul(a[7], a[7], w2);
+    NttOps<E>::mul(a[3], a[3], w2);
+    NttOps<E>::mul(a[7], a[7], w2);
     bfly(a[0], a[2]); bfly(a[1], a[3]); bfly(a[4], a[6]); bfly(a[5], a[7]);
-    fp_mul(a[5], a[5], w1);
-    fp_mul(a[6], a[6], w2);
-    fp_mul(a[7], a[7], w3);
+    NttOps<E>::mul(a[5], a[5], w1);
+    NttOps<E>::mul(a[6], a[6], w2);
+    NttOps<E>::mul(a[7], a[7], w3);
     bfly(a[0], a[4]); bfly(a[1], a[5]); bfly(a[2], a[6]); bfly(a[3], a[7]);
 }
 // order in which a DIT 8-point DFT wants its inputs
@@ -290,7 +311,7 @@ __global__ __launch_bounds__(N8_THREADS, 2) void k_ntt512(const uint32_t* __rest
         if (k1 != 0 && n2 != 0) {  // * w512^(n2 k1)
             E w;
             fp_load(w, wp + (size_t)(n2 * k1) * 8);
-            fp_mul(a[k1], a[k1], w);
+            NttOps<E>::mul(a[k1], a[k1], w);
         }
         lds_store(lds, (64u * k1 + n2) * N8_RS + col * 8, a[k1]);
     }
@@ -307,7 +328,7 @@ __global__ __launch_bounds__(N8_THREADS, 2) void k_ntt512(const uint32_t* __rest
             if (k1p != 0 && n2p != 0) {  // * w64^(n2' k1') = w512^(8 n2' k1')
                 E w;
                 fp_load(w, wp + (size_t)(8u * n2p * k1p) * 8);
-                fp_mul(a[k1p], a[k1p], w);
+                NttOps<E>::mul(a[k1p], a[k1p], w);
             }
             lds_store(lds, (64u * k1 + 8u * k1p + n2p) * N8_RS + col * 8, a[k1p]);
         }
@@ -341,13 +362,13 @@ __global__ __launch_bounds__(N8_THREADS, 2) void k_ntt512(const uint32_t* __rest
             const uint32_t row = kb + 64u * k2p;
             uint64_t oaddr;
             if (PASS == 3) {
-                if (T.ninv) fp_mul(a[k2p], a[k2p], sc);  // inverse transform: * n^-1
-                if constexpr (Fr::LAZY) fp_reduce(a[k2p]);       // the wire format is canonical
+                if (T.ninv) NttOps<E>::mul(a[k2p], a[k2p], sc);  // inverse transform: * n^-1
+                NttOps<E>::canon(a[k2p]);                        // the wire format is canonical
                 oaddr = (col_base + col) + (uint64_t)C * fixed + (uint64_t)C * B * row;
             } else {
                 if (tw) {
-                    if (k2p != 0 || kb != 0) fp_mul(a[k2p], a[k2p], w);
-                    if (k2p != 7) fp_mul(w, w, step);
+                    if (k2p != 0 || kb != 0) NttOps<E>::mul(a[k2p], a[k2p], w);
+                    if (k2p != 7) fp_mul(w, w, step);   // twiddle x twiddle: stays canonical
                 }
                 oaddr = in_base + row * in_rstride + col;
             }
