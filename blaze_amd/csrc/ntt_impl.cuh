@@ -293,6 +293,16 @@ __global__ __launch_bounds__(N8_THREADS, 2) void k_ntt512(const uint32_t* __rest
         col = threadIdx.x & (N8_COLS - 1);
         n2 = threadIdx.x >> N8_COLS_LOG;
     }
+    // the step of the inter-pass twiddle chain, w^(64 m), depends on the column only: 4 lanes compute
+    // it once per tile and leave it in the padding element of tile row `col` (the tile is exactly half of
+    // the CU's LDS: there is no room behind it); one table product less for the other 252 lanes
+    uint32_t* lds_step = lds + N8_COLS * 8;   // + col * N8_RS
+    if (PASS != 3 && n2 == 0) {
+        const uint64_t m = PASS == 1 ? col_base + col + ((uint64_t)fixed << g.logA) : (col_base + col) << g.logC;
+        E st;
+        tw_pow(st, T, (uint32_t)(64u * m));
+        lds_store(lds_step, col * N8_RS, st);
+    }
     const uint32_t* wp = T.wpass[PASS - 1];  // w512^j, j < 512
     E w1, w2, w3;
     fp_load(w1, wp + 64 * 8);
@@ -348,12 +358,12 @@ __global__ __launch_bounds__(N8_THREADS, 2) void k_ntt512(const uint32_t* __rest
             // x(i0, i1, k2 = row) *= w^(row * (i0 + A i1)),  m = i0 + A i1 < 2^18
             const uint64_t m = col_base + col + ((uint64_t)fixed << g.logA);
             tw = m != 0;
-            if (tw) { tw_pow(w, T, (uint32_t)(kb * m)); tw_pow(step, T, (uint32_t)(64u * m)); }
+            if (tw) { tw_pow(w, T, (uint32_t)(kb * m)); lds_load(step, lds_step, col * N8_RS); }
         } else if (PASS == 2) {
             // x(i0, k1 = row, k2) *= w^(C i0 row)
             const uint64_t m = (col_base + col) << g.logC;
             tw = m != 0;
-            if (tw) { tw_pow(w, T, (uint32_t)(kb * m)); tw_pow(step, T, (uint32_t)(64u * m)); }
+            if (tw) { tw_pow(w, T, (uint32_t)(kb * m)); lds_load(step, lds_step, col * N8_RS); }
         }
         E sc;
         if (PASS == 3 && T.ninv) fp_load(sc, T.ninv);
