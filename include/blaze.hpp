@@ -131,8 +131,11 @@ class NTTClient : public DriverPrimitive<NTT, NttInit, NTTInput, std::vector<uin
 
    public:
     DriverClient driver_client;
-    NTTClient(NTT, DriverClient dclient, int log_size = 27) : nbytes_(size_t(32) << log_size), driver_client(dclient) {
-        check(blz_ntt_new(dclient.id, log_size, &h_));  // ntt_api.rs:26-31; 2^27 is the reference shape
+    // ntt_api.rs:26-31; 2^27 over BLS12-381 Fr, forward, is the reference shape.  `field` (a Curve: the
+    // scalar field of that curve) and `inverse` have no reference counterpart.
+    NTTClient(NTT, DriverClient dclient, int log_size = 27, Curve field = Curve::BLS381, bool inverse = false)
+        : nbytes_(size_t(32) << log_size), driver_client(dclient) {
+        check(blz_ntt_new_field(dclient.id, int(field), log_size, inverse ? 1 : 0, &h_));
     }
     ~NTTClient() override { blz_ntt_free(h_); }
     NTTClient(const NTTClient&) = delete;
