@@ -1,19 +1,20 @@
 // Pippenger windowed-bucket G1 MSM for gfx950 (the device task of SURVEY.md a7: what the FPGA
 // bitstream behind src/ingo_msm/msm_hw_code.rs:6-54 computes; kernels are new design).
 //
-// Pipeline (one stream):
-//   k_count        signed c-bit digits of every scalar -> per-(window,bucket) histogram
+// Pipeline (main stream, then the tail stream from the second reduce level on):
+//   msm_sort.hip   signed window digits of every scalar, two-level LDS counting sort ->
+//                  count[] per bucket, then (point index | sign) entries grouped by bucket
 //   k_scan_*       exclusive scan: bucket offsets + accumulate-unit offsets (runs split at L)
-//   k_scatter      (point index | sign) written to its bucket's slice of `entries`
 //   k_fill_units   unit -> bucket map;  k_unit_* order the units by run length (descending)
 //   k_accumulate   one lane per unit: gathers its run of points, XYZZ mixed adds   [phase 1]
 //   k_combine_units   only when a bucket needed more than one unit
-//   k_reduce_level Sum_b b*S_b per window by segmented running sums, a few levels  [phase 2]
-//   k_finish       Horner over windows, single inversion, canonical Z=1|y|x        [phase 3]
+//   k_reduce_level Sum_b b*S_b per virtual window by segmented running sums        [phase 2]
+//   k_finish       stitch virtual windows, Horner over windows, one inversion, Z=1|y|x  [phase 3]
+// (k_count / k_scatter below: the original one-global-atomic-per-entry sort, BLAZE_MSM_SORT=0.)
 //
-// HBM layout: points AoS Montgomery (one 128-B line per BLS point, 64 B per BN254 point), scalars raw 32 B LE, entries
-// u32, bucket partials AoS XYZZ (4N dwords).  The gathers are 96-B (64-B) contiguous per lane;
-// the arithmetic (v_mad_u64_u32) bounds every kernel here, not HBM.
+// HBM layout: points AoS Montgomery (one 128-B line per BLS point, 64 B per BN254 point), scalars raw
+// 32 B LE, entries u32, bucket partials AoS XYZZ (4N dwords).  The arithmetic (v_mad_u64_u32) bounds
+// the dominant kernels, not HBM.
 #include "msm_engine.hpp"
 #include "field.cuh"
 #include "msm_digits.cuh"

@@ -2,19 +2,20 @@
 //
 // Two-level LDS-privatised counting sort (replaces one global atomic per entry, which ran at
 // ~25 G atomics/s and cost 105 ms of a 2^26 MSM):
-//   bucket index (c-1 bits) = coarse (ch bits) | fine (cl bits, 11 by default: fewer, fuller coarse bins
-//   combine writes better than more bins do),  W * 2^ch <= 24576 coarse bins
+//   bucket index of a window = coarse bin | fine (cl bits, 11 by default); windows may differ in width
+//   (MsmPlan), so window w owns coarse bins binoff[w] .. binoff[w+1]; G >> cl <= 24576 bins in all
 //   k_coarse_count    per block: LDS histogram of its points' digits over all coarse bins, flushed
 //                     with one global atomic per (block, non-empty bin)
 //   k_coarse_scan     exclusive scan over the coarse bins (one block)
-//   k_coarse_scatter  per block: LDS count, one global reservation per (block, bin), then every
-//                     entry gets base + LDS rank; writes (entry, fine) pairs grouped by coarse bin
+//   k_coarse_scatter_staged   16 scalars per lane in registers, window by window: LDS rank, bin-major
+//                     LDS stage, slot-major copy-out of (entry, fine) pairs grouped by coarse bin
+//                     (k_coarse_scatter: the unstaged form, BLAZE_SORT_STAGED=0)
 //   k_slice_map       device-built work list: every coarse bin cut into slices of <= 65536 entries
 //   k_fine_count      per (coarse bin, slice): LDS histogram over the 2^cl fine buckets -> count[]
-//   (k_scan_* of msm.hip: bucket offsets + unit offsets, unchanged)
-//   k_fine_scatter    per (coarse bin, slice): LDS count, reservation per (block, bucket) on the
-//                     scatter cursor, entries written to their final bucket slice
-// HBM traffic: scalars read 3x (32 B each), 8 B/entry written + read twice, 4 B/entry written.
+//   (k_scan_* of msm.hip: bucket offsets + unit offsets)
+//   k_fine_scatter    per (coarse bin, slice): LDS rank, reservation per (block, bucket) on the
+//                     scatter cursor, bucket-major LDS stage, slot-major copy-out to the final runs
+// HBM traffic: scalars read twice (32 B each), 8 B/entry written + read twice, 4 B/entry written.
 #include "msm_engine.hpp"
 #include "msm_digits.cuh"
 
