@@ -469,3 +469,38 @@ def test_non_canonical_scalars(gpu, orc, curve, monkeypatch):
         cl = msm_client(curve, 1)
         assert run_msm(cl, pts, bytes(sc), n) == exp, f"{curve} split={split}"
         cl.close()
+
+
+def test_two_clients_interleaved(gpu, orc):
+    """Independent handles (own streams, own workspaces) used alternately, each with two tasks in
+    flight; one of them reads its bases from the device arena."""
+    blaze_amd.lib().blz_arena_release(0)
+    a = msm_client("BLS381", 1)
+    b = msm_client("BN254", 8, PointMemoryType.HBM)
+    ja = [orc.input_generator("BLS381", n, 1, 70 + n) for n in (900, 3000, 1700)]
+    nb = 800
+    pb, _, _ = orc.input_generator("BN254", nb, 8, 5)
+    b.load_data_to_hbm(pb, 0, 0)
+    jb = []
+    for seed in (1, 2, 3):
+        _, sc, _ = orc.input_generator("BN254", nb, 8, 100 + seed)
+        jb.append((sc, orc.msm_pippenger("BN254", pb, sc, nb, 8, threads=4)))
+
+    def sub_a(j):
+        pts, sc, _ = ja[j]
+        p = MSMParams(len(sc) // 32, None)
+        a.initialize(p); a.start_process(); a.set_data(MSMInput(pts, sc, p))
+
+    def sub_b(j):
+        p = MSMParams(nb, (0, 0))
+        b.initialize(p); b.start_process(); b.set_data(MSMInput(None, jb[j][0], p))
+
+    sub_a(0); sub_b(0); sub_a(1); sub_b(1)
+    a.wait_result(); assert a.result().result == ja[0][2]
+    b.wait_result(); assert b.result().result == jb[0][1]
+    sub_b(2); sub_a(2)
+    for j in (1, 2):
+        a.wait_result(); assert a.result().result == ja[j][2]
+        b.wait_result(); assert b.result().result == jb[j][1]
+    a.close(); b.close()
+    blaze_amd.lib().blz_arena_release(0)
