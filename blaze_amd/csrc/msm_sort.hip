@@ -537,7 +537,7 @@ int msm_sort_lds_scatter(MsmEngine& E) {
         attr_done = true;
     }
     // staging entries per round (6 bytes each): what is left of the LDS after the two per-bucket arrays
-    size_t budget = (size_t)157 * 1024 - ((size_t)2 << E.sort_cl) * 4;
+    size_t budget = (size_t)msm_env_int("BLAZE_SORT_FS_KB", 157) * 1024 - ((size_t)2 << E.sort_cl) * 4;
     uint32_t round_cap = (uint32_t)(budget / 6);
     if (round_cap > (uint32_t)FS_ROUND) round_cap = FS_ROUND;
     round_cap &= ~1023u;
