@@ -57,6 +57,7 @@ struct MsmEngine {
     float last_ms[8] = {};
     uint32_t sort_slices = 1, sort_nc = 0;  // geometry of the last LDS sort (msm_sort.hip)
     int sort_cl = 0;
+    void* sort_inter_fine = nullptr;  // u16 fine digits of the sort intermediate (second half of `inter`)
 
     int init(int device_id, int curve_id);
     void destroy();

@@ -112,7 +112,8 @@ __global__ __launch_bounds__(1024) void k_coarse_scan(uint32_t* __restrict__ coa
 template <int SW>
 __global__ __launch_bounds__(SORT_THREADS) void k_coarse_scatter(const uint32_t* __restrict__ scalars, uint32_t npts, SortGeom g,
                                                                  uint32_t* __restrict__ coarse_cursor,
-                                                                 uint2* __restrict__ inter) {
+                                                                 uint32_t* __restrict__ inter_idx,
+                                                                 uint16_t* __restrict__ inter_fine) {
     extern __shared__ __attribute__((aligned(16))) uint32_t sh[];
     for (uint32_t i = threadIdx.x; i < g.NC; i += SORT_THREADS) sh[i] = 0;
     __syncthreads();
@@ -166,7 +167,8 @@ __global__ __launch_bounds__(SORT_THREADS) void k_coarse_scatter(const uint32_t*
                 if (d != 0) {
                     uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1u;
                     uint32_t pos = atomicAdd(&sh[g.binoff[w] + (b >> g.cl)], 1u);
-                    inter[pos] = make_uint2(p | (d < 0 ? 0x80000000u : 0u), b & fmask);
+                    inter_idx[pos] = p | (d < 0 ? 0x80000000u : 0u);
+                    inter_fine[pos] = (uint16_t)(b & fmask);
                 }
             }
         }
@@ -186,7 +188,8 @@ constexpr int CS_PTS = CS_THREADS * CS_T;  // 8192 points per block: 64 KiB of s
 template <int SW>
 __global__ __launch_bounds__(CS_THREADS) void k_coarse_scatter_staged(const uint32_t* __restrict__ scalars, uint32_t npts,
                                                                       SortGeom g, uint32_t* __restrict__ coarse_cursor,
-                                                                      uint2* __restrict__ inter) {
+                                                                      uint32_t* __restrict__ inter_idx,
+                                                                      uint16_t* __restrict__ inter_fine) {
     extern __shared__ __attribute__((aligned(16))) uint32_t sh[];
     const uint32_t nbmax = 1u << g.chmax;
     uint32_t* hist = sh;              // [nb] counts of this window
@@ -268,7 +271,9 @@ __global__ __launch_bounds__(CS_THREADS) void k_coarse_scatter_staged(const uint
         for (uint32_t slot = tid; slot < total; slot += CS_THREADS) {
             uint2 e = stage[slot];
             uint32_t bin = e.y >> 16;
-            inter[gbase[bin] + (slot - lstart[bin])] = make_uint2(e.x, e.y & 0xffffu);
+            const uint32_t dst = gbase[bin] + (slot - lstart[bin]);
+            inter_idx[dst] = e.x;
+            inter_fine[dst] = (uint16_t)e.y;
         }
         __syncthreads();
     }
@@ -321,7 +326,7 @@ __device__ __forceinline__ bool slice_range(const uint32_t* coarse_off, const ui
     return lo < hi;
 }
 
-__global__ __launch_bounds__(FINE_THREADS) void k_fine_count(const uint2* __restrict__ inter, const uint32_t* __restrict__ coarse_off,
+__global__ __launch_bounds__(FINE_THREADS) void k_fine_count(const uint16_t* __restrict__ inter_fine, const uint32_t* __restrict__ coarse_off,
                                                              const uint2* __restrict__ slice_map, const uint32_t* __restrict__ nslices,
                                                              int cl, uint32_t* __restrict__ count) {
     extern __shared__ __attribute__((aligned(16))) uint32_t sh[];
@@ -337,11 +342,11 @@ __global__ __launch_bounds__(FINE_THREADS) void k_fine_count(const uint2* __rest
     for (; j + 7 * FINE_THREADS < hi; j += 8 * FINE_THREADS) {
         uint32_t key[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) key[u] = inter[j + u * FINE_THREADS].y;
+        for (int u = 0; u < 8; ++u) key[u] = inter_fine[j + u * FINE_THREADS];
 #pragma unroll
         for (int u = 0; u < 8; ++u) atomicAdd(&sh[key[u]], 1u);
     }
-    for (; j < hi; j += FINE_THREADS) atomicAdd(&sh[inter[j].y], 1u);
+    for (; j < hi; j += FINE_THREADS) atomicAdd(&sh[inter_fine[j]], 1u);
     __syncthreads();
     uint32_t* dst = count + ((size_t)k << cl);
     for (uint32_t i = threadIdx.x; i < nf; i += FINE_THREADS) {
@@ -363,7 +368,8 @@ constexpr int FS_THREADS = 1024;
 constexpr int FS_PER_THREAD = 24;
 constexpr int FS_ROUND = FS_THREADS * FS_PER_THREAD;  // up to 24576 entries: 6 bytes of staging each
 
-__global__ __launch_bounds__(FS_THREADS) void k_fine_scatter(const uint2* __restrict__ inter, const uint32_t* __restrict__ coarse_off,
+__global__ __launch_bounds__(FS_THREADS) void k_fine_scatter(const uint32_t* __restrict__ inter_idx, const uint16_t* __restrict__ inter_fine,
+                                                             const uint32_t* __restrict__ coarse_off,
                                                              const uint2* __restrict__ slice_map, const uint32_t* __restrict__ nslices,
                                                              int cl, uint32_t round_cap,
                                                              uint32_t* __restrict__ cursor, uint32_t* __restrict__ entries) {
@@ -388,10 +394,10 @@ __global__ __launch_bounds__(FS_THREADS) void k_fine_scatter(const uint2* __rest
         for (int t = 0; t < FS_PER_THREAD; ++t) {
             uint32_t j = t * FS_THREADS + threadIdx.x;
             if (j < rn) {
-                uint2 e = inter[r0 + j];
-                uint32_t rank = atomicAdd(&hist[e.y], 1u);
-                ex[t] = e.x;
-                ey[t] = e.y | (rank << 12);
+                const uint32_t f = inter_fine[r0 + j];
+                uint32_t rank = atomicAdd(&hist[f], 1u);
+                ex[t] = inter_idx[r0 + j];
+                ey[t] = f | (rank << 12);
             }
         }
         __syncthreads();
@@ -478,7 +484,11 @@ int msm_sort_lds(MsmEngine& E, const void* d_scalars, uint32_t npts, int sbits) 
     const uint32_t nblk = (npts + ppb - 1) / ppb;
     const uint64_t max_entries = (uint64_t)npts * P.W;
     BLZ_TRY(E.coarse.reserve(((size_t)g.NC * 2 + 2) * 4));
-    BLZ_TRY(E.inter.reserve(max_entries * 8));
+    // (index | sign) as u32 and the fine digit as u16, in two arrays: the fine count reads only the second
+    BLZ_TRY(E.inter.reserve(max_entries * 6 + 64));
+    uint32_t* inter_idx = E.inter.as<uint32_t>();
+    uint16_t* inter_fine = reinterpret_cast<uint16_t*>(inter_idx + max_entries);
+    E.sort_inter_fine = inter_fine;
     uint32_t* coarse_count = E.coarse.as<uint32_t>();
     uint32_t* coarse_off = coarse_count + g.NC;
     BLZ_HIP(hipMemsetAsync(coarse_count, 0, (size_t)g.NC * 4, st), BLZ_ERR_UNKNOWN);
@@ -506,13 +516,13 @@ int msm_sort_lds(MsmEngine& E, const void* d_scalars, uint32_t npts, int sbits) 
         const size_t lds_cs = ((size_t)3 << g.chmax) * 4 + (size_t)CS_PTS * 8;
         const uint32_t nblk_cs = (npts + CS_PTS - 1) / CS_PTS;
         if (sbits == 256)
-            hipLaunchKernelGGL(k_coarse_scatter_staged<8>, dim3(nblk_cs), dim3(CS_THREADS), lds_cs, st, sc, npts, g, coarse_count, E.inter.as<uint2>());
+            hipLaunchKernelGGL(k_coarse_scatter_staged<8>, dim3(nblk_cs), dim3(CS_THREADS), lds_cs, st, sc, npts, g, coarse_count, inter_idx, inter_fine);
         else
-            hipLaunchKernelGGL(k_coarse_scatter_staged<1>, dim3(nblk_cs), dim3(CS_THREADS), lds_cs, st, sc, npts, g, coarse_count, E.inter.as<uint2>());
+            hipLaunchKernelGGL(k_coarse_scatter_staged<1>, dim3(nblk_cs), dim3(CS_THREADS), lds_cs, st, sc, npts, g, coarse_count, inter_idx, inter_fine);
     } else if (sbits == 256)
-        hipLaunchKernelGGL(k_coarse_scatter<8>, dim3(nblk), dim3(SORT_THREADS), lds, st, sc, npts, g, coarse_count, E.inter.as<uint2>());
+        hipLaunchKernelGGL(k_coarse_scatter<8>, dim3(nblk), dim3(SORT_THREADS), lds, st, sc, npts, g, coarse_count, inter_idx, inter_fine);
     else
-        hipLaunchKernelGGL(k_coarse_scatter<1>, dim3(nblk), dim3(SORT_THREADS), lds, st, sc, npts, g, coarse_count, E.inter.as<uint2>());
+        hipLaunchKernelGGL(k_coarse_scatter<1>, dim3(nblk), dim3(SORT_THREADS), lds, st, sc, npts, g, coarse_count, inter_idx, inter_fine);
     // work list of the fine passes (device-built, no host sync)
     const uint32_t max_slices = (uint32_t)(max_entries / SLICE) + g.NC + 1;
     BLZ_TRY(E.slice_map.reserve(((size_t)max_slices + 2) * 8));
@@ -522,7 +532,7 @@ int msm_sort_lds(MsmEngine& E, const void* d_scalars, uint32_t npts, int sbits) 
     E.sort_slices = max_slices;
     E.sort_cl = g.cl;
     E.sort_nc = g.NC;
-    hipLaunchKernelGGL(k_fine_count, dim3(max_slices), dim3(FINE_THREADS), (size_t)4 << g.cl, st, E.inter.as<uint2>(), coarse_off,
+    hipLaunchKernelGGL(k_fine_count, dim3(max_slices), dim3(FINE_THREADS), (size_t)4 << g.cl, st, inter_fine, coarse_off,
                        slice_map, nslices, g.cl, E.count.as<uint32_t>());
     BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
     return BLZ_OK;
@@ -542,7 +552,7 @@ int msm_sort_lds_scatter(MsmEngine& E) {
     if (round_cap > (uint32_t)FS_ROUND) round_cap = FS_ROUND;
     round_cap &= ~1023u;
     const size_t lds = ((size_t)2 << E.sort_cl) * 4 + (size_t)round_cap * 6;
-    hipLaunchKernelGGL(k_fine_scatter, dim3(E.sort_slices), dim3(FS_THREADS), lds, st, E.inter.as<uint2>(), coarse_off,
+    hipLaunchKernelGGL(k_fine_scatter, dim3(E.sort_slices), dim3(FS_THREADS), lds, st, E.inter.as<uint32_t>(), (const uint16_t*)E.sort_inter_fine, coarse_off,
                        E.slice_map.as<uint2>() + 1, E.slice_map.as<uint32_t>(), E.sort_cl, round_cap, E.count.as<uint32_t>(),
                        E.entries.as<uint32_t>());
     BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
