@@ -209,11 +209,30 @@ def test_bench_workload_2e26_bls381_linearity_and_split(gpu, orc):
 
 
 def test_config4_2e26_bls377(gpu, orc):
+    """Config 4's shape on one GPU: 2^26 BLS12-377 whole, then as 8 shards of 2^23 submitted with two
+    tasks in flight (the multi-GPU ranks' flow) and combined in rank order: identical bytes."""
     curve, n = "BLS377", 1 << 26
     dp, ds = synth(curve, n, start=12345)
     exp = _expected_synth(orc, curve, ds, n, start=12345)
     cl = msm_client(curve, 1)
     assert run_msm(cl, dp, ds, n) == exp
+    shards = 8
+    per = n // shards
+    views = []
+    for s in range(shards):
+        vp = DeviceBuffer.__new__(DeviceBuffer); vp.device_id = 0; vp.ptr = dp.ptr + s * per * 96; vp.nbytes = per * 96
+        vs = DeviceBuffer.__new__(DeviceBuffer); vs.device_id = 0; vs.ptr = ds.ptr + s * per * 32; vs.nbytes = per * 32
+        views.append((vp, vs))
+    params = MSMParams(per, None)
+    parts = b""
+    for s, (vp, vs) in enumerate(views):
+        cl.initialize(params); cl.start_process(); cl.set_data(MSMInput(vp, vs, params))
+        if s >= 1:
+            cl.wait_result(); parts += cl.result().result
+    cl.wait_result(); parts += cl.result().result
+    for vp, vs in views:
+        vp.ptr = None; vs.ptr = None
+    assert cl.combine_partials(parts, shards) == exp
     cl.close(); dp.free(); ds.free()
 
 
