@@ -35,7 +35,7 @@ NTT_LOG = int(os.environ.get("BLAZE_BENCH_NTT_LOGN", "27"))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-ntt", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
