@@ -1,0 +1,113 @@
+// Mixed addition on y^2 = x^3 + b in XYZZ coordinates over the reduced-radix field (field_rr.cuh): the hot
+// loop of the bucket accumulation.  Same formulas as ec.cuh (EFD madd-2008-s / mdbl-2008-s-1), same
+// completeness (infinity, P + P, P - P), different arithmetic: no carry chains, no conditional
+// subtractions; every intermediate's limb and value bounds are carried in its type and checked at
+// compile time (Frr<Q, F, V>: limbs < F 2^B, value < V m).
+//
+// Cost in v_mad_u64_u32 (NL = 14): 6 products x 392 + 2 squarings x 301 + 1 fused sum of two products x 588
+// = 3542 per mixed add, against 2844 multiply-add PAIRS (v_mad_u64_u32 + v_addc_co_u32) in ec.cuh.
+#pragma once
+#include "field_rr.cuh"
+#include "ec.cuh"
+
+namespace blz {
+
+template <class Q>
+struct AffineRR {
+    Frr<Q, 1, 2> x, y;  // Montgomery (Rrr), normalised, < 2m
+};
+// accumulator: X3 = R^2 - PPP - 2Q is kept as the lazy difference it is (normalised limbs, value < 14 m)
+template <class Q>
+struct XYZZRR {
+    static constexpr int VX = 16, VY = 4;
+    Frr<Q, 1, VX> x;
+    Frr<Q, 1, VY> y;
+    Frr<Q, 1, 2> zz, zzz;
+};
+
+template <class Q>
+BLZ_DEV void ptrr_set_inf(XYZZRR<Q>& p) {
+    rr_zero(p.x);
+    rr_zero(p.y);
+    rr_zero(p.zz);
+    rr_zero(p.zzz);
+}
+template <class Q>
+BLZ_DEV bool ptrr_is_inf(const XYZZRR<Q>& p) { return rr_all_zero(p.zz); }
+
+// 2 (x, y) for an affine point whose y may be the lazy negation 4m - y.  By value and out of line: the rare
+// P + P branch must not force the hot loop's accumulator into scratch (see ec.cuh's pt_mdbl_val).
+// TAG: one copy per calling kernel (a shared out-of-line callee is compiled for its most permissive caller and
+// then sets the register count of every kernel that reaches it).
+template <class Q, int TAG = 0>
+__device__ __noinline__ XYZZRR<Q> ptrr_mdbl_val(Frr<Q, 1, 2> x, Frr<Q, 2, 4> y) {
+    XYZZRR<Q> r;
+    const auto U = rr_add(y, y);                       // (4, 8)
+    Frr<Q, 1, 2> V, W, S, t, Msq, y3;
+    rr_sqr(V, U);
+    rr_mul(W, U, V);
+    rr_mul(S, x, V);
+    rr_sqr(t, x);
+    const auto M = rr_add(rr_add(t, t), t);            // (3, 6)
+    rr_sqr(Msq, M);
+    const auto X3 = rr_norm(rr_sub_twice<2>(Msq, S));  // M^2 - 2S + 8m: (1, 10)
+    const auto D = rr_sub<5>(S, X3);                   // S - X3 + 32m: (3, 34)
+    const auto nW = rr_neg<2>(W);                      // 4m - W: (2, 4)
+    rr_mul2(y3, M, D, nW, y);                          // M (S - X3) - W y
+    r.x = rr_as<1, XYZZRR<Q>::VX>(X3);
+    r.y = rr_as<1, XYZZRR<Q>::VY>(y3);
+    r.zz = V;
+    r.zzz = W;
+    return r;
+}
+
+// acc += +-(x2, y2)   (affine operand, never infinity; `neg` subtracts it)
+template <class Q, int TAG = 0>
+BLZ_DEV void ptrr_madd(XYZZRR<Q>& acc, const AffineRR<Q>& q, bool neg) {
+    const auto y2 = rr_cneg<2>(q.y, neg);              // (2, 4)
+    if (ptrr_is_inf(acc)) {
+        acc.x = rr_as<1, XYZZRR<Q>::VX>(q.x);
+        acc.y = rr_norm(y2);
+        rr_one(acc.zz);
+        rr_one(acc.zzz);
+        return;
+    }
+    Frr<Q, 1, 2> U2, S2, PP, PPP, Qv, t, y3;
+    rr_mul(U2, q.x, acc.zz);
+    rr_mul(S2, y2, acc.zzz);
+    const auto P = rr_sub<5>(U2, acc.x);               // U2 - X1 + 32m: (3, 34)
+    const auto R = rr_sub<3>(S2, acc.y);               // S2 - Y1 + 8m: (3, 10)
+    if (__builtin_expect(rr_maybe_equal(U2, acc.x), 0)) {
+        if (rr_is_zero(P)) {
+            if (rr_is_zero(R)) acc = ptrr_mdbl_val<Q, TAG>(q.x, y2);
+            else ptrr_set_inf(acc);
+            return;
+        }
+    }
+    // ordered so that every input coordinate dies as early as possible (see ec.cuh's pt_madd)
+    rr_sqr(PP, P);
+    rr_mul(acc.zz, acc.zz, PP);                        // ZZ3
+    rr_mul(PPP, P, PP);
+    rr_mul(acc.zzz, acc.zzz, PPP);                     // ZZZ3
+    rr_mul(Qv, acc.x, PP);
+    rr_sqr(t, R);
+    const auto X3 = rr_norm(rr_sub_twice<2>(rr_sub<2>(t, PPP), Qv));  // R^2 - PPP - 2Q + 12m: (1, 14)
+    const auto D = rr_sub<5>(Qv, X3);                  // Q - X3 + 32m: (3, 34)
+    const auto nY = rr_neg<3>(acc.y);                  // 8m - Y1: (2, 8)
+    rr_mul2(y3, R, D, nY, PPP);                        // R (Q - X3) - Y1 PPP, one reduction
+    acc.x = rr_as<1, XYZZRR<Q>::VX>(X3);
+    acc.y = rr_as<1, XYZZRR<Q>::VY>(y3);
+}
+
+// accumulator -> ec.cuh's XYZZ over the 32-bit twin field (Montgomery R32, lazy [0, 2m)); infinity stays
+// literal zero
+template <class F>
+BLZ_DEV void ptrr_to_xyzz32(XYZZ<F>& r, const XYZZRR<typename F::RR>& a) {
+    using Q = typename F::RR;
+    rr_to_mont32_words<Q>(r.x.v, a.x);
+    rr_to_mont32_words<Q>(r.y.v, a.y);
+    rr_to_mont32_words<Q>(r.zz.v, a.zz);
+    rr_to_mont32_words<Q>(r.zzz.v, a.zzz);
+}
+
+}  // namespace blz

@@ -1,0 +1,332 @@
+// Reduced-radix prime-field arithmetic for gfx950: NL limbs of B < 32 bits in 32-bit registers,
+// Montgomery radix Rrr = 2^(B NL)  (BLS12-377/381 Fq: 14 x 28 bits).
+//
+// Why a second representation.  With full 32-bit limbs (field.cuh) a column sum of 32x32 products
+// needs 64 + log2(count) bits, so every v_mad_u64_u32 is followed by a v_addc_co_u32 that folds its
+// carry-out into a third accumulator word: 2 issue slots per multiply-add, and both are "long"
+// (VOP3-class) instructions that issue at half the rate of a plain 32-bit add on this chip.  With B-bit
+// limbs a product is < 2^(2B + slack) and a whole column (2 NL products) fits the 64-bit accumulator of
+// v_mad_u64_u32 itself: ONE instruction per multiply-add, no carry word, and the per-column
+// bookkeeping (mask, shift) is 3 more.  14 x 14 x 2 = 392 multiply-adds instead of 12 x 12 x 2 x 2 = 576
+// instructions for a BLS base-field product: 7.8e10 instead of 6.2e10 products/s on the chip, which is
+// the bare v_mad_u64_u32 rate (3.1e13 lane-ops/s / 392); a squaring does its off-diagonal products once
+// against the doubled operand (301 multiply-adds: 9.65e10 /s).  profiles/r02_mul_variants.txt holds
+// these and the alternatives that lost (13 x 30 bits two-phase, DFMA, v_lshl_add_u64 column sums).
+// The spare bits also make add / sub carry-free: limbs are allowed to grow ("limb slack") and values
+// are allowed to grow ("value slack", Rrr / m = 2^HEAD) between products; only a product renormalises.
+//
+// Ranges are part of the TYPE, so every bound below is checked at compile time:
+//   Frr<Q, F, V>:  every limb < F 2^B   and   the integer < V m.
+//   F = 1: "normalised" (the top limb holds whatever is left; < 2^B because V m < Rrr).
+// rr_mul(a, b):    needs (Fa Fb + 1) NL + 1 <= 2^(64 - 2B)  (64-bit column sums) and Va Vb <= 2^HEAD;
+//                  result Frr<Q, 1, 2>  (< (Va Vb / 2^HEAD + 1) m).
+// rr_sub<J>(a, b): a - b + 2^J m, b normalised with Vb <= 2^(J-1): Frr<Q, Fa + 2, Va + 2^J>.
+// Values are never canonical in flight; zero tests are done modulo m on demand (rr_is_zero).
+#pragma once
+#include "field.cuh"
+
+namespace blz {
+
+template <class Q>
+constexpr int rr_head() { return Q::B * Q::NL - Q::BITS; }  // log2(Rrr / 2^BITS) <= log2(Rrr / m)
+
+template <class Q, int F = 1, int V = 2>
+struct Frr {
+    static_assert(F >= 1 && F <= 15 && V >= 1 && V <= (1 << rr_head<Q>()), "bound out of range");
+    uint32_t v[Q::NL];
+};
+
+// 64-bit column sums: fsum = sum over the product kinds of Fa Fb (1 kind for a b, 2 for a b + c d)
+template <class Q>
+constexpr bool rr_cols_ok(unsigned fsum) {
+    return (unsigned long long)(fsum + 1) * Q::NL + 1 <= (1ull << (64 - 2 * Q::B));
+}
+template <class Q>
+constexpr bool rr_vals_ok(unsigned vsum) { return vsum <= (1u << rr_head<Q>()); }
+
+// widen the bounds (free)
+template <int F2, int V2, class Q, int F, int V>
+BLZ_DEV const Frr<Q, F2, V2>& rr_as(const Frr<Q, F, V>& a) {
+    static_assert(F2 >= F && V2 >= V, "rr_as only widens");
+    return reinterpret_cast<const Frr<Q, F2, V2>&>(a);
+}
+
+template <class Q, int F, int V>
+BLZ_DEV void rr_zero(Frr<Q, F, V>& r) {
+#pragma unroll
+    for (int i = 0; i < Q::NL; ++i) r.v[i] = 0;
+}
+template <class Q, int F, int V>
+BLZ_DEV void rr_one(Frr<Q, F, V>& r) {  // Montgomery one
+#pragma unroll
+    for (int i = 0; i < Q::NL; ++i) r.v[i] = Q::ONE[i];
+}
+template <class Q, int F, int V>
+BLZ_DEV bool rr_all_zero(const Frr<Q, F, V>& a) {  // literal zero limbs
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < Q::NL; ++i) o |= a.v[i];
+    return o == 0;
+}
+
+#include "rr_gen.inc"
+
+// ---- product scanning over asm columns ----------------------------------------------------------------
+// column K: the caller's products (AB), the reduction products q_i m_j of this column, then either the next
+// quotient digit q_K (K < NL) or the next result limb
+template <class Q, int K, class AB>
+BLZ_DEV void rr_column(uint64_t& acc, uint32_t (&q)[Q::NL], uint32_t (&t)[Q::NL], AB&& ab) {
+    constexpr int NL = Q::NL;
+    ab(std::integral_constant<int, K>{}, acc);
+    rr_qm<NL, K>(acc, q, Q::MOD);
+    if constexpr (K < NL) {
+        q[K] = ((uint32_t)acc * Q::N0) & Q::MASK;
+        acc = (uint64_t)q[K] * Q::MOD[0] + acc;  // low B bits become zero
+    } else {
+        t[K - NL] = (uint32_t)acc & Q::MASK;
+    }
+    acc >>= Q::B;
+}
+template <class Q, class AB, int... Ks>
+BLZ_DEV void rr_columns(Frr<Q, 1, 2>& r, AB&& ab, std::integer_sequence<int, Ks...>) {
+    uint32_t q[Q::NL], t[Q::NL];
+    uint64_t acc = 0;
+    (rr_column<Q, Ks>(acc, q, t, ab), ...);
+    t[Q::NL - 1] = (uint32_t)acc;
+#pragma unroll
+    for (int i = 0; i < Q::NL; ++i) r.v[i] = t[i];
+}
+
+// r = a b / Rrr  (mod m)
+template <class Q, int Fa, int Va, int Fb, int Vb>
+BLZ_DEV void rr_mul(Frr<Q, 1, 2>& r, const Frr<Q, Fa, Va>& a, const Frr<Q, Fb, Vb>& b) {
+    static_assert(rr_cols_ok<Q>(Fa * Fb), "column sum would overflow 64 bits: normalise an operand");
+    static_assert(rr_vals_ok<Q>(Va * Vb), "product would leave the lazy value range");
+    rr_columns<Q>(r, [&](auto k, uint64_t& acc) { rr_ab<Q::NL, decltype(k)::value>(acc, a.v, b.v); },
+                  std::make_integer_sequence<int, 2 * Q::NL - 1>{});
+}
+// r = a^2 / Rrr: the off-diagonal products once, against the doubled operand
+template <class Q, int Fa, int Va>
+BLZ_DEV void rr_sqr(Frr<Q, 1, 2>& r, const Frr<Q, Fa, Va>& a) {
+    static_assert(rr_cols_ok<Q>(Fa * Fa) && 2 * Fa <= 15, "column sum would overflow 64 bits");
+    static_assert(rr_vals_ok<Q>(Va * Va), "product would leave the lazy value range");
+    uint32_t a2[Q::NL];
+#pragma unroll
+    for (int i = 0; i < Q::NL; ++i) a2[i] = a.v[i] << 1;
+    rr_columns<Q>(r, [&](auto k, uint64_t& acc) { rr_sq<Q::NL, decltype(k)::value>(acc, a.v, a2); },
+                  std::make_integer_sequence<int, 2 * Q::NL - 1>{});
+}
+// r = (a b + c d) / Rrr with ONE reduction (the group law's Y3 = R (Q - X3) - Y1 PPP)
+template <class Q, int Fa, int Va, int Fb, int Vb, int Fc, int Vc, int Fd, int Vd>
+BLZ_DEV void rr_mul2(Frr<Q, 1, 2>& r, const Frr<Q, Fa, Va>& a, const Frr<Q, Fb, Vb>& b, const Frr<Q, Fc, Vc>& c,
+                     const Frr<Q, Fd, Vd>& d) {
+    static_assert(rr_cols_ok<Q>(Fa * Fb + Fc * Fd), "column sum would overflow 64 bits");
+    static_assert(rr_vals_ok<Q>(Va * Vb + Vc * Vd), "sum of products would leave the lazy value range");
+    rr_columns<Q>(r, [&](auto k, uint64_t& acc) {
+        rr_ab<Q::NL, decltype(k)::value>(acc, a.v, b.v);
+        rr_ab<Q::NL, decltype(k)::value>(acc, c.v, d.v);
+    }, std::make_integer_sequence<int, 2 * Q::NL - 1>{});
+}
+
+// the same product in plain C++ (what hipcc schedules by itself: kept as the readable reference and for
+// tools/mul_variants.hip; it re-associates every column into "products first, carry-in last")
+template <class Q, int Fa, int Va, int Fb, int Vb>
+BLZ_DEV void rr_mul_ref(Frr<Q, 1, 2>& r, const Frr<Q, Fa, Va>& a, const Frr<Q, Fb, Vb>& b) {
+    constexpr int NL = Q::NL, B = Q::B;
+    uint32_t q[NL], t[NL];
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 2 * NL - 1; ++k) {
+        const int ilo = k < NL ? 0 : k - NL + 1;
+        const int ihi = k < NL ? k : NL - 1;
+#pragma unroll
+        for (int i = ilo; i <= ihi; ++i) acc += (uint64_t)a.v[i] * b.v[k - i];
+        if (k < NL) {
+#pragma unroll
+            for (int i = 0; i < k; ++i) acc += (uint64_t)q[i] * Q::MOD[k - i];
+            q[k] = ((uint32_t)acc * Q::N0) & Q::MASK;
+            acc += (uint64_t)q[k] * Q::MOD[0];
+        } else {
+#pragma unroll
+            for (int i = k - NL + 1; i < NL; ++i) acc += (uint64_t)q[i] * Q::MOD[k - i];
+            t[k - NL] = (uint32_t)acc & Q::MASK;
+        }
+        acc >>= B;
+    }
+    t[NL - 1] = (uint32_t)acc;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) r.v[i] = t[i];
+}
+
+// ---- carry-free add / sub ---------------------------------------------------------------------------
+template <class Q, int Fa, int Va, int Fb, int Vb>
+BLZ_DEV Frr<Q, Fa + Fb, Va + Vb> rr_add(const Frr<Q, Fa, Va>& a, const Frr<Q, Fb, Vb>& b) {
+    Frr<Q, Fa + Fb, Va + Vb> r;
+#pragma unroll
+    for (int i = 0; i < Q::NL; ++i) r.v[i] = a.v[i] + b.v[i];
+    return r;
+}
+// a - b + 2^J m.  KM[J-1] is 2^J m in borrow form: every limb but the top is >= 2^B - 1 >= b_i and the top limb
+// is >= the top limb of any b < 2^(J-1) m (tools/gen_constants.py), so no limb goes negative.
+template <int J, class Q, int Fa, int Va, int Vb>
+BLZ_DEV Frr<Q, Fa + 2, Va + (1 << J)> rr_sub(const Frr<Q, Fa, Va>& a, const Frr<Q, 1, Vb>& b) {
+    static_assert(J >= 1 && J <= Q::NKM && Vb <= (1 << (J - 1)), "multiple of m too small for this subtrahend");
+    Frr<Q, Fa + 2, Va + (1 << J)> r;
+#pragma unroll
+    for (int i = 0; i < Q::NL; ++i) r.v[i] = a.v[i] + (Q::KM[J - 1][i] - b.v[i]);
+    return r;
+}
+// a - 2 b + 2^(J+1) m
+template <int J, class Q, int Fa, int Va, int Vb>
+BLZ_DEV Frr<Q, Fa + 4, Va + (2 << J)> rr_sub_twice(const Frr<Q, Fa, Va>& a, const Frr<Q, 1, Vb>& b) {
+    static_assert(J >= 1 && J <= Q::NKM && Vb <= (1 << (J - 1)), "multiple of m too small for this subtrahend");
+    Frr<Q, Fa + 4, Va + (2 << J)> r;
+#pragma unroll
+    for (int i = 0; i < Q::NL; ++i) r.v[i] = a.v[i] + 2u * (Q::KM[J - 1][i] - b.v[i]);
+    return r;
+}
+// 2^J m - b
+template <int J, class Q, int Vb>
+BLZ_DEV Frr<Q, 2, (1 << J)> rr_neg(const Frr<Q, 1, Vb>& b) {
+    static_assert(J >= 1 && J <= Q::NKM && Vb <= (1 << (J - 1)), "multiple of m too small");
+    Frr<Q, 2, (1 << J)> r;
+#pragma unroll
+    for (int i = 0; i < Q::NL; ++i) r.v[i] = Q::KM[J - 1][i] - b.v[i];
+    return r;
+}
+// sign ? 2^J m - b : b   (per lane)
+template <int J, class Q, int Vb>
+BLZ_DEV Frr<Q, 2, (1 << J)> rr_cneg(const Frr<Q, 1, Vb>& b, bool sign) {
+    static_assert(J >= 1 && J <= Q::NKM && Vb <= (1 << (J - 1)), "multiple of m too small");
+    Frr<Q, 2, (1 << J)> r;
+#pragma unroll
+    for (int i = 0; i < Q::NL; ++i) r.v[i] = sign ? Q::KM[J - 1][i] - b.v[i] : b.v[i];
+    return r;
+}
+// carry propagation: limbs < 2^B again (the top limb keeps the rest; V m < Rrr by the type's own bound)
+template <class Q, int F, int V>
+BLZ_DEV Frr<Q, 1, V> rr_norm(const Frr<Q, F, V>& a) {
+    Frr<Q, 1, V> r;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < Q::NL - 1; ++i) {
+        uint32_t s = a.v[i] + c;
+        r.v[i] = s & Q::MASK;
+        c = s >> Q::B;
+    }
+    r.v[Q::NL - 1] = a.v[Q::NL - 1] + c;
+    return r;
+}
+
+// ---- conversions -----------------------------------------------------------------------------------
+// plain integer in 32-bit words (any value < 2^(32 N32)) -> B-bit limbs, normalised
+template <class Q, int V>
+BLZ_DEV void rr_from_words(Frr<Q, 1, V>& r, const uint32_t (&w)[Q::N32]) {
+    static_assert(32 * Q::N32 <= Q::B * Q::NL, "words do not fit the limbs");
+#pragma unroll
+    for (int i = 0; i < Q::NL; ++i) {
+        const int bit = i * Q::B, j = bit >> 5, s = bit & 31;
+        uint32_t lo = j < Q::N32 ? w[j] : 0u;
+        uint32_t hi = j + 1 < Q::N32 ? w[j + 1] : 0u;
+        uint32_t x = s == 0 ? lo : __builtin_amdgcn_alignbit(hi, lo, s);
+        r.v[i] = x & Q::MASK;
+    }
+}
+// normalised B-bit limbs of a value < 2^(32 N32) -> 32-bit words
+template <class Q, int V>
+BLZ_DEV void rr_to_words(uint32_t (&w)[Q::N32], const Frr<Q, 1, V>& a) {
+    static_assert(Q::BITS + 1 <= 32 * Q::N32 && V <= 2, "value does not fit the words");
+#pragma unroll
+    for (int j = 0; j < Q::N32; ++j) {
+        uint32_t x = 0;
+#pragma unroll
+        for (int i = 0; i < Q::NL; ++i) {
+            const int sh = i * Q::B - 32 * j;  // position of limb i inside word j
+            if (sh > -Q::B && sh < 32) x |= sh >= 0 ? (a.v[i] << sh) : (a.v[i] >> (-sh));
+        }
+        w[j] = x;
+    }
+}
+
+// wire integer (32-bit words; any 32 N32-bit value, canonical or not) -> Montgomery form x Rrr mod m
+template <class Q>
+BLZ_DEV void rr_to_mont_from_words(Frr<Q, 1, 2>& r, const uint32_t (&w)[Q::N32]) {
+    // x < 2^(32 N32) = 2^(32 N32 - BITS) 2^BITS < 2^(32 N32 - BITS + 1) m
+    constexpr int VRAW = 1 << (32 * Q::N32 - Q::BITS + 1);
+    Frr<Q, 1, VRAW> x;
+    rr_from_words<Q>(x, w);
+    Frr<Q, 1, 1> k;
+#pragma unroll
+    for (int i = 0; i < Q::NL; ++i) k.v[i] = Q::RR2[i];
+    rr_mul(r, x, k);
+}
+// x Rrr (normalised) -> x R32 as 32-bit words in the lazy range [0, 2m) of field.cuh's twin field
+template <class Q, int V>
+BLZ_DEV void rr_to_mont32_words(uint32_t (&w)[Q::N32], const Frr<Q, 1, V>& a) {
+    Frr<Q, 1, 1> k;
+#pragma unroll
+    for (int i = 0; i < Q::NL; ++i) k.v[i] = Q::TO32[i];
+    Frr<Q, 1, 2> t;
+    rr_mul(t, a, k);
+    rr_to_words<Q>(w, t);
+}
+// x R32 in 32-bit words (lazy [0, 2m]) -> x Rrr
+template <class Q>
+BLZ_DEV void rr_from_mont32_words(Frr<Q, 1, 2>& r, const uint32_t (&w)[Q::N32]) {
+    Frr<Q, 1, 3> x;
+    rr_from_words<Q>(x, w);
+    Frr<Q, 1, 1> k;
+#pragma unroll
+    for (int i = 0; i < Q::NL; ++i) k.v[i] = Q::FROM32[i];
+    rr_mul(r, x, k);
+}
+
+// exact test a == 0 (mod m): a / Rrr (mod m) is < 2m after one reduction, so it is 0 or m exactly
+template <class Q, int F, int V>
+BLZ_DEV bool rr_is_zero(const Frr<Q, F, V>& a) {
+    Frr<Q, 1, 1> one;
+#pragma unroll
+    for (int i = 0; i < Q::NL; ++i) one.v[i] = i == 0 ? 1u : 0u;
+    Frr<Q, 1, 2> t;
+    rr_mul(t, a, one);
+    uint32_t z = 0, e = 0;
+#pragma unroll
+    for (int i = 0; i < Q::NL; ++i) {
+        z |= t.v[i];
+        e |= t.v[i] ^ Q::MOD[i];
+    }
+    return z == 0 || e == 0;
+}
+// cheap filter: can a - b be 0 (mod m)?  a - b = c m for an integer -Vb < c < Va, and c = (a_0 - b_0) m^-1 mod 2^B
+// whatever the limb slack (only the low B bits of the low limbs matter).  False positives ~ (Va + Vb) / 2^B.
+template <class Q, int Fa, int Va, int Fb, int Vb>
+BLZ_DEV bool rr_maybe_equal(const Frr<Q, Fa, Va>& a, const Frr<Q, Fb, Vb>& b) {
+    const uint32_t c = ((a.v[0] - b.v[0]) * Q::MINV) & Q::MASK;
+    return c < (uint32_t)Va || c > Q::MASK - (uint32_t)Vb;
+}
+
+// global-memory I/O: NL dwords, 16-byte vector accesses where the count allows
+template <class Q, int F, int V>
+BLZ_DEV void rr_load(Frr<Q, F, V>& r, const uint32_t* p) {
+    static_assert(Q::NL % 2 == 0, "even limb count expected");
+    const uint4* q4 = reinterpret_cast<const uint4*>(p);
+#pragma unroll
+    for (int i = 0; i < Q::NL / 4; ++i) {
+        uint4 x = q4[i];
+        r.v[4 * i] = x.x; r.v[4 * i + 1] = x.y; r.v[4 * i + 2] = x.z; r.v[4 * i + 3] = x.w;
+    }
+    if constexpr (Q::NL % 4 == 2) {
+        uint2 x = *reinterpret_cast<const uint2*>(p + Q::NL - 2);
+        r.v[Q::NL - 2] = x.x; r.v[Q::NL - 1] = x.y;
+    }
+}
+template <class Q, int F, int V>
+BLZ_DEV void rr_store(uint32_t* p, const Frr<Q, F, V>& a) {
+    static_assert(Q::NL % 2 == 0, "even limb count expected");
+    uint4* q4 = reinterpret_cast<uint4*>(p);
+#pragma unroll
+    for (int i = 0; i < Q::NL / 4; ++i) q4[i] = make_uint4(a.v[4 * i], a.v[4 * i + 1], a.v[4 * i + 2], a.v[4 * i + 3]);
+    if constexpr (Q::NL % 4 == 2) *reinterpret_cast<uint2*>(p + Q::NL - 2) = make_uint2(a.v[Q::NL - 2], a.v[Q::NL - 1]);
+}
+
+}  // namespace blz

@@ -4,11 +4,9 @@
 #pragma once
 #include "msm_engine.hpp"
 #include "ec.cuh"
+#include "ec_rr.cuh"
 #include "ec_quad.cuh"
-
-#ifndef BLZ_ACC_PREFETCH
-#define BLZ_ACC_PREFETCH 0
-#endif
+#include <type_traits>
 
 namespace blz {
 
@@ -19,6 +17,11 @@ namespace blz {
 // ------------------------------------------------------------------------------------------------
 template <class F>
 constexpr int MONT_STRIDE = 2 * F::N > 16 ? 32 : 2 * F::N;  // dwords per Montgomery point
+// Fields with a reduced-radix twin (field_rr.cuh: the two BLS base fields) run the bucket accumulation in it:
+// their Montgomery point copy holds 2 x NL limbs of B bits (x R_rr, y R_rr: 112 of the line's 128 bytes) and
+// k_accumulate converts a unit's sum to the 32-bit form once, when it stores it.
+template <class F>
+constexpr bool USE_RR = !std::is_void_v<typename F::RR>;
 
 template <class F>
 __global__ __launch_bounds__(256) void k_points_to_mont(const uint32_t* __restrict__ raw, uint32_t* __restrict__ mont,
@@ -28,10 +31,35 @@ __global__ __launch_bounds__(256) void k_points_to_mont(const uint32_t* __restri
     Fp<F> x, y;
     fp_load(x, raw + (size_t)p * 2 * F::N);
     fp_load(y, raw + (size_t)p * 2 * F::N + F::N);
-    fp_to_mont(x, x);
-    fp_to_mont(y, y);
-    fp_store(mont + (size_t)p * MONT_STRIDE<F>, x);
-    fp_store(mont + (size_t)p * MONT_STRIDE<F> + F::N, y);
+    if constexpr (USE_RR<F>) {
+        using Q = typename F::RR;
+        static_assert(2 * Q::NL <= MONT_STRIDE<F> && Q::NL % 2 == 0, "reduced-radix point does not fit its line");
+        Frr<Q, 1, 2> xr, yr;
+        rr_to_mont_from_words<Q>(xr, x.v);
+        rr_to_mont_from_words<Q>(yr, y.v);
+        rr_store(mont + (size_t)p * MONT_STRIDE<F>, xr);
+        rr_store(mont + (size_t)p * MONT_STRIDE<F> + Q::NL, yr);
+    } else {
+        fp_to_mont(x, x);
+        fp_to_mont(y, y);
+        fp_store(mont + (size_t)p * MONT_STRIDE<F>, x);
+        fp_store(mont + (size_t)p * MONT_STRIDE<F> + F::N, y);
+    }
+}
+template <class F>
+BLZ_DEV void load_affine_rr(AffineRR<typename F::RR>& a, const uint32_t* pts, uint32_t idx) {
+    using Q = typename F::RR;
+    // 2 NL dwords, 16-byte aligned: x and y share a vector load in the middle when NL is not a multiple of 4
+    const uint4* q4 = reinterpret_cast<const uint4*>(pts + (size_t)idx * MONT_STRIDE<F>);
+    uint32_t w[2 * Q::NL];
+    static_assert((2 * Q::NL) % 4 == 0, "point not a whole number of 16-byte pieces");
+#pragma unroll
+    for (int i = 0; i < 2 * Q::NL / 4; ++i) {
+        uint4 v = q4[i];
+        w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+    }
+#pragma unroll
+    for (int i = 0; i < Q::NL; ++i) { a.x.v[i] = w[i]; a.y.v[i] = w[Q::NL + i]; }
 }
 
 template <class F>
@@ -67,7 +95,7 @@ BLZ_DEV void store_xyzz(uint32_t* base, size_t idx, const XYZZ<F>& a) {
 // phase 1: bucket accumulation.  One lane per unit (a run of <= L entries of one bucket).
 // ------------------------------------------------------------------------------------------------
 template <class F>
-__global__ __launch_bounds__(128, 3) void k_accumulate(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ entries,
+__global__ __launch_bounds__(128, USE_RR<F> ? 2 : 3) void k_accumulate(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ entries,
                                                     const uint32_t* __restrict__ off, const uint32_t* __restrict__ unit_off,
                                                     const uint32_t* __restrict__ unit_bucket,
                                                     const uint32_t* __restrict__ unit_order, uint32_t U, uint32_t L,
@@ -80,37 +108,44 @@ __global__ __launch_bounds__(128, 3) void k_accumulate(const uint32_t* __restric
     uint32_t start = off[g] + k * L;
     uint32_t end = off[g + 1];
     if (end - start > L) end = start + L;
-    XYZZ<F> acc;
-    pt_set_inf(acc);
-#if BLZ_ACC_PREFETCH
-    Affine<F> nxt;
-    uint32_t e = entries[start];
-    load_affine(nxt, pts, e & 0x7fffffffu);
-    for (uint32_t j = start; j < end; ++j) {
-        Affine<F> cur = nxt;
-        uint32_t ecur = e;
-        if (j + 1 < end) {  // prefetch the next point under the current add
-            e = entries[j + 1];
-            load_affine(nxt, pts, e & 0x7fffffffu);
+    if constexpr (USE_RR<F>) {
+        // reduced-radix arithmetic (ec_rr.cuh): 2 waves per SIMD reach 95 % of the multiplier's rate
+        // (profiles/r02_mul_variants.txt), which leaves 256 VGPRs: room for the next point's prefetch
+        using Q = typename F::RR;
+        XYZZRR<Q> acc;
+        ptrr_set_inf(acc);
+        uint32_t e = entries[start];
+        AffineRR<Q> nxt;
+        load_affine_rr<F>(nxt, pts, e & 0x7fffffffu);
+        for (uint32_t j = start; j < end; ++j) {
+            const AffineRR<Q> cur = nxt;
+            const bool neg = (e & 0x80000000u) != 0;
+            if (j + 1 < end) {
+                e = entries[j + 1];
+                load_affine_rr<F>(nxt, pts, e & 0x7fffffffu);
+            }
+            ptrr_madd<Q, 1>(acc, cur, neg);
         }
-        if (ecur & 0x80000000u) fp_neg(cur.y, cur.y);
-        pt_madd(acc, cur);
+        XYZZ<F> out;
+        ptrr_to_xyzz32<F>(out, acc);
+        store_xyzz(partial, u, out);
+    } else {
+        XYZZ<F> acc;
+        pt_set_inf(acc);
+        // only the next entry INDEX is prefetched: holding the next point as well costs 24 VGPRs, which at
+        // 3 waves per SIMD (168 VGPRs) turned into scratch spills (100 GB of HBM writes per 2^26 MSM in
+        // the WRITE_SIZE counter); the other two waves of the SIMD cover the gather latency instead
+        uint32_t e = entries[start];
+        for (uint32_t j = start; j < end; ++j) {
+            Affine<F> cur;
+            load_affine(cur, pts, e & 0x7fffffffu);
+            const uint32_t ecur = e;
+            if (j + 1 < end) e = entries[j + 1];
+            if (ecur & 0x80000000u) fp_neg(cur.y, cur.y);
+            pt_madd(acc, cur);
+        }
+        store_xyzz(partial, u, acc);
     }
-#else
-    // only the next entry INDEX is prefetched: holding the next point as well costs 24 VGPRs, which at
-    // 3 waves per SIMD (168 VGPRs) turned into scratch spills (100 GB of HBM writes per 2^26 MSM in
-    // the WRITE_SIZE counter); the other two waves of the SIMD cover the gather latency instead
-    uint32_t e = entries[start];
-    for (uint32_t j = start; j < end; ++j) {
-        Affine<F> cur;
-        load_affine(cur, pts, e & 0x7fffffffu);
-        const uint32_t ecur = e;
-        if (j + 1 < end) e = entries[j + 1];
-        if (ecur & 0x80000000u) fp_neg(cur.y, cur.y);
-        pt_madd(acc, cur);
-    }
-#endif
-    store_xyzz(partial, u, acc);
 }
 
 // buckets that needed several units: fold partial[u0 + k*stride] for k in the same 16-group.

@@ -50,6 +50,60 @@ def field_struct(name, m, n, extra=""):
     return "\n".join(out)
 
 
+def rr_struct(name, m, n32, B, NL):
+    """Reduced-radix twin of a field: NL limbs of B bits in 32-bit registers, Montgomery radix
+    Rrr = 2^(B NL).  Limbs leave 32 - B spare bits (carry-free add / sub) and the 64-bit column sums of
+    v_mad_u64_u32 never overflow, so a 32x32 multiply-add is ONE instruction (field_rr.cuh)."""
+    Rrr = 1 << (B * NL)
+    assert Rrr > (m << 5), "value head-room of the lazy range"
+    nk = min(7, B * NL - m.bit_length() - 1)  # multiples 2^j m that still fit NL limbs
+    mask = (1 << B) - 1
+
+    def L(v, cnt=NL):
+        assert v >> (B * cnt) == 0
+        return ", ".join("0x%08xu" % ((v >> (B * i)) & mask) for i in range(cnt))
+
+    n0 = (-pow(m, -1, 1 << B)) % (1 << B)
+    out = [f"struct {name} {{"]
+    out.append(f"    static constexpr int B = {B};    // bits per limb")
+    out.append(f"    static constexpr int NL = {NL};  // limbs")
+    out.append(f"    static constexpr int N32 = {n32};  // limbs of the 32-bit twin")
+    out.append(f"    static constexpr int BITS = {m.bit_length()};")
+    out.append(f"    static constexpr uint32_t MASK = 0x{mask:08x}u;")
+    out.append(f"    static constexpr uint32_t N0 = 0x{n0:08x}u;    // -m^-1 mod 2^B")
+    out.append(f"    static constexpr uint32_t MINV = 0x{pow(m, -1, 1 << B):08x}u;  // m^-1 mod 2^B")
+    out.append(f"    static constexpr uint32_t MOD[{NL}] = {{{L(m)}}};")
+    out.append(f"    static constexpr uint32_t ONE[{NL}] = {{{L(Rrr % m)}}};  // Rrr mod m")
+    out.append(f"    static constexpr uint32_t RR2[{NL}] = {{{L(Rrr * Rrr % m)}}};  // Rrr^2 mod m")
+    out.append(f"    static constexpr uint32_t TO32[{NL}] = {{{L((1 << (32 * n32)) % m)}}};  // 2^(32 N32) mod m, plain: x Rrr -> x R32")
+    out.append(f"    static constexpr uint32_t FROM32[{NL}] = {{{L(Rrr * Rrr * pow(1 << (32 * n32), -1, m) % m)}}};  // Rrr^2 / R32: x R32 -> x Rrr")
+    # K m in "borrow form" for carry-free subtraction a - b + K m: limb i gains 2^B, limb i + 1 loses 1,
+    # so every limb but the top is >= 2^B - 1 >= any normalised limb of b, and the top limb is
+    # (K m)_top - 1 >= b_top whenever b < (K / 2) m.
+    rows = []
+    for j in range(1, nk + 1):
+        v = m << j
+        d = [(v >> (B * i)) & mask for i in range(NL)]
+        d[NL - 1] = v >> (B * (NL - 1))
+        e = [0] * NL
+        for i in range(NL):
+            e[i] = d[i] + ((1 << B) if i < NL - 1 else 0) - (1 if i > 0 else 0)
+        assert sum(e[i] << (B * i) for i in range(NL)) == v and all(0 <= x < (1 << 32) for x in e)
+        assert e[NL - 1] >= ((m << (j - 1)) >> (B * (NL - 1)))
+        rows.append("{" + ", ".join("0x%08xu" % x for x in e) + "}")
+    out.append(f"    static constexpr int NKM = {nk};")
+    out.append(f"    static constexpr uint32_t KM[{nk}][{NL}] = {{  // KM[j-1] = 2^j m, borrow form")
+    out.append("        " + ",\n        ".join(rows) + "};")
+    out.append("};")
+    return "\n".join(out)
+
+
+# reduced-radix twins: (field, B, NL)
+# (BN254's 254-bit field would take 9 x 29 bits, whose 64-bit column sums leave no room for lazy operands,
+# or 10 x 28 bits, which is no cheaper than 8 x 32 with carries: it stays on field.cuh)
+RR = {"Fq_BLS377": (28, 14), "Fq_BLS381": (28, 14)}
+
+
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
     dst = os.path.join(here, "..", "blaze_amd", "csrc", "curve_constants.h")
@@ -65,6 +119,11 @@ def main():
         extra.append(f"    static constexpr uint32_t CURVE_B[{nq}] = {{{limbs(b * Rq % q, nq)}}};  // b, Montgomery")
         extra.append(f"    static constexpr uint32_t GX[{nq}] = {{{limbs(gx * Rq % q, nq)}}};  // generator x, Montgomery")
         extra.append(f"    static constexpr uint32_t GY[{nq}] = {{{limbs(gy * Rq % q, nq)}}};  // generator y, Montgomery")
+        if f"Fq_{name}" in RR:
+            o.append(rr_struct(f"Fq_{name}_RR", q, nq, *RR[f"Fq_{name}"]))
+            extra.append(f"    using RR = Fq_{name}_RR;  // reduced-radix twin (field_rr.cuh)")
+        else:
+            extra.append("    using RR = void;")
         o.append(field_struct(f"Fq_{name}", q, nq, "\n".join(extra)))
         Rr = 1 << 256
         root = pow(g, (r - 1) >> s, r)
@@ -73,6 +132,7 @@ def main():
         extra.append(f"    static constexpr int TWO_ADICITY = {s};")
         extra.append(f"    static constexpr uint32_t ROOT[8] = {{{limbs(root * Rr % r, 8)}}};  // primitive 2^{s}-th root, Montgomery")
         extra.append(f"    static constexpr uint32_t ROOT_INV[8] = {{{limbs(pow(root, -1, r) * Rr % r, 8)}}};  // its inverse, Montgomery")
+        extra.append("    using RR = void;")
         o.append(field_struct(f"Fr_{name}", r, 8, "\n".join(extra)))
         o.append(f"struct Curve_{name} {{ using Fq = Fq_{name}; using Fr = Fr_{name}; static constexpr int ID = {cid}; }};")
     o.append("}  // namespace blz")
