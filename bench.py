@@ -12,8 +12,13 @@ N > 1 the SAME 2^26 job is sharded by contiguous element chunk over the N GPUs o
 scaling): each rank runs its shard, one all-gather of the 144-byte partials (RCCL), every rank adds
 them in rank order.  value = MSMs per second, whole job.
 
+With --gpus N > 1 and no WORLD_SIZE in the environment the script starts the N ranks itself (a child
+`torch.distributed.run`, before this process touches the GPU) and relays their output.
+
 Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` for the dominant
-kernel (k_accumulate) and `cpu_baseline` (the CPU oracle's Pippenger on a bounded sample)."""
+kernel (k_accumulate) and `cpu_baseline` (the CPU oracle's Pippenger on a bounded sample).  The last
+timed result is CHECKED before anything is printed (`result_check`): the synthetic points are
+P_i = (i + 1) G, so the MSM must equal (sum_i s_i (i + 1) mod r) G; a mismatch raises."""
 import argparse
 import ctypes as C
 import json
@@ -32,6 +37,41 @@ MSM_BYTES_PER_ELEM = 128  # 32 B scalar + 96 B point
 NTT_LOG = int(os.environ.get("BLAZE_BENCH_NTT_LOGN", "27"))
 
 
+def spawn_ranks(n_ranks: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children of a fresh
+    torch.distributed.run (this process has not initialised the GPU and never will) and wait."""
+    import socket
+    import subprocess
+
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def host_threads() -> int:
+    """Threads this process may really use: the affinity mask, capped by the cgroup CPU quota (a container on a
+    256-thread host is often allowed a fraction of it; threads beyond the quota only add contention)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            pr = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(q / pr + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -39,7 +79,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-ntt", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true", help="skip the result check (profiling runs only)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     import torch
 
@@ -47,7 +91,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the flag disagree")
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -103,6 +147,24 @@ def main():
     # overlaps the sort + accumulation of the next.  BLAZE_BENCH_QUEUE=1 runs strictly one at a time.
     queue = max(1, min(2, int(os.environ.get("BLAZE_BENCH_QUEUE", "2"))))
 
+    # N > 1: the exchange runs inside the library (blz_msm_all_gather_combine: RCCL all-gather on the handle's
+    # own stream + rank-ordered add); the communicator id travels over the torch.distributed process group.  If
+    # any rank cannot bring the native communicator up, every rank uses the torch.distributed all-gather instead.
+    exchange = "none"
+    if world > 1:
+        native_ok = 0
+        if os.environ.get("BLAZE_BENCH_EXCHANGE", "native") == "native" and dist.get_backend() == "nccl":
+            try:
+                ids = [MSMClient.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(ids, src=0)
+                client.comm_init(rank, world, ids[0])
+                native_ok = 1
+            except Exception as e:   # noqa: BLE001 - any failure means "use the fallback", on every rank
+                print(f"[bench rank {rank}] native RCCL exchange unavailable: {e}", file=sys.stderr, flush=True)
+        flag = torch.tensor([native_ok], dtype=torch.int32, device=gather_dev if gather_dev is not None else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        exchange = "library (ncclAllGather + k_combine_partials)" if int(flag.item()) == 1 else "torch.distributed all_gather + combine_partials"
+
     def submit():
         client.initialize(params)
         client.start_process()
@@ -113,7 +175,10 @@ def main():
         part = client.result().result
         api = client.get_api()  # HIP-event timers recorded on the streams the kernels run on
         if world > 1:
-            part = sharded_msm(part, client.combine_partials, dist, gather_dev)
+            if exchange.startswith("library"):
+                part = client.all_gather_combine(part)
+            else:
+                part = sharded_msm(part, client.combine_partials, dist, gather_dev)
         return part, api
 
     def run_steps(k):
@@ -149,6 +214,31 @@ def main():
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
     value = args.steps / dt
+
+    # ---- the number is only worth printing if the timed result is right: linearity over P_i = (i + 1) G
+    # (oracle = test infrastructure, used here as the checker only, outside the timed region)
+    check_rec = None
+    if not args.no_check:
+        if rank == 0:
+            import oracle
+
+            if world == 1:
+                sc_all = d_sc.download()
+            else:   # the other ranks' scalars: same generator, same global indices
+                d_all = DeviceBuffer(dev, n * 32)
+                check(L.blz_synth_scalars_at(dev, cid, d_all.ptr, n, 0xB1A2E, 0))
+                sc_all = d_all.download()
+                d_all.free()
+            t1 = time.perf_counter()
+            k = oracle.index_weighted_sum(CURVE, sc_all, n, 0, threads=min(64, host_threads()))
+            exp = oracle.result_from_affine(CURVE, oracle.generator_mul(CURVE, k))
+            del sc_all
+            if res != exp:
+                raise SystemExit(f"bench: the timed MSM result is WRONG (got {res.hex()[:32]}..., expected {exp.hex()[:32]}...)")
+            check_rec = {"ok": True, "method": "result == (sum_i s_i (i+1) mod r) G over all 2^%d scalars, CPU oracle, %.1f s"
+                         % (LOG_N, time.perf_counter() - t1)}
+        if world > 1:
+            dist.barrier()
 
     # ---- roofline of the dominant kernel (k_accumulate: one launch covers this rank's whole shard)
     acc_avg_ms = statistics.mean(accum_ms)
@@ -199,35 +289,72 @@ def main():
                             "algorithmic_bytes": nb}}
         nc.close()
 
-    # ---- CPU baseline: the oracle's multithreaded Pippenger on a bounded sample of the same workload
-    cpu = None
+    # ---- CPU baselines on this box's host cores (baseline only): the oracle's Pippenger, parallel over
+    # (element chunk x window) tasks on every affinity-visible thread, on the largest prefix of the workload that
+    # an estimate says finishes in ~20 s (the whole 2^26 on a 256-thread host, 2^22 on 8 cores); the
+    # reference-semantics path (naive sum of double-and-add scalar multiplications, tests/msm/mod.rs:326-335, one
+    # core, n = 2^10); and a threaded radix-2 NTT beside ntt_2e27.
+    cpu = cpu_ref = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle  # test infrastructure, used here only as the timed CPU baseline
 
-        ls = int(os.environ.get("BLAZE_BENCH_CPU_LOGN", "20"))
+        cores = host_threads()
+        cbits = 16
+        ls = int(os.environ.get("BLAZE_BENCH_CPU_LOGN", "0"))
+        if ls == 0:
+            # calibrate on 2^18 elements, then take the largest power of two (up to the whole workload) that the
+            # measured rate finishes in about 20 s
+            nc = min(1 << 18, n_loc)
+            pc, scc = d_pts.download(nc * 96), d_sc.download(nc * 32)
+            t1 = time.perf_counter()
+            oracle.msm_pippenger(CURVE, pc, scc, nc, 1, threads=cores, cbits=cbits)
+            per_elem = (time.perf_counter() - t1) / nc
+            del pc, scc
+            ls = 18
+            while ls < LOG_N and (2 << ls) * per_elem <= 20.0:
+                ls += 1
         ns = min(1 << ls, n_loc)
         pts = d_pts.download(ns * 96)
         sc = d_sc.download(ns * 32)
-        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        cbits = 13
-        threads = min(cores, (257 + cbits - 1) // cbits)  # the oracle parallelises over windows
         t1 = time.perf_counter()
-        oracle.msm_pippenger(CURVE, pts, sc, ns, 1, threads=threads, cbits=cbits)
+        got = oracle.msm_pippenger(CURVE, pts, sc, ns, 1, threads=cores, cbits=cbits)
         tc = time.perf_counter() - t1
-        cpu = {"value": round((ns / n) / tc, 6), "unit": "MSM/s", "cores": threads, "kind": "port",
-               "sample": f"first 2^{ls} of the 2^{LOG_N} elements: {tc:.2f} s wall on {threads} threads "
-                         f"(host offers {cores} hardware threads); value scaled linearly to 2^{LOG_N}"}
+        kk = oracle.index_weighted_sum(CURVE, sc, ns, 0, threads=min(64, cores))
+        assert got == oracle.result_from_affine(CURVE, oracle.generator_mul(CURVE, kk)), "CPU baseline result wrong"
+        cpu = {"value": round((ns / n) / tc, 6), "unit": "MSM/s", "cores": cores, "kind": "port",
+               "sample": f"first 2^{ls} of the 2^{LOG_N} elements, {cbits}-bit signed windows: {tc:.2f} s wall on {cores} threads"
+                         + ("" if ns == n else f"; value scaled linearly to 2^{LOG_N}")}
+        nr = 1 << 10
+        t1 = time.perf_counter()
+        oracle.msm_naive(CURVE, pts[: nr * 96], sc[: nr * 32], nr, 1)
+        tr = time.perf_counter() - t1
+        cpu_ref = {"value": round(nr / tr, 1), "unit": "elements/s", "cores": 1, "kind": "port", "seconds": round(tr, 3),
+                   "sample": "reference-semantics check path (tests/msm/mod.rs:326-335): sum of 2^10 double-and-add scalar "
+                             "multiplications on one core (config 1's shape)"}
+        del pts, sc
+        if ntt is not None:
+            lc = NTT_LOG if cores >= 64 else min(NTT_LOG, 24)
+            import numpy as np
+            xin = np.random.default_rng(1).integers(0, 256, size=32 << lc, dtype=np.uint8)
+            xin[31::32] &= 0x3F
+            t1 = time.perf_counter()
+            oracle.ntt(CURVE, xin, lc, threads=min(cores, 64))
+            tn = time.perf_counter() - t1
+            ntt["cpu_baseline"] = {"value": round(tn * 1e3, 1), "unit": "ms", "cores": min(cores, 64), "kind": "port",
+                                   "sample": f"threaded radix-2 NTT of 2^{lc} elements (oracle), one transform"}
+            del xin
 
     if rank == 0:
         line = {
             "metric": f"BLS12-381 MSM/s at 2^{LOG_N}", "value": round(value, 4), "unit": "MSM/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "u32 limbs (381-bit Fq Montgomery)", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None, "dtype": "u32 registers holding 28-bit limbs (381-bit Fq, Montgomery)", "data": "synthetic",
             "config": {"workload": f"2^{LOG_N} BLS12-381 G1 MSM, pf=1, scalars+points resident in HBM"
                                    + (" (points in the device arena, scalars-only set_data)" if hbm_mode else " (DMA-mode set_data with device pointers)"),
-                       "elements": n, "elements_per_gpu": n_loc, "parallelism": f"shard{world}" if world > 1 else "single", "tasks_in_flight": queue,
+                       "elements": n, "elements_per_gpu": n_loc, "parallelism": f"shard{world}" if world > 1 else "single", "exchange": exchange, "tasks_in_flight": queue,
                        "window_bits": int(api["window_bits"]), "windows": int(api["windows"])},
-            "roofline": roofline, "cpu_baseline": cpu, "ntt_2e27": ntt,
+            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_ref_semantics": cpu_ref, "result_check": check_rec,
+            "ntt_2e27": ntt,
             "phases_ms": {k: round(v, 3) for k, v in api.items() if k.endswith("_ms")},
         }
         if os.environ.get("BLAZE_BENCH_EMIT_RESULT") == "1":

@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libblaze_hip.so")
+# BLAZE_HIP_LIB: an A/B build of the same library (development aid; csrc/Makefile)
+LIB_PATH = os.environ.get("BLAZE_HIP_LIB") or os.path.join(_HERE, "lib", "libblaze_hip.so")
 
 
 class DriverClientError(Exception):
@@ -52,11 +53,17 @@ _SIGS = {
     "blz_msm_load_data_to_hbm_device": (C.c_int, [C.c_void_p, _u8p, C.c_size_t, C.c_uint64, C.c_uint64]),
     "blz_msm_get_data_from_hbm": (C.c_int, [C.c_void_p, _u8p, C.c_size_t, C.c_uint64, C.c_uint64]),
     "blz_arena_release": (C.c_int, [C.c_int]),
+    "blz_arena_export": (C.c_int, [C.c_int, C.c_char_p]),
+    "blz_arena_attach": (C.c_int, [C.c_int, C.c_char_p]),
     "blz_msm_task_label": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "blz_msm_nof_elements": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "blz_msm_is_engine_ready": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "blz_msm_reset": (C.c_int, [C.c_void_p]),
     "blz_msm_last_timings": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "blz_comm_unique_id": (C.c_int, [_u8p]),
+    "blz_msm_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _u8p]),
+    "blz_msm_all_gather_combine": (C.c_int, [C.c_void_p, _u8p, _u8p, C.c_size_t]),
+    "blz_msm_comm_free": (C.c_int, [C.c_void_p]),
     "blz_msm_precompute_bases_device": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64]),
     "blz_msm_combine_partials": (C.c_int, [C.c_void_p, _u8p, C.c_size_t, _u8p, C.c_size_t]),
     "blz_msm_plan": (C.c_int, [C.c_int, C.c_uint32, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)]),

@@ -1,0 +1,195 @@
+// The device arena: flat, byte-addressed "HBM" per device (common.hpp), plus its cross-process form.
+//
+// Cross-process persistence (the reference's HBM tests rely on bases that an earlier
+// process loaded: tests/integration_msm_hbm.rs:51-56 keeps the load commented out).  GPU memory belongs to a
+// process, so "persistent" means: a holder process loads the bases and EXPORTS its arena (one
+// hipIpcMemHandle per extent, written to a registry file); any other process ATTACHES the registry and
+// addresses the same bytes through load_data_to_hbm / hbm_point_addr.  The bytes live as long as the holder.
+#include "common.hpp"
+
+#include <cstdlib>
+#include <string>
+
+namespace blz {
+
+static std::mutex g_arena_mu;
+static std::map<int, Arena*> g_arenas;
+
+Arena& arena_for(int device_id) {
+    std::lock_guard<std::mutex> lk(g_arena_mu);
+    auto it = g_arenas.find(device_id);
+    if (it == g_arenas.end()) it = g_arenas.emplace(device_id, new Arena()).first;
+    return *it->second;
+}
+
+ArenaExtent* arena_find(Arena& a, uint64_t pos, size_t len) {
+    for (auto& e : a.ext)
+        if (pos >= e.start && pos + len <= e.start + e.len) return &e;
+    return nullptr;
+}
+
+void arena_free_extent(ArenaExtent& x) {
+    if (x.raw) {
+        if (x.imported) (void)hipIpcCloseMemHandle(x.raw);
+        else (void)hipFree(x.raw);
+    }
+    if (x.mont) (void)hipFree(x.mont);
+    if (x.shadow_ready) (void)hipEventDestroy(x.shadow_ready);
+    x = ArenaExtent();
+}
+
+static void mark_dirty(ArenaExtent& e, uint64_t lo, uint64_t hi) {
+    if (e.dirty_lo >= e.dirty_hi) { e.dirty_lo = lo; e.dirty_hi = hi; }
+    else { if (lo < e.dirty_lo) e.dirty_lo = lo; if (hi > e.dirty_hi) e.dirty_hi = hi; }
+}
+
+int arena_write(int device_id, uint64_t pos, const void* src, size_t len, bool src_is_device, hipStream_t st) {
+    BLZ_TRY(use_device(device_id));
+    if (len == 0) return BLZ_OK;
+    Arena& A = arena_for(device_id);
+    std::lock_guard<std::mutex> lk(A.mu);
+    const uint64_t end = pos + len;
+    // extents the write overlaps or touches
+    std::vector<size_t> hit;
+    for (size_t i = 0; i < A.ext.size(); ++i) {
+        const ArenaExtent& x = A.ext[i];
+        if (pos <= x.start + x.len && x.start <= end) hit.push_back(i);
+    }
+    ArenaExtent* e = nullptr;
+    if (hit.size() == 1) {
+        ArenaExtent& x = A.ext[hit[0]];
+        if (pos >= x.start && end <= x.start + x.cap) {   // inside it, or an append within its allocation
+            e = &x;
+            if (end > x.start + x.len) x.len = (size_t)(end - x.start);
+        }
+    }
+    if (!e) {
+        // a new extent over the union; the old bytes outside [pos, end) are carried over (flat memory)
+        uint64_t nstart = pos, nend = end;
+        for (size_t i : hit) {
+            const ArenaExtent& x = A.ext[i];
+            if (x.imported)
+                return fail(BLZ_ERR_WRITE, "arena: a write beyond an attached (imported) extent cannot extend it");
+            if (x.start < nstart) nstart = x.start;
+            if (x.start + x.len > nend) nend = x.start + x.len;
+        }
+        const size_t nlen = (size_t)(nend - nstart);
+        ArenaExtent n;
+        n.start = nstart;
+        n.len = nlen;
+        n.cap = hit.empty() ? nlen : nlen + nlen / 2;   // growing: leave room, so piecewise loads copy O(total) bytes
+        hipError_t he = hipMalloc(&n.raw, n.cap);
+        if (he != hipSuccess && n.cap != nlen) { n.cap = nlen; he = hipMalloc(&n.raw, n.cap); }
+        if (he != hipSuccess)
+            return fail(BLZ_ERR_WRITE, "arena: hipMalloc(%zu) at offset %llu failed: %s", n.cap, (unsigned long long)nstart,
+                        hipGetErrorString(he));
+        if (!hit.empty()) {
+            // tasks in flight may still read the old extents or their shadows: drain before they go
+            BLZ_HIP(hipDeviceSynchronize(), BLZ_ERR_WRITE);
+            for (size_t i : hit) {
+                const ArenaExtent& x = A.ext[i];
+                BLZ_HIP(hipMemcpyAsync((char*)n.raw + (x.start - nstart), x.raw, x.len, hipMemcpyDeviceToDevice, st), BLZ_ERR_WRITE);
+            }
+            BLZ_HIP(hipStreamSynchronize(st), BLZ_ERR_WRITE);
+            for (size_t k = hit.size(); k-- > 0;) {
+                arena_free_extent(A.ext[hit[k]]);
+                A.ext.erase(A.ext.begin() + hit[k]);
+            }
+        }
+        A.ext.push_back(n);
+        e = &A.ext.back();
+        e->mont_curve = -1;   // no shadow yet
+    }
+    mark_dirty(*e, pos - e->start, end - e->start);
+    char* dst = (char*)e->raw + (pos - e->start);
+    hipError_t he = hipMemcpyAsync(dst, src, len, src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st);
+    if (he == hipSuccess) he = hipStreamSynchronize(st);
+    if (he != hipSuccess)
+        return fail(BLZ_ERR_WRITE, "arena write of %zu bytes at offset %llu failed: %s", len, (unsigned long long)pos,
+                    hipGetErrorString(he));
+    return BLZ_OK;
+}
+
+// registry file: magic, count, then per extent {start, len, hipIpcMemHandle_t}
+static const uint64_t kRegistryMagic = 0x314152415a4c42ull;   // "BLZARA1"
+struct RegistryRecord {
+    uint64_t start, len;
+    hipIpcMemHandle_t handle;
+};
+
+}  // namespace blz
+
+using namespace blz;
+
+extern "C" {
+
+int blz_arena_release(int device_id) {
+    BLZ_TRY(use_device(device_id));
+    Arena& A = arena_for(device_id);
+    std::lock_guard<std::mutex> lk(A.mu);
+    (void)hipDeviceSynchronize();
+    for (auto& x : A.ext) arena_free_extent(x);
+    A.ext.clear();
+    return BLZ_OK;
+}
+
+int blz_arena_export(int device_id, const char* path) {
+    if (!path) return fail(BLZ_ERR_INVALID_PARAM, "null path");
+    BLZ_TRY(use_device(device_id));
+    Arena& A = arena_for(device_id);
+    std::lock_guard<std::mutex> lk(A.mu);
+    std::vector<RegistryRecord> recs;
+    for (auto& x : A.ext) {
+        if (x.imported) continue;   // only what this process owns
+        RegistryRecord r;
+        memset(&r, 0, sizeof(r));
+        r.start = x.start;
+        r.len = x.len;
+        BLZ_HIP(hipIpcGetMemHandle(&r.handle, x.raw), BLZ_ERR_UNKNOWN);
+        recs.push_back(r);
+    }
+    std::string tmp = std::string(path) + ".tmp";
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f) return fail(BLZ_ERR_FILE, "arena export: cannot write %s", tmp.c_str());
+    uint64_t hdr[2] = {kRegistryMagic, (uint64_t)recs.size()};
+    bool ok = fwrite(hdr, sizeof(hdr), 1, f) == 1;
+    if (ok && !recs.empty()) ok = fwrite(recs.data(), sizeof(RegistryRecord), recs.size(), f) == recs.size();
+    ok = (fclose(f) == 0) && ok;
+    if (!ok || rename(tmp.c_str(), path) != 0) return fail(BLZ_ERR_FILE, "arena export: writing %s failed", path);
+    return BLZ_OK;
+}
+
+int blz_arena_attach(int device_id, const char* path) {
+    if (!path) return fail(BLZ_ERR_INVALID_PARAM, "null path");
+    BLZ_TRY(use_device(device_id));
+    FILE* f = fopen(path, "rb");
+    if (!f) return fail(BLZ_ERR_FILE, "arena attach: cannot read %s", path);
+    uint64_t hdr[2] = {0, 0};
+    std::vector<RegistryRecord> recs;
+    bool ok = fread(hdr, sizeof(hdr), 1, f) == 1 && hdr[0] == kRegistryMagic && hdr[1] < (1u << 20);
+    if (ok) {
+        recs.resize((size_t)hdr[1]);
+        ok = recs.empty() || fread(recs.data(), sizeof(RegistryRecord), recs.size(), f) == recs.size();
+    }
+    fclose(f);
+    if (!ok) return fail(BLZ_ERR_FILE, "arena attach: %s is not an arena registry", path);
+    Arena& A = arena_for(device_id);
+    std::lock_guard<std::mutex> lk(A.mu);
+    for (const RegistryRecord& r : recs) {
+        for (const ArenaExtent& x : A.ext)
+            if (r.start < x.start + x.len && x.start < r.start + r.len)
+                return fail(BLZ_ERR_INVALID_PARAM, "arena attach: [%llu, +%llu) overlaps an extent of this process",
+                            (unsigned long long)r.start, (unsigned long long)r.len);
+        ArenaExtent n;
+        n.start = r.start;
+        n.len = n.cap = (size_t)r.len;
+        n.imported = true;
+        BLZ_HIP(hipIpcOpenMemHandle(&n.raw, r.handle, hipIpcMemLazyEnablePeerAccess), BLZ_ERR_UNKNOWN);
+        n.dirty_lo = 0;
+        n.dirty_hi = n.len;   // this process has no shadow of it yet
+        A.ext.push_back(n);
+    }
+    return BLZ_OK;
+}
+
+}  // extern "C"

@@ -42,57 +42,17 @@ int use_device(int device_id) {
     return BLZ_OK;
 }
 
-static std::mutex g_arena_mu;
-static std::map<int, Arena*> g_arenas;
-
-Arena& arena_for(int device_id) {
-    std::lock_guard<std::mutex> lk(g_arena_mu);
-    auto it = g_arenas.find(device_id);
-    if (it == g_arenas.end()) it = g_arenas.emplace(device_id, new Arena()).first;
-    return *it->second;
-}
-
-ArenaExtent* arena_find(Arena& a, uint64_t pos, size_t len) {
-    for (auto& e : a.ext)
-        if (pos >= e.start && pos + len <= e.start + e.len) return &e;
-    return nullptr;
-}
-
-int arena_write(int device_id, uint64_t pos, const void* src, size_t len, bool src_is_device, hipStream_t st) {
-    BLZ_TRY(use_device(device_id));
-    if (len == 0) return BLZ_OK;
-    Arena& A = arena_for(device_id);
-    std::lock_guard<std::mutex> lk(A.mu);
-    ArenaExtent* e = arena_find(A, pos, len);
-    if (!e) {
-        // drop every extent the new range overlaps, then create a fresh one
-        for (size_t i = 0; i < A.ext.size();) {
-            ArenaExtent& x = A.ext[i];
-            bool overlap = pos < x.start + x.len && x.start < pos + len;
-            if (overlap) {
-                if (x.raw) (void)hipFree(x.raw);
-                if (x.mont) (void)hipFree(x.mont);
-                A.ext.erase(A.ext.begin() + i);
-            } else {
-                ++i;
-            }
-        }
-        ArenaExtent n;
-        n.start = pos;
-        n.len = len;
-        hipError_t he = hipMalloc(&n.raw, len);
-        if (he != hipSuccess) return fail(BLZ_ERR_WRITE, "arena: hipMalloc(%zu) at offset %llu failed: %s", len,
-                                          (unsigned long long)pos, hipGetErrorString(he));
-        A.ext.push_back(n);
-        e = &A.ext.back();
-    }
-    e->mont_curve = -1;  // shadow is stale
-    char* dst = (char*)e->raw + (pos - e->start);
-    hipError_t he = hipMemcpyAsync(dst, src, len, src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st);
-    if (he == hipSuccess) he = hipStreamSynchronize(st);
-    if (he != hipSuccess)
-        return fail(BLZ_ERR_WRITE, "arena write of %zu bytes at offset %llu failed: %s", len, (unsigned long long)pos,
-                    hipGetErrorString(he));
+int ensure_dynamic_lds(const void* kernel, int bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, int> done;   // (device, kernel) -> bytes granted
+    int dev = 0;
+    BLZ_HIP(hipGetDevice(&dev), BLZ_ERR_UNKNOWN);
+    std::lock_guard<std::mutex> lk(mu);
+    auto key = std::make_pair(dev, kernel);
+    auto it = done.find(key);
+    if (it != done.end() && it->second >= bytes) return BLZ_OK;
+    BLZ_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes), BLZ_ERR_UNKNOWN);
+    done[key] = bytes;
     return BLZ_OK;
 }
 
@@ -104,18 +64,6 @@ const char* blz_last_error_message(void) { return blz::g_err; }
 int blz_device_count(void) { return blz::device_count(); }
 size_t blz_point_size(int curve) { return curve == BLZ_BN254 ? 64 : (curve == BLZ_BLS377 || curve == BLZ_BLS381) ? 96 : 0; }
 size_t blz_result_size(int curve) { return curve == BLZ_BN254 ? 96 : (curve == BLZ_BLS377 || curve == BLZ_BLS381) ? 144 : 0; }
-
-int blz_arena_release(int device_id) {
-    BLZ_TRY(blz::use_device(device_id));
-    blz::Arena& A = blz::arena_for(device_id);
-    std::lock_guard<std::mutex> lk(A.mu);
-    for (auto& x : A.ext) {
-        if (x.raw) (void)hipFree(x.raw);
-        if (x.mont) (void)hipFree(x.mont);
-    }
-    A.ext.clear();
-    return BLZ_OK;
-}
 
 int blz_device_malloc(int device_id, size_t bytes, void** out) {
     if (!out) return blz::fail(BLZ_ERR_INVALID_PARAM, "null out");

@@ -58,6 +58,10 @@ int device_count();
 // of /dev/xdma{id}_*: src/utils.rs:74)
 int use_device(int device_id);
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (current device, kernel): the opt-in for more than
+// 64 KiB of dynamic LDS is per device, and a host may open clients on several devices of one process.
+int ensure_dynamic_lds(const void* kernel, int bytes);
+
 // growable device buffer
 struct DevBuf {
     void* p = nullptr;
@@ -87,16 +91,25 @@ struct DevBuf {
     T* as() const { return reinterpret_cast<T*>(p); }
 };
 
-// Per-device, process-global byte-addressed arena: the "HBM" of load_data_to_hbm / hbm_point_addr
-// (src/ingo_msm/msm_api.rs:299-322).  An extent is one contiguous load; reads and MSM tasks must
-// fall inside a single extent.  Each extent may carry a Montgomery-form shadow of its points for a
-// given curve, built lazily by the MSM engine.
+// Per-device, process-global byte-addressed arena: the card's "HBM" of load_data_to_hbm / hbm_point_addr
+// (src/ingo_msm/msm_api.rs:299-322), with the card's semantics: flat memory.  Writes that touch or overlap
+// earlier ones extend the same extent (bytes outside the written range are kept), so a 48 GiB table loaded in
+// pieces is one extent; only a gap that was never written separates extents, and reads / MSM tasks must not
+// cross one.  Each extent may carry a Montgomery-form shadow of its points for one (curve, phase) - phase =
+// byte offset of the point grid inside the extent - built lazily by the MSM engine; a write dirties only the
+// byte span it touched, and the next task converts only the points of that span.  arena.hip.
 struct ArenaExtent {
     uint64_t start = 0;
-    size_t len = 0;
+    size_t len = 0, cap = 0;     // bytes written / allocated (appends within cap are in place)
     void* raw = nullptr;
-    void* mont = nullptr;  // shadow, same size, valid for mont_curve
+    bool imported = false;       // opened from another process's export (hipIpcOpenMemHandle): fixed size
+    // shadow
+    void* mont = nullptr;
+    size_t mont_bytes = 0;
     int mont_curve = -1;
+    uint32_t mont_phase = 0;
+    uint64_t dirty_lo = 0, dirty_hi = 0;   // byte span (relative to start) whose points are stale in the shadow
+    hipEvent_t shadow_ready = nullptr;     // recorded after the last conversion; consumers on other streams wait
 };
 struct Arena {
     std::mutex mu;
@@ -105,7 +118,8 @@ struct Arena {
 Arena& arena_for(int device_id);
 // find extent containing [pos, pos+len); nullptr if none
 ArenaExtent* arena_find(Arena& a, uint64_t pos, size_t len);
-// write bytes (host or device source) at pos; creates / replaces extents as needed
+// write bytes (host or device source) at pos; extends / merges extents as needed; blocking
 int arena_write(int device_id, uint64_t pos, const void* src, size_t len, bool src_is_device, hipStream_t st);
+void arena_free_extent(ArenaExtent& x);
 
 }  // namespace blz

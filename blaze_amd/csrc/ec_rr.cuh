@@ -9,8 +9,12 @@
 #pragma once
 #include "field_rr.cuh"
 #include "ec.cuh"
+#include <type_traits>
 
 namespace blz {
+
+template <class F>
+constexpr bool USE_RR = !std::is_void_v<typename F::RR>;  // the field has a reduced-radix twin (curve_constants.h)
 
 template <class Q>
 struct AffineRR {
@@ -108,6 +112,20 @@ BLZ_DEV void ptrr_to_xyzz32(XYZZ<F>& r, const XYZZRR<typename F::RR>& a) {
     rr_to_mont32_words<Q>(r.y.v, a.y);
     rr_to_mont32_words<Q>(r.zz.v, a.zz);
     rr_to_mont32_words<Q>(r.zzz.v, a.zzz);
+}
+
+// ... and back (test hooks; the pipeline never needs it)
+template <class F>
+BLZ_DEV void ptrr_from_xyzz32(XYZZRR<typename F::RR>& r, const XYZZ<F>& a) {
+    using Q = typename F::RR;
+    if (pt_is_inf(a)) { ptrr_set_inf(r); return; }
+    Frr<Q, 1, 2> t;
+    rr_from_mont32_words<Q>(t, a.x.v);
+    r.x = rr_as<1, XYZZRR<Q>::VX>(t);
+    rr_from_mont32_words<Q>(t, a.y.v);
+    r.y = rr_as<1, XYZZRR<Q>::VY>(t);
+    rr_from_mont32_words<Q>(r.zz, a.zz.v);
+    rr_from_mont32_words<Q>(r.zzz, a.zzz.v);
 }
 
 }  // namespace blz

@@ -71,6 +71,12 @@ BLZ_DEV bool rr_all_zero(const Frr<Q, F, V>& a) {  // literal zero limbs
 
 #include "rr_gen.inc"
 
+// 1: plain C++ products, scheduled by hipcc (A/B experiment: k_accumulate 119 ms against 106 ms with the asm
+// columns at 2^26; tools/gen_rr_asm.py's header says why)
+#ifndef BLZ_RR_PLAIN
+#define BLZ_RR_PLAIN 0
+#endif
+
 // ---- product scanning over asm columns ----------------------------------------------------------------
 // column K: the caller's products (AB), the reduction products q_i m_j of this column, then either the next
 // quotient digit q_K (K < NL) or the next result limb
@@ -78,7 +84,15 @@ template <class Q, int K, class AB>
 BLZ_DEV void rr_column(uint64_t& acc, uint32_t (&q)[Q::NL], uint32_t (&t)[Q::NL], AB&& ab) {
     constexpr int NL = Q::NL;
     ab(std::integral_constant<int, K>{}, acc);
+#if BLZ_RR_PLAIN
+    {
+        constexpr int ilo = K < NL ? 0 : K - NL + 1, ihi = K < NL ? K - 1 : NL - 1;
+#pragma unroll
+        for (int i = ilo; i <= ihi; ++i) acc += (uint64_t)q[i] * Q::MOD[K - i];
+    }
+#else
     rr_qm<NL, K>(acc, q, Q::MOD);
+#endif
     if constexpr (K < NL) {
         q[K] = ((uint32_t)acc * Q::N0) & Q::MASK;
         acc = (uint64_t)q[K] * Q::MOD[0] + acc;  // low B bits become zero
@@ -97,12 +111,30 @@ BLZ_DEV void rr_columns(Frr<Q, 1, 2>& r, AB&& ab, std::integer_sequence<int, Ks.
     for (int i = 0; i < Q::NL; ++i) r.v[i] = t[i];
 }
 
+#if BLZ_RR_PLAIN
+template <int NL, int K> BLZ_DEV void rr_ab_c(uint64_t& acc, const uint32_t (&a)[NL], const uint32_t (&b)[NL]) {
+    constexpr int ilo = K < NL ? 0 : K - NL + 1, ihi = K < NL ? K : NL - 1;
+#pragma unroll
+    for (int i = ilo; i <= ihi; ++i) acc += (uint64_t)a[i] * b[K - i];
+}
+template <int NL, int K> BLZ_DEV void rr_sq_c(uint64_t& acc, const uint32_t (&a)[NL], const uint32_t (&a2)[NL]) {
+    constexpr int ilo = K < NL ? 0 : K - NL + 1, ihi = K < NL ? K : NL - 1;
+#pragma unroll
+    for (int i = ilo; i <= ihi; ++i) if (i < K - i) acc += (uint64_t)a[i] * a2[K - i];
+    if constexpr (K % 2 == 0) acc += (uint64_t)a[K / 2] * a[K / 2];
+}
+#define BLZ_RR_AB rr_ab_c
+#define BLZ_RR_SQ rr_sq_c
+#else
+#define BLZ_RR_AB rr_ab
+#define BLZ_RR_SQ rr_sq
+#endif
 // r = a b / Rrr  (mod m)
 template <class Q, int Fa, int Va, int Fb, int Vb>
 BLZ_DEV void rr_mul(Frr<Q, 1, 2>& r, const Frr<Q, Fa, Va>& a, const Frr<Q, Fb, Vb>& b) {
     static_assert(rr_cols_ok<Q>(Fa * Fb), "column sum would overflow 64 bits: normalise an operand");
     static_assert(rr_vals_ok<Q>(Va * Vb), "product would leave the lazy value range");
-    rr_columns<Q>(r, [&](auto k, uint64_t& acc) { rr_ab<Q::NL, decltype(k)::value>(acc, a.v, b.v); },
+    rr_columns<Q>(r, [&](auto k, uint64_t& acc) { BLZ_RR_AB<Q::NL, decltype(k)::value>(acc, a.v, b.v); },
                   std::make_integer_sequence<int, 2 * Q::NL - 1>{});
 }
 // r = a^2 / Rrr: the off-diagonal products once, against the doubled operand
@@ -113,7 +145,7 @@ BLZ_DEV void rr_sqr(Frr<Q, 1, 2>& r, const Frr<Q, Fa, Va>& a) {
     uint32_t a2[Q::NL];
 #pragma unroll
     for (int i = 0; i < Q::NL; ++i) a2[i] = a.v[i] << 1;
-    rr_columns<Q>(r, [&](auto k, uint64_t& acc) { rr_sq<Q::NL, decltype(k)::value>(acc, a.v, a2); },
+    rr_columns<Q>(r, [&](auto k, uint64_t& acc) { BLZ_RR_SQ<Q::NL, decltype(k)::value>(acc, a.v, a2); },
                   std::make_integer_sequence<int, 2 * Q::NL - 1>{});
 }
 // r = (a b + c d) / Rrr with ONE reduction (the group law's Y3 = R (Q - X3) - Y1 PPP)
@@ -123,8 +155,8 @@ BLZ_DEV void rr_mul2(Frr<Q, 1, 2>& r, const Frr<Q, Fa, Va>& a, const Frr<Q, Fb, 
     static_assert(rr_cols_ok<Q>(Fa * Fb + Fc * Fd), "column sum would overflow 64 bits");
     static_assert(rr_vals_ok<Q>(Va * Vb + Vc * Vd), "sum of products would leave the lazy value range");
     rr_columns<Q>(r, [&](auto k, uint64_t& acc) {
-        rr_ab<Q::NL, decltype(k)::value>(acc, a.v, b.v);
-        rr_ab<Q::NL, decltype(k)::value>(acc, c.v, d.v);
+        BLZ_RR_AB<Q::NL, decltype(k)::value>(acc, a.v, b.v);
+        BLZ_RR_AB<Q::NL, decltype(k)::value>(acc, c.v, d.v);
     }, std::make_integer_sequence<int, 2 * Q::NL - 1>{});
 }
 

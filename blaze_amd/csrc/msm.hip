@@ -62,6 +62,7 @@ MsmPlan make_plan(uint32_t npts, int sbits, int ebits, int force_c) {
                 int top = need - low_bits;
                 if (top < cmin) top = cmin;
                 if (top > 23) continue;
+                if (top - cmin > 7) continue;                  // k_finish walks 2^(top - cmin) virtual windows in sequence
                 if (force_c > 0 && top != cmin) continue;
                 // cost over the windows
                 double cost = 0;
@@ -407,7 +408,7 @@ static const MsmCurveOps* ops_for(int curve) {
     return nullptr;
 }
 
-int launch_fill_units(MsmEngine& E, uint32_t U) {
+int launch_fill_units(MsmEngine& E, uint32_t U /* upper bound of the unit count */) {
     const uint64_t G = E.last_plan.G;
     const uint32_t L = E.last_plan.L;
     hipStream_t st = E.stream;
@@ -440,8 +441,10 @@ int MsmEngine::init(int device_id, int curve_id) {
         BLZ_HIP(hipEventCreateWithFlags(&S.ev_l0, hipEventDisableTiming), BLZ_ERR_UNKNOWN);
         BLZ_HIP(hipEventCreateWithFlags(&S.ev_done, hipEventDisableTiming), BLZ_ERR_UNKNOWN);
         BLZ_HIP(hipHostMalloc((void**)&S.result_h, 256), BLZ_ERR_UNKNOWN);
+        BLZ_HIP(hipHostMalloc((void**)&S.stats_h, 64), BLZ_ERR_UNKNOWN);
+        memset(S.stats_h, 0, 64);
     }
-    BLZ_HIP(hipHostMalloc((void**)&stats_h, 64), BLZ_ERR_UNKNOWN);
+    BLZ_HIP(hipEventCreateWithFlags(&ev_inputs_consumed, hipEventDisableTiming), BLZ_ERR_UNKNOWN);
     BLZ_HIP(hipHostMalloc((void**)&combine_h, 256), BLZ_ERR_UNKNOWN);
     BLZ_TRY(stats.reserve(64));
     BLZ_TRY(result.reserve(256 * 64));
@@ -463,11 +466,13 @@ void MsmEngine::destroy() {
         if (S.ev_l0) (void)hipEventDestroy(S.ev_l0);
         if (S.ev_done) (void)hipEventDestroy(S.ev_done);
         if (S.result_h) (void)hipHostFree(S.result_h);
+        if (S.stats_h) (void)hipHostFree(S.stats_h);
         S = MsmSlot();
     }
-    if (stats_h) (void)hipHostFree(stats_h);
+    if (ev_inputs_consumed) (void)hipEventDestroy(ev_inputs_consumed);
+    ev_inputs_consumed = nullptr;
+    inputs_consumed_valid = false;
     if (combine_h) (void)hipHostFree(combine_h);
-    stats_h = nullptr;
     combine_h = nullptr;
     (void)hipStreamDestroy(stream);
     (void)hipStreamDestroy(tail_stream);
@@ -494,6 +499,13 @@ int MsmEngine::points_to_mont(const void* d_raw, void* d_mont, uint32_t npts) {
     return ops_for(curve)->points_to_mont(*this, d_raw, d_mont, npts);
 }
 
+static const int kScalarFieldBits[3] = {253, 255, 254};  // bit length of r (BLS12-377 / 381 / BN254)
+
+MsmPlan MsmEngine::plan_for(uint32_t npts, int sbits) const {
+    const int ebits = sbits == 256 ? kScalarFieldBits[curve] : sbits;
+    return make_plan(npts, sbits, ebits, msm_env_int("BLAZE_MSM_C", 0));
+}
+
 int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int sbits, int* slot_out) {
     BLZ_TRY(use_device(device));
     const MsmCurveOps* ops = ops_for(curve);
@@ -517,11 +529,10 @@ int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int 
         S.busy = true;
         return BLZ_OK;
     }
-    static const int r_bits[3] = {253, 255, 254};  // bit length of the scalar field modulus (BLS12-377 / 381 / BN254)
     // BLAZE_MSM_SORT=0 selects the one-global-atomic-per-entry path (kept for A/B measurements; it only
     // knows uniform windows)
     const bool lds_sort = msm_env_int("BLAZE_MSM_SORT", 1) != 0;
-    const int ebits = sbits == 256 ? r_bits[curve] : sbits;
+    const int ebits = sbits == 256 ? kScalarFieldBits[curve] : sbits;
     MsmPlan P = make_plan(npts, sbits, ebits, msm_env_int("BLAZE_MSM_C", 0));
     if (!lds_sort && P.c) P = make_plan(npts, sbits, ebits, P.width[0]);
     if (P.c == 0) return fail(BLZ_ERR_INVALID_PARAM, "no window plan for npts=%u sbits=%d", npts, sbits);
@@ -532,6 +543,7 @@ int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int 
     const uint64_t G = P.G;
     const uint64_t max_entries = (uint64_t)npts * P.W;
     const uint64_t max_units = G + max_entries / P.L + 1;
+    if (max_units >= (1ull << 32)) return fail(BLZ_ERR_INVALID_PARAM, "unit bound %llu exceeds 32 bits", (unsigned long long)max_units);
     const uint32_t nscan = (uint32_t)((G + 1 + SCAN_TILE - 1) / SCAN_TILE);
     BLZ_TRY(count.reserve((G + 1) * 4 + 16));
     BLZ_TRY(off.reserve((G + 2) * 4));
@@ -567,13 +579,16 @@ int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int 
         hipLaunchKernelGGL(k_scatter<1>, gp, b256, 0, st, sc, npts, (int)P.width[0], P.W, P.Bw, count.as<uint32_t>(), entries.as<uint32_t>());
     }
     BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
-    // unit totals are needed on the host to size the accumulate launch
-    BLZ_HIP(hipMemcpyAsync(stats_h, stats.p, 16, hipMemcpyDeviceToHost, st), BLZ_ERR_READ);
-    BLZ_HIP(hipStreamSynchronize(st), BLZ_ERR_UNKNOWN);
-    const uint32_t U = stats_h[0], maxcount = stats_h[1];
-    if ((uint64_t)U > max_units) return fail(BLZ_ERR_UNKNOWN, "unit count %u exceeds bound", U);
-    BLZ_LOG(2, "msm: units=%u max_bucket=%u entries=%u", U, maxcount, stats_h[2]);
-    BLZ_TRY(ops->run_tail(E, d_pts, U, maxcount));
+    // the staged inputs (scalars, raw points) have been consumed: the next task's host -> device copies may
+    // overwrite them once this event has passed (msm_capi.hip makes its copy stream wait for it)
+    BLZ_HIP(hipEventRecord(ev_inputs_consumed, st), BLZ_ERR_UNKNOWN);
+    inputs_consumed_valid = true;
+    // No host round trip: the unit count stays on the device.  Buffers and grids are sized by the bound
+    // (every bucket at most one short unit, plus entries / L full ones) and the kernels read the real count
+    // from `stats`; the host copy below is for the log line and the sanity check of finish() only.
+    BLZ_HIP(hipMemcpyAsync(S.stats_h, stats.p, 16, hipMemcpyDeviceToHost, st), BLZ_ERR_READ);
+    S.max_units = max_units;
+    BLZ_TRY(ops->run_tail(E, d_pts, (uint32_t)max_units));
     S.busy = true;
     return BLZ_OK;
 }
@@ -584,6 +599,10 @@ int MsmEngine::finish(int slot, uint8_t* out) {
     MsmSlot& S = slots[slot];
     BLZ_HIP(hipEventSynchronize(S.ev_done), BLZ_ERR_UNKNOWN);
     S.busy = false;
+    if (S.plan.c) {
+        BLZ_LOG(2, "msm: units=%u max_bucket=%u entries=%u", S.stats_h[0], S.stats_h[1], S.stats_h[2]);
+        if ((uint64_t)S.stats_h[0] > S.max_units) return fail(BLZ_ERR_UNKNOWN, "unit count %u exceeds its bound", S.stats_h[0]);
+    }
     memcpy(out, S.result_h, 3 * fq_bytes(curve));
     float t = 0;
     (void)hipEventElapsedTime(&t, S.ev[0], S.ev[4]); last_ms[0] = t;
@@ -598,9 +617,9 @@ int MsmEngine::finish(int slot, uint8_t* out) {
     return BLZ_OK;
 }
 
-int MsmEngine::combine_partials(const uint8_t* partials, size_t cnt, uint8_t* out) {
+int MsmEngine::combine_partials(const uint8_t* partials, size_t cnt, uint8_t* out, bool on_device) {
     BLZ_TRY(use_device(device));
-    return ops_for(curve)->combine(*this, partials, cnt, out);
+    return ops_for(curve)->combine(*this, partials, cnt, out, on_device);
 }
 
 }  // namespace blz

@@ -3,6 +3,7 @@
 #include <deque>
 
 #include "msm_engine.hpp"
+#include "rccl_dyn.hpp"
 
 using namespace blz;
 
@@ -30,7 +31,13 @@ struct blz_msm {
     const void* d_scalars = nullptr;
     const void* d_points_mont = nullptr;
     uint32_t staged_n = 0;
+    bool staged_from_arena = false;
+    uint64_t staged_arena_pos = 0;
     MsmEngine eng;
+    // multi-GPU exchange (blz_msm_comm_*): one communicator rank per handle
+    ncclComm_t comm = nullptr;
+    int comm_rank = 0, comm_size = 0;
+    DevBuf comm_buf;   // [send: one partial | recv: comm_size partials]
 };
 
 namespace {
@@ -38,27 +45,48 @@ namespace {
 size_t point_size(const blz_msm* h) { return blz_point_size(h->curve); }
 size_t result_size(const blz_msm* h) { return blz_result_size(h->curve); }
 
-// resolve the Montgomery-form view of `npts` points stored at arena offset `pos`
+// Resolve the Montgomery-form view of `npts` points stored at arena offset `pos`: (re)builds the part of the
+// extent's shadow that is stale, on this handle's main stream, and orders this stream behind conversions other
+// handles may have enqueued.
 int arena_points_mont(blz_msm* h, uint64_t pos, uint32_t npts, const void** out) {
-    size_t len = (size_t)npts * point_size(h);
+    const size_t ps = point_size(h), mp = mont_point_bytes(h->curve);
+    const size_t len = (size_t)npts * ps;
     Arena& A = arena_for(h->device);
     std::lock_guard<std::mutex> lk(A.mu);
     ArenaExtent* e = arena_find(A, pos, len);
     if (!e)
         return fail(BLZ_ERR_INVALID_PARAM, "HBM bases: no loaded extent covers [%llu, +%zu) on device %d",
                     (unsigned long long)pos, len, h->device);
-    // the shadow holds the Montgomery form of the extent's whole points, one per mont_point_bytes()
-    if ((pos - e->start) % point_size(h) != 0)
-        return fail(BLZ_ERR_INVALID_PARAM, "HBM point address must be a whole number of points into its loaded extent");
-    const size_t mp = mont_point_bytes(h->curve);
-    if (e->mont_curve != h->curve) {
-        uint32_t ext_pts = (uint32_t)(e->len / point_size(h));
-        if (e->mont) { (void)hipFree(e->mont); e->mont = nullptr; }   // stride differs between curves
-        BLZ_HIP(hipMalloc(&e->mont, (size_t)ext_pts * mp + 16), BLZ_ERR_UNKNOWN);
-        BLZ_TRY(h->eng.points_to_mont(e->raw, e->mont, ext_pts));
+    const uint32_t phase = (uint32_t)((pos - e->start) % ps);   // where the point grid sits inside the extent
+    const size_t cap_pts = (e->cap - phase) / ps, ext_pts = (e->len - phase) / ps;
+    if (e->mont_curve != h->curve || e->mont_phase != phase || e->mont_bytes < cap_pts * mp) {
+        // another curve / grid (or the first use): a fresh shadow, everything stale
+        if (e->mont) {
+            BLZ_HIP(hipDeviceSynchronize(), BLZ_ERR_UNKNOWN);   // a task of another handle may still read the old one
+            (void)hipFree(e->mont);
+            e->mont = nullptr;
+        }
+        e->mont_bytes = cap_pts * mp + 16;
+        BLZ_HIP(hipMalloc(&e->mont, e->mont_bytes), BLZ_ERR_UNKNOWN);
         e->mont_curve = h->curve;
+        e->mont_phase = phase;
+        e->dirty_lo = 0;
+        e->dirty_hi = e->len;
     }
-    *out = (const char*)e->mont + (pos - e->start) / point_size(h) * mp;
+    if (!e->shadow_ready) BLZ_HIP(hipEventCreateWithFlags(&e->shadow_ready, hipEventDisableTiming), BLZ_ERR_UNKNOWN);
+    if (e->dirty_lo < e->dirty_hi) {
+        // only the points the written span touches
+        uint64_t lo = e->dirty_lo > phase ? (e->dirty_lo - phase) / ps : 0;
+        uint64_t hi = e->dirty_hi > phase ? (e->dirty_hi - phase + ps - 1) / ps : 0;
+        if (hi > ext_pts) hi = ext_pts;
+        if (lo < hi)
+            BLZ_TRY(h->eng.points_to_mont((const char*)e->raw + phase + lo * ps, (char*)e->mont + lo * mp, (uint32_t)(hi - lo)));
+        BLZ_HIP(hipEventRecord(e->shadow_ready, h->eng.stream), BLZ_ERR_UNKNOWN);
+        e->dirty_lo = e->dirty_hi = 0;
+    } else {
+        BLZ_HIP(hipStreamWaitEvent(h->eng.stream, e->shadow_ready, 0), BLZ_ERR_UNKNOWN);
+    }
+    *out = (const char*)e->mont + (pos - e->start - phase) / ps * mp;
     return BLZ_OK;
 }
 
@@ -69,6 +97,9 @@ int launch_if_ready(blz_msm* h) {
     uint32_t npts = h->staged_n * h->pf;
     int sbits = h->pf == 1 ? 256 : 32;
     int slot = 0;
+    // bases in the arena: the shadow pointer is resolved now, not when the data was staged - a load by another
+    // handle in between may have moved or re-converted the extent
+    if (h->staged_from_arena) BLZ_TRY(arena_points_mont(h, h->staged_arena_pos, npts, &h->d_points_mont));
     BLZ_TRY(h->eng.run(h->d_points_mont, h->d_scalars, npts, sbits, &slot));
     h->armed = false;
     h->data_ready = false;
@@ -89,15 +120,23 @@ int stage_common(blz_msm* h, bool have_points, const void* points, size_t points
         return fail(BLZ_ERR_INVALID_PARAM, "points length %zu != nof_elements %u * precompute_factor %u * %zu", points_len,
                     n, h->pf, point_size(h));
     if ((uint64_t)n * h->pf >= (1ull << 31)) return fail(BLZ_ERR_INVALID_PARAM, "too many points");
+    // refuse sizes the window planner cannot serve BEFORE anything is copied or converted (u32 entry indexing:
+    // 256-bit scalars stop below 2^29 points, 32-bit chunks of pf = 8 below 2^31)
+    if (n && h->eng.plan_for(n * h->pf, h->pf == 1 ? 256 : 32).c == 0)
+        return fail(BLZ_ERR_INVALID_PARAM, "no window plan for %llu points of %d-bit scalars (maximum: 2^29 - 1 points at pf = 1)",
+                    (unsigned long long)n * h->pf, h->pf == 1 ? 256 : 32);
     if (!h->eng.can_accept())
         return fail(BLZ_ERR_INVALID_PARAM, "task queue full (%d in flight); call wait_result first", MSM_QUEUE_DEPTH);
     hipStream_t st = h->eng.stream;
     // Host buffers are staged on their own stream, so the PCIe transfer of this task overlaps the
     // accumulation of the task in flight (the reference's DMA writes overlap device compute the same
-    // way).  The staging buffers are free: everything that read them (to-Montgomery,
-    // digit sort) had completed when the previous set_data returned.
+    // way).
     hipStream_t cst = h->copy_stream;
     uint32_t npts = n * h->pf;
+    // the staging buffers are shared with the task enqueued before: its to-Montgomery pass and digit sort must
+    // have read them before this task's copies land (an event on the main stream, not a host wait)
+    if (!on_device && h->eng.inputs_consumed_valid)
+        BLZ_HIP(hipStreamWaitEvent(cst, h->eng.ev_inputs_consumed, 0), BLZ_ERR_UNKNOWN);
 
     if (have_points && has_hbm) {
         // msm_api.rs:203-206: load_data_to_hbm(points, addr, offset) first
@@ -109,8 +148,17 @@ int stage_common(blz_msm* h, bool have_points, const void* points, size_t points
         // bases come from the arena.  The reference's initialize() programs only hbm_point_addr.0
         // as the start address (msm_api.rs:84-95) while load_data_to_hbm writes at addr+offset
         // (msm_api.rs:312); both tests use offset 0.  Here the task reads where the load wrote.
-        BLZ_TRY(arena_points_mont(h, hbm_addr + hbm_off, npts, &h->d_points_mont));
+        {
+            Arena& A = arena_for(h->device);
+            std::lock_guard<std::mutex> lk(A.mu);
+            if (!arena_find(A, hbm_addr + hbm_off, (size_t)npts * point_size(h)))
+                return fail(BLZ_ERR_INVALID_PARAM, "HBM bases: no loaded extent covers [%llu, +%zu) on device %d",
+                            (unsigned long long)(hbm_addr + hbm_off), (size_t)npts * point_size(h), h->device);
+        }
+        h->staged_from_arena = true;
+        h->staged_arena_pos = hbm_addr + hbm_off;
     } else {
+        h->staged_from_arena = false;
         const size_t want_mont = (size_t)npts * mont_point_bytes(h->curve);
         BLZ_TRY(h->points_mont.reserve(want_mont ? want_mont : 16));
         if (on_device) {
@@ -169,6 +217,7 @@ int blz_msm_new(int device_id, int mem_type, int is_precompute, int curve, blz_m
 void blz_msm_free(blz_msm* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
+    if (h->comm) (void)blz_msm_comm_free(h);
     h->eng.destroy();
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     h->scalars_buf.release();
@@ -177,14 +226,30 @@ void blz_msm_free(blz_msm* h) {
     delete h;
 }
 
+// field value v into bits [lo, hi] of the image-parameter word, most significant bit at `lo`: the layout
+// MSMImageParametrs::parse_image_params reads (msm_api.rs:333-354: reverse_bits, then packed_struct msb0 ranges)
+static uint32_t put_msb_first(uint32_t v, int lo, int hi) {
+    uint32_t w = 0;
+    for (int k = 0, b = hi; b >= lo; ++k, --b) w |= ((v >> k) & 1u) << b;
+    return w;
+}
+
 int blz_msm_loaded_binary_parameters(blz_msm* h, uint32_t out[2]) {
     if (!h || !out) return fail(BLZ_ERR_INVALID_PARAM, "null argument");
-    // image id: 'MI35'; parameters packed like MSMImageParametrs (msm_api.rs:333-347, msb0 numbering):
-    // [31:28]... the reference decodes with packed_struct; we expose curve in bits 11:4 and the
-    // number of "EC adders" (compute units) in bits 3:0 scaled by 16.
+    // [0] image id 'MI35'; [1] decodes with MSMImageParametrs::parse_image_params: is_stub 0, curve code (0 BLS12-377,
+    // 1 BN254, 2 BLS12-381: the numbering debug_information implies, msm_api.rs:359-364) above two flag bits,
+    // "EC adders" = compute units / 16 (saturated at the field's 15), bucket-memory address width = the widest
+    // window's bucket index bits at the headline size (2^26 elements), segments = XCDs
     out[0] = 0x4D493335u;
-    uint32_t curve_code = h->curve == BLZ_BLS377 ? 0u : h->curve == BLZ_BN254 ? 1u : 2u;
-    out[1] = (curve_code << 4) | 0x0u;
+    const uint32_t curve_code = h->curve == BLZ_BLS377 ? 0u : h->curve == BLZ_BN254 ? 1u : 2u;
+    int cus = 0, dev = h->device;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+    uint32_t adders = (uint32_t)cus / 16u;
+    if (adders > 15u) adders = 15u;
+    const MsmPlan P = h->eng.plan_for(h->pf == 1 ? (1u << 26) : (1u << 29), h->pf == 1 ? 256 : 32);
+    const uint32_t width = P.c > 0 ? (uint32_t)(P.c - 1) : 0u;
+    out[1] = put_msb_first(0, 28, 31) | put_msb_first((curve_code << 2) & 0xffu, 20, 27) | put_msb_first(adders, 16, 19) |
+             put_msb_first(width & 0xffu, 8, 15) | put_msb_first(8u, 4, 7);
     return BLZ_OK;
 }
 
@@ -342,7 +407,72 @@ int blz_msm_plan(int curve, uint32_t nof_elements, int is_precompute, uint32_t o
 int blz_msm_combine_partials(blz_msm* h, const uint8_t* partials, size_t count, uint8_t* out, size_t out_cap) {
     if (!h || !out || (!partials && count)) return fail(BLZ_ERR_INVALID_PARAM, "null argument");
     if (out_cap < result_size(h)) return fail(BLZ_ERR_INVALID_PARAM, "result buffer too small");
-    return h->eng.combine_partials(partials, count, out);
+    return h->eng.combine_partials(partials, count, out, false);
+}
+
+// ---- multi-GPU exchange: RCCL all-gather of the per-rank partial results + rank-ordered add
+#define BLZ_NCCL(api, call)                                                                                  \
+    do {                                                                                                     \
+        ncclResult_t r__ = (call);                                                                           \
+        if (r__ != ncclSuccess) return fail(BLZ_ERR_UNKNOWN, "%s failed: %s", #call, (api)->GetErrorString(r__)); \
+    } while (0)
+
+int blz_comm_unique_id(uint8_t out[BLZ_COMM_ID_BYTES]) {
+    if (!out) return fail(BLZ_ERR_INVALID_PARAM, "null argument");
+    const RcclApi* api = rccl_api();
+    if (!api) return BLZ_ERR_LOAD_FAILED;
+    static_assert(BLZ_COMM_ID_BYTES == sizeof(ncclUniqueId), "id size");
+    ncclUniqueId id;
+    BLZ_NCCL(api, api->GetUniqueId(&id));
+    memcpy(out, &id, sizeof(id));
+    return BLZ_OK;
+}
+
+int blz_msm_comm_init(blz_msm* h, int rank, int nranks, const uint8_t id_bytes[BLZ_COMM_ID_BYTES]) {
+    if (!h || !id_bytes) return fail(BLZ_ERR_INVALID_PARAM, "null argument");
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(BLZ_ERR_INVALID_PARAM, "rank %d of %d", rank, nranks);
+    if (h->comm) return fail(BLZ_ERR_INVALID_PARAM, "communicator already initialised on this handle");
+    const RcclApi* api = rccl_api();
+    if (!api) return BLZ_ERR_LOAD_FAILED;
+    BLZ_TRY(use_device(h->device));
+    ncclUniqueId id;
+    memcpy(&id, id_bytes, sizeof(id));
+    BLZ_NCCL(api, api->CommInitRank(&h->comm, nranks, id, rank));   // collective: every rank calls it
+    h->comm_rank = rank;
+    h->comm_size = nranks;
+    return h->comm_buf.reserve((size_t)(nranks + 1) * result_size(h) + 64);
+}
+
+int blz_msm_all_gather_combine(blz_msm* h, const uint8_t* partial, uint8_t* out, size_t out_cap) {
+    if (!h || !partial || !out) return fail(BLZ_ERR_INVALID_PARAM, "null argument");
+    if (!h->comm) return fail(BLZ_ERR_INVALID_PARAM, "all_gather_combine before comm_init");
+    if (out_cap < result_size(h)) return fail(BLZ_ERR_INVALID_PARAM, "result buffer too small");
+    const RcclApi* api = rccl_api();
+    if (!api) return BLZ_ERR_LOAD_FAILED;
+    BLZ_TRY(use_device(h->device));
+    // own stream: the exchange must not queue behind the next task's accumulation on the main stream
+    hipStream_t st = h->eng.aux_stream;
+    const size_t rs = result_size(h);
+    uint8_t* send = h->comm_buf.as<uint8_t>();
+    uint8_t* recv = send + ((rs + 63) / 64) * 64;
+    BLZ_HIP(hipMemcpyAsync(send, partial, rs, hipMemcpyHostToDevice, st), BLZ_ERR_WRITE);
+    BLZ_NCCL(api, api->AllGather(send, recv, rs, ncclUint8, h->comm, st));
+    return h->eng.combine_partials(recv, (size_t)h->comm_size, out, true);   // rank order = buffer order
+}
+
+int blz_msm_comm_free(blz_msm* h) {
+    if (!h) return fail(BLZ_ERR_INVALID_PARAM, "null handle");
+    if (!h->comm) return BLZ_OK;
+    const RcclApi* api = rccl_api();
+    if (api) {
+        (void)hipSetDevice(h->device);
+        (void)hipStreamSynchronize(h->eng.aux_stream);
+        (void)api->CommDestroy(h->comm);
+    }
+    h->comm = nullptr;
+    h->comm_size = 0;
+    h->comm_buf.release();
+    return BLZ_OK;
 }
 
 }  // extern "C"

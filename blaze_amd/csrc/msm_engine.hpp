@@ -39,6 +39,8 @@ struct MsmSlot {
     hipEvent_t ev_done = nullptr;  // tail_stream: result bytes are in result_h
     DevBuf lvlA[2], lvlC[2];
     uint8_t* result_h = nullptr;   // pinned result bytes
+    uint32_t* stats_h = nullptr;   // pinned: [0] total units, [1] max bucket count, [2] total entries (read in finish())
+    uint64_t max_units = 0;        // the bound the launches of this task were sized by
     MsmPlan plan;
     bool accum_timed = false;
     bool busy = false;             // enqueued, result not collected yet
@@ -51,7 +53,8 @@ struct MsmEngine {
     MsmSlot slots[MSM_QUEUE_DEPTH];
     int cur = 0;                   // slot of the task being enqueued
     DevBuf count, off, unit_off, unit_bucket, unit_order, lenhist, coarse, inter, slice_map, entries, partial, blocksums, stats, result;
-    uint32_t* stats_h = nullptr;   // pinned: [0] total units, [1] max bucket count, [2] total entries
+    hipEvent_t ev_inputs_consumed = nullptr;  // stream: the last enqueued task has read its scalars / raw points
+    bool inputs_consumed_valid = false;
     uint8_t* combine_h = nullptr;  // pinned bytes of combine_partials
     MsmPlan last_plan;
     float last_ms[8] = {};
@@ -64,14 +67,16 @@ struct MsmEngine {
     // device result bytes of slot s / scratch of combine_partials inside `result`
     uint32_t* slot_result(int s) { return result.as<uint32_t>() + (size_t)s * 64; }
     bool can_accept() const;
+    MsmPlan plan_for(uint32_t npts, int sbits) const;   // the plan run() will use (host-side only)
     // raw wire-format points (x||y canonical LE) -> Montgomery AoS at mont_point_bytes() stride (never in place)
     int points_to_mont(const void* d_raw, void* d_mont, uint32_t npts);
     // enqueue the whole pipeline; *slot identifies the task for finish().  Fails when both slots are busy.
     int run(const void* d_points_mont, const void* d_scalars, uint32_t npts, int sbits, int* slot);
     // wait for task `slot`, copy the result out (result_size bytes), collect its phase timings
     int finish(int slot, uint8_t* out);
-    // add `count` partial results (host bytes) on the device, normalised output
-    int combine_partials(const uint8_t* partials, size_t count, uint8_t* out);
+    // add `count` partial results (host bytes, or device bytes already ordered on aux_stream) on the device,
+    // normalised output
+    int combine_partials(const uint8_t* partials, size_t count, uint8_t* out, bool on_device);
     int sync_all();
 };
 
@@ -87,8 +92,8 @@ int launch_fill_units(MsmEngine& E, uint32_t units);  // unit->bucket map + leng
 struct MsmCurveOps {
     int (*points_to_mont)(MsmEngine&, const void* d_raw, void* d_mont, uint32_t npts);
     int (*emit_infinity)(MsmEngine&);
-    int (*run_tail)(MsmEngine&, const void* d_pts, uint32_t units, uint32_t maxcount);
-    int (*combine)(MsmEngine&, const uint8_t* partials, size_t count, uint8_t* out);
+    int (*run_tail)(MsmEngine&, const void* d_pts, uint32_t max_units);
+    int (*combine)(MsmEngine&, const uint8_t* partials, size_t count, uint8_t* out, bool on_device);
 };
 const MsmCurveOps& msm_ops_bls377();
 const MsmCurveOps& msm_ops_bls381();

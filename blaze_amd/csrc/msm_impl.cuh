@@ -17,11 +17,9 @@ namespace blz {
 // ------------------------------------------------------------------------------------------------
 template <class F>
 constexpr int MONT_STRIDE = 2 * F::N > 16 ? 32 : 2 * F::N;  // dwords per Montgomery point
-// Fields with a reduced-radix twin (field_rr.cuh: the two BLS base fields) run the bucket accumulation in it:
-// their Montgomery point copy holds 2 x NL limbs of B bits (x R_rr, y R_rr: 112 of the line's 128 bytes) and
+// Fields with a reduced-radix twin (USE_RR, ec_rr.cuh: the two BLS base fields) run the bucket accumulation in
+// it: their Montgomery point copy holds 2 x NL limbs of B bits (x R_rr, y R_rr: 112 of the line's 128 bytes) and
 // k_accumulate converts a unit's sum to the 32-bit form once, when it stores it.
-template <class F>
-constexpr bool USE_RR = !std::is_void_v<typename F::RR>;
 
 template <class F>
 __global__ __launch_bounds__(256) void k_points_to_mont(const uint32_t* __restrict__ raw, uint32_t* __restrict__ mont,
@@ -94,14 +92,19 @@ BLZ_DEV void store_xyzz(uint32_t* base, size_t idx, const XYZZ<F>& a) {
 // ------------------------------------------------------------------------------------------------
 // phase 1: bucket accumulation.  One lane per unit (a run of <= L entries of one bucket).
 // ------------------------------------------------------------------------------------------------
+#ifndef BLZ_ACC_RR_WAVES
+#define BLZ_ACC_RR_WAVES 2
+#endif
 template <class F>
-__global__ __launch_bounds__(128, USE_RR<F> ? 2 : 3) void k_accumulate(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ entries,
+__global__ __launch_bounds__(128, USE_RR<F> ? BLZ_ACC_RR_WAVES : 3) void k_accumulate(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ entries,
                                                     const uint32_t* __restrict__ off, const uint32_t* __restrict__ unit_off,
                                                     const uint32_t* __restrict__ unit_bucket,
-                                                    const uint32_t* __restrict__ unit_order, uint32_t U, uint32_t L,
+                                                    const uint32_t* __restrict__ unit_order,
+                                                    const uint32_t* __restrict__ stats, uint32_t L,
                                                     uint32_t* __restrict__ partial) {
+    // the grid covers the host's upper bound of the unit count; the real count is on the device (stats[0])
     uint32_t t = blockIdx.x * 128u + threadIdx.x;
-    if (t >= U) return;
+    if (t >= stats[0]) return;
     const uint32_t u = unit_order[t];  // units of equal run length sit in the same wave
     uint32_t g = unit_bucket[u];
     uint32_t k = u - unit_off[g];
@@ -115,6 +118,7 @@ __global__ __launch_bounds__(128, USE_RR<F> ? 2 : 3) void k_accumulate(const uin
         XYZZRR<Q> acc;
         ptrr_set_inf(acc);
         uint32_t e = entries[start];
+#if BLZ_ACC_RR_WAVES == 2
         AffineRR<Q> nxt;
         load_affine_rr<F>(nxt, pts, e & 0x7fffffffu);
         for (uint32_t j = start; j < end; ++j) {
@@ -126,6 +130,15 @@ __global__ __launch_bounds__(128, USE_RR<F> ? 2 : 3) void k_accumulate(const uin
             }
             ptrr_madd<Q, 1>(acc, cur, neg);
         }
+#else
+        for (uint32_t j = start; j < end; ++j) {
+            AffineRR<Q> cur;
+            load_affine_rr<F>(cur, pts, e & 0x7fffffffu);
+            const bool neg = (e & 0x80000000u) != 0;
+            if (j + 1 < end) e = entries[j + 1];
+            ptrr_madd<Q, 1>(acc, cur, neg);
+        }
+#endif
         XYZZ<F> out;
         ptrr_to_xyzz32<F>(out, acc);
         store_xyzz(partial, u, out);
@@ -156,7 +169,11 @@ __global__ __launch_bounds__(128, 3) void k_combine_units(const uint32_t* __rest
                                                        const uint32_t* __restrict__ unit_bucket,
                                                        const uint32_t* __restrict__ unit_order,
                                                        const uint32_t* __restrict__ nfull_ptr,
+                                                       const uint32_t* __restrict__ stats, uint32_t L,
                                                        uint32_t stride, uint32_t* __restrict__ partial) {
+    // the host launches one pass per power of 16 up to the LARGEST possible bucket; the passes beyond this
+    // task's longest bucket (stats[1] entries) have nothing to fold
+    if (stride >= (stats[1] + L - 1) / L) return;
     // One DPP quad per 16 consecutive entries of the full-unit list (ec_quad.cuh): it scans them for
     // group leaders (at most two: a bucket's full units are contiguous in the list) and folds each
     // leader's group.  The chain of up to 15 additions is sequential and only hot buckets have any, so
@@ -275,7 +292,7 @@ __device__ void emit_result(uint32_t* out, const XYZZ<F>& p) {
 // window table of k_finish: window w owns virtual windows v0 .. v0 + m - 1 and starts at scalar bit `off`
 struct FinishPlan {
     int W, logV;
-    uint16_t v0[MSM_MAX_W], off[MSM_MAX_W];
+    uint16_t v0[MSM_MAX_W], off[MSM_MAX_W];   // make_plan keeps m <= 128 and sum m < 2^16 (checked when filled)
     uint8_t m[MSM_MAX_W];
 };
 
@@ -410,9 +427,9 @@ int emit_infinity_t(MsmEngine& E) {
     return BLZ_OK;
 }
 
-// phases 1-3 after the digit sort: U units, longest bucket run `maxcount`
+// phases 1-3 after the digit sort: at most U units (the real count is in E.stats on the device)
 template <class F>
-int run_tail_t(MsmEngine& E, const void* d_pts, uint32_t U, uint32_t maxcount) {
+int run_tail_t(MsmEngine& E, const void* d_pts, uint32_t U) {
     hipStream_t st = E.stream;
     MsmSlot& S = E.slots[E.cur];
     const MsmPlan& P = E.last_plan;
@@ -422,21 +439,22 @@ int run_tail_t(MsmEngine& E, const void* d_pts, uint32_t U, uint32_t maxcount) {
     BLZ_HIP(hipEventRecord(S.ev[1], st), BLZ_ERR_UNKNOWN);
 
     // ---- phase 1
-    S.accum_timed = U != 0;
-    if (U) {
+    S.accum_timed = true;
+    {
         BLZ_TRY(launch_fill_units(E, U));
         BLZ_HIP(hipEventRecord(S.ev[5], st), BLZ_ERR_UNKNOWN);  // ev5..ev6 bracket the dominant kernel alone
         hipLaunchKernelGGL(k_accumulate<F>, dim3((U + 127) / 128), dim3(128), 0, st, (const uint32_t*)d_pts,
                            E.entries.as<uint32_t>(), E.off.as<uint32_t>(), E.unit_off.as<uint32_t>(),
-                           E.unit_bucket.as<uint32_t>(), E.unit_order.as<uint32_t>(), U, P.L, E.partial.as<uint32_t>());
+                           E.unit_bucket.as<uint32_t>(), E.unit_order.as<uint32_t>(), E.stats.as<uint32_t>(), P.L,
+                           E.partial.as<uint32_t>());
         BLZ_HIP(hipEventRecord(S.ev[6], st), BLZ_ERR_UNKNOWN);
-        uint32_t maxunits = (maxcount + P.L - 1) / P.L;
+        const uint32_t maxunits = (P.npts + P.L - 1) / P.L;   // a bucket holds at most one entry per point
         uint64_t full_bound = (uint64_t)P.npts * P.W / P.L + 1;  // units of length L: at most entries / L
         if (full_bound > U) full_bound = U;
         for (uint32_t stride = 1; stride < maxunits; stride *= 16)
             hipLaunchKernelGGL(k_combine_units<F>, dim3((uint32_t)((full_bound / 16 + 1) * 4 / 128 + 1)), dim3(128), 0, st,
                                E.unit_off.as<uint32_t>(), E.unit_bucket.as<uint32_t>(), E.unit_order.as<uint32_t>(),
-                               E.lenhist.as<uint32_t>() + P.L, stride, E.partial.as<uint32_t>());
+                               E.lenhist.as<uint32_t>() + P.L, E.stats.as<uint32_t>(), P.L, stride, E.partial.as<uint32_t>());
         BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
     }
     BLZ_HIP(hipEventRecord(S.ev[2], st), BLZ_ERR_UNKNOWN);
@@ -495,8 +513,11 @@ int run_tail_t(MsmEngine& E, const void* d_pts, uint32_t U, uint32_t maxcount) {
     {
         int off = 0;
         for (int w = 0; w < P.W; ++w) {
-            fp.v0[w] = (uint16_t)(P.boff[w] >> fp.logV);
-            fp.m[w] = (uint8_t)((P.boff[w + 1] - P.boff[w]) >> fp.logV);
+            const uint32_t v0 = P.boff[w] >> fp.logV, m = (P.boff[w + 1] - P.boff[w]) >> fp.logV;
+            if (v0 > 0xffffu || m > 0xffu || off > 0xffff)
+                return fail(BLZ_ERR_UNKNOWN, "window plan outside k_finish's table range (window %d: v0=%u m=%u off=%d)", w, v0, m, off);
+            fp.v0[w] = (uint16_t)v0;
+            fp.m[w] = (uint8_t)m;
             fp.off[w] = (uint16_t)off;
             off += P.width[w];
         }
@@ -510,18 +531,22 @@ int run_tail_t(MsmEngine& E, const void* d_pts, uint32_t U, uint32_t maxcount) {
 }
 
 template <class F>
-int combine_t(MsmEngine& E, const uint8_t* partials, size_t count, uint8_t* out) {
+int combine_t(MsmEngine& E, const uint8_t* partials, size_t count, uint8_t* out, bool on_device) {
     // own stream: it must not queue behind a task in flight (its tail waits for its accumulation)
     hipStream_t st = E.aux_stream;
     size_t rs = 3 * F::N * 4;
     DevBuf tmp;
     uint32_t* d_out = E.result.as<uint32_t>() + 128;
     uint32_t* d_in = E.result.as<uint32_t>() + 256;  // 15 KiB of the result buffer: up to 100 partials without an allocation
-    if (rs * count > 15 * 1024) {
-        BLZ_TRY(tmp.reserve(rs * count));
-        d_in = tmp.as<uint32_t>();
+    if (on_device) {
+        d_in = (uint32_t*)partials;   // e.g. the receive buffer of the RCCL all-gather, written on this stream
+    } else {
+        if (rs * count > 15 * 1024) {
+            BLZ_TRY(tmp.reserve(rs * count));
+            d_in = tmp.as<uint32_t>();
+        }
+        if (count) BLZ_HIP(hipMemcpyAsync(d_in, partials, rs * count, hipMemcpyHostToDevice, st), BLZ_ERR_WRITE);
     }
-    if (count) BLZ_HIP(hipMemcpyAsync(d_in, partials, rs * count, hipMemcpyHostToDevice, st), BLZ_ERR_WRITE);
     hipLaunchKernelGGL(k_combine_partials<F>, dim3(1), dim3(64), 0, st, d_in, (uint32_t)count, d_out);
     BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
     BLZ_HIP(hipMemcpyAsync(E.combine_h, d_out, rs, hipMemcpyDeviceToHost, st), BLZ_ERR_READ);

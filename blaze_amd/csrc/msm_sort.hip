@@ -493,26 +493,18 @@ int msm_sort_lds(MsmEngine& E, const void* d_scalars, uint32_t npts, int sbits) 
     uint32_t* coarse_off = coarse_count + g.NC;
     BLZ_HIP(hipMemsetAsync(coarse_count, 0, (size_t)g.NC * 4, st), BLZ_ERR_UNKNOWN);
     const size_t lds = (size_t)g.NC * 4;
-    static bool attr_done = false;
-    if (!attr_done) {
-        BLZ_HIP(hipFuncSetAttribute((const void*)k_coarse_count<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024), BLZ_ERR_UNKNOWN);
-        BLZ_HIP(hipFuncSetAttribute((const void*)k_coarse_count<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024), BLZ_ERR_UNKNOWN);
-        BLZ_HIP(hipFuncSetAttribute((const void*)k_coarse_scatter<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024), BLZ_ERR_UNKNOWN);
-        BLZ_HIP(hipFuncSetAttribute((const void*)k_coarse_scatter<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024), BLZ_ERR_UNKNOWN);
-        attr_done = true;
-    }
+    BLZ_TRY(ensure_dynamic_lds((const void*)k_coarse_count<8>, 128 * 1024));
+    BLZ_TRY(ensure_dynamic_lds((const void*)k_coarse_count<1>, 128 * 1024));
+    BLZ_TRY(ensure_dynamic_lds((const void*)k_coarse_scatter<8>, 128 * 1024));
+    BLZ_TRY(ensure_dynamic_lds((const void*)k_coarse_scatter<1>, 128 * 1024));
     const uint32_t* sc = (const uint32_t*)d_scalars;
     if (sbits == 256) hipLaunchKernelGGL(k_coarse_count<8>, dim3(nblk), dim3(SORT_THREADS), lds, st, sc, npts, g, coarse_count);
     else hipLaunchKernelGGL(k_coarse_count<1>, dim3(nblk), dim3(SORT_THREADS), lds, st, sc, npts, g, coarse_count);
     hipLaunchKernelGGL(k_coarse_scan, dim3(1), dim3(1024), 0, st, coarse_count, g.NC, coarse_off);
     // BLAZE_SORT_STAGED=0 selects the unstaged coarse scatter (kept for A/B measurements)
     if (msm_env_int("BLAZE_SORT_STAGED", 1) != 0 && g.chmax <= 11 && g.cl <= 12) {
-        static bool attr_cs = false;
-        if (!attr_cs) {
-            BLZ_HIP(hipFuncSetAttribute((const void*)k_coarse_scatter_staged<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024), BLZ_ERR_UNKNOWN);
-            BLZ_HIP(hipFuncSetAttribute((const void*)k_coarse_scatter_staged<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024), BLZ_ERR_UNKNOWN);
-            attr_cs = true;
-        }
+        BLZ_TRY(ensure_dynamic_lds((const void*)k_coarse_scatter_staged<8>, 96 * 1024));
+        BLZ_TRY(ensure_dynamic_lds((const void*)k_coarse_scatter_staged<1>, 96 * 1024));
         const size_t lds_cs = ((size_t)3 << g.chmax) * 4 + (size_t)CS_PTS * 8;
         const uint32_t nblk_cs = (npts + CS_PTS - 1) / CS_PTS;
         if (sbits == 256)
@@ -541,11 +533,7 @@ int msm_sort_lds(MsmEngine& E, const void* d_scalars, uint32_t npts, int sbits) 
 int msm_sort_lds_scatter(MsmEngine& E) {
     hipStream_t st = E.stream;
     uint32_t* coarse_off = E.coarse.as<uint32_t>() + E.sort_nc;
-    static bool attr_done = false;
-    if (!attr_done) {
-        BLZ_HIP(hipFuncSetAttribute((const void*)k_fine_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024), BLZ_ERR_UNKNOWN);
-        attr_done = true;
-    }
+    BLZ_TRY(ensure_dynamic_lds((const void*)k_fine_scatter, 158 * 1024));
     // staging entries per round (6 bytes each): what is left of the LDS after the two per-bucket arrays
     size_t budget = (size_t)msm_env_int("BLAZE_SORT_FS_KB", 157) * 1024 - ((size_t)2 << E.sort_cl) * 4;
     uint32_t round_cap = (uint32_t)(budget / 6);

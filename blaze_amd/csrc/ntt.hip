@@ -62,7 +62,7 @@ struct blz_ntt {
     DevBuf buf[2], scratch, tables;
     NttTables T{};
     bool in_flight = false;
-    bool has_data[2] = {false, false};
+    int in_flight_buf = -1;   // buffer under transform while in_flight
     float last_ms = 0.f;
 };
 
@@ -107,6 +107,14 @@ int ntt_setup(blz_ntt* h) {
     h->T.t2 = p; p += 512 * 8;
     h->T.ninv = h->inverse ? p : nullptr;
     BLZ_TRY(h->ops->setup(h->stream, h->T, h->geom, h->inverse));
+    // both transform buffers exist from the start, zero-filled, like the card's two HBM buffers: the reference's
+    // double-buffer loop opens with start_process on a buffer nobody wrote and result on the other
+    // (tests/integration_ntt.rs:102-136, cycle 0)
+    for (int b = 0; b < 2; ++b) {
+        BLZ_TRY(h->buf[b].reserve(ntt_bytes(h)));
+        BLZ_HIP(hipMemsetAsync(h->buf[b].p, 0, ntt_bytes(h), h->stream), BLZ_ERR_UNKNOWN);
+    }
+    BLZ_TRY(h->scratch.reserve(ntt_bytes(h)));
     BLZ_HIP(hipStreamSynchronize(h->stream), BLZ_ERR_UNKNOWN);
     return BLZ_OK;
 }
@@ -175,15 +183,15 @@ static int ntt_set_data_common(blz_ntt* h, size_t buf_host, const void* data, si
     if (!h || !data) return fail(BLZ_ERR_INVALID_PARAM, "null argument");
     if (buf_host > 1) return fail(BLZ_ERR_INVALID_PARAM, "buf_host must be 0 or 1");
     if (len != ntt_bytes(h)) return fail(BLZ_ERR_INVALID_PARAM, "data length %zu != %zu", len, ntt_bytes(h));
+    if (h->in_flight && h->in_flight_buf == (int)buf_host)
+        return fail(BLZ_ERR_INVALID_PARAM, "buffer %zu is being transformed; call wait_result first", buf_host);
     BLZ_TRY(use_device(h->device));
-    BLZ_TRY(h->buf[buf_host].reserve(len));
     // a dedicated copy stream: the compute stream may be busy on the other buffer (double-buffer
     // contract, tests/integration_ntt.rs:102-136).  Synchronised before returning: set_data is
     // blocking, and a device-to-device hipMemcpy alone is not ordered against other streams.
     BLZ_HIP(hipMemcpyAsync(h->buf[buf_host].p, data, len, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
                            h->copy_stream), BLZ_ERR_WRITE);
     BLZ_HIP(hipStreamSynchronize(h->copy_stream), BLZ_ERR_WRITE);
-    h->has_data[buf_host] = true;
     return BLZ_OK;
 }
 
@@ -197,10 +205,8 @@ int blz_ntt_set_data_device(blz_ntt* h, size_t buf_host, const void* d_data, siz
 int blz_ntt_start_process(blz_ntt* h, size_t buf_kernel) {
     if (!h) return fail(BLZ_ERR_INVALID_PARAM, "null handle");
     if (buf_kernel > 1) return fail(BLZ_ERR_INVALID_PARAM, "buf_kernel must be 0 or 1");
-    if (!h->has_data[buf_kernel]) return fail(BLZ_ERR_INVALID_PARAM, "buffer %zu holds no data", buf_kernel);
     if (h->in_flight) return fail(BLZ_ERR_INVALID_PARAM, "a transform is already running; call wait_result first");
     BLZ_TRY(use_device(h->device));
-    BLZ_TRY(h->scratch.reserve(ntt_bytes(h)));
     void* b = h->buf[buf_kernel].p;
     void* s = h->scratch.p;
     BLZ_HIP(hipEventRecord(h->ev0, h->stream), BLZ_ERR_UNKNOWN);
@@ -214,6 +220,7 @@ int blz_ntt_start_process(blz_ntt* h, size_t buf_kernel) {
     BLZ_TRY(launch_pass(h, 3, cur, b));
     BLZ_HIP(hipEventRecord(h->ev1, h->stream), BLZ_ERR_UNKNOWN);
     h->in_flight = true;
+    h->in_flight_buf = (int)buf_kernel;
     return BLZ_OK;
 }
 
@@ -229,7 +236,9 @@ int blz_ntt_wait_result(blz_ntt* h) {
 
 static int ntt_result_common(blz_ntt* h, size_t buf, void* out, size_t out_cap, bool on_device) {
     if (!h || !out) return fail(BLZ_ERR_INVALID_PARAM, "null argument");
-    if (buf > 1 || !h->has_data[buf]) return fail(BLZ_ERR_INVALID_PARAM, "buffer %zu holds no data", buf);
+    if (buf > 1) return fail(BLZ_ERR_INVALID_PARAM, "buffer index must be 0 or 1");
+    if (h->in_flight && h->in_flight_buf == (int)buf)
+        return fail(BLZ_ERR_INVALID_PARAM, "buffer %zu is being transformed; call wait_result first", buf);
     if (out_cap < ntt_bytes(h)) return fail(BLZ_ERR_INVALID_PARAM, "output buffer too small");
     BLZ_TRY(use_device(h->device));
     BLZ_HIP(hipMemcpyAsync(out, h->buf[buf].p, ntt_bytes(h), on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,

@@ -413,12 +413,7 @@ int ntt_pass_t(hipStream_t st, const void* in, void* out, const NttGeom& g, cons
     int lr = PASS == 1 ? g.logC : PASS == 2 ? g.logB : g.logA;
     const int cols_avail = PASS == 3 ? g.logC : g.logA;  // extent of the tile's column index
     if (lr == 9 && cols_avail >= N8_COLS_LOG && !force_generic) {
-        static bool attr8 = false;
-        if (!attr8) {
-            BLZ_HIP(hipFuncSetAttribute((const void*)k_ntt512<Fr, PASS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
-                    BLZ_ERR_UNKNOWN);
-            attr8 = true;
-        }
+        BLZ_TRY(ensure_dynamic_lds((const void*)k_ntt512<Fr, PASS>, 160 * 1024));
         size_t lds8 = (size_t)512 * N8_RS * 4;
         uint64_t tiles8 = (1ull << g.logn) >> (9 + N8_COLS_LOG);
         hipLaunchKernelGGL((k_ntt512<Fr, PASS>), dim3((unsigned)tiles8), dim3(N8_THREADS), lds8, st, (const uint32_t*)in,
@@ -428,12 +423,7 @@ int ntt_pass_t(hipStream_t st, const void* in, void* out, const NttGeom& g, cons
     }
     size_t lds = ((size_t)4 << lr) * (((size_t)8 << cl) + 8);  // rows x (COLS*8 + 8) dwords
     uint64_t tiles = (1ull << g.logn) >> (lr + cl);
-    static bool attr_set = false;
-    if (!attr_set) {
-        BLZ_HIP(hipFuncSetAttribute((const void*)k_ntt_pass<Fr, PASS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
-                BLZ_ERR_UNKNOWN);
-        attr_set = true;
-    }
+    BLZ_TRY(ensure_dynamic_lds((const void*)k_ntt_pass<Fr, PASS>, 160 * 1024));
     hipLaunchKernelGGL((k_ntt_pass<Fr, PASS>), dim3((unsigned)tiles), dim3(NTT_THREADS), lds, st, (const uint32_t*)in,
                        (uint32_t*)out, g, T, cl);
     BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);

@@ -1,7 +1,7 @@
 // Element-wise kernels over the device field / group primitives, so tests can compare each of them
 // with the CPU oracle (include/blaze_hip.h "test hooks").  Not on the MSM/NTT product path.
 #include "common.hpp"
-#include "ec.cuh"
+#include "ec_rr.cuh"
 
 namespace blz {
 
@@ -27,6 +27,33 @@ __global__ __launch_bounds__(64) void k_test_field(int op, const uint32_t* a, co
                 fp_sub(d, x, y);
                 if (op == 5) fp_mul2(r, x, y, s, d);
                 else fp_mulsub2(r, x, y, s, d);
+            } else {
+                fp_zero(r);
+            }
+            break;
+        case 10: case 11: case 12: case 13: case 14:
+            // the reduced-radix twin (field_rr.cuh): product, square, fused sum of products on lazy operands,
+            // carry propagation, zero tests; operands go in through the wire-word conversion and come back
+            // through the 32-bit Montgomery form, so both conversions are under test as well
+            if constexpr (USE_RR<P>) {
+                using Q = typename P::RR;
+                fp_load(x, a + (size_t)i * P::N);
+                fp_load(y, b + (size_t)i * P::N);
+                Frr<Q, 1, 2> xr, yr, rr;
+                rr_to_mont_from_words<Q>(xr, x.v);
+                rr_to_mont_from_words<Q>(yr, y.v);
+                if (op == 10) rr_mul(rr, xr, yr);
+                else if (op == 11) rr_sqr(rr, xr);
+                else if (op == 12) rr_mul2(rr, xr, yr, rr_add(xr, yr), rr_sub<2>(xr, yr));   // x y + (x + y)(x - y)
+                else if (op == 13) rr_mul(rr, rr_norm(rr_sub_twice<2>(rr_sub<2>(xr, yr), yr)), yr);  // (x - 3y) y
+                else {  // 1 if x == y (exact test behind the cheap filter), else 0; Montgomery one / zero
+                    const auto d = rr_sub<2>(xr, yr);
+                    const bool eq = rr_maybe_equal(xr, yr) && rr_is_zero(d);
+                    if (rr_is_zero(d) != eq) { rr_zero(rr); rr.v[0] = 7; }   // the filter must never hide an equality
+                    else if (eq) rr_one(rr);
+                    else rr_zero(rr);
+                }
+                rr_to_mont32_words<Q>(r.v, rr);
             } else {
                 fp_zero(r);
             }
@@ -73,6 +100,25 @@ __global__ __launch_bounds__(64) void k_test_ec(int op, const uint32_t* p, const
             }
             pt_add(acc, qq);
         } break;
+        case 4: case 5:   // the reduced-radix mixed add of the bucket accumulation (ec_rr.cuh); 5 subtracts
+            if constexpr (USE_RR<F>) {
+                if (!(fl & 2)) {
+                    using QQ = typename F::RR;
+                    XYZZRR<QQ> a;
+                    ptrr_from_xyzz32<F>(a, acc);
+                    AffineRR<QQ> q;
+                    rr_from_mont32_words<QQ>(q.x, Q.x.v);
+                    rr_from_mont32_words<QQ>(q.y, Q.y.v);
+                    ptrr_madd<QQ, 2>(a, q, op == 5);
+                    // a second, cancelling pair keeps the lazy ranges honest: (acc + Q) + Q - Q
+                    ptrr_madd<QQ, 2>(a, q, op == 5);
+                    ptrr_madd<QQ, 2>(a, q, op != 5);
+                    ptrr_to_xyzz32<F>(acc, a);
+                }
+            } else {
+                pt_set_inf(acc);
+            }
+            break;
         default: if (!(fl & 2)) { fp_neg(Q.y, Q.y); pt_madd(acc, Q); } break;
     }
     Affine<F> r;

@@ -10,7 +10,7 @@ import enum
 from dataclasses import dataclass
 from typing import Generic, Optional, TypeVar
 
-from ._lib import DriverClientError, lib  # noqa: F401  (re-exported)
+from ._lib import check, DriverClientError, lib  # noqa: F401  (re-exported)
 
 T = TypeVar("T")
 P = TypeVar("P")
@@ -51,6 +51,13 @@ class DriverClient:
         if not (0 <= self.id < n):
             # the reference unwraps the open() of the char device (utils.rs:74)
             raise DriverClientError(7, f"no HIP device with ordinal {self.id} ({n} visible)")
+
+    # the card's HBM outlives the process that loaded it; GPU memory needs a holder process (include/blaze_hip.h)
+    def arena_export(self, registry_path: str) -> None:
+        check(lib().blz_arena_export(self.id, registry_path.encode()))
+
+    def arena_attach(self, registry_path: str) -> None:
+        check(lib().blz_arena_attach(self.id, registry_path.encode()))
 
     # FPGA-shell management (dclient.rs:88-279): accepted, nothing to do on a GPU
     def reset(self) -> None:

@@ -68,6 +68,50 @@ def _hbm(params: MSMParams):
     return 1, int(params.hbm_point_addr[0]), int(params.hbm_point_addr[1])
 
 
+def _field_msb_first(p: int, lo: int, hi: int) -> int:
+    v = 0
+    for b in range(lo, hi + 1):      # bit `lo` of the word is the field's most significant bit
+        v = (v << 1) | ((p >> b) & 1)
+    return v
+
+
+def _put_msb_first(v: int, lo: int, hi: int) -> int:
+    w = 0
+    for k, b in enumerate(range(hi, lo - 1, -1)):   # the field's bit k sits at word bit hi - k
+        w |= ((v >> k) & 1) << b
+    return w
+
+
+def pack_image_params(curve_code: int, ec_adders: int, buckets_mem_addr_width: int, segments: int, is_stub: int = 0) -> int:
+    """The word MSMImageParametrs.parse_image_params decodes (what blz_msm_loaded_binary_parameters emits)."""
+    return (_put_msb_first(is_stub, 28, 31) | _put_msb_first((curve_code << 2) & 0xFF, 20, 27) | _put_msb_first(ec_adders, 16, 19)
+            | _put_msb_first(buckets_mem_addr_width, 8, 15) | _put_msb_first(segments, 4, 7))
+
+
+@dataclass
+class MSMImageParametrs:  # msm_api.rs:333-347 (packed_struct, msb0, after params.reverse_bits(): :350-354)
+    hif2cpu_c_is_stub: int
+    hif2_cpu_c_curve: int
+    hif2_cpu_c_number_of_ec_adders: int
+    hif2_cpu_c_buckets_mem_addr_width: int
+    hif2_cpu_c_number_of_segments: int
+    hif2_cpu_c_place_holder: int
+
+    @staticmethod
+    def parse_image_params(params: int) -> "MSMImageParametrs":
+        return MSMImageParametrs(_field_msb_first(params, 28, 31), _field_msb_first(params, 20, 27), _field_msb_first(params, 16, 19),
+                                 _field_msb_first(params, 8, 15), _field_msb_first(params, 4, 7), _field_msb_first(params, 0, 3))
+
+    def curve_name(self) -> str:
+        """msm_api.rs:359-364 intends 0 / 1 / 2 = BLS12_377 / BN254 / BLS12_381 above the low two flag bits."""
+        return {0: "BLS12_377", 1: "BN254", 2: "BLS12_381"}.get(self.hif2_cpu_c_curve >> 2, "UNKNOWN")
+
+    def debug_information(self) -> str:
+        return (f"Is Stub: {self.hif2cpu_c_is_stub}; curve: {self.curve_name()}; EC adders (x16 CUs): "
+                f"{self.hif2_cpu_c_number_of_ec_adders}; buckets memory address width: {self.hif2_cpu_c_buckets_mem_addr_width}; "
+                f"segments (XCDs): {self.hif2_cpu_c_number_of_segments}")
+
+
 class MSMClient(DriverPrimitive[MSMInit, MSMParams, MSMInput, MSMResult]):
     """msm_api.rs:8-14, 42-331."""
 
@@ -167,6 +211,29 @@ class MSMClient(DriverPrimitive[MSMInit, MSMParams, MSMInput, MSMResult]):
 
     def reset(self) -> None:
         check(lib().blz_msm_reset(self._h))
+
+    # ---- multi-GPU exchange inside the library (include/blaze_hip.h, blz_msm_comm_*): RCCL over xGMI
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """Rank 0 makes the communicator id; the host ships these 128 bytes to the other ranks."""
+        out = C.create_string_buffer(128)
+        check(lib().blz_comm_unique_id(C.cast(out, C.c_void_p)))
+        return out.raw
+
+    def comm_init(self, rank: int, nranks: int, comm_id: bytes) -> None:
+        p, _n, _k = buf_ptr(comm_id)
+        check(lib().blz_msm_comm_init(self._h, rank, nranks, p))
+
+    def all_gather_combine(self, partial: bytes) -> bytes:
+        """All-gather of the ranks' partial results + rank-ordered add on the device: the full result, identical
+        bytes on every rank."""
+        out = C.create_string_buffer(self.msm_cfg.result_point_size)
+        p, _n, _k = buf_ptr(partial)
+        check(lib().blz_msm_all_gather_combine(self._h, p, C.cast(out, C.c_void_p), len(out)))
+        return out.raw
+
+    def comm_free(self) -> None:
+        check(lib().blz_msm_comm_free(self._h))
 
     def combine_partials(self, partials: bytes, count: int) -> bytes:
         """Multi-GPU: rank-ordered sum of `count` partial results."""

@@ -118,6 +118,24 @@ class MSMClient : public DriverPrimitive<MSMInit, MSMParams, MSMInput, MSMResult
         check(blz_msm_get_data_from_hbm(h_, out.data(), data_len, addr, offset));
         return out;
     }
+    // multi-GPU (no reference counterpart: README.md:20-22 leaves it to a "management layer"): one communicator
+    // rank per client; comm_unique_id() on rank 0, shipped to the others by the host
+    static std::vector<uint8_t> comm_unique_id() {
+        std::vector<uint8_t> id(BLZ_COMM_ID_BYTES);
+        check(blz_comm_unique_id(id.data()));
+        return id;
+    }
+    void comm_init(int rank, int nranks, const std::vector<uint8_t>& id) { check(blz_msm_comm_init(h_, rank, nranks, id.data())); }
+    std::vector<uint8_t> all_gather_combine(const std::vector<uint8_t>& partial) {
+        std::vector<uint8_t> out(result_size_);
+        check(blz_msm_all_gather_combine(h_, partial.data(), out.data(), out.size()));
+        return out;
+    }
+    std::vector<uint8_t> combine_partials(const std::vector<uint8_t>& partials, size_t count) {
+        std::vector<uint8_t> out(result_size_);
+        check(blz_msm_combine_partials(h_, partials.data(), count, out.data(), out.size()));
+        return out;
+    }
 };
 
 // ---------------------------------------------------------------- NTT (src/ingo_ntt)

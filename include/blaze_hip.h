@@ -29,7 +29,7 @@ enum blz_error {
     BLZ_ERR_HBICAP_NOT_READY = 3,    /* HBICAPNotReady: never produced (no bitstream to load)        */
     BLZ_ERR_INVALID_PARAM = 4,       /* InvalidPrimitiveParam: bad mode combination / sizes / state  */
     BLZ_ERR_CSV = 5,                 /* CsvError: never produced                                     */
-    BLZ_ERR_LOAD_FAILED = 6,         /* LoadFailed{path}: never produced                             */
+    BLZ_ERR_LOAD_FAILED = 6,         /* LoadFailed{path}: librccl.so.1 could not be loaded (comm API) */
     BLZ_ERR_FILE = 7,                /* FileError: device could not be opened (no GPU / bad ordinal) */
     BLZ_ERR_UNKNOWN = 8              /* Unknown: kernel launch / runtime failure                     */
 };
@@ -107,12 +107,23 @@ int blz_msm_result(blz_msm* h, uint8_t* out, size_t out_cap, size_t* out_len, ui
 
 /* MSMClient::load_data_to_hbm / get_data_from_hbm (msm_api.rs:299-322): raw bytes at arena byte
  * offset addr+off.  The arena is per device and process-global (points persist across handles, as
- * they persist across clients on the card: tests/integration_msm_hbm.rs:51-56). */
+ * they persist across clients on the card: tests/integration_msm_hbm.rs:51-56) and behaves like the
+ * card's flat memory: a write keeps every byte outside its own range, writes that touch or overlap
+ * earlier ones form one contiguous extent (a table may be loaded in pieces), and only a range that
+ * was never written cannot be read or used as bases. */
 int blz_msm_load_data_to_hbm(blz_msm* h, const uint8_t* points, size_t len, uint64_t addr, uint64_t off);
 int blz_msm_load_data_to_hbm_device(blz_msm* h, const void* d_points, size_t len, uint64_t addr, uint64_t off);
 int blz_msm_get_data_from_hbm(blz_msm* h, uint8_t* out, size_t len, uint64_t addr, uint64_t off);
 /* drop every arena extent of a device (no reference counterpart; the card keeps HBM until reset) */
 int blz_arena_release(int device_id);
+/* Cross-process arena (the card's HBM outlives the process that loaded it; GPU memory does not, so a holder
+ * process keeps it): blz_arena_export writes one IPC handle per extent of this process to `registry_path`;
+ * blz_arena_attach, in ANOTHER process, maps those extents at the same arena offsets, after which
+ * hbm_point_addr / get_data_from_hbm / in-place load_data_to_hbm address the holder's bytes.  The extents live
+ * as long as the holder does; an attached extent cannot be extended.  (HSA_ENABLE_IPC_MODE_LEGACY=0 where the
+ * host driver only supports dmabuf IPC.) */
+int blz_arena_export(int device_id, const char* registry_path);
+int blz_arena_attach(int device_id, const char* registry_path);
 
 /* MSMClient::task_label / nof_elements / is_msm_engine_ready (msm_api.rs:278-297) */
 int blz_msm_task_label(blz_msm* h, uint32_t* out);
@@ -140,9 +151,25 @@ int blz_msm_precompute_bases_device(int device_id, int curve, const void* d_poin
 int blz_msm_plan(int curve, uint32_t nof_elements, int is_precompute, uint32_t out[4], uint8_t* widths);
 
 /* Multi-GPU: add G partial results (each result_size bytes, as returned by blz_msm_result on each
- * rank, in rank order) on this handle's device and emit the normalised sum.  The exchange itself
- * (RCCL all-gather of the 144-byte partials) is the host's: SURVEY.md 8(e). */
+ * rank, in rank order) on this handle's device and emit the normalised sum, for hosts that move the
+ * partials themselves (blz_msm_all_gather_combine below does the exchange too). */
 int blz_msm_combine_partials(blz_msm* h, const uint8_t* partials, size_t count, uint8_t* out, size_t out_cap);
+
+/* Multi-GPU exchange inside the library (one process per GPU, or one handle per device of one process): an
+ * RCCL communicator rank per handle, then  all-gather of the ranks' partial results over xGMI + rank-ordered
+ * add on the device + normalise, so every rank returns the same bytes.  (RCCL's reduce operators are
+ * arithmetic, not a group law: all-gather + local add instead of all-reduce)  The reference
+ * leaves the multi-device layer to a "management layer" (README.md:20-22); this is that layer for a Rust / C++
+ * host.  RCCL is resolved at run time (dlopen of librccl.so.1); without it these return LoadFailed.
+ *   rank 0:        blz_comm_unique_id(id); the host ships the 128 bytes to the other ranks (MPI, a file, a pipe ...)
+ *   every rank:    blz_msm_comm_init(h, rank, nranks, id)                        -- collective
+ *   per MSM:       blz_msm_result(h, partial ...); blz_msm_all_gather_combine(h, partial, out, cap) -- collective
+ *   every rank:    blz_msm_comm_free(h)   (blz_msm_free does it too) */
+#define BLZ_COMM_ID_BYTES 128
+int blz_comm_unique_id(uint8_t out[BLZ_COMM_ID_BYTES]);
+int blz_msm_comm_init(blz_msm* h, int rank, int nranks, const uint8_t id[BLZ_COMM_ID_BYTES]);
+int blz_msm_all_gather_combine(blz_msm* h, const uint8_t* partial, uint8_t* out, size_t out_cap);
+int blz_msm_comm_free(blz_msm* h);
 
 /* ------------------------------------------------------------------ NTT (src/ingo_ntt/ntt_api.rs) */
 
@@ -201,8 +228,11 @@ int blz_synth_field_elements(int device_id, void* d_out, uint64_t n, uint64_t se
 /* ------------------------------------------------------------------ test hooks (element-wise kernels)
  * Run the device field / group primitives on arrays so tests can compare them one by one with the
  * CPU oracle.  Host pointers; canonical little-endian encodings.
- *   fq ops (field = 0: Fq, 1: Fr): 0 mul, 1 add, 2 sub, 3 inverse(a), 4 sqr(a)
- *   ec ops: 0 P+Q (mixed, P as accumulator), 1 2P, 2 P+Q (full XYZZ add), 3 P-Q (mixed, negated)
+ *   fq ops (field = 0: Fq, 1: Fr): 0 mul, 1 add, 2 sub, 3 inverse(a), 4 sqr(a), 5/6 a b +- (a + b)(a - b);
+ *     reduced-radix twin of the BLS base fields (all-zero output for other fields): 10 mul, 11 sqr,
+ *     12 a b + (a + b)(a - b), 13 (a - 3b) b, 14 [a == b]
+ *   ec ops: 0 P+Q (mixed, P as accumulator), 1 2P, 2 P+Q (full XYZZ add), 3 P-Q (mixed, negated),
+ *     4 / 5 P+Q / P-Q through the reduced-radix mixed add (BLS curves)
  *     points x||y; inf_flags[i] bit0: P is infinity, bit1: Q is infinity; out_inf[i]=1 if result inf */
 int blz_test_field_op(int device_id, int curve, int field, int op, const uint8_t* a, const uint8_t* b,
                       uint8_t* out, size_t n);

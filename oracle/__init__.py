@@ -42,7 +42,9 @@ def lib():
         L.orc_precompute_base.argtypes = [C.c_int, u8p, C.c_int, u8p]
         L.orc_msm_naive.argtypes = [C.c_int, C.c_void_p, C.c_void_p, u64, C.c_int, u8p]
         L.orc_input_generator.argtypes = [C.c_int, u64, C.c_int, u64, C.c_void_p, C.c_void_p, u8p]
+        L.orc_input_tile.argtypes = [C.c_int, u64, C.c_int, u64, C.c_void_p, C.c_void_p, u8p]
         L.orc_index_weighted_sum.argtypes = [C.c_int, C.c_void_p, u64, u64, u8p]
+        L.orc_index_weighted_sum_mt.argtypes = [C.c_int, C.c_void_p, u64, u64, C.c_int, u8p]
         L.orc_msm_pippenger.argtypes = [C.c_int, C.c_void_p, C.c_void_p, u64, C.c_int, C.c_int, C.c_int, u8p]
         L.orc_omega.argtypes = [C.c_int, C.c_int, u8p]
         L.orc_ntt.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
@@ -139,9 +141,24 @@ def input_generator(curve, n: int, pf: int, seed: int):
     return pts, sc, exp.raw
 
 
-def index_weighted_sum(curve, scalars, n: int, start: int = 0) -> int:
+def input_tile(curve, n: int, pf: int, seed: int):
+    """The generator's <= 256-element tile only (points, scalars) and the expected result for all n elements
+    (same stream as input_generator: input_generator(...) == tile repeated)."""
+    t = min(n, 256)
+    pts = bytearray(t * pf * point_bytes(curve))
+    sc = bytearray(t * 32)
+    exp = C.create_string_buffer(result_bytes(curve))
+    rc = lib().orc_input_tile(_cid(curve), n, pf, seed, _ptr(pts), _ptr(sc), exp)
+    assert rc == 0
+    return pts, sc, exp.raw
+
+
+def index_weighted_sum(curve, scalars, n: int, start: int = 0, threads: int = 1) -> int:
     out = C.create_string_buffer(32)
-    rc = lib().orc_index_weighted_sum(_cid(curve), _ptr(scalars), n, start, out)
+    if threads > 1:
+        rc = lib().orc_index_weighted_sum_mt(_cid(curve), _ptr(scalars), n, start, threads, out)
+    else:
+        rc = lib().orc_index_weighted_sum(_cid(curve), _ptr(scalars), n, start, out)
     assert rc == 0
     return int.from_bytes(out.raw, "little")
 

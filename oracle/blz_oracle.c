@@ -554,7 +554,8 @@ static void rand_scalar(const curve_t* c, u64* st, u64* k) { /* uniform in [0, r
 /* Generates the <=256-element tile and repeats it like the reference generator.
  * points: n*pf*pb bytes, scalars: n*32 bytes, expected: result bytes (Z=1|y|x) of
  * floor(n/256)*S_256 + S_(n%256)  (mod.rs:388-395), computed through the running sums. */
-int orc_input_generator(int curve, u64 n, int pf, u64 seed, uint8_t* points, uint8_t* scalars, uint8_t* expected) {
+static int input_generator_impl(int curve, u64 n, int pf, u64 seed, uint8_t* points, uint8_t* scalars, uint8_t* expected,
+                                int tile_only) {
     const curve_t* c = get_curve(curve);
     if (!c) return -1;
     int pb = 2 * c->fq.nbytes;
@@ -586,12 +587,14 @@ int orc_input_generator(int curve, u64 n, int pf, u64 seed, uint8_t* points, uin
     }
     if (n > 256) {
         u64 mult = n / 256, rest = n % 256;
-        for (u64 m = 1; m < mult; ++m) {
-            memcpy(points + m * 256 * pf * pb, points, 256 * (size_t)pf * pb);
-            memcpy(scalars + m * 256 * 32, scalars, 256 * 32);
+        if (!tile_only) {
+            for (u64 m = 1; m < mult; ++m) {
+                memcpy(points + m * 256 * pf * pb, points, 256 * (size_t)pf * pb);
+                memcpy(scalars + m * 256 * 32, scalars, 256 * 32);
+            }
+            memcpy(points + mult * 256 * pf * pb, points, rest * (size_t)pf * pb);
+            memcpy(scalars + mult * 256 * 32, scalars, rest * 32);
         }
-        memcpy(points + mult * 256 * pf * pb, points, rest * (size_t)pf * pb);
-        memcpy(scalars + mult * 256 * 32, scalars, rest * 32);
         aff_t s256;
         j_to_aff(c, &s256, &running[255]);
         u64 km[1] = {mult};
@@ -604,12 +607,57 @@ int orc_input_generator(int curve, u64 n, int pf, u64 seed, uint8_t* points, uin
     free(running);
     return 0;
 }
+int orc_input_generator(int curve, u64 n, int pf, u64 seed, uint8_t* points, uint8_t* scalars, uint8_t* expected) {
+    return input_generator_impl(curve, n, pf, seed, points, scalars, expected, 0);
+}
+/* Same generator, but only the (<= 256-element) tile is written: points = min(n,256)*pf*pb bytes, scalars =
+ * min(n,256)*32 bytes; `expected` is still the result for all n elements.  For the reference's largest shape
+ * (n = 2^26, pf = 8: 48 GiB of points, tests/integration_msm.rs:386-467) the caller repeats the tile itself. */
+int orc_input_tile(int curve, u64 n, int pf, u64 seed, uint8_t* points, uint8_t* scalars, uint8_t* expected) {
+    return input_generator_impl(curve, n, pf, seed, points, scalars, expected, 1);
+}
 
 /* ------------------------------------------------------------------------------------------
  * Linearity helper for full-size checks: the build's synthetic point set is P_i = (start+i+1)*G
  * so  sum s_i P_i = (sum s_i (start+i+1) mod r) G.  Returns the 32-byte LE canonical coefficient.
  * For pf=8 bases B_{i,j} = 2^(32 j) P_i the same coefficient applies (sum_j s_{i,j} 2^(32j) = s_i).
  * ------------------------------------------------------------------------------------------ */
+static void index_weighted_sum_range(const curve_t* c, const uint8_t* scalars, u64 lo, u64 hi, u64 start, u64* acc) {
+    const fctx* f = &c->fr;
+    memset(acc, 0, 32);
+    for (u64 i = lo; i < hi; ++i) {
+        u64 s[4], sm[MAXL] = {0}, w[MAXL] = {start + i + 1, 0, 0, 0, 0, 0}, wm[MAXL], p[MAXL];
+        scalar_from_bytes(s, scalars + 32 * i);
+        while (mp_cmp(s, f->m, 4) >= 0) mp_sub(s, s, f->m, 4);
+        memcpy(sm, s, sizeof(s));
+        f_to_mont(f, wm, w);
+        f_mul(f, p, sm, wm); /* = s*w plain (one operand Montgomery) */
+        f_add(f, acc, acc, p);
+    }
+}
+typedef struct { const curve_t* c; const uint8_t* scalars; u64 lo, hi, start; u64 acc[4]; } iws_job;
+static void* iws_worker(void* arg) {
+    iws_job* J = (iws_job*)arg;
+    index_weighted_sum_range(J->c, J->scalars, J->lo, J->hi, J->start, J->acc);
+    return NULL;
+}
+/* threaded form (full-size checks of bench.py: 2^26 scalars) */
+int orc_index_weighted_sum_mt(int curve, const uint8_t* scalars, u64 n, u64 start, int threads, uint8_t* out32) {
+    const curve_t* c = get_curve(curve);
+    if (!c) return -1;
+    if (threads < 1) threads = 1;
+    pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * threads);
+    iws_job* jobs = (iws_job*)malloc(sizeof(iws_job) * threads);
+    for (int t = 0; t < threads; ++t) {
+        jobs[t].c = c; jobs[t].scalars = scalars; jobs[t].lo = n * t / threads; jobs[t].hi = n * (t + 1) / threads; jobs[t].start = start;
+        pthread_create(&th[t], NULL, iws_worker, &jobs[t]);
+    }
+    u64 acc[4] = {0, 0, 0, 0};
+    for (int t = 0; t < threads; ++t) { pthread_join(th[t], NULL); f_add(&c->fr, acc, acc, jobs[t].acc); }
+    for (int b = 0; b < 32; ++b) out32[b] = (uint8_t)(acc[b / 8] >> (8 * (b % 8)));
+    free(th); free(jobs);
+    return 0;
+}
 int orc_index_weighted_sum(int curve, const uint8_t* scalars, u64 n, u64 start, uint8_t* out32) {
     const curve_t* c = get_curve(curve);
     if (!c) return -1;
@@ -633,30 +681,60 @@ int orc_index_weighted_sum(int curve, const uint8_t* scalars, u64 n, u64 start, 
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
     const curve_t* c;
-    const uint8_t* points;
-    const uint8_t* scalars;
     u64 n;
-    int pf, cbits, nwin, sbits;
-    const aff_t* aff; /* pre-decoded points (n*pf) */
-    const int32_t* digits; /* [npts][nwin] */
-    jac_t* win_sum;
-    int next_win;
+    int pf, cbits, nwin, sbits, nchunks;
+    const uint8_t* points; const uint8_t* scalars;
+    aff_t* aff;      /* decoded points (n*pf) */
+    int32_t* digits; /* [npts][nwin] signed window digits */
+    jac_t* win_sum;  /* [nwin][nchunks] */
+    int next_task, nthreads;
     pthread_mutex_t mu;
 } pip_t;
+typedef struct { pip_t* P; int tid; } pip_arg;
 
+/* round 1: decode the points and recode the scalars, one contiguous slice of the elements per thread */
+static void* pip_decode_worker(void* arg) {
+    pip_t* P = ((pip_arg*)arg)->P;
+    const int tid = ((pip_arg*)arg)->tid;
+    const curve_t* c = P->c;
+    const int pb = 2 * c->fq.nbytes, nwin = P->nwin, cbits = P->cbits;
+    u64 npts = P->n * P->pf;
+    u64 lo = npts * tid / P->nthreads, hi = npts * (tid + 1) / P->nthreads;
+    for (u64 i = lo; i < hi; ++i) {
+        aff_from_bytes(c, &P->aff[i], P->points + pb * i);
+        u64 k[5] = {0, 0, 0, 0, 0};
+        if (P->pf == 1) scalar_from_bytes(k, P->scalars + 32 * i);
+        else { const uint8_t* sp = P->scalars + 4 * i; k[0] = (u64)sp[0] | ((u64)sp[1] << 8) | ((u64)sp[2] << 16) | ((u64)sp[3] << 24); }
+        int carry = 0;
+        for (int w = 0; w < nwin; ++w) {
+            int bit = w * cbits;
+            u64 v = (k[bit / 64] >> (bit % 64));
+            if (bit % 64 + cbits > 64) v |= k[bit / 64 + 1] << (64 - bit % 64);
+            int64_t d = (int64_t)(v & (((u64)1 << cbits) - 1)) + carry;
+            carry = 0;
+            if (d > ((int64_t)1 << (cbits - 1))) { d -= (int64_t)1 << cbits; carry = 1; }
+            P->digits[i * nwin + w] = (int32_t)d;
+        }
+    }
+    return NULL;
+}
+/* round 2: tasks (window, chunk of the elements) from a shared counter: bucket sums of the chunk, then
+ * sum_b b * S_b by running sums */
 static void* pip_worker(void* arg) {
-    pip_t* P = (pip_t*)arg;
+    pip_t* P = ((pip_arg*)arg)->P;
     const curve_t* c = P->c;
     u64 npts = P->n * P->pf;
     u64 nb = (u64)1 << (P->cbits - 1);
     jac_t* buckets = (jac_t*)malloc(sizeof(jac_t) * (nb + 1));
     for (;;) {
         pthread_mutex_lock(&P->mu);
-        int w = P->next_win++;
+        int task = P->next_task++;
         pthread_mutex_unlock(&P->mu);
-        if (w >= P->nwin) break;
+        if (task >= P->nwin * P->nchunks) break;
+        const int w = task / P->nchunks, ch = task % P->nchunks;
+        u64 lo = npts * ch / P->nchunks, hi = npts * (ch + 1) / P->nchunks;
         memset(buckets, 0, sizeof(jac_t) * (nb + 1));
-        for (u64 i = 0; i < npts; ++i) {
+        for (u64 i = lo; i < hi; ++i) {
             int32_t d = P->digits[i * P->nwin + w];
             if (d == 0) continue;
             if (d > 0) {
@@ -674,7 +752,7 @@ static void* pip_worker(void* arg) {
             j_add(c, &run, &run, &buckets[b]);
             j_add(c, &sum, &sum, &run);
         }
-        P->win_sum[w] = sum;
+        P->win_sum[(size_t)w * P->nchunks + ch] = sum;
     }
     free(buckets);
     return NULL;
@@ -684,49 +762,40 @@ int orc_msm_pippenger(int curve, const uint8_t* points, const uint8_t* scalars, 
                       int cbits, uint8_t* out_result) {
     const curve_t* c = get_curve(curve);
     if (!c) return -1;
-    int pb = 2 * c->fq.nbytes;
     u64 npts = n * pf;
     int sbits = pf == 1 ? 256 : 32;
     if (cbits <= 0) {
         cbits = 4;
         while (((u64)1 << (cbits + 4)) < npts && cbits < 16) ++cbits;
     }
+    if (threads < 1) threads = 1;
     int nwin = (sbits + 1 + cbits - 1) / cbits;
-    aff_t* aff = (aff_t*)malloc(sizeof(aff_t) * (npts ? npts : 1));
-    int32_t* digits = (int32_t*)malloc(sizeof(int32_t) * (npts ? npts : 1) * nwin);
-    for (u64 i = 0; i < npts; ++i) aff_from_bytes(c, &aff[i], points + pb * i);
-    for (u64 i = 0; i < npts; ++i) {
-        u64 k[5] = {0, 0, 0, 0, 0};
-        if (pf == 1) scalar_from_bytes(k, scalars + 32 * i);
-        else { const uint8_t* s = scalars + 4 * i; k[0] = (u64)s[0] | ((u64)s[1] << 8) | ((u64)s[2] << 16) | ((u64)s[3] << 24); }
-        int carry = 0;
-        for (int w = 0; w < nwin; ++w) {
-            int bit = w * cbits;
-            u64 v = (k[bit / 64] >> (bit % 64));
-            if (bit % 64 + cbits > 64) v |= k[bit / 64 + 1] << (64 - bit % 64);
-            int64_t d = (int64_t)(v & (((u64)1 << cbits) - 1)) + carry;
-            carry = 0;
-            if (d > ((int64_t)1 << (cbits - 1))) { d -= (int64_t)1 << cbits; carry = 1; }
-            digits[i * nwin + w] = (int32_t)d;
-        }
-    }
     pip_t P;
     memset(&P, 0, sizeof(P));
-    P.c = c; P.n = n; P.pf = pf; P.cbits = cbits; P.nwin = nwin; P.sbits = sbits; P.aff = aff; P.digits = digits;
-    P.win_sum = (jac_t*)malloc(sizeof(jac_t) * nwin);
+    P.c = c; P.n = n; P.pf = pf; P.cbits = cbits; P.nwin = nwin; P.sbits = sbits; P.nthreads = threads;
+    P.points = points; P.scalars = scalars;
+    /* enough (window, chunk) tasks to keep every thread busy, but chunks long enough that the bucket reduce
+     * (2 * 2^(c-1) additions per task) stays small beside the accumulation */
+    P.nchunks = 1;
+    while (P.nchunks * nwin < 3 * threads && npts / (P.nchunks * 2) >= ((u64)8 << cbits)) P.nchunks *= 2;
+    P.aff = (aff_t*)malloc(sizeof(aff_t) * (npts ? npts : 1));
+    P.digits = (int32_t*)malloc(sizeof(int32_t) * (npts ? npts : 1) * nwin);
+    P.win_sum = (jac_t*)malloc(sizeof(jac_t) * nwin * P.nchunks);
     pthread_mutex_init(&P.mu, NULL);
-    if (threads < 1) threads = 1;
     pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * threads);
-    for (int t = 0; t < threads; ++t) pthread_create(&th[t], NULL, pip_worker, &P);
+    pip_arg* args = (pip_arg*)malloc(sizeof(pip_arg) * threads);
+    for (int t = 0; t < threads; ++t) { args[t].P = &P; args[t].tid = t; pthread_create(&th[t], NULL, pip_decode_worker, &args[t]); }
+    for (int t = 0; t < threads; ++t) pthread_join(th[t], NULL);
+    for (int t = 0; t < threads; ++t) pthread_create(&th[t], NULL, pip_worker, &args[t]);
     for (int t = 0; t < threads; ++t) pthread_join(th[t], NULL);
     jac_t acc;
     j_set_inf(&acc);
     for (int w = nwin - 1; w >= 0; --w) {
         for (int d = 0; d < cbits; ++d) j_dbl(c, &acc, &acc);
-        j_add(c, &acc, &acc, &P.win_sum[w]);
+        for (int ch = 0; ch < P.nchunks; ++ch) j_add(c, &acc, &acc, &P.win_sum[(size_t)w * P.nchunks + ch]);
     }
     encode_result(c, out_result, &acc);
-    free(th); free(P.win_sum); free(aff); free(digits);
+    free(th); free(args); free(P.win_sum); free(P.aff); free(P.digits);
     pthread_mutex_destroy(&P.mu);
     return 0;
 }
@@ -750,7 +819,8 @@ static void* ntt_stage_worker(void* arg) {
     ntt_job* J = (ntt_job*)arg;
     const fctx* f = &J->c->fr;
     u64 half = J->len / 2, nb = J->n / 2, step = J->n / J->len;
-    for (u64 t = J->tid; t < nb; t += J->nth) {
+    u64 t0 = nb * J->tid / J->nth, t1 = nb * (J->tid + 1) / J->nth;
+    for (u64 t = t0; t < t1; ++t) {
         u64 blk = t / half, k = t % half;
         u64* u = J->a + 4 * (blk * J->len + k);
         u64* v = u + 4 * half;
@@ -763,30 +833,74 @@ static void* ntt_stage_worker(void* arg) {
     }
     return NULL;
 }
+/* the three element-wise sweeps of orc_ntt (bit-reversed load, twiddle table, scaled store), split over threads */
+typedef struct { const curve_t* c; int phase, logn, tid, nth; u64 n; const uint8_t* in; uint8_t* out; u64* a; u64* tw;
+                 const u64* w; const u64* ninv; int inverse; } ntt_sweep;
+static void* ntt_sweep_worker(void* arg) {
+    ntt_sweep* S = (ntt_sweep*)arg;
+    const fctx* f = &S->c->fr;
+    if (S->phase == 0) {
+        u64 lo = S->n * S->tid / S->nth, hi = S->n * (S->tid + 1) / S->nth;
+        for (u64 i = lo; i < hi; ++i) {
+            u64 rev = 0;
+            for (int b = 0; b < S->logn; ++b) rev |= ((i >> b) & 1) << (S->logn - 1 - b);
+            u64 t[MAXL];
+            f_from_bytes(f, t, S->in + 32 * i);
+            memcpy(S->a + 4 * rev, t, 32);
+        }
+    } else if (S->phase == 1) {
+        u64 h = S->n / 2, lo = h * S->tid / S->nth, hi = h * (S->tid + 1) / S->nth;
+        if (lo < hi) {
+            /* cur = w^lo by square-and-multiply, then step */
+            u64 cur[MAXL], base[MAXL];
+            memcpy(cur, f->one, sizeof(cur));
+            memcpy(base, S->w, sizeof(base));
+            for (u64 e = lo; e; e >>= 1) {
+                if (e & 1) f_mul(f, cur, cur, base);
+                f_sqr(f, base, base);
+            }
+            for (u64 i = lo; i < hi; ++i) { memcpy(S->tw + 4 * i, cur, 32); f_mul(f, cur, cur, S->w); }
+        }
+    } else {
+        u64 lo = S->n * S->tid / S->nth, hi = S->n * (S->tid + 1) / S->nth;
+        for (u64 i = lo; i < hi; ++i) {
+            u64 t[MAXL];
+            memcpy(t, S->a + 4 * i, 32);
+            if (S->inverse) f_mul(f, t, t, S->ninv);
+            f_to_bytes(f, S->out + 32 * i, t);
+        }
+    }
+    return NULL;
+}
 int orc_ntt(int curve, const uint8_t* in, uint8_t* out, int logn, int inverse, int threads) {
     const curve_t* c = get_curve(curve);
     if (!c || logn > c->two_adicity) return -1;
     const fctx* f = &c->fr;
     u64 n = (u64)1 << logn;
+    if (threads < 1) threads = 1;
     u64* a = (u64*)malloc(32 * n);
-    for (u64 i = 0; i < n; ++i) {
-        u64 rev = 0;
-        for (int b = 0; b < logn; ++b) rev |= ((i >> b) & 1) << (logn - 1 - b);
-        u64 t[MAXL];
-        f_from_bytes(f, t, in + 32 * i);
-        memcpy(a + 4 * rev, t, 32);
-    }
+    u64* tw = (u64*)malloc(32 * (n / 2 ? n / 2 : 1));
+    pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * threads);
+    ntt_job* jobs = (ntt_job*)malloc(sizeof(ntt_job) * threads);
+    ntt_sweep* sw = (ntt_sweep*)malloc(sizeof(ntt_sweep) * threads);
     u64 w[MAXL];
     memcpy(w, c->root, sizeof(w));
     for (int i = 0; i < c->two_adicity - logn; ++i) f_sqr(f, w, w);
     if (inverse) f_inv(f, w, w);
-    u64* tw = (u64*)malloc(32 * (n / 2 ? n / 2 : 1));
-    u64 cur[MAXL];
-    memcpy(cur, f->one, sizeof(cur));
-    for (u64 i = 0; i < n / 2; ++i) { memcpy(tw + 4 * i, cur, 32); f_mul(f, cur, cur, w); }
-    if (threads < 1) threads = 1;
-    pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * threads);
-    ntt_job* jobs = (ntt_job*)malloc(sizeof(ntt_job) * threads);
+    u64 ninv[MAXL];
+    memset(ninv, 0, sizeof(ninv));
+    if (inverse) {
+        u64 nn[MAXL] = {n, 0, 0, 0, 0, 0};
+        f_to_mont(f, ninv, nn);
+        f_inv(f, ninv, ninv);
+    }
+    for (int phase = 0; phase < 2; ++phase) {   /* x[bitrev(i)] into a; tw[i] = w^i */
+        for (int t = 0; t < threads; ++t) {
+            sw[t] = (ntt_sweep){c, phase, logn, t, threads, n, in, out, a, tw, w, ninv, inverse};
+            pthread_create(&th[t], NULL, ntt_sweep_worker, &sw[t]);
+        }
+        for (int t = 0; t < threads; ++t) pthread_join(th[t], NULL);
+    }
     for (u64 len = 2; len <= n; len <<= 1) {
         for (int t = 0; t < threads; ++t) {
             jobs[t] = (ntt_job){c, a, n, len, tw, t, threads};
@@ -794,19 +908,12 @@ int orc_ntt(int curve, const uint8_t* in, uint8_t* out, int logn, int inverse, i
         }
         for (int t = 0; t < threads; ++t) pthread_join(th[t], NULL);
     }
-    u64 ninv[MAXL];
-    if (inverse) {
-        u64 nn[MAXL] = {n, 0, 0, 0, 0, 0};
-        f_to_mont(f, ninv, nn);
-        f_inv(f, ninv, ninv);
+    for (int t = 0; t < threads; ++t) {
+        sw[t] = (ntt_sweep){c, 2, logn, t, threads, n, in, out, a, tw, w, ninv, inverse};
+        pthread_create(&th[t], NULL, ntt_sweep_worker, &sw[t]);
     }
-    for (u64 i = 0; i < n; ++i) {
-        u64 t[MAXL];
-        memcpy(t, a + 4 * i, 32);
-        if (inverse) f_mul(f, t, t, ninv);
-        f_to_bytes(f, out + 32 * i, t);
-    }
-    free(a); free(tw); free(th); free(jobs);
+    for (int t = 0; t < threads; ++t) pthread_join(th[t], NULL);
+    free(a); free(tw); free(th); free(jobs); free(sw);
     return 0;
 }
 /* X[k] = sum_i x[i] (w^k)^i by Horner: one output coefficient of a transform of any size, O(n).

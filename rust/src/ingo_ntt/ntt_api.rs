@@ -1,0 +1,94 @@
+//! `NTTClient` of `/root/reference/src/ingo_ntt/ntt_api.rs:8-125` over libblaze_hip.  The transform: size 2^27 over
+//! the BLS12-381 scalar field, forward, natural order in and out, omega = 7^((r-1)/2^27) (the reference states none
+//! of these).
+use crate::{
+    driver_client::{hip_ffi::*, *},
+    error::*,
+};
+
+pub const NTT_LOG_SIZE: i32 = 27; // ntt_data.rs:65: NTT_SIZE = 2^27
+pub const NTT_WORD_SIZE: usize = 32; // ntt_data.rs:66
+
+pub enum NTT {
+    Ntt,
+}
+
+pub struct NTTClient {
+    nbytes: usize,
+    pub driver_client: DriverClient,
+    h: *mut BlzNtt,
+}
+unsafe impl Send for NTTClient {}
+
+pub struct NttInit {}
+
+#[derive(Debug, Clone)]
+pub struct NTTInput {
+    pub buf_host: usize,
+    pub data: Vec<u8>,
+}
+
+impl DriverPrimitive<NTT, NttInit, NTTInput, Vec<u8>> for NTTClient {
+    /// ntt_api.rs:26-31
+    fn new(_ptype: NTT, dclient: DriverClient) -> Self {
+        NTTClient::with_log_size(dclient, NTT_LOG_SIZE)
+    }
+
+    /// `todo!()` in the reference too (ntt_api.rs:33-35)
+    fn loaded_binary_parameters(&self) -> Vec<u32> {
+        todo!()
+    }
+
+    /// ntt_api.rs:37-56 writes the debug program; nothing to program here
+    fn initialize(&self, _: NttInit) -> Result<()> {
+        check(unsafe { blz_ntt_initialize(self.h) })
+    }
+
+    /// ntt_api.rs:58-70: select the buffer and AP_START
+    fn start_process(&self, buf_kernel: Option<usize>) -> Result<()> {
+        check(unsafe { blz_ntt_start_process(self.h, buf_kernel.unwrap()) })
+    }
+
+    /// ntt_api.rs:72-87: `NTTBanks::preprocess` and the 16 bank writes become one flat copy
+    fn set_data(&self, input: NTTInput) -> Result<()> {
+        check(unsafe { blz_ntt_set_data(self.h, input.buf_host, input.data.as_ptr(), input.data.len()) })
+    }
+
+    /// ntt_api.rs:89-108: the spin on AP_DONE
+    fn wait_result(&self) -> Result<()> {
+        check(unsafe { blz_ntt_wait_result(self.h) })
+    }
+
+    /// ntt_api.rs:110-124: 16 bank reads + `postprocess` become one flat copy
+    fn result(&self, buf_num: Option<usize>) -> Result<Option<Vec<u8>>> {
+        let mut res = vec![0u8; self.nbytes];
+        check(unsafe { blz_ntt_result(self.h, buf_num.unwrap(), res.as_mut_ptr(), res.len()) })?;
+        Ok(Some(res))
+    }
+}
+
+impl Drop for NTTClient {
+    fn drop(&mut self) {
+        unsafe { blz_ntt_free(self.h) }
+    }
+}
+
+impl NTTClient {
+    /// Smaller transforms exist for tests (the reference has no such knob).
+    pub fn with_log_size(dclient: DriverClient, log_size: i32) -> Self {
+        let mut h: *mut BlzNtt = std::ptr::null_mut();
+        check(unsafe { blz_ntt_new(dclient.id, log_size, &mut h) }).expect("blz_ntt_new failed");
+        NTTClient { nbytes: NTT_WORD_SIZE << log_size, driver_client: dclient, h }
+    }
+
+    /// Device time of the last transform in ms (HIP events around its three passes).
+    pub fn last_kernel_ms(&self) -> Result<f32> {
+        let mut v = 0f32;
+        check(unsafe { blz_ntt_last_kernel_ms(self.h, &mut v) })?;
+        Ok(v)
+    }
+
+    pub fn reset_engine(&self) -> Result<()> {
+        check(unsafe { blz_ntt_reset(self.h) })
+    }
+}

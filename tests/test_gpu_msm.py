@@ -30,6 +30,31 @@ def test_golden_vectors(gpu):
 
 
 @pytest.mark.parametrize("curve", CURVES)
+def test_known_answers_on_device(gpu, curve):
+    """Published constants, no oracle in the loop (tests/golden/kat.json): 1*G = G, 1*G + 1*G = 2G, and
+    (r-1)*G + 1*G = infinity, through the whole pipeline."""
+    with open(os.path.join(HERE, "golden", "kat.json")) as f:
+        kat = json.load(f)
+    c = pyref.CURVES[curve]
+    fb = c["fq_bytes"]
+    gx, gy = int(kat[f"{curve}_G_x"], 16), int(kat[f"{curve}_G_y"], 16)
+    g = gx.to_bytes(fb, "little") + gy.to_bytes(fb, "little")
+    one = (1).to_bytes(32, "little")
+    cl = msm_client(curve, 1)
+
+    def res(x, y):
+        return (1).to_bytes(fb, "little") + y.to_bytes(fb, "little") + x.to_bytes(fb, "little")
+
+    assert run_msm(cl, g, one, 1) == res(gx, gy)
+    assert run_msm(cl, g + g, one + one, 2) == res(int(kat[f"{curve}_2G_x"], 16), int(kat[f"{curve}_2G_y"], 16))
+    assert run_msm(cl, g, (2).to_bytes(32, "little"), 1) == res(int(kat[f"{curve}_2G_x"], 16), int(kat[f"{curve}_2G_y"], 16))
+    inf = bytes(fb) + (1).to_bytes(fb, "little") + bytes(fb)
+    assert run_msm(cl, g + g, (c["r"] - 1).to_bytes(32, "little") + one, 2) == inf
+    assert run_msm(cl, g, c["r"].to_bytes(32, "little"), 1) == inf      # r*G, the scalar taken as the integer it is
+    cl.close()
+
+
+@pytest.mark.parametrize("curve", CURVES)
 @pytest.mark.parametrize("pf", [1, 8])
 def test_reference_harness_sizes(gpu, orc, curve, pf):
     """tests/integration_msm.rs: sizes 2, 8192 (default MSM_SIZE) and the 256-tile boundaries; the
@@ -99,6 +124,72 @@ def test_hbm_modes(gpu, orc):
     cl2.reset()
     cl2.close()
     blaze_amd.lib().blz_arena_release(0)
+
+
+def test_arena_is_flat_memory(gpu, orc):
+    """load_data_to_hbm is a raw write into the card's memory (msm_api.rs:299-313): overlapping and adjacent loads
+    keep every byte they do not cover, a table loaded in pieces is one address range, and only the rewritten
+    points change in the next MSM (the Montgomery copy is refreshed for the written span alone)."""
+    curve = "BLS381"
+    blaze_amd.lib().blz_arena_release(0)
+    n = 1500
+    ptsA, sc, _ = orc.input_generator(curve, n, 1, 11)
+    ptsB, _, _ = orc.input_generator(curve, n, 1, 12)
+    cl = msm_client(curve, 1, PointMemoryType.HBM)
+    base = 0x40000
+    cl.load_data_to_hbm(ptsA[: 96 * 1000], base, 0)                     # [0, 1000)
+    cl.load_data_to_hbm(ptsB[96 * 500: 96 * 1500], base, 96 * 500)      # [500, 1500) overlaps the first load
+    mem = bytes(ptsA[: 96 * 500]) + bytes(ptsB[96 * 500: 96 * 1500])
+    assert cl.get_data_from_hbm(96 * 1500, base, 0) == mem              # the first 500 points survived
+    assert run_msm(cl, None, sc, n, hbm=(base, 0)) == orc.msm_pippenger(curve, mem, sc, n, 1, threads=4)
+    # rewrite 10 points in the middle: only they change
+    cl.load_data_to_hbm(ptsA[96 * 700: 96 * 710], base, 96 * 700)
+    mem = mem[: 96 * 700] + bytes(ptsA[96 * 700: 96 * 710]) + mem[96 * 710:]
+    assert cl.get_data_from_hbm(96 * 1500, base, 0) == mem
+    assert run_msm(cl, None, sc, n, hbm=(base, 0)) == orc.msm_pippenger(curve, mem, sc, n, 1, threads=4)
+    # a piece that only touches the end extends the same range; one before the start does too
+    cl.load_data_to_hbm(ptsB[: 96 * 100], base, 96 * 1500)
+    cl.load_data_to_hbm(ptsB[96 * 100: 96 * 164], base - 96 * 64, 0)
+    mem2 = bytes(ptsB[96 * 100: 96 * 164]) + mem + bytes(ptsB[: 96 * 100])
+    assert cl.get_data_from_hbm(len(mem2), base - 96 * 64, 0) == mem2
+    sc2 = (bytes(sc) * 2)[: 32 * 1664]
+    assert run_msm(cl, None, sc2, 1664, hbm=(base - 96 * 64, 0)) == orc.msm_pippenger(curve, mem2, sc2, 1664, 1, threads=4)
+    # a range with a hole that was never written is not readable
+    cl.load_data_to_hbm(ptsA[: 96 * 10], base + 96 * 5000, 0)
+    with pytest.raises(DriverClientError):
+        cl.get_data_from_hbm(96 * 4000, base, 0)
+    cl.close()
+    blaze_amd.lib().blz_arena_release(0)
+
+
+def test_arena_across_processes(gpu, orc, tmp_path):
+    """tests/integration_msm_hbm.rs:51-56: the bases were loaded by an earlier process.  Here a holder process
+    loads and exports them (blz_arena_export); this process attaches (blz_arena_attach) and runs the scalars-only
+    flow against bases it never loaded."""
+    import subprocess
+    import sys as _sys
+
+    curve, n = "BLS381", 4096
+    blaze_amd.lib().blz_arena_release(0)
+    pts, sc, exp = orc.input_generator(curve, n, 1, 21)
+    (tmp_path / "pts.bin").write_bytes(bytes(pts))
+    reg = str(tmp_path / "arena.reg")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    holder = subprocess.Popen([_sys.executable, os.path.join(HERE, "arena_holder.py"), str(tmp_path / "pts.bin"), str(0x2000), reg],
+                              stdin=subprocess.PIPE, stdout=subprocess.PIPE, env=env)
+    try:
+        line = holder.stdout.readline().decode().strip()
+        assert line == "READY", f"holder said {line!r}"
+        from blaze_amd.driver_client import DriverClient
+        DriverClient(0).arena_attach(reg)
+        cl = msm_client(curve, 1, PointMemoryType.HBM)
+        assert cl.get_data_from_hbm(96 * 16, 0x2000, 96 * 100) == bytes(pts[96 * 100: 96 * 116])
+        assert run_msm(cl, None, sc, n, hbm=(0x2000, 0)) == exp
+        cl.close()
+    finally:
+        blaze_amd.lib().blz_arena_release(0)       # unmap before the holder frees
+        holder.stdin.close()
+        holder.wait(timeout=60)
 
 
 def test_bn254_hbm_precompute_small(gpu, orc):
@@ -248,6 +339,60 @@ def test_config3_2e26_bn254_precompute_hbm_resident(gpu, orc):
     assert run_msm(cl, None, ds, n, hbm=(0, 0)) == exp
     cl.close(); ds.free()
     blaze_amd.lib().blz_arena_release(0)
+
+
+@pytest.mark.parametrize("curve", ["BLS377", "BLS381"])
+def test_reference_harness_2e24_dma(gpu, orc, curve):
+    """The reference's own big input shape: its generator's 256-element tile repeated (tests/msm/mod.rs:337-354),
+    host Vec<u8>s through set_data in DMA mode, n = 2^24, pf = 1 (tests/integration_msm.rs:571-650 runs the same
+    flow).  Every bucket that is hit holds 2^16 copies of the same point: P + P, runs split into units,
+    k_combine_units and the hot-bucket paths of the sort all carry the result."""
+    n = 1 << 24
+    tp, ts, exp = orc.input_tile(curve, n, 1, 31)
+    pts, sc = bytes(tp) * (n // 256), bytes(ts) * (n // 256)
+    cl = msm_client(curve, 1)
+    assert run_msm(cl, pts, sc, n) == exp
+    # ... and its negation: every scalar s -> r - s gives the opposite point
+    r = pyref.CURVES[curve]["r"]
+    tsn = b"".join(((r - int.from_bytes(ts[32 * i: 32 * i + 32], "little")) % r).to_bytes(32, "little") for i in range(256))
+    fb = pyref.CURVES[curve]["fq_bytes"]
+    q = pyref.CURVES[curve]["q"]
+    expn = exp[:fb] + ((q - int.from_bytes(exp[fb: 2 * fb], "little")) % q).to_bytes(fb, "little") + exp[2 * fb:]
+    assert run_msm(cl, pts, tsn * (n // 256), n) == expn
+    cl.close()
+
+
+@pytest.mark.parametrize("curve", ["BLS377", "BLS381"])
+def test_reference_max_shape_2e26_precompute(gpu, orc, curve):
+    """msm_bls12_377_precompute_max_test / msm_bls12_381_precompute_max_test (tests/integration_msm.rs:386-467):
+    n = 2^26, PRECOMPUTE_FACTOR = 8, the generator's tile repeated 2^18 times: 2^29 bases, 48 GiB.  The bases go
+    to the device arena in 3 GiB pieces (load_data_to_hbm, msm_api.rs:299-313) instead of one 48 GiB host
+    vector; set_data then carries the scalars only (msm_api.rs:163-174)."""
+    blaze_amd.lib().blz_arena_release(0)
+    n, pf = 1 << 26, 8
+    tp, ts, exp = orc.input_tile(curve, n, pf, 77)
+    tile_bytes = len(tp)                       # 256 * 8 * 96
+    reps = 1 << 14
+    chunk = bytes(tp) * reps                   # 3 GiB
+    cl = msm_client(curve, pf, PointMemoryType.HBM)
+    for k in range((n // 256) // reps):
+        cl.load_data_to_hbm(chunk, 0, k * len(chunk))
+    assert cl.get_data_from_hbm(tile_bytes, 0, 5 * len(chunk) + 3 * tile_bytes) == bytes(tp)
+    del chunk
+    assert run_msm(cl, None, bytes(ts) * (n // 256), n, hbm=(0, 0)) == exp
+    cl.close()
+    blaze_amd.lib().blz_arena_release(0)
+
+
+@pytest.mark.parametrize("curve", ["BLS377", "BLS381"])
+def test_reference_precompute_2e21_dma(gpu, orc, curve):
+    """The same precompute flow with the reference's exact call shape (points: Some(Vec<u8>) in DMA mode,
+    tests/integration_msm.rs:386-467) at 2^21 elements (2^24 bases, 1.5 GiB host vector)."""
+    n, pf = 1 << 21, 8
+    tp, ts, exp = orc.input_tile(curve, n, pf, 78)
+    cl = msm_client(curve, pf)
+    assert run_msm(cl, bytes(tp) * (n // 256), bytes(ts) * (n // 256), n) == exp
+    cl.close()
 
 
 def test_cpp_host_mirror(gpu, orc, tmp_path):

@@ -82,6 +82,40 @@ def test_double_buffer_contract(gpu, orc):
     cl.close()
 
 
+def test_parallel_correctness_reference_sequence(gpu, orc):
+    """ntt_parallel_test_correctness replayed call for call (tests/integration_ntt.rs:99-143): every cycle starts
+    the kernel on one buffer, READS the other buffer's result, writes the next input into it and only then waits.
+    Cycle 0 starts a transform on a buffer nobody wrote and reads a buffer nobody wrote: both must succeed (the
+    card's buffers simply exist); outputs are collected from cycle 2 on."""
+    logn, nof_vectors = 14, 3
+    n = 1 << logn
+    rng = random.Random(77)
+    in_vecs = [b"".join(rng.randrange(R).to_bytes(32, "little") for _ in range(n)) for _ in range(nof_vectors)]
+    ref_vecs = [bytes(orc.ntt("BLS381", v, logn, threads=8)) for v in in_vecs]
+    driver = NTTClient(NTT.Ntt, DriverClient(0), log_size=logn)
+    driver.initialize(NttInit())
+    outputs = []
+    for i in range(nof_vectors + 2):
+        buf_host = i % 2
+        buf_kernel = 1 - buf_host
+        driver.start_process(buf_kernel)
+        res = driver.result(buf_host)
+        assert len(res) == 32 * n
+        if i == 0:
+            assert bytes(res) == bytes(32 * n)          # never written: zero-filled, like freshly reset HBM
+        if i >= 2:
+            outputs.append(bytes(res))
+        driver.set_data(NTTInput(buf_host, in_vecs[min(i, nof_vectors - 1)]))
+        # the buffer under transform is off limits until wait_result
+        with pytest.raises(DriverClientError):
+            driver.result(buf_kernel)
+        with pytest.raises(DriverClientError):
+            driver.set_data(NTTInput(buf_kernel, in_vecs[0]))
+        driver.wait_result()
+    assert outputs == ref_vecs
+    driver.close()
+
+
 def test_full_size_2e27_properties(gpu, orc):
     """The reference shape (2^27 x 32 B = 4 GiB, ntt_data.rs:65-66).  Checked by: delta -> all ones,
     X[0] = sum x, sum_k X[k] = n x[0], spot coefficients against the O(n) Horner oracle."""
@@ -127,6 +161,42 @@ def test_full_size_2e27_properties(gpu, orc):
     for k in (0, 1, 2, 511, 512, 513, 1 << 18, (1 << 18) + 1, 99999999, n - 1):
         assert elem(z, k) == pow(w, k, R), k
     cl.close()
+
+
+def test_full_size_2e27_every_output(gpu, orc):
+    """Every one of the 2^27 outputs of the reference shape, byte for byte against the oracle's threaded radix-2
+    transform of the same 4 GiB input, and inverse(forward(x)) == x at 2^27 (the 512^3 kernel k_ntt512 only
+    ever runs at this size)."""
+    import numpy as np
+    logn = 27
+    n = 1 << logn
+    cl = NTTClient(NTT.Ntt, DriverClient(0), log_size=logn)
+    d_in = DeviceBuffer(0, 32 * n)
+    blaze_amd._lib.check(blaze_amd.lib().blz_synth_field_elements(0, d_in.ptr, n, 4242))
+    cl.set_data(NTTInput(0, d_in))
+    cl.initialize(NttInit())
+    cl.start_process(0)
+    cl.wait_result()
+    x = np.frombuffer(d_in.download(), dtype=np.uint8)
+    y = np.frombuffer(cl.result(0), dtype=np.uint8)
+    threads = max(1, min(64, (os.cpu_count() or 8)))
+    exp = np.frombuffer(orc.ntt("BLS381", x, logn, threads=threads), dtype=np.uint8)
+    if not np.array_equal(y, exp):
+        bad = np.flatnonzero(y.reshape(-1, 32) != exp.reshape(-1, 32))
+        raise AssertionError(f"2^27 forward transform differs from the oracle, first at element {int(bad[0]) // 32}")
+    del exp
+    # round trip on the device: the forward result goes back through the inverse transform
+    inv = NTTClient(NTT.Ntt, DriverClient(0), log_size=logn, inverse=True)
+    d_y = DeviceBuffer(0, 32 * n)
+    cl.result_device(0, d_y)
+    cl.close()
+    inv.set_data(NTTInput(0, d_y))
+    inv.initialize(NttInit())
+    inv.start_process(0)
+    inv.wait_result()
+    z = np.frombuffer(inv.result(0), dtype=np.uint8)
+    assert np.array_equal(z, x), "inverse(forward(x)) != x at 2^27"
+    inv.close(); d_in.free(); d_y.free()
 
 
 @pytest.mark.parametrize("logn", [3, 11, 19])

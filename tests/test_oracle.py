@@ -19,9 +19,14 @@ def _golden(name):
 
 def test_known_answers(orc):
     kat = _golden("kat.json")
-    for curve, key in (("BLS381", "BLS381"), ("BN254", "BN254")):
+    for curve, key in (("BLS381", "BLS381"), ("BN254", "BN254"), ("BLS377", "BLS377")):
         two_g = orc.generator_mul(curve, 2)
         fb = pyref.CURVES[curve]["fq_bytes"]
+        g = orc.generator_mul(curve, 1)
+        assert int.from_bytes(g[:fb], "little") == int(kat[f"{key}_G_x"], 16)
+        assert int.from_bytes(g[fb:], "little") == int(kat[f"{key}_G_y"], 16)
+        assert orc.generator_mul(curve, pyref.CURVES[curve]["r"]) is None          # r G = infinity
+        assert pyref.enc_point(curve, pyref.mul(curve, pyref.generator(curve), 2)) == two_g   # both implementations
         assert int.from_bytes(two_g[:fb], "little") == int(kat[f"{key}_2G_x"], 16)
         assert int.from_bytes(two_g[fb:], "little") == int(kat[f"{key}_2G_y"], 16)
     assert orc.omega("BLS381", 27) == int(kat["BLS381_omega_2_27"], 16)
