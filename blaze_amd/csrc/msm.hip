@@ -444,7 +444,6 @@ int MsmEngine::init(int device_id, int curve_id) {
         BLZ_HIP(hipHostMalloc((void**)&S.stats_h, 64), BLZ_ERR_UNKNOWN);
         memset(S.stats_h, 0, 64);
     }
-    BLZ_HIP(hipEventCreateWithFlags(&ev_inputs_consumed, hipEventDisableTiming), BLZ_ERR_UNKNOWN);
     BLZ_HIP(hipHostMalloc((void**)&combine_h, 256), BLZ_ERR_UNKNOWN);
     BLZ_TRY(stats.reserve(64));
     BLZ_TRY(result.reserve(256 * 64));
@@ -469,9 +468,7 @@ void MsmEngine::destroy() {
         if (S.stats_h) (void)hipHostFree(S.stats_h);
         S = MsmSlot();
     }
-    if (ev_inputs_consumed) (void)hipEventDestroy(ev_inputs_consumed);
-    ev_inputs_consumed = nullptr;
-    inputs_consumed_valid = false;
+    inputs_event = nullptr;
     if (combine_h) (void)hipHostFree(combine_h);
     combine_h = nullptr;
     (void)hipStreamDestroy(stream);
@@ -579,10 +576,9 @@ int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int 
         hipLaunchKernelGGL(k_scatter<1>, gp, b256, 0, st, sc, npts, (int)P.width[0], P.W, P.Bw, count.as<uint32_t>(), entries.as<uint32_t>());
     }
     BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
-    // the staged inputs (scalars, raw points) have been consumed: the next task's host -> device copies may
-    // overwrite them once this event has passed (msm_capi.hip makes its copy stream wait for it)
-    BLZ_HIP(hipEventRecord(ev_inputs_consumed, st), BLZ_ERR_UNKNOWN);
-    inputs_consumed_valid = true;
+    // the staged inputs (scalars, raw points) have been consumed: a later task's host -> device copies may
+    // overwrite this staging set once the caller's event has passed (msm_capi.hip's copy stream waits for it)
+    if (inputs_event) BLZ_HIP(hipEventRecord(inputs_event, st), BLZ_ERR_UNKNOWN);
     // No host round trip: the unit count stays on the device.  Buffers and grids are sized by the bound
     // (every bucket at most one short unit, plus entries / L full ones) and the kernels read the real count
     // from `stats`; the host copy below is for the log line and the sanity check of finish() only.

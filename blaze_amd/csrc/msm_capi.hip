@@ -25,8 +25,13 @@ struct blz_msm {
     uint32_t task_label = 0;
     struct Res { std::vector<uint8_t> bytes; uint32_t label; };
     std::deque<Res> results;
-    // staged input
-    DevBuf scalars_buf, points_raw, points_mont;
+    // staged input.  Host buffers land in one of TWO staging sets, used alternately: the copy of task k+1 must not
+    // wait for task k's digit sort (which itself waits for task k-1's accumulation), or the PCIe link idles for
+    // a sort per task; set_free[i] is recorded on the main stream when the task staged in set i has read it.
+    DevBuf scalars_buf[2], points_raw[2], points_mont;
+    hipEvent_t set_free[2] = {nullptr, nullptr};
+    bool set_used[2] = {false, false};
+    int stage_idx = 0, staged_set = -1;
     hipStream_t copy_stream = nullptr;  // host -> device staging: runs under the previous task's accumulation
     const void* d_scalars = nullptr;
     const void* d_points_mont = nullptr;
@@ -100,7 +105,10 @@ int launch_if_ready(blz_msm* h) {
     // bases in the arena: the shadow pointer is resolved now, not when the data was staged - a load by another
     // handle in between may have moved or re-converted the extent
     if (h->staged_from_arena) BLZ_TRY(arena_points_mont(h, h->staged_arena_pos, npts, &h->d_points_mont));
+    h->eng.inputs_event = h->staged_set >= 0 ? h->set_free[h->staged_set] : nullptr;
     BLZ_TRY(h->eng.run(h->d_points_mont, h->d_scalars, npts, sbits, &slot));
+    if (h->staged_set >= 0) h->set_used[h->staged_set] = true;
+    h->staged_set = -1;
     h->armed = false;
     h->data_ready = false;
     h->in_flight.push_back({slot, h->task_label});
@@ -133,10 +141,16 @@ int stage_common(blz_msm* h, bool have_points, const void* points, size_t points
     // way).
     hipStream_t cst = h->copy_stream;
     uint32_t npts = n * h->pf;
-    // the staging buffers are shared with the task enqueued before: its to-Montgomery pass and digit sort must
-    // have read them before this task's copies land (an event on the main stream, not a host wait)
-    if (!on_device && h->eng.inputs_consumed_valid)
-        BLZ_HIP(hipStreamWaitEvent(cst, h->eng.ev_inputs_consumed, 0), BLZ_ERR_UNKNOWN);
+    // this task's staging set was last used two tasks ago: its to-Montgomery pass and digit sort must have read
+    // it before the new copies land (an event on the main stream, not a host wait; normally long past)
+    const int set = h->stage_idx;
+    if (!on_device) {
+        if (h->set_used[set]) BLZ_HIP(hipStreamWaitEvent(cst, h->set_free[set], 0), BLZ_ERR_UNKNOWN);
+        h->stage_idx ^= 1;
+        h->staged_set = set;
+    } else {
+        h->staged_set = -1;
+    }
 
     if (have_points && has_hbm) {
         // msm_api.rs:203-206: load_data_to_hbm(points, addr, offset) first
@@ -165,10 +179,10 @@ int stage_common(blz_msm* h, bool have_points, const void* points, size_t points
             if (((uintptr_t)points) % 16) return fail(BLZ_ERR_INVALID_PARAM, "device points must be 16-byte aligned");
             BLZ_TRY(h->eng.points_to_mont(points, h->points_mont.p, npts));
         } else {
-            BLZ_TRY(h->points_raw.reserve(want_pts ? want_pts : 16));
-            if (want_pts) BLZ_HIP(hipMemcpyAsync(h->points_raw.p, points, want_pts, hipMemcpyHostToDevice, cst), BLZ_ERR_WRITE);
+            BLZ_TRY(h->points_raw[set].reserve(want_pts ? want_pts : 16));
+            if (want_pts) BLZ_HIP(hipMemcpyAsync(h->points_raw[set].p, points, want_pts, hipMemcpyHostToDevice, cst), BLZ_ERR_WRITE);
             BLZ_HIP(hipStreamSynchronize(cst), BLZ_ERR_WRITE);
-            BLZ_TRY(h->eng.points_to_mont(h->points_raw.p, h->points_mont.p, npts));
+            BLZ_TRY(h->eng.points_to_mont(h->points_raw[set].p, h->points_mont.p, npts));
         }
         h->d_points_mont = h->points_mont.p;
     }
@@ -176,9 +190,9 @@ int stage_common(blz_msm* h, bool have_points, const void* points, size_t points
         if (((uintptr_t)scalars) % 16) return fail(BLZ_ERR_INVALID_PARAM, "device scalars must be 16-byte aligned");
         h->d_scalars = scalars;
     } else {
-        BLZ_TRY(h->scalars_buf.reserve(scalars_len ? scalars_len : 16));
-        if (scalars_len) BLZ_HIP(hipMemcpyAsync(h->scalars_buf.p, scalars, scalars_len, hipMemcpyHostToDevice, cst), BLZ_ERR_WRITE);
-        h->d_scalars = h->scalars_buf.p;
+        BLZ_TRY(h->scalars_buf[set].reserve(scalars_len ? scalars_len : 16));
+        if (scalars_len) BLZ_HIP(hipMemcpyAsync(h->scalars_buf[set].p, scalars, scalars_len, hipMemcpyHostToDevice, cst), BLZ_ERR_WRITE);
+        h->d_scalars = h->scalars_buf[set].p;
         // the caller may drop its buffers as soon as we return (set_data is synchronous: utils.rs:71)
         BLZ_HIP(hipStreamSynchronize(cst), BLZ_ERR_WRITE);
     }
@@ -205,6 +219,9 @@ int blz_msm_new(int device_id, int mem_type, int is_precompute, int curve, blz_m
     int rc = h->eng.init(device_id, curve);
     if (rc == BLZ_OK && hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess)
         rc = fail(BLZ_ERR_UNKNOWN, "copy stream creation failed");
+    for (int i = 0; i < 2 && rc == BLZ_OK; ++i)
+        if (hipEventCreateWithFlags(&h->set_free[i], hipEventDisableTiming) != hipSuccess)
+            rc = fail(BLZ_ERR_UNKNOWN, "event creation failed");
     if (rc != BLZ_OK) {
         h->eng.destroy();
         delete h;
@@ -220,8 +237,11 @@ void blz_msm_free(blz_msm* h) {
     if (h->comm) (void)blz_msm_comm_free(h);
     h->eng.destroy();
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
-    h->scalars_buf.release();
-    h->points_raw.release();
+    for (int i = 0; i < 2; ++i) {
+        h->scalars_buf[i].release();
+        h->points_raw[i].release();
+        if (h->set_free[i]) (void)hipEventDestroy(h->set_free[i]);
+    }
     h->points_mont.release();
     delete h;
 }

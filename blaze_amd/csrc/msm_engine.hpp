@@ -53,8 +53,8 @@ struct MsmEngine {
     MsmSlot slots[MSM_QUEUE_DEPTH];
     int cur = 0;                   // slot of the task being enqueued
     DevBuf count, off, unit_off, unit_bucket, unit_order, lenhist, coarse, inter, slice_map, entries, partial, blocksums, stats, result;
-    hipEvent_t ev_inputs_consumed = nullptr;  // stream: the last enqueued task has read its scalars / raw points
-    bool inputs_consumed_valid = false;
+    hipEvent_t inputs_event = nullptr;   // set by the caller of run(): recorded on `stream` once the task has read
+                                         // its scalars / raw points (after the digit sort)
     uint8_t* combine_h = nullptr;  // pinned bytes of combine_partials
     MsmPlan last_plan;
     float last_ms[8] = {};
