@@ -103,6 +103,83 @@ BLZ_DEV void ptrr_madd(XYZZRR<Q>& acc, const AffineRR<Q>& q, bool neg) {
     acc.y = rr_as<1, XYZZRR<Q>::VY>(y3);
 }
 
+// 2 p for an accumulator (dbl-2008-s-1).  By value and out of line, like ptrr_mdbl_val.
+template <class Q, int TAG = 0>
+__device__ __noinline__ XYZZRR<Q> ptrr_dbl_val(XYZZRR<Q> p) {
+    XYZZRR<Q> r;
+    if (ptrr_is_inf(p)) { ptrr_set_inf(r); return r; }
+    const auto U = rr_add(p.y, p.y);                   // (2, 8)
+    Frr<Q, 1, 2> V, W, S, t, Msq, y3;
+    rr_sqr(V, U);
+    rr_mul(W, U, V);
+    rr_mul(S, p.x, V);
+    rr_sqr(t, p.x);
+    const auto M = rr_add(rr_add(t, t), t);            // (3, 6)
+    rr_sqr(Msq, M);
+    const auto X3 = rr_norm(rr_sub_twice<2>(Msq, S));  // (1, 10)
+    const auto D = rr_sub<5>(S, X3);                   // (3, 34)
+    const auto nW = rr_neg<2>(W);                      // (2, 4)
+    rr_mul2(y3, M, D, nW, p.y);                        // M (S - X3) - W Y1
+    r.x = rr_as<1, XYZZRR<Q>::VX>(X3);
+    r.y = rr_as<1, XYZZRR<Q>::VY>(y3);
+    rr_mul(r.zz, V, p.zz);
+    rr_mul(r.zzz, W, p.zzz);
+    return r;
+}
+
+// acc += q   (both accumulators; add-2008-s), inlined for the throughput-bound bucket reduce
+template <class Q, int TAG = 0>
+BLZ_DEV void ptrr_add(XYZZRR<Q>& acc, const XYZZRR<Q>& q) {
+    if (ptrr_is_inf(q)) return;
+    if (ptrr_is_inf(acc)) { acc = q; return; }
+    Frr<Q, 1, 2> U1, U2, S1, S2, PP, PPP, Qv, t, y3, zt;
+    rr_mul(U1, acc.x, q.zz);
+    rr_mul(U2, q.x, acc.zz);
+    rr_mul(S1, acc.y, q.zzz);
+    rr_mul(S2, q.y, acc.zzz);
+    const auto P = rr_sub<2>(U2, U1);                  // (3, 6)
+    const auto R = rr_sub<2>(S2, S1);                  // (3, 6)
+    if (__builtin_expect(rr_maybe_equal(U2, U1), 0)) {
+        if (rr_is_zero(P)) {
+            if (rr_is_zero(R)) acc = ptrr_dbl_val<Q, TAG>(q);
+            else ptrr_set_inf(acc);
+            return;
+        }
+    }
+    rr_sqr(PP, P);
+    rr_mul(PPP, P, PP);
+    rr_mul(Qv, U1, PP);
+    rr_sqr(t, R);
+    const auto X3 = rr_norm(rr_sub_twice<2>(rr_sub<2>(t, PPP), Qv));  // (1, 14)
+    const auto D = rr_sub<5>(Qv, X3);                  // (3, 34)
+    const auto nS1 = rr_neg<2>(S1);                    // (2, 4)
+    rr_mul2(y3, R, D, nS1, PPP);                       // R (Q - X3) - S1 PPP
+    acc.x = rr_as<1, XYZZRR<Q>::VX>(X3);
+    acc.y = rr_as<1, XYZZRR<Q>::VY>(y3);
+    rr_mul(zt, acc.zz, q.zz);
+    rr_mul(acc.zz, zt, PP);
+    rr_mul(zt, acc.zzz, q.zzz);
+    rr_mul(acc.zzz, zt, PPP);
+}
+
+// memory image of an accumulator: 4 x NL dwords (x | y | zz | zzz)
+template <class Q>
+BLZ_DEV void ptrr_load(XYZZRR<Q>& a, const uint32_t* base, size_t idx) {
+    const uint32_t* q = base + idx * 4 * Q::NL;
+    rr_load(a.x, q);
+    rr_load(a.y, q + Q::NL);
+    rr_load(a.zz, q + 2 * Q::NL);
+    rr_load(a.zzz, q + 3 * Q::NL);
+}
+template <class Q>
+BLZ_DEV void ptrr_store(uint32_t* base, size_t idx, const XYZZRR<Q>& a) {
+    uint32_t* q = base + idx * 4 * Q::NL;
+    rr_store(q, a.x);
+    rr_store(q + Q::NL, a.y);
+    rr_store(q + 2 * Q::NL, a.zz);
+    rr_store(q + 3 * Q::NL, a.zzz);
+}
+
 // accumulator -> ec.cuh's XYZZ over the 32-bit twin field (Montgomery R32, lazy [0, 2m)); infinity stays
 // literal zero
 template <class F>

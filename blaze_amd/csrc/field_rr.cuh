@@ -32,7 +32,7 @@ constexpr int rr_head() { return Q::B * Q::NL - Q::BITS; }  // log2(Rrr / 2^BITS
 
 template <class Q, int F = 1, int V = 2>
 struct Frr {
-    static_assert(F >= 1 && F <= 15 && V >= 1 && V <= (1 << rr_head<Q>()), "bound out of range");
+    static_assert(F >= 1 && F < (1 << (32 - Q::B)) && V >= 1 && V <= (1 << rr_head<Q>()), "bound out of range");
     uint32_t v[Q::NL];
 };
 
@@ -140,7 +140,7 @@ BLZ_DEV void rr_mul(Frr<Q, 1, 2>& r, const Frr<Q, Fa, Va>& a, const Frr<Q, Fb, V
 // r = a^2 / Rrr: the off-diagonal products once, against the doubled operand
 template <class Q, int Fa, int Va>
 BLZ_DEV void rr_sqr(Frr<Q, 1, 2>& r, const Frr<Q, Fa, Va>& a) {
-    static_assert(rr_cols_ok<Q>(Fa * Fa) && 2 * Fa <= 15, "column sum would overflow 64 bits");
+    static_assert(rr_cols_ok<Q>(Fa * Fa) && 2 * Fa < (1 << (32 - Q::B)), "column sum would overflow 64 bits");
     static_assert(rr_vals_ok<Q>(Va * Va), "product would leave the lazy value range");
     uint32_t a2[Q::NL];
 #pragma unroll

@@ -60,6 +60,37 @@ BLZ_DEV void load_affine_rr(AffineRR<typename F::RR>& a, const uint32_t* pts, ui
     for (int i = 0; i < Q::NL; ++i) { a.x.v[i] = w[i]; a.y.v[i] = w[Q::NL + i]; }
 }
 
+// dwords per unit / bucket sum in `partial`: fields with a reduced-radix twin keep the sums in it (4 x 14 limbs),
+// so neither the accumulation nor the first bucket-reduce level converts anything
+template <class F>
+constexpr int partial_dwords() {
+    if constexpr (USE_RR<F>) return 4 * F::RR::NL;
+    else return 4 * F::N;
+}
+// (for the few kernels that still work on 32-bit limbs: k_combine_units)
+template <class F>
+BLZ_DEV void load_partial32(XYZZ<F>& a, const uint32_t* partial, size_t idx) {
+    if constexpr (USE_RR<F>) {
+        XYZZRR<typename F::RR> r;
+        ptrr_load(r, partial, idx);
+        ptrr_to_xyzz32<F>(a, r);
+    } else {
+        const uint32_t* q = partial + idx * 4 * F::N;
+        fp_load(a.x, q); fp_load(a.y, q + F::N); fp_load(a.zz, q + 2 * F::N); fp_load(a.zzz, q + 3 * F::N);
+    }
+}
+template <class F>
+BLZ_DEV void store_partial32(uint32_t* partial, size_t idx, const XYZZ<F>& a) {
+    if constexpr (USE_RR<F>) {
+        XYZZRR<typename F::RR> r;
+        ptrr_from_xyzz32<F>(r, a);
+        ptrr_store(partial, idx, r);
+    } else {
+        uint32_t* q = partial + idx * 4 * F::N;
+        fp_store(q, a.x); fp_store(q + F::N, a.y); fp_store(q + 2 * F::N, a.zz); fp_store(q + 3 * F::N, a.zzz);
+    }
+}
+
 template <class F>
 BLZ_DEV void load_affine(Affine<F>& a, const uint32_t* pts, uint32_t idx) {
     const uint32_t* q = pts + (size_t)idx * MONT_STRIDE<F>;
@@ -139,9 +170,7 @@ __global__ __launch_bounds__(128, USE_RR<F> ? BLZ_ACC_RR_WAVES : 3) void k_accum
             ptrr_madd<Q, 1>(acc, cur, neg);
         }
 #endif
-        XYZZ<F> out;
-        ptrr_to_xyzz32<F>(out, acc);
-        store_xyzz(partial, u, out);
+        ptrr_store(partial, u, acc);
     } else {
         XYZZ<F> acc;
         pt_set_inf(acc);
@@ -199,15 +228,15 @@ __global__ __launch_bounds__(128, 3) void k_combine_units(const uint32_t* __rest
         const uint32_t u = unit_order[q * 16u + i];
         const uint32_t u1 = unit_off[unit_bucket[u] + 1];
         XYZZ<F> acc;
-        load_xyzz(acc, partial, u);
+        load_partial32(acc, partial, u);
         for (uint32_t j = 1; j < 16; ++j) {
             uint32_t v = u + j * stride;
             if (v >= u1) break;
             XYZZ<F> t;
-            load_xyzz(t, partial, v);
+            load_partial32(t, partial, v);
             quad_add(acc, t, ql);
         }
-        if (ql == 0) store_xyzz(partial, u, acc);
+        if (ql == 0) store_partial32(partial, u, acc);
     }
 }
 
@@ -263,6 +292,44 @@ __global__ __launch_bounds__(64, FIRST ? 2 : 3) void k_reduce_level(const uint32
     }
     store_xyzz(outA, (size_t)w * T + t, run);
     store_xyzz(outC, (size_t)w * T + t, cs);
+}
+
+// level 0 on the reduced-radix field (ec_rr.cuh): the bucket sums arrive in it straight from k_accumulate, the two
+// running sums stay in it, and only the segment's two results are converted to the 32-bit form the upper levels
+// (DPP quads) work in.  20 % fewer multiply-adds than the 32-bit full add, and no conversion per bucket.
+#ifndef BLZ_REDUCE_RR_WAVES
+#define BLZ_REDUCE_RR_WAVES 2
+#endif
+template <class F>
+__global__ __launch_bounds__(64, BLZ_REDUCE_RR_WAVES) void k_reduce_level0_rr(const uint32_t* __restrict__ inA,
+                                                                            const uint32_t* __restrict__ unit_off, uint32_t M,
+                                                                            uint32_t SEG, uint32_t T, int W,
+                                                                            uint32_t* __restrict__ outA, uint32_t* __restrict__ outC) {
+    using Q = typename F::RR;
+    const uint32_t tid = blockIdx.x * 64u + threadIdx.x;
+    if (tid >= T * (uint32_t)W) return;
+    const uint32_t w = tid / T, t = tid - w * T;
+    const uint32_t lo = t * SEG;
+    uint32_t hi = lo + SEG;
+    if (hi > M) hi = M;
+    XYZZRR<Q> run, s;
+    ptrr_set_inf(run);
+    ptrr_set_inf(s);
+    for (uint32_t i = hi; i-- > lo;) {
+        const size_t idx = (size_t)w * M + i;
+        const uint32_t u0 = unit_off[idx], u1 = unit_off[idx + 1];
+        if (u1 > u0) {
+            XYZZRR<Q> a;
+            ptrr_load(a, inA, u0);
+            ptrr_add<Q, 3>(run, a);
+        }
+        ptrr_add<Q, 3>(s, run);  // weights i + 1 at the first level
+    }
+    XYZZ<F> o;
+    ptrr_to_xyzz32<F>(o, run);
+    store_xyzz(outA, (size_t)w * T + t, o);
+    ptrr_to_xyzz32<F>(o, s);
+    store_xyzz(outC, (size_t)w * T + t, o);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -435,7 +502,7 @@ int run_tail_t(MsmEngine& E, const void* d_pts, uint32_t U) {
     const MsmPlan& P = E.last_plan;
     const uint64_t G = P.G;
     BLZ_TRY(E.unit_bucket.reserve(((size_t)U + 1) * 4));
-    BLZ_TRY(E.partial.reserve(((size_t)U + 1) * 16 * F::N));
+    BLZ_TRY(E.partial.reserve(((size_t)U + 1) * 4 * partial_dwords<F>()));
     BLZ_HIP(hipEventRecord(S.ev[1], st), BLZ_ERR_UNKNOWN);
 
     // ---- phase 1
@@ -484,8 +551,12 @@ int run_tail_t(MsmEngine& E, const void* d_pts, uint32_t U) {
         BLZ_TRY(oC.reserve((size_t)T * P.Wv * 16 * F::N));
         uint32_t nthreads = T * (uint32_t)P.Wv;
         if (level == 0) {
-            hipLaunchKernelGGL((k_reduce_level<F, true>), dim3((nthreads + 63) / 64), dim3(64), 0, st, curA, curC,
-                               E.unit_off.as<uint32_t>(), M, SEG, T, P.Wv, shift, oA.as<uint32_t>(), oC.as<uint32_t>());
+            if constexpr (USE_RR<F>)
+                hipLaunchKernelGGL(k_reduce_level0_rr<F>, dim3((nthreads + 63) / 64), dim3(64), 0, st, curA, E.unit_off.as<uint32_t>(), M,
+                                   SEG, T, P.Wv, oA.as<uint32_t>(), oC.as<uint32_t>());
+            else
+                hipLaunchKernelGGL((k_reduce_level<F, true>), dim3((nthreads + 63) / 64), dim3(64), 0, st, curA, curC,
+                                   E.unit_off.as<uint32_t>(), M, SEG, T, P.Wv, shift, oA.as<uint32_t>(), oC.as<uint32_t>());
             // the rest is a few lanes of sequential work: hand it to the tail stream, so this stream can
             // start the next task's sort while it runs
             BLZ_HIP(hipEventRecord(S.ev_l0, st), BLZ_ERR_UNKNOWN);

@@ -59,8 +59,9 @@ struct blz_ntt {
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;  // host<->buffer traffic, concurrent with the compute stream
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    DevBuf buf[2], scratch, tables;
+    DevBuf buf[2], scratch, tables, tables_rr;
     NttTables T{};
+    NttTablesRR TR{};
     bool in_flight = false;
     int in_flight_buf = -1;   // buffer under transform while in_flight
     float last_ms = 0.f;
@@ -106,7 +107,16 @@ int ntt_setup(blz_ntt* h) {
     h->T.t1 = p; p += 512 * 8;
     h->T.t2 = p; p += 512 * 8;
     h->T.ninv = h->inverse ? p : nullptr;
-    BLZ_TRY(h->ops->setup(h->stream, h->T, h->geom, h->inverse));
+    BLZ_TRY(h->tables_rr.reserve(NTT_RR_TABLE_BYTES));
+    {
+        uint32_t* q = h->tables_rr.as<uint32_t>();
+        for (int i = 0; i < 3; ++i) { h->TR.wpass[i] = q; q += 512 * NTT_RR_ENTRY_DWORDS; }
+        h->TR.t0 = q; q += 512 * NTT_RR_ENTRY_DWORDS;
+        h->TR.t1 = q; q += 512 * NTT_RR_ENTRY_DWORDS;
+        h->TR.t2 = q; q += 512 * NTT_RR_ENTRY_DWORDS;
+        h->TR.fin = q;
+    }
+    BLZ_TRY(h->ops->setup(h->stream, h->T, h->TR, h->geom, h->inverse));
     // both transform buffers exist from the start, zero-filled, like the card's two HBM buffers: the reference's
     // double-buffer loop opens with start_process on a buffer nobody wrote and result on the other
     // (tests/integration_ntt.rs:102-136, cycle 0)
@@ -120,7 +130,7 @@ int ntt_setup(blz_ntt* h) {
 }
 
 int launch_pass(blz_ntt* h, int pass, const void* in, void* out) {
-    return h->ops->pass(pass, h->stream, in, out, h->geom, h->T, h->cols_log[pass - 1], h->force_generic);
+    return h->ops->pass(pass, h->stream, in, out, h->geom, h->T, h->TR, h->cols_log[pass - 1], h->force_generic);
 }
 
 }  // namespace
@@ -166,7 +176,7 @@ void blz_ntt_free(blz_ntt* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    h->buf[0].release(); h->buf[1].release(); h->scratch.release(); h->tables.release();
+    h->buf[0].release(); h->buf[1].release(); h->scratch.release(); h->tables.release(); h->tables_rr.release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);

@@ -12,6 +12,18 @@ struct NttTables {  // all Montgomery form, device memory
     uint32_t* ninv;      // n^-1 (Montgomery) for the inverse transform, else nullptr
 };
 
+// reduced-radix twiddle tables of the 512-point kernel (ntt_rr.cuh): entries of 10 dwords (27-bit limbs), Montgomery
+// R_rr, < 2m
+struct NttTablesRR {
+    uint32_t* wpass[3];
+    uint32_t* t0;
+    uint32_t* t1;
+    uint32_t* t2;
+    uint32_t* fin;   // closing factor of the last pass: R_rr mod m (forward: x * 1) or n^-1 R_rr (inverse)
+};
+constexpr size_t NTT_RR_ENTRY_DWORDS = 10;
+constexpr size_t NTT_RR_TABLE_BYTES = (6 * 512 + 1) * NTT_RR_ENTRY_DWORDS * 4;
+
 struct NttGeom {
     int logA, logB, logC, logn;
 };
@@ -20,10 +32,10 @@ struct NttGeom {
 struct NttFieldOps {
     int two_adicity;
     // fill the twiddle tables (device memory already carved into T) for a 2^logn transform
-    int (*setup)(hipStream_t st, NttTables& T, const NttGeom& g, int inverse);
+    int (*setup)(hipStream_t st, NttTables& T, NttTablesRR& TR, const NttGeom& g, int inverse);
     // one of the three passes; cols_log is the tile width of the radix-2-in-LDS kernel
-    int (*pass)(int pass, hipStream_t st, const void* in, void* out, const NttGeom& g, const NttTables& T, int cols_log,
-                bool force_generic);
+    int (*pass)(int pass, hipStream_t st, const void* in, void* out, const NttGeom& g, const NttTables& T, const NttTablesRR& TR,
+                int cols_log, bool force_generic);
 };
 const NttFieldOps& ntt_ops_bls377();
 const NttFieldOps& ntt_ops_bls381();

@@ -3,6 +3,7 @@
 #pragma once
 #include "ntt_engine.hpp"
 #include "field.cuh"
+#include "ntt_rr.cuh"
 
 namespace blz {
 
@@ -391,7 +392,7 @@ __global__ __launch_bounds__(N8_THREADS, 2) void k_ntt512(const uint32_t* __rest
 // host launchers
 // ------------------------------------------------------------------------------------------------
 template <class Fr>
-int ntt_setup_t(hipStream_t st, NttTables& T, const NttGeom& g, int inverse) {
+int ntt_setup_t(hipStream_t st, NttTables& T, NttTablesRR& TR, const NttGeom& g, int inverse) {
     const int l = g.logn;
     if (l > Fr::TWO_ADICITY) return fail(BLZ_ERR_INVALID_PARAM, "log_size %d exceeds the field's two-adicity %d", l, Fr::TWO_ADICITY);
     if (inverse) hipLaunchKernelGGL(k_ntt_ninv<Fr>, dim3(1), dim3(64), 0, st, T.ninv, l);
@@ -404,14 +405,34 @@ int ntt_setup_t(hipStream_t st, NttTables& T, const NttGeom& g, int inverse) {
     hipLaunchKernelGGL(k_ntt_table<Fr>, dim3(2), dim3(256), 0, st, T.t0, 512, l, (uint64_t)1, inverse);
     hipLaunchKernelGGL(k_ntt_table<Fr>, dim3(2), dim3(256), 0, st, T.t1, 512, l, (uint64_t)512, inverse);
     hipLaunchKernelGGL(k_ntt_table<Fr>, dim3(2), dim3(256), 0, st, T.t2, 512, l, (uint64_t)1 << 18, inverse);
+    // the same tables in the reduced radix for the 512-point kernel (ntt_rr.cuh)
+    static_assert(Fr::RR::NL == NTT_RR_ENTRY_DWORDS, "table entry size");
+    for (int i = 0; i < 3; ++i)
+        hipLaunchKernelGGL(k_ntt_table_to_rr<Fr>, dim3(2), dim3(256), 0, st, T.wpass[i], TR.wpass[i], lrs[i] ? (1 << lrs[i]) : 1);
+    hipLaunchKernelGGL(k_ntt_table_to_rr<Fr>, dim3(2), dim3(256), 0, st, T.t0, TR.t0, 512);
+    hipLaunchKernelGGL(k_ntt_table_to_rr<Fr>, dim3(2), dim3(256), 0, st, T.t1, TR.t1, 512);
+    hipLaunchKernelGGL(k_ntt_table_to_rr<Fr>, dim3(2), dim3(256), 0, st, T.t2, TR.t2, 512);
+    hipLaunchKernelGGL(k_ntt_fin_rr<Fr>, dim3(1), dim3(64), 0, st, inverse ? T.ninv : (const uint32_t*)nullptr, TR.fin);
     BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
     return BLZ_OK;
 }
 
 template <class Fr, int PASS>
-int ntt_pass_t(hipStream_t st, const void* in, void* out, const NttGeom& g, const NttTables& T, int cl, bool force_generic) {
+int ntt_pass_t(hipStream_t st, const void* in, void* out, const NttGeom& g, const NttTables& T, const NttTablesRR& TR, int cl,
+               bool force_generic) {
     int lr = PASS == 1 ? g.logC : PASS == 2 ? g.logB : g.logA;
     const int cols_avail = PASS == 3 ? g.logC : g.logA;  // extent of the tile's column index
+    // BLAZE_NTT_RR=0: the 32-bit-limb 512-point kernel (kept for A/B measurements)
+    static const bool use_rr = []() { const char* e = getenv("BLAZE_NTT_RR"); return !(e && *e == '0'); }();
+    if (lr == 9 && cols_avail >= NR_COLS_LOG && !force_generic && use_rr) {
+        BLZ_TRY(ensure_dynamic_lds((const void*)k_ntt512_rr<Fr, PASS>, 160 * 1024));
+        const size_t ldsr = (size_t)512 * NR_COLS * Fr::RR::NL * 4;
+        const uint64_t tilesr = (1ull << g.logn) >> (9 + NR_COLS_LOG);
+        hipLaunchKernelGGL((k_ntt512_rr<Fr, PASS>), dim3((unsigned)tilesr), dim3(NR_THREADS), ldsr, st, (const uint32_t*)in,
+                           (uint32_t*)out, g, TR);
+        BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
+        return BLZ_OK;
+    }
     if (lr == 9 && cols_avail >= N8_COLS_LOG && !force_generic) {
         BLZ_TRY(ensure_dynamic_lds((const void*)k_ntt512<Fr, PASS>, 160 * 1024));
         size_t lds8 = (size_t)512 * N8_RS * 4;
@@ -431,12 +452,12 @@ int ntt_pass_t(hipStream_t st, const void* in, void* out, const NttGeom& g, cons
 }
 
 template <class Fr>
-int ntt_pass_dispatch(int pass, hipStream_t st, const void* in, void* out, const NttGeom& g, const NttTables& T, int cl,
-                      bool force_generic) {
+int ntt_pass_dispatch(int pass, hipStream_t st, const void* in, void* out, const NttGeom& g, const NttTables& T,
+                      const NttTablesRR& TR, int cl, bool force_generic) {
     switch (pass) {
-        case 1: return ntt_pass_t<Fr, 1>(st, in, out, g, T, cl, force_generic);
-        case 2: return ntt_pass_t<Fr, 2>(st, in, out, g, T, cl, force_generic);
-        default: return ntt_pass_t<Fr, 3>(st, in, out, g, T, cl, force_generic);
+        case 1: return ntt_pass_t<Fr, 1>(st, in, out, g, T, TR, cl, force_generic);
+        case 2: return ntt_pass_t<Fr, 2>(st, in, out, g, T, TR, cl, force_generic);
+        default: return ntt_pass_t<Fr, 3>(st, in, out, g, T, TR, cl, force_generic);
     }
 }
 

@@ -1,0 +1,312 @@
+// The 512-point NTT pass (k_ntt512 of ntt_impl.cuh) on the reduced-radix scalar field: 10 limbs of 27 bits
+// (field_rr.cuh; curve_constants.h Fr_*_RR).  Same decomposition (512 = 8 * 8 * 8, a lane holds 8 elements, two
+// LDS exchanges per pass, inter-pass twiddle stepped along the lane's outputs), different arithmetic:
+//   * a field product is 200 v_mad_u64_u32 (+ 19 shifts, 10 v_mul_lo) instead of 128 x (v_mad_u64_u32 +
+//     v_addc_co_u32);
+//   * a butterfly is 30 plain 32-bit adds / subs - no carry chain, no compare, no select - because the 5 spare
+//     bits per limb and the 15-17 spare bits of R_rr / m absorb three butterfly levels of growth: u - v is
+//     u + (k 2^J m - v) limb by limb, with the multiple of m in borrow form (tools/gen_constants.py);
+//   * every intermediate's limb and value bounds are part of its type, so the compiler proves that no 32-bit
+//     limb and no 64-bit column sum can overflow anywhere in the three DFT steps (a step's un-multiplied outputs
+//     are carry-propagated, not reduced: their value bound is carried into the next step's types).
+// Data in HBM stay 32-byte words (canonical on the wire, < 2m between passes), tile elements in LDS are 10
+// dwords (the 40-dword row of the 32-bit kernel: 4 x 10 instead of 4 x 8 + 8 of padding), twiddle tables hold
+// t R_rr mod m as 10 limbs.
+#pragma once
+#include "field_rr.cuh"
+#include "ntt_engine.hpp"
+
+namespace blz {
+
+template <class T> struct rr_bounds;
+template <class Q, int F, int V>
+struct rr_bounds<Frr<Q, F, V>> {
+    static constexpr int f = F, v = V;
+};
+
+// smallest J >= 1 with 2^(J-1) >= vb: the multiple 2^J m dominates any normalised b < vb m
+constexpr int rr_j_norm(int vb) {
+    int j = 1;
+    while ((1 << (j - 1)) < vb) ++j;
+    return j;
+}
+// smallest J >= 1 with (fb + 1) 2^J >= vb + 1: (fb + 1) x (2^J m in borrow form) dominates a lazy b limb by limb
+constexpr int rr_j_lazy(int fb, int vb) {
+    int j = 1;
+    while ((fb + 1) * (1 << j) < vb + 1) ++j;
+    return j;
+}
+
+template <class A, class B>
+struct RRPair {
+    A s;  // u + v
+    B d;  // u - v + (multiple of m)
+};
+
+// butterfly against a normalised v
+template <class Q, int Fu, int Vu, int Vv>
+BLZ_DEV auto rr_bfly(const Frr<Q, Fu, Vu>& u, const Frr<Q, 1, Vv>& v) {
+    constexpr int J = rr_j_norm(Vv);
+    static_assert(J <= Q::NKM, "no multiple of m that large");
+    RRPair<Frr<Q, Fu + 1, Vu + Vv>, Frr<Q, Fu + 2, Vu + (1 << J)>> r;
+#pragma unroll
+    for (int i = 0; i < Q::NL; ++i) {
+        r.s.v[i] = u.v[i] + v.v[i];
+        r.d.v[i] = u.v[i] + (Q::KM[J - 1][i] - v.v[i]);
+    }
+    return r;
+}
+// butterfly against a lazy v (limbs < Fv 2^B): the constant is (Fv + 1) x the borrow form, whose limbs are
+// >= (Fv + 1)(2^B - 1) >= Fv 2^B - 1
+template <class Q, int Fu, int Vu, int Fv, int Vv, std::enable_if_t<(Fv >= 2), int> = 0>
+BLZ_DEV auto rr_bfly(const Frr<Q, Fu, Vu>& u, const Frr<Q, Fv, Vv>& v) {
+    constexpr int K = Fv + 1, J = rr_j_lazy(Fv, Vv);
+    static_assert(J <= Q::NKM, "no multiple of m that large");
+    static_assert((unsigned long long)K << (Q::B + 1) <= (1ull << 32), "constant limb would overflow 32 bits");
+    RRPair<Frr<Q, Fu + Fv, Vu + Vv>, Frr<Q, Fu + 2 * K, Vu + K * (1 << J)>> r;
+#pragma unroll
+    for (int i = 0; i < Q::NL; ++i) {
+        r.s.v[i] = u.v[i] + v.v[i];
+        r.d.v[i] = u.v[i] + ((uint32_t)K * Q::KM[J - 1][i] - v.v[i]);
+    }
+    return r;
+}
+
+template <class T0, class T1, class T2, class T3, class T4, class T5, class T6, class T7>
+struct RROct {
+    T0 x0; T1 x1; T2 x2; T3 x3; T4 x4; T5 x5; T6 x6; T7 x7;
+    static constexpr int cmax(int a, int b) { return a > b ? a : b; }
+    static constexpr int maxv = cmax(cmax(cmax(rr_bounds<T0>::v, rr_bounds<T1>::v), cmax(rr_bounds<T2>::v, rr_bounds<T3>::v)),
+                                     cmax(cmax(rr_bounds<T4>::v, rr_bounds<T5>::v), cmax(rr_bounds<T6>::v, rr_bounds<T7>::v)));
+};
+template <class T0, class T1, class T2, class T3, class T4, class T5, class T6, class T7>
+BLZ_DEV RROct<T0, T1, T2, T3, T4, T5, T6, T7> rr_oct(const T0& a, const T1& b, const T2& c, const T3& d, const T4& e, const T5& f,
+                                                     const T6& g, const T7& h) {
+    return {a, b, c, d, e, f, g, h};
+}
+
+// in-register 8-point DFT, decimation in time: a[] holds x[0],x[4],x[2],x[6],x[1],x[5],x[3],x[7] (normalised, value
+// < VIN m); outputs in natural order, lazy.  w1, w2, w3 = w8, w8^2, w8^3 (Montgomery, R_rr).
+template <class Q, int VIN, class W>
+BLZ_DEV auto dft8_rr(const Frr<Q, 1, VIN> (&a)[8], const W& w1, const W& w2, const W& w3) {
+    const auto p01 = rr_bfly(a[0], a[1]);
+    const auto p23 = rr_bfly(a[2], a[3]);
+    const auto p45 = rr_bfly(a[4], a[5]);
+    const auto p67 = rr_bfly(a[6], a[7]);
+    Frr<Q, 1, 2> m3, m7;
+    rr_mul(m3, p23.d, w2);
+    rr_mul(m7, p67.d, w2);
+    const auto q02 = rr_bfly(p01.s, p23.s);
+    const auto q13 = rr_bfly(p01.d, m3);
+    const auto q46 = rr_bfly(p45.s, p67.s);
+    const auto q57 = rr_bfly(p45.d, m7);
+    Frr<Q, 1, 2> m5, m6, m7b;
+    rr_mul(m5, q57.s, w1);
+    rr_mul(m6, q46.d, w2);
+    rr_mul(m7b, q57.d, w3);
+    const auto r04 = rr_bfly(q02.s, q46.s);
+    const auto r15 = rr_bfly(q13.s, m5);
+    const auto r26 = rr_bfly(q02.d, m6);
+    const auto r37 = rr_bfly(q13.d, m7b);
+    return rr_oct(r04.s, r15.s, r26.s, r37.s, r04.d, r15.d, r26.d, r37.d);
+}
+
+// expands STMT for the 8 outputs of an RROct: X names the member, K its index
+// (variadic: the statement may contain template argument lists, whose commas the preprocessor would split on)
+#define BLZ_RR_FOR8(o, ...)                                                                                       \
+    { constexpr int K = 0; auto& X = (o).x0; __VA_ARGS__ } { constexpr int K = 1; auto& X = (o).x1; __VA_ARGS__ } \
+    { constexpr int K = 2; auto& X = (o).x2; __VA_ARGS__ } { constexpr int K = 3; auto& X = (o).x3; __VA_ARGS__ } \
+    { constexpr int K = 4; auto& X = (o).x4; __VA_ARGS__ } { constexpr int K = 5; auto& X = (o).x5; __VA_ARGS__ } \
+    { constexpr int K = 6; auto& X = (o).x6; __VA_ARGS__ } { constexpr int K = 7; auto& X = (o).x7; __VA_ARGS__ }
+
+// 10-dword tile elements: 8-byte LDS accesses (40-byte elements are not 16-byte aligned)
+template <class Q, int F, int V>
+BLZ_DEV void rr_lds_load(Frr<Q, F, V>& r, const uint32_t* lds, uint32_t dw) {
+    static_assert(Q::NL % 2 == 0, "even limb count");
+    const uint2* q = reinterpret_cast<const uint2*>(lds + dw);
+#pragma unroll
+    for (int i = 0; i < Q::NL / 2; ++i) {
+        uint2 x = q[i];
+        r.v[2 * i] = x.x;
+        r.v[2 * i + 1] = x.y;
+    }
+}
+template <class Q, int F, int V>
+BLZ_DEV void rr_lds_store(uint32_t* lds, uint32_t dw, const Frr<Q, F, V>& a) {
+    uint2* q = reinterpret_cast<uint2*>(lds + dw);
+#pragma unroll
+    for (int i = 0; i < Q::NL / 2; ++i) q[i] = make_uint2(a.v[2 * i], a.v[2 * i + 1]);
+}
+
+// out[j] = in[j] (32-bit Montgomery, R32) re-expressed in the reduced radix (Montgomery, R_rr)
+template <class Fr>
+__global__ void k_ntt_table_to_rr(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int count) {
+    using Q = typename Fr::RR;
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    Fp<Fr> w;
+    fp_load(w, in + (size_t)j * 8);
+    Frr<Q, 1, 2> r;
+    rr_from_mont32_words<Q>(r, w.v);
+    rr_store(out + (size_t)j * Q::NL, r);
+}
+// fin = R_rr mod m (inverse == 0) or n^-1 in Montgomery R_rr form (from the 32-bit ninv)
+template <class Fr>
+__global__ void k_ntt_fin_rr(const uint32_t* __restrict__ ninv32, uint32_t* __restrict__ out) {
+    using Q = typename Fr::RR;
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    Frr<Q, 1, 2> r;
+    if (ninv32) {
+        Fp<Fr> w;
+        fp_load(w, ninv32);
+        rr_from_mont32_words<Q>(r, w.v);
+    } else {
+        rr_one(r);
+    }
+    rr_store(out, r);
+}
+
+// w^e for e < 2^27 from the three 512-entry tables
+template <class Q>
+BLZ_DEV void tw_pow_rr(Frr<Q, 1, 2>& r, const NttTablesRR& T, uint32_t e) {
+    Frr<Q, 1, 2> a;
+    rr_load(r, T.t0 + (size_t)(e & 511u) * Q::NL);
+    const uint32_t e1 = (e >> 9) & 511u, e2 = e >> 18;
+    if (e1) { rr_load(a, T.t1 + (size_t)e1 * Q::NL); rr_mul(r, r, a); }
+    if (e2) { rr_load(a, T.t2 + (size_t)e2 * Q::NL); rr_mul(r, r, a); }
+}
+
+constexpr int NR_COLS_LOG = 2;
+constexpr int NR_COLS = 1 << NR_COLS_LOG;
+constexpr int NR_THREADS = 64 * NR_COLS;
+
+template <class Fr, int PASS>
+__global__ __launch_bounds__(NR_THREADS, 2) void k_ntt512_rr(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, NttGeom g,
+                                                            NttTablesRR T) {
+    using Q = typename Fr::RR;
+    constexpr uint32_t NL = Q::NL;
+    constexpr uint32_t RS = NR_COLS * NL;   // tile row stride in dwords (40: the 32-bit kernel's 4 x 8 + 8)
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t A = 1u << g.logA, B = 1u << g.logB, C = 1u << g.logC;
+    uint64_t col_base, fixed, in_base, in_rstride, in_cstride;
+    const uint64_t tile = blockIdx.x;
+    const uint32_t col = threadIdx.x & (NR_COLS - 1), n2 = threadIdx.x >> NR_COLS_LOG;
+    if (PASS == 1) {   // rows i2 (stride AB), cols i0 (stride 1), fixed i1
+        const uint64_t tiles_per = A >> NR_COLS_LOG;
+        fixed = tile / tiles_per;
+        col_base = (tile % tiles_per) << NR_COLS_LOG;
+        in_base = col_base + (uint64_t)A * fixed;
+        in_rstride = (uint64_t)A * B;
+        in_cstride = 1;
+    } else if (PASS == 2) {  // rows i1 (stride A), cols i0, fixed k2
+        const uint64_t tiles_per = A >> NR_COLS_LOG;
+        fixed = tile / tiles_per;
+        col_base = (tile % tiles_per) << NR_COLS_LOG;
+        in_base = col_base + (uint64_t)A * B * fixed;
+        in_rstride = A;
+        in_cstride = 1;
+    } else {  // rows i0 (stride 1, contiguous), cols k2 (stride AB), fixed k1
+        const uint64_t tiles_per = C >> NR_COLS_LOG;
+        fixed = tile / tiles_per;
+        col_base = (tile % tiles_per) << NR_COLS_LOG;
+        in_base = (uint64_t)A * fixed + (uint64_t)A * B * col_base;
+        in_rstride = 1;
+        in_cstride = (uint64_t)A * B;
+    }
+    const uint32_t* wp = T.wpass[PASS - 1];  // w512^j, j < 512
+    using W = Frr<Q, 1, 2>;
+    W w1, w2, w3;
+    rr_load(w1, wp + 64 * NL);
+    rr_load(w2, wp + 128 * NL);
+    rr_load(w3, wp + 192 * NL);
+
+    // ---- step 1: 8-point DFTs over n1 (rows 64 n1 + n2), straight from global memory.  The words on the wire are
+    // any 256-bit values (< 4m); between passes they are < 2m.
+    constexpr int BR[8] = {0, 4, 2, 6, 1, 5, 3, 7};
+    constexpr int VIN1 = 4;
+    Frr<Q, 1, VIN1> a1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t row = 64u * BR[j] + n2;
+        Fp<Fr> x;
+        fp_load(x, in + (in_base + row * in_rstride + col * in_cstride) * 8);
+        rr_from_words<Q>(a1[j], x.v);
+    }
+    auto o1 = dft8_rr<Q>(a1, w1, w2, w3);
+    constexpr int VS1 = decltype(o1)::maxv;   // an un-multiplied output is only carry-propagated: it keeps its value bound
+    BLZ_RR_FOR8(o1, {
+        Frr<Q, 1, VS1> y;
+        if (K != 0 && n2 != 0) {  // * w512^(n2 k1)
+            W w, t;
+            rr_load(w, wp + (size_t)(n2 * K) * NL);
+            rr_mul(t, X, w);
+            y = rr_as<1, VS1>(t);
+        } else {
+            y = rr_as<1, VS1>(rr_norm(X));
+        }
+        rr_lds_store(lds, (64u * K + n2) * RS + col * NL, y);
+    })
+    __syncthreads();
+    // ---- step 2a: lane (k1, n2', col): 8-point DFTs over n1' (rows 64 k1 + 8 n1' + n2')
+    const uint32_t k1 = n2 >> 3, n2p = n2 & 7u;
+    Frr<Q, 1, VS1> a2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) rr_lds_load(a2[j], lds, (64u * k1 + 8u * BR[j] + n2p) * RS + col * NL);
+    auto o2 = dft8_rr<Q>(a2, w1, w2, w3);
+    constexpr int VS2 = decltype(o2)::maxv;
+    __syncthreads();
+    BLZ_RR_FOR8(o2, {
+        Frr<Q, 1, VS2> y;
+        if (K != 0 && n2p != 0) {  // * w64^(n2' k1') = w512^(8 n2' k1')
+            W w, t;
+            rr_load(w, wp + (size_t)(8u * n2p * K) * NL);
+            rr_mul(t, X, w);
+            y = rr_as<1, VS2>(t);
+        } else {
+            y = rr_as<1, VS2>(rr_norm(X));
+        }
+        rr_lds_store(lds, (64u * k1 + 8u * K + n2p) * RS + col * NL, y);
+    })
+    __syncthreads();
+    // ---- step 2b: lane (k1, k1', col): 8-point DFTs over n2' (rows 64 k1 + 8 k1' + n2'); outputs k = k1 + 8 k1' + 64 k2'
+    // leave with the inter-pass twiddle (passes 1, 2) or the closing factor (pass 3), which also brings them back
+    // below 2m for the 32-byte word
+    const uint32_t k1p = n2 & 7u;
+    Frr<Q, 1, VS2> a3[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) rr_lds_load(a3[j], lds, (64u * k1 + 8u * k1p + BR[j]) * RS + col * NL);
+    auto o3 = dft8_rr<Q>(a3, w1, w2, w3);
+    const uint32_t kb = k1 + 8u * k1p;  // output row of x_(k2') is kb + 64 k2'
+    W w, step;
+    if (PASS == 1) {
+        // x(i0, i1, k2 = row) *= w^(row (i0 + A i1)),  m = i0 + A i1 < 2^18
+        const uint64_t m = col_base + col + ((uint64_t)fixed << g.logA);
+        tw_pow_rr<Q>(w, T, (uint32_t)(kb * m));
+        tw_pow_rr<Q>(step, T, (uint32_t)(64u * m));
+    } else if (PASS == 2) {
+        // x(i0, k1 = row, k2) *= w^(C i0 row)
+        const uint64_t m = (col_base + col) << g.logC;
+        tw_pow_rr<Q>(w, T, (uint32_t)(kb * m));
+        tw_pow_rr<Q>(step, T, (uint32_t)(64u * m));
+    } else {
+        rr_load(w, T.fin);
+    }
+    BLZ_RR_FOR8(o3, {
+        const uint32_t row = kb + 64u * K;
+        W t;
+        rr_mul(t, X, w);
+        Fp<Fr> y;
+        rr_to_words<Q>(y.v, t);
+        uint64_t oaddr;
+        if (PASS == 3) {
+            fp_csub_const<Fr, Fr::MOD>(y);   // < 2m -> canonical: the wire format
+            oaddr = (col_base + col) + (uint64_t)C * fixed + (uint64_t)C * B * row;
+        } else {
+            if (K != 7) rr_mul(w, w, step);  // twiddle x twiddle
+            oaddr = in_base + row * in_rstride + col;
+        }
+        fp_store(out + oaddr * 8, y);
+    })
+}
+
+}  // namespace blz

@@ -56,7 +56,7 @@ def rr_struct(name, m, n32, B, NL):
     v_mad_u64_u32 never overflow, so a 32x32 multiply-add is ONE instruction (field_rr.cuh)."""
     Rrr = 1 << (B * NL)
     assert Rrr > (m << 5), "value head-room of the lazy range"
-    nk = min(7, B * NL - m.bit_length() - 1)  # multiples 2^j m that still fit NL limbs
+    nk = min(14, B * NL - m.bit_length() - 1)  # multiples 2^j m that still fit NL limbs
     mask = (1 << B) - 1
 
     def L(v, cnt=NL):
@@ -101,7 +101,10 @@ def rr_struct(name, m, n32, B, NL):
 # reduced-radix twins: (field, B, NL)
 # (BN254's 254-bit field would take 9 x 29 bits, whose 64-bit column sums leave no room for lazy operands,
 # or 10 x 28 bits, which is no cheaper than 8 x 32 with carries: it stays on field.cuh)
-RR = {"Fq_BLS377": (28, 14), "Fq_BLS381": (28, 14)}
+# The scalar fields (NTT): 10 x 27 bits = 270 bits.  15-17 bits of value head-room and 5 spare bits per limb keep a
+# whole 8-point DFT (three butterfly levels) free of carries AND of normalisations; 9 x 29 bits would be 21 % fewer
+# multiply-adds per product but needs a carry propagation per butterfly level, which costs more than it saves.
+RR = {"Fq_BLS377": (28, 14), "Fq_BLS381": (28, 14), "Fr_BLS377": (27, 10), "Fr_BLS381": (27, 10), "Fr_BN254": (27, 10)}
 
 
 def main():
@@ -132,7 +135,11 @@ def main():
         extra.append(f"    static constexpr int TWO_ADICITY = {s};")
         extra.append(f"    static constexpr uint32_t ROOT[8] = {{{limbs(root * Rr % r, 8)}}};  // primitive 2^{s}-th root, Montgomery")
         extra.append(f"    static constexpr uint32_t ROOT_INV[8] = {{{limbs(pow(root, -1, r) * Rr % r, 8)}}};  // its inverse, Montgomery")
-        extra.append("    using RR = void;")
+        if f"Fr_{name}" in RR:
+            o.append(rr_struct(f"Fr_{name}_RR", r, 8, *RR[f"Fr_{name}"]))
+            extra.append(f"    using RR = Fr_{name}_RR;  // reduced-radix twin (field_rr.cuh), used by the 2^27 NTT")
+        else:
+            extra.append("    using RR = void;")
         o.append(field_struct(f"Fr_{name}", r, 8, "\n".join(extra)))
         o.append(f"struct Curve_{name} {{ using Fq = Fq_{name}; using Fr = Fr_{name}; static constexpr int ID = {cid}; }};")
     o.append("}  // namespace blz")
