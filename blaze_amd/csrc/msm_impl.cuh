@@ -152,7 +152,25 @@ __global__ __launch_bounds__(128, USE_RR<F> ? BLZ_ACC_RR_WAVES : 3) void k_accum
 #if BLZ_ACC_RR_WAVES == 2
         AffineRR<Q> nxt;
         load_affine_rr<F>(nxt, pts, e & 0x7fffffffu);
-        for (uint32_t j = start; j < end; ++j) {
+        uint32_t j = start;
+#ifndef BLZ_ACC_NO_AADD
+        if (end - start >= 2) {
+            // the run's first two points are both affine: a cheaper addition than the mixed one (ptrr_aadd);
+            // units are ordered by length, so the lanes of a wave take this branch together
+            const AffineRR<Q> p0 = nxt;
+            const bool neg0 = (e & 0x80000000u) != 0;
+            const uint32_t e1 = entries[start + 1];
+            AffineRR<Q> p1;
+            load_affine_rr<F>(p1, pts, e1 & 0x7fffffffu);
+            if (start + 2 < end) {
+                e = entries[start + 2];
+                load_affine_rr<F>(nxt, pts, e & 0x7fffffffu);
+            }
+            ptrr_aadd<Q, 1>(acc, p0, neg0, p1, (e1 & 0x80000000u) != 0);
+            j = start + 2;
+        }
+#endif
+        for (; j < end; ++j) {
             const AffineRR<Q> cur = nxt;
             const bool neg = (e & 0x80000000u) != 0;
             if (j + 1 < end) {

@@ -119,6 +119,24 @@ __global__ __launch_bounds__(64) void k_test_ec(int op, const uint32_t* p, const
                 pt_set_inf(acc);
             }
             break;
+        case 6: case 7:   // both operands affine (the first addition of a run, ptrr_aadd): 6 = P + Q, 7 = Q - P
+            if constexpr (USE_RR<F>) {
+                using QQ = typename F::RR;
+                AffineRR<QQ> p, q;
+                rr_from_mont32_words<QQ>(p.x, P.x.v);
+                rr_from_mont32_words<QQ>(p.y, P.y.v);
+                rr_from_mont32_words<QQ>(q.x, Q.x.v);
+                rr_from_mont32_words<QQ>(q.y, Q.y.v);
+                XYZZRR<QQ> a;
+                ptrr_set_inf(a);
+                if (fl == 0) ptrr_aadd<QQ, 2>(a, p, op == 7, q, false);
+                else if (fl == 1) ptrr_madd<QQ, 2>(a, q, false);
+                else if (fl == 2) ptrr_madd<QQ, 2>(a, p, op == 7);
+                ptrr_to_xyzz32<F>(acc, a);
+            } else {
+                pt_set_inf(acc);
+            }
+            break;
         default: if (!(fl & 2)) { fp_neg(Q.y, Q.y); pt_madd(acc, Q); } break;
     }
     Affine<F> r;

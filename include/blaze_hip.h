@@ -232,7 +232,8 @@ int blz_synth_field_elements(int device_id, void* d_out, uint64_t n, uint64_t se
  *     reduced-radix twin of the BLS base fields (all-zero output for other fields): 10 mul, 11 sqr,
  *     12 a b + (a + b)(a - b), 13 (a - 3b) b, 14 [a == b]
  *   ec ops: 0 P+Q (mixed, P as accumulator), 1 2P, 2 P+Q (full XYZZ add), 3 P-Q (mixed, negated),
- *     4 / 5 P+Q / P-Q through the reduced-radix mixed add (BLS curves)
+ *     4 / 5 P+Q / P-Q through the reduced-radix mixed add (BLS curves); 6 / 7 P+Q / Q-P with both operands
+ *     affine (the first addition of a bucket run)
  *     points x||y; inf_flags[i] bit0: P is infinity, bit1: Q is infinity; out_inf[i]=1 if result inf */
 int blz_test_field_op(int device_id, int curve, int field, int op, const uint8_t* a, const uint8_t* b,
                       uint8_t* out, size_t n);
