@@ -119,61 +119,12 @@ BLZ_DEV void fp_dbl(Fp<P>& r, const Fp<P>& a) { fp_add(r, a, a); }
 // ------------------------------------------------------------------------------------------
 // Montgomery multiplication.
 //
-// fp_mul_cios: plain C++ coarsely-integrated operand scanning (what hipcc schedules by itself: per
-//   MAC one v_mad_u64_u32 plus ~2 v_mov and a 64-bit add - kept as the readable reference variant).
 // fp_mul_ps:   finely-integrated PRODUCT scanning with a 96-bit column accumulator (lo64, hi32):
 //   every MAC is exactly  v_mad_u64_u32 lo64 += x*y (carry -> SGPR pair) ; v_addc_co_u32 hi32 += carry
 //   i.e. 2 issue slots per 32x32 MAC and no register shuffling; modulus limbs ride the constant bus
 //   as SGPRs.  One accumulator for a*b and q*m products (a second one costs a 3-add merge per
 //   column and measured slower); the dependent v_mad chain is covered by the other waves.
 // ------------------------------------------------------------------------------------------
-template <class P>
-BLZ_DEV void fp_mul_cios(Fp<P>& r, const Fp<P>& a, const Fp<P>& b) {
-    constexpr int N = P::N;
-    uint32_t t[N + 1];
-#pragma unroll
-    for (int j = 0; j <= N; ++j) t[j] = 0;
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        uint64_t c = 0;
-        const uint32_t bi = b.v[i];
-#pragma unroll
-        for (int j = 0; j < N; ++j) {
-            c += (uint64_t)a.v[j] * bi + t[j];
-            t[j] = (uint32_t)c;
-            c >>= 32;
-        }
-        c += t[N];
-        t[N] = (uint32_t)c;
-        uint32_t hi = (uint32_t)(c >> 32);
-        const uint32_t m = t[0] * P::N0;
-        c = (uint64_t)m * P::MOD[0] + t[0];
-        c >>= 32;
-#pragma unroll
-        for (int j = 1; j < N; ++j) {
-            c += (uint64_t)m * P::MOD[j] + t[j];
-            t[j - 1] = (uint32_t)c;
-            c >>= 32;
-        }
-        c += t[N];
-        t[N - 1] = (uint32_t)c;
-        t[N] = hi + (uint32_t)(c >> 32);
-    }
-    if constexpr (P::LAZY) {
-#pragma unroll
-        for (int j = 0; j < N; ++j) r.v[j] = t[j];
-    } else {
-        // t < 2m, possibly with t[N] = 1
-        uint32_t u[N];
-        uint32_t br = 0;
-#pragma unroll
-        for (int j = 0; j < N; ++j) u[j] = sub_bb(t[j], P::MOD[j], br);
-        uint32_t keep = (t[N] == 0) & br;  // t < m
-#pragma unroll
-        for (int j = 0; j < N; ++j) r.v[j] = keep ? t[j] : u[j];
-    }
-}
-
 // gfx950 hazard: a VALU instruction that reads an SGPR (here: the carry) written by a previous VALU
 // instruction needs 2 wait states in between (LLVM GCNHazardRecognizer, VALUWriteSGPRVALURead; hipcc
 // pads its own v_add_co/v_addc pairs with s_nop 1).  Inside an asm statement nothing is padded, so
@@ -443,17 +394,8 @@ BLZ_DEV void fp_canon_wide(Fp<P>& a) {
     for (int i = 0; i < P::N; ++i) a.v[i] = br ? a.v[i] : u[i];
 }
 
-#ifndef BLZ_MUL_VARIANT
-#define BLZ_MUL_VARIANT 1
-#endif
 template <class P>
-BLZ_DEV void fp_mul(Fp<P>& r, const Fp<P>& a, const Fp<P>& b) {
-#if BLZ_MUL_VARIANT == 0
-    fp_mul_cios(r, a, b);
-#else
-    fp_mul_ps(r, a, b);
-#endif
-}
+BLZ_DEV void fp_mul(Fp<P>& r, const Fp<P>& a, const Fp<P>& b) { fp_mul_ps(r, a, b); }
 
 template <class P>
 BLZ_DEV void fp_sqr(Fp<P>& r, const Fp<P>& a) { fp_mul(r, a, a); }

@@ -10,7 +10,6 @@
 //   k_combine_units   only when a bucket needed more than one unit
 //   k_reduce_level Sum_b b*S_b per virtual window by segmented running sums        [phase 2]
 //   k_finish       stitch virtual windows, Horner over windows, one inversion, Z=1|y|x  [phase 3]
-// (k_count / k_scatter below: the original one-global-atomic-per-entry sort, BLAZE_MSM_SORT=0.)
 //
 // HBM layout: points AoS Montgomery (one 128-B line per BLS point, 64 B per BN254 point), scalars raw
 // 32 B LE, entries u32, bucket partials AoS XYZZ (4N dwords).  The arithmetic (v_mad_u64_u32) bounds
@@ -119,44 +118,6 @@ MsmPlan make_plan(uint32_t npts, int sbits, int ebits, int force_c) {
         best.L = L;
     }
     return best;
-}
-
-template <int SW>
-__global__ __launch_bounds__(256) void k_count(const uint32_t* __restrict__ scalars, uint32_t npts, int c, int W,
-                                               uint32_t Bw, uint32_t* __restrict__ count) {
-    uint32_t p = blockIdx.x * 256u + threadIdx.x;
-    if (p >= npts) return;
-    ScalarWords<SW> sw;
-    sw.load(scalars, p);
-    const uint32_t mask = (1u << c) - 1u, half = 1u << (c - 1);
-    uint32_t carry = 0;
-    for (int w = 0; w < W; ++w) {
-        int d = sw.next(c, mask, half, carry);
-        if (d != 0) {
-            uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1u;
-            atomicAdd(&count[(size_t)w * Bw + b], 1u);
-        }
-    }
-}
-
-template <int SW>
-__global__ __launch_bounds__(256) void k_scatter(const uint32_t* __restrict__ scalars, uint32_t npts, int c, int W,
-                                                 uint32_t Bw, uint32_t* __restrict__ cursor,
-                                                 uint32_t* __restrict__ entries) {
-    uint32_t p = blockIdx.x * 256u + threadIdx.x;
-    if (p >= npts) return;
-    ScalarWords<SW> sw;
-    sw.load(scalars, p);
-    const uint32_t mask = (1u << c) - 1u, half = 1u << (c - 1);
-    uint32_t carry = 0;
-    for (int w = 0; w < W; ++w) {
-        int d = sw.next(c, mask, half, carry);
-        if (d != 0) {
-            uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1u;
-            uint32_t pos = atomicAdd(&cursor[(size_t)w * Bw + b], 1u);
-            entries[pos] = p | (d < 0 ? 0x80000000u : 0u);
-        }
-    }
 }
 
 // zero-fill (hipMemsetAsync's fill kernel took 0.7 ms for the 71 MB bucket-count array: ~100 GB/s)
@@ -526,12 +487,8 @@ int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int 
         S.busy = true;
         return BLZ_OK;
     }
-    // BLAZE_MSM_SORT=0 selects the one-global-atomic-per-entry path (kept for A/B measurements; it only
-    // knows uniform windows)
-    const bool lds_sort = msm_env_int("BLAZE_MSM_SORT", 1) != 0;
     const int ebits = sbits == 256 ? kScalarFieldBits[curve] : sbits;
     MsmPlan P = make_plan(npts, sbits, ebits, msm_env_int("BLAZE_MSM_C", 0));
-    if (!lds_sort && P.c) P = make_plan(npts, sbits, ebits, P.width[0]);
     if (P.c == 0) return fail(BLZ_ERR_INVALID_PARAM, "no window plan for npts=%u sbits=%d", npts, sbits);
     P.L = (uint32_t)msm_env_int("BLAZE_MSM_L", (int)P.L);
     if (P.L < 1) P.L = 1;
@@ -555,26 +512,14 @@ int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int 
         hipLaunchKernelGGL(k_zero, dim3(2048), dim3(256), 0, st, (uint4*)count.p, n16);
     }
     BLZ_HIP(hipMemsetAsync(stats.p, 0, 64, st), BLZ_ERR_UNKNOWN);
-    const uint32_t* sc = (const uint32_t*)d_scalars;
-    dim3 gp((npts + 255) / 256), b256(256);
-    if (lds_sort) {
-        BLZ_TRY(msm_sort_lds(E, d_scalars, npts, sbits));
-    } else {
-        if (sbits == 256) hipLaunchKernelGGL(k_count<8>, gp, b256, 0, st, sc, npts, (int)P.width[0], P.W, P.Bw, count.as<uint32_t>());
-        else hipLaunchKernelGGL(k_count<1>, gp, b256, 0, st, sc, npts, (int)P.width[0], P.W, P.Bw, count.as<uint32_t>());
-    }
+    dim3 b256(256);
+    BLZ_TRY(msm_sort_lds(E, d_scalars, npts, sbits));
     hipLaunchKernelGGL(k_scan_reduce, dim3(nscan), b256, 0, st, count.as<uint32_t>(), G, P.L, blocksums.as<uint64_t>(),
                        stats.as<uint32_t>());
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, blocksums.as<uint64_t>(), nscan, stats.as<uint32_t>());
     hipLaunchKernelGGL(k_scan_final, dim3(nscan), b256, 0, st, count.as<uint32_t>(), G, P.L, blocksums.as<uint64_t>(),
                        off.as<uint32_t>(), unit_off.as<uint32_t>());
-    if (lds_sort) {
-        BLZ_TRY(msm_sort_lds_scatter(E));
-    } else if (sbits == 256) {
-        hipLaunchKernelGGL(k_scatter<8>, gp, b256, 0, st, sc, npts, (int)P.width[0], P.W, P.Bw, count.as<uint32_t>(), entries.as<uint32_t>());
-    } else {
-        hipLaunchKernelGGL(k_scatter<1>, gp, b256, 0, st, sc, npts, (int)P.width[0], P.W, P.Bw, count.as<uint32_t>(), entries.as<uint32_t>());
-    }
+    BLZ_TRY(msm_sort_lds_scatter(E));
     BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
     // the staged inputs (scalars, raw points) have been consumed: a later task's host -> device copies may
     // overwrite this staging set once the caller's event has passed (msm_capi.hip's copy stream waits for it)
