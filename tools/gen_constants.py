@@ -101,6 +101,8 @@ def rr_struct(name, m, n32, B, NL):
 # reduced-radix twins: (field, B, NL)
 # (BN254's 254-bit field would take 9 x 29 bits, whose 64-bit column sums leave no room for lazy operands,
 # or 10 x 28 bits, which is no cheaper than 8 x 32 with carries: it stays on field.cuh)
+# BN254's base field stays on field.cuh: measured on 10 x 27 bits its bucket accumulation takes the same 60 ms at 2^26
+# (81 ms at pf = 8) as on 8 x 32 - with 64-byte points the kernel waits for its 805 M random gathers, not for the multiplier.
 # The scalar fields (NTT): 10 x 27 bits = 270 bits.  15-17 bits of value head-room and 5 spare bits per limb keep a
 # whole 8-point DFT (three butterfly levels) free of carries AND of normalisations; 9 x 29 bits would be 21 % fewer
 # multiply-adds per product but needs a carry propagation per butterfly level, which costs more than it saves.
