@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 
 __global__ __launch_bounds__(256) void k_fill_idx(uint32_t* idx, uint64_t n, uint32_t mask) {
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
@@ -65,8 +66,11 @@ __global__ __launch_bounds__(128) void k_gather(const uint4* __restrict__ pts, c
     if (acc.x == 0x12345678u && acc.y == 0x9abcdef0u) sink[0] = acc;
 }
 
-int main() {
-    const uint64_t npts = 1ull << 26, entries = 12ull << 26;
+int main(int argc, char** argv) {
+    // optional argument: log2 of the table size in points (26 = the 8 GiB table of the 2^26 MSM); the entry count stays
+    const int logp = argc > 1 ? atoi(argv[1]) : 26;
+    const uint64_t npts = 1ull << logp, entries = 12ull << 26;
+    printf("table: 2^%d points x 128 B = %.2f GiB\n", logp, (double)npts * 128 / (1ull << 30));
     const uint32_t len = 44;   // mean run length of the 2^26 plan (805 M entries over ~18 M buckets)
     const uint64_t nruns = entries / len;
     uint4 *pts, *side, *sink;
