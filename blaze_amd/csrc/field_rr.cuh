@@ -1,5 +1,6 @@
 // Reduced-radix prime-field arithmetic for gfx950: NL limbs of B < 32 bits in 32-bit registers,
-// Montgomery radix Rrr = 2^(B NL)  (BLS12-377/381 Fq: 14 x 28 bits).
+// Montgomery radix Rrr = 2^(B NL)  (BLS12-377/381 Fq: 14 x 28 bits, bucket accumulation and first reduce level;
+// the three scalar fields: 10 x 27 bits, the 2^27 NTT).
 //
 // Why a second representation.  With full 32-bit limbs (field.cuh) a column sum of 32x32 products
 // needs 64 + log2(count) bits, so every v_mad_u64_u32 is followed by a v_addc_co_u32 that folds its
