@@ -107,14 +107,20 @@ int ntt_setup(blz_ntt* h) {
     h->T.t1 = p; p += 512 * 8;
     h->T.t2 = p; p += 512 * 8;
     h->T.ninv = h->inverse ? p : nullptr;
-    BLZ_TRY(h->tables_rr.reserve(NTT_RR_TABLE_BYTES));
+    // the boundary table exists only where all three passes run the 512-point kernel (2^27), so that the factor it
+    // splits off is re-joined by the same kernel in pass 2; BLAZE_NTT_TABLE=0 keeps the stepping chain (A/B runs)
+    const char* envt = getenv("BLAZE_NTT_TABLE");
+    const char* envr = getenv("BLAZE_NTT_RR");
+    const bool want_ta = lc == 9 && !h->force_generic && !(envt && *envt == '0') && !(envr && *envr == '0');
+    BLZ_TRY(h->tables_rr.reserve(NTT_RR_TABLE_BYTES + (want_ta ? NTT_RR_BOUNDARY_ENTRIES * NTT_RR_ENTRY_DWORDS * 4 : 0)));
     {
         uint32_t* q = h->tables_rr.as<uint32_t>();
         for (int i = 0; i < 3; ++i) { h->TR.wpass[i] = q; q += 512 * NTT_RR_ENTRY_DWORDS; }
         h->TR.t0 = q; q += 512 * NTT_RR_ENTRY_DWORDS;
         h->TR.t1 = q; q += 512 * NTT_RR_ENTRY_DWORDS;
         h->TR.t2 = q; q += 512 * NTT_RR_ENTRY_DWORDS;
-        h->TR.fin = q;
+        h->TR.fin = q; q += NTT_RR_ENTRY_DWORDS;
+        h->TR.tA = want_ta ? q : nullptr;
     }
     BLZ_TRY(h->ops->setup(h->stream, h->T, h->TR, h->geom, h->inverse));
     // both transform buffers exist from the start, zero-filled, like the card's two HBM buffers: the reference's

@@ -166,6 +166,27 @@ __global__ void k_ntt_fin_rr(const uint32_t* __restrict__ ninv32, uint32_t* __re
     rr_store(out, r);
 }
 
+// out[j] = w^(j * mult) in the reduced radix, straight from the exponent (the boundary table tA)
+template <class Fr>
+__global__ void k_ntt_table_rr_pow(uint32_t* __restrict__ out, uint32_t count, int logn, uint64_t mult, int inverse) {
+    using Q = typename Fr::RR;
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    Fp<Fr> w, acc;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w.v[i] = inverse ? Fr::ROOT_INV[i] : Fr::ROOT[i];
+    for (int i = 0; i < Fr::TWO_ADICITY - logn; ++i) fp_sqr(w, w);
+    const uint64_t e = (uint64_t)j * mult;
+    fp_one(acc);
+    for (int b = 63; b >= 0; --b) {
+        fp_sqr(acc, acc);
+        if ((e >> b) & 1) fp_mul(acc, acc, w);
+    }
+    Frr<Q, 1, 2> r;
+    rr_from_mont32_words<Q>(r, acc.v);
+    rr_store(out + (size_t)j * Q::NL, r);
+}
+
 // w^e for e < 2^27 from the three 512-entry tables
 template <class Q>
 BLZ_DEV void tw_pow_rr(Frr<Q, 1, 2>& r, const NttTablesRR& T, uint32_t e) {
@@ -277,22 +298,31 @@ __global__ __launch_bounds__(NR_THREADS, 2) void k_ntt512_rr(const uint32_t* __r
     for (int j = 0; j < 8; ++j) rr_lds_load(a3[j], lds, (64u * k1 + 8u * k1p + BR[j]) * RS + col * NL);
     auto o3 = dft8_rr<Q>(a3, w1, w2, w3);
     const uint32_t kb = k1 + 8u * k1p;  // output row of x_(k2') is kb + 64 k2'
+    // Boundary factors.  Between passes 1 and 2 every element owes w^(k2 (i0 + A i1)), between 2 and 3 w^(C i0 k1).
+    // With the table tA (2^27 transforms) the first one is split: its column-independent part w^(A i1 k2) is READ
+    // after pass 1 (index k2 i1 < 2^18: no stepping chain, 11 products less per lane), and w^(i0 k2), which does
+    // not involve the index pass 2 transforms over, joins pass 2's own factor: w^(i0 (C k1 + k2)), still one
+    // geometric sequence along the lane's rows.
+    const bool split = T.tA != nullptr;
     W w, step;
     if (PASS == 1) {
-        // x(i0, i1, k2 = row) *= w^(row (i0 + A i1)),  m = i0 + A i1 < 2^18
-        const uint64_t m = col_base + col + ((uint64_t)fixed << g.logA);
-        tw_pow_rr<Q>(w, T, (uint32_t)(kb * m));
-        tw_pow_rr<Q>(step, T, (uint32_t)(64u * m));
+        if (!split) {
+            // x(i0, i1, k2 = row) *= w^(row (i0 + A i1)),  m = i0 + A i1 < 2^18
+            const uint64_t m = col_base + col + ((uint64_t)fixed << g.logA);
+            tw_pow_rr<Q>(w, T, (uint32_t)(kb * m));
+            tw_pow_rr<Q>(step, T, (uint32_t)(64u * m));
+        }
     } else if (PASS == 2) {
-        // x(i0, k1 = row, k2) *= w^(C i0 row)
-        const uint64_t m = (col_base + col) << g.logC;
-        tw_pow_rr<Q>(w, T, (uint32_t)(kb * m));
-        tw_pow_rr<Q>(step, T, (uint32_t)(64u * m));
+        // x(i0, k1 = row, k2) *= w^(C i0 row)   [split: * w^(i0 k2) as well; k2 = fixed]
+        const uint64_t i0 = col_base + col;
+        tw_pow_rr<Q>(w, T, (uint32_t)((((uint64_t)kb << g.logC) + (split ? fixed : 0)) * i0));
+        tw_pow_rr<Q>(step, T, (uint32_t)((64u * i0) << g.logC));
     } else {
         rr_load(w, T.fin);
     }
     BLZ_RR_FOR8(o3, {
         const uint32_t row = kb + 64u * K;
+        if (PASS == 1 && split) rr_load(w, T.tA + (size_t)(row * (uint32_t)fixed) * NL);   // w^(A i1 k2)
         W t;
         rr_mul(t, X, w);
         Fp<Fr> y;
@@ -302,7 +332,7 @@ __global__ __launch_bounds__(NR_THREADS, 2) void k_ntt512_rr(const uint32_t* __r
             fp_csub_const<Fr, Fr::MOD>(y);   // < 2m -> canonical: the wire format
             oaddr = (col_base + col) + (uint64_t)C * fixed + (uint64_t)C * B * row;
         } else {
-            if (K != 7) rr_mul(w, w, step);  // twiddle x twiddle
+            if (K != 7 && !(PASS == 1 && split)) rr_mul(w, w, step);  // twiddle x twiddle
             oaddr = in_base + row * in_rstride + col;
         }
         fp_store(out + oaddr * 8, y);
