@@ -1,6 +1,6 @@
 // Reduced-radix prime-field arithmetic for gfx950: NL limbs of B < 32 bits in 32-bit registers,
 // Montgomery radix Rrr = 2^(B NL)  (BLS12-377/381 Fq: 14 x 28 bits, bucket accumulation and first reduce level;
-// the three scalar fields: 10 x 27 bits, the 2^27 NTT).
+// the three scalar fields: 9 x 29 bits, the 2^27 NTT).
 //
 // Why a second representation.  With full 32-bit limbs (field.cuh) a column sum of 32x32 products
 // needs 64 + log2(count) bits, so every v_mad_u64_u32 is followed by a v_addc_co_u32 that folds its
@@ -338,28 +338,33 @@ BLZ_DEV bool rr_maybe_equal(const Frr<Q, Fa, Va>& a, const Frr<Q, Fb, Vb>& b) {
     return c < (uint32_t)Va || c > Q::MASK - (uint32_t)Vb;
 }
 
-// global-memory I/O: NL dwords, 16-byte vector accesses where the count allows
+// global-memory I/O: NL dwords, 16-byte vector accesses where the count allows.  Arrays of elements use a stride of
+// rr_stride<Q>() dwords (NL rounded up to even: 8-byte alignment for every element).
+template <class Q>
+constexpr int rr_stride() { return (Q::NL + 1) & ~1; }
 template <class Q, int F, int V>
 BLZ_DEV void rr_load(Frr<Q, F, V>& r, const uint32_t* p) {
-    static_assert(Q::NL % 2 == 0, "even limb count expected");
+    constexpr int NL = Q::NL;
     const uint4* q4 = reinterpret_cast<const uint4*>(p);
 #pragma unroll
-    for (int i = 0; i < Q::NL / 4; ++i) {
+    for (int i = 0; i < NL / 4; ++i) {
         uint4 x = q4[i];
         r.v[4 * i] = x.x; r.v[4 * i + 1] = x.y; r.v[4 * i + 2] = x.z; r.v[4 * i + 3] = x.w;
     }
-    if constexpr (Q::NL % 4 == 2) {
-        uint2 x = *reinterpret_cast<const uint2*>(p + Q::NL - 2);
-        r.v[Q::NL - 2] = x.x; r.v[Q::NL - 1] = x.y;
+    if constexpr (NL % 4 >= 2) {
+        uint2 x = *reinterpret_cast<const uint2*>(p + (NL & ~3));
+        r.v[NL & ~3] = x.x; r.v[(NL & ~3) + 1] = x.y;
     }
+    if constexpr (NL % 2 == 1) r.v[NL - 1] = p[NL - 1];
 }
 template <class Q, int F, int V>
 BLZ_DEV void rr_store(uint32_t* p, const Frr<Q, F, V>& a) {
-    static_assert(Q::NL % 2 == 0, "even limb count expected");
+    constexpr int NL = Q::NL;
     uint4* q4 = reinterpret_cast<uint4*>(p);
 #pragma unroll
-    for (int i = 0; i < Q::NL / 4; ++i) q4[i] = make_uint4(a.v[4 * i], a.v[4 * i + 1], a.v[4 * i + 2], a.v[4 * i + 3]);
-    if constexpr (Q::NL % 4 == 2) *reinterpret_cast<uint2*>(p + Q::NL - 2) = make_uint2(a.v[Q::NL - 2], a.v[Q::NL - 1]);
+    for (int i = 0; i < NL / 4; ++i) q4[i] = make_uint4(a.v[4 * i], a.v[4 * i + 1], a.v[4 * i + 2], a.v[4 * i + 3]);
+    if constexpr (NL % 4 >= 2) *reinterpret_cast<uint2*>(p + (NL & ~3)) = make_uint2(a.v[NL & ~3], a.v[(NL & ~3) + 1]);
+    if constexpr (NL % 2 == 1) p[NL - 1] = a.v[NL - 1];
 }
 
 }  // namespace blz

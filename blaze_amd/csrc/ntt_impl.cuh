@@ -406,7 +406,7 @@ int ntt_setup_t(hipStream_t st, NttTables& T, NttTablesRR& TR, const NttGeom& g,
     hipLaunchKernelGGL(k_ntt_table<Fr>, dim3(2), dim3(256), 0, st, T.t1, 512, l, (uint64_t)512, inverse);
     hipLaunchKernelGGL(k_ntt_table<Fr>, dim3(2), dim3(256), 0, st, T.t2, 512, l, (uint64_t)1 << 18, inverse);
     // the same tables in the reduced radix for the 512-point kernel (ntt_rr.cuh)
-    static_assert(Fr::RR::NL == NTT_RR_ENTRY_DWORDS, "table entry size");
+    static_assert(rr_stride<typename Fr::RR>() == NTT_RR_ENTRY_DWORDS, "table entry size");
     for (int i = 0; i < 3; ++i)
         hipLaunchKernelGGL(k_ntt_table_to_rr<Fr>, dim3(2), dim3(256), 0, st, T.wpass[i], TR.wpass[i], lrs[i] ? (1 << lrs[i]) : 1);
     hipLaunchKernelGGL(k_ntt_table_to_rr<Fr>, dim3(2), dim3(256), 0, st, T.t0, TR.t0, 512);
@@ -429,7 +429,7 @@ int ntt_pass_t(hipStream_t st, const void* in, void* out, const NttGeom& g, cons
     static const bool use_rr = []() { const char* e = getenv("BLAZE_NTT_RR"); return !(e && *e == '0'); }();
     if (lr == 9 && cols_avail >= NR_COLS_LOG && !force_generic && use_rr) {
         BLZ_TRY(ensure_dynamic_lds((const void*)k_ntt512_rr<Fr, PASS>, 160 * 1024));
-        const size_t ldsr = (size_t)512 * NR_COLS * Fr::RR::NL * 4;
+        const size_t ldsr = (size_t)512 * NR_COLS * rr_stride<typename Fr::RR>() * 4;
         const uint64_t tilesr = (1ull << g.logn) >> (9 + NR_COLS_LOG);
         hipLaunchKernelGGL((k_ntt512_rr<Fr, PASS>), dim3((unsigned)tilesr), dim3(NR_THREADS), ldsr, st, (const uint32_t*)in,
                            (uint32_t*)out, g, TR);

@@ -1,17 +1,18 @@
-// The 512-point NTT pass (k_ntt512 of ntt_impl.cuh) on the reduced-radix scalar field: 10 limbs of 27 bits
+// The 512-point NTT pass (k_ntt512 of ntt_impl.cuh) on the reduced-radix scalar field: 9 limbs of 29 bits
 // (field_rr.cuh; curve_constants.h Fr_*_RR).  Same decomposition (512 = 8 * 8 * 8, a lane holds 8 elements, two
 // LDS exchanges per pass, inter-pass twiddle stepped along the lane's outputs), different arithmetic:
-//   * a field product is 200 v_mad_u64_u32 (+ 19 shifts, 10 v_mul_lo) instead of 128 x (v_mad_u64_u32 +
+//   * a field product is 162 v_mad_u64_u32 (+ 17 shifts, 9 quotient digits) instead of 128 x (v_mad_u64_u32 +
 //     v_addc_co_u32);
-//   * a butterfly is 30 plain 32-bit adds / subs - no carry chain, no compare, no select - because the 5 spare
-//     bits per limb and the 15-17 spare bits of R_rr / m absorb three butterfly levels of growth: u - v is
-//     u + (k 2^J m - v) limb by limb, with the multiple of m in borrow form (tools/gen_constants.py);
+//   * a butterfly is 27 plain 32-bit adds / subs - no carry chain, no compare, no select: u - v is
+//     u + (2^J m - v) limb by limb, with the multiple of m in borrow form (tools/gen_constants.py).  The 3 spare
+//     bits per limb and the 6-8 spare bits of R_rr / m are a tight budget, so the subtrahend is always a
+//     normalised value (three of an 8-point DFT's twelve are sums and get a carry propagation first), every DFT
+//     output leaves through a product (w^0 = one included: that is what brings its value back under 2m), and
+//     the twiddle tables are canonical (< m);
 //   * every intermediate's limb and value bounds are part of its type, so the compiler proves that no 32-bit
-//     limb and no 64-bit column sum can overflow anywhere in the three DFT steps (a step's un-multiplied outputs
-//     are carry-propagated, not reduced: their value bound is carried into the next step's types).
-// Data in HBM stay 32-byte words (canonical on the wire, < 2m between passes), tile elements in LDS are 10
-// dwords (the 40-dword row of the 32-bit kernel: 4 x 10 instead of 4 x 8 + 8 of padding), twiddle tables hold
-// t R_rr mod m as 10 limbs.
+//     limb and no 64-bit column sum can overflow anywhere in the three DFT steps.
+// Data in HBM stay 32-byte words (canonical on the wire, < 2m between passes); tile elements in LDS and table
+// entries are rr_stride = 10 dwords apart (9 used), twiddle tables hold t R_rr mod m.
 #pragma once
 #include "field_rr.cuh"
 #include "ntt_engine.hpp"
@@ -56,19 +57,49 @@ BLZ_DEV auto rr_bfly(const Frr<Q, Fu, Vu>& u, const Frr<Q, 1, Vv>& v) {
     }
     return r;
 }
-// butterfly against a lazy v (limbs < Fv 2^B): the constant is (Fv + 1) x the borrow form, whose limbs are
-// >= (Fv + 1)(2^B - 1) >= Fv 2^B - 1
+// butterfly against a lazy v (limbs < Fv 2^B).  Where the limb slack allows it the constant is (Fv + 1) x the borrow
+// form, whose limbs are >= (Fv + 1)(2^B - 1) >= Fv 2^B - 1 (10 x 27 bits); otherwise (9 x 29 bits) v is
+// carry-propagated first.
+template <class Q, int Fu, int Fv>
+constexpr bool rr_bfly_lazy_fits() {
+    return ((unsigned long long)(Fv + 1) << (Q::B + 1)) <= (1ull << 32) && Fu + 2 * (Fv + 1) < (1 << (32 - Q::B));
+}
 template <class Q, int Fu, int Vu, int Fv, int Vv, std::enable_if_t<(Fv >= 2), int> = 0>
 BLZ_DEV auto rr_bfly(const Frr<Q, Fu, Vu>& u, const Frr<Q, Fv, Vv>& v) {
-    constexpr int K = Fv + 1, J = rr_j_lazy(Fv, Vv);
-    static_assert(J <= Q::NKM, "no multiple of m that large");
-    static_assert((unsigned long long)K << (Q::B + 1) <= (1ull << 32), "constant limb would overflow 32 bits");
-    RRPair<Frr<Q, Fu + Fv, Vu + Vv>, Frr<Q, Fu + 2 * K, Vu + K * (1 << J)>> r;
+    if constexpr (rr_bfly_lazy_fits<Q, Fu, Fv>()) {
+        constexpr int K = Fv + 1, J = rr_j_lazy(Fv, Vv);
+        static_assert(J <= Q::NKM, "no multiple of m that large");
+        RRPair<Frr<Q, Fu + Fv, Vu + Vv>, Frr<Q, Fu + 2 * K, Vu + K * (1 << J)>> r;
+#pragma unroll
+        for (int i = 0; i < Q::NL; ++i) {
+            r.s.v[i] = u.v[i] + v.v[i];
+            r.d.v[i] = u.v[i] + ((uint32_t)K * Q::KM[J - 1][i] - v.v[i]);
+        }
+        return r;
+    } else {
+        return rr_bfly(u, rr_norm(v));
+    }
+}
+
+// a product whose lazy operand is carry-propagated first if the 64-bit column sums need it
+template <class Q, int Fa, int Va, int Fb, int Vb>
+BLZ_DEV void rr_mul_n(Frr<Q, 1, 2>& r, const Frr<Q, Fa, Va>& a, const Frr<Q, Fb, Vb>& b) {
+    if constexpr (rr_cols_ok<Q>(Fa * Fb)) rr_mul(r, a, b);
+    else rr_mul(r, rr_norm(a), b);
+}
+// a value < 2m (normalised) -> canonical
+template <class Q>
+BLZ_DEV Frr<Q, 1, 1> rr_canon(const Frr<Q, 1, 2>& a) {
+    Frr<Q, 1, 1> r;
+    uint32_t d[Q::NL], borrow = 0;
 #pragma unroll
     for (int i = 0; i < Q::NL; ++i) {
-        r.s.v[i] = u.v[i] + v.v[i];
-        r.d.v[i] = u.v[i] + ((uint32_t)K * Q::KM[J - 1][i] - v.v[i]);
+        const uint32_t t = a.v[i] - Q::MOD[i] - borrow;
+        borrow = t >> 31;              // limbs are < 2^B <= 2^31: a negative difference has bit 31 set
+        d[i] = t & Q::MASK;
     }
+#pragma unroll
+    for (int i = 0; i < Q::NL; ++i) r.v[i] = borrow ? a.v[i] : d[i];
     return r;
 }
 
@@ -86,7 +117,7 @@ BLZ_DEV RROct<T0, T1, T2, T3, T4, T5, T6, T7> rr_oct(const T0& a, const T1& b, c
 }
 
 // in-register 8-point DFT, decimation in time: a[] holds x[0],x[4],x[2],x[6],x[1],x[5],x[3],x[7] (normalised, value
-// < VIN m); outputs in natural order, lazy.  w1, w2, w3 = w8, w8^2, w8^3 (Montgomery, R_rr).
+// < VIN m); outputs in natural order, lazy.  w1, w2, w3 = w8, w8^2, w8^3 (Montgomery, R_rr; canonical).
 template <class Q, int VIN, class W>
 BLZ_DEV auto dft8_rr(const Frr<Q, 1, VIN> (&a)[8], const W& w1, const W& w2, const W& w3) {
     const auto p01 = rr_bfly(a[0], a[1]);
@@ -94,16 +125,16 @@ BLZ_DEV auto dft8_rr(const Frr<Q, 1, VIN> (&a)[8], const W& w1, const W& w2, con
     const auto p45 = rr_bfly(a[4], a[5]);
     const auto p67 = rr_bfly(a[6], a[7]);
     Frr<Q, 1, 2> m3, m7;
-    rr_mul(m3, p23.d, w2);
-    rr_mul(m7, p67.d, w2);
+    rr_mul_n(m3, p23.d, w2);
+    rr_mul_n(m7, p67.d, w2);
     const auto q02 = rr_bfly(p01.s, p23.s);
     const auto q13 = rr_bfly(p01.d, m3);
     const auto q46 = rr_bfly(p45.s, p67.s);
     const auto q57 = rr_bfly(p45.d, m7);
     Frr<Q, 1, 2> m5, m6, m7b;
-    rr_mul(m5, q57.s, w1);
-    rr_mul(m6, q46.d, w2);
-    rr_mul(m7b, q57.d, w3);
+    rr_mul_n(m5, q57.s, w1);
+    rr_mul_n(m6, q46.d, w2);
+    rr_mul_n(m7b, q57.d, w3);
     const auto r04 = rr_bfly(q02.s, q46.s);
     const auto r15 = rr_bfly(q13.s, m5);
     const auto r26 = rr_bfly(q02.d, m6);
@@ -119,10 +150,9 @@ BLZ_DEV auto dft8_rr(const Frr<Q, 1, VIN> (&a)[8], const W& w1, const W& w2, con
     { constexpr int K = 4; auto& X = (o).x4; __VA_ARGS__ } { constexpr int K = 5; auto& X = (o).x5; __VA_ARGS__ } \
     { constexpr int K = 6; auto& X = (o).x6; __VA_ARGS__ } { constexpr int K = 7; auto& X = (o).x7; __VA_ARGS__ }
 
-// 10-dword tile elements: 8-byte LDS accesses (40-byte elements are not 16-byte aligned)
+// tile elements are rr_stride dwords apart: 8-byte LDS accesses (40-byte elements are not 16-byte aligned)
 template <class Q, int F, int V>
 BLZ_DEV void rr_lds_load(Frr<Q, F, V>& r, const uint32_t* lds, uint32_t dw) {
-    static_assert(Q::NL % 2 == 0, "even limb count");
     const uint2* q = reinterpret_cast<const uint2*>(lds + dw);
 #pragma unroll
     for (int i = 0; i < Q::NL / 2; ++i) {
@@ -130,15 +160,17 @@ BLZ_DEV void rr_lds_load(Frr<Q, F, V>& r, const uint32_t* lds, uint32_t dw) {
         r.v[2 * i] = x.x;
         r.v[2 * i + 1] = x.y;
     }
+    if constexpr (Q::NL % 2 == 1) r.v[Q::NL - 1] = lds[dw + Q::NL - 1];
 }
 template <class Q, int F, int V>
 BLZ_DEV void rr_lds_store(uint32_t* lds, uint32_t dw, const Frr<Q, F, V>& a) {
     uint2* q = reinterpret_cast<uint2*>(lds + dw);
 #pragma unroll
     for (int i = 0; i < Q::NL / 2; ++i) q[i] = make_uint2(a.v[2 * i], a.v[2 * i + 1]);
+    if constexpr (Q::NL % 2 == 1) lds[dw + Q::NL - 1] = a.v[Q::NL - 1];
 }
 
-// out[j] = in[j] (32-bit Montgomery, R32) re-expressed in the reduced radix (Montgomery, R_rr)
+// out[j] = in[j] (32-bit Montgomery, R32) re-expressed in the reduced radix (Montgomery, R_rr), canonical
 template <class Fr>
 __global__ void k_ntt_table_to_rr(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int count) {
     using Q = typename Fr::RR;
@@ -148,7 +180,7 @@ __global__ void k_ntt_table_to_rr(const uint32_t* __restrict__ in, uint32_t* __r
     fp_load(w, in + (size_t)j * 8);
     Frr<Q, 1, 2> r;
     rr_from_mont32_words<Q>(r, w.v);
-    rr_store(out + (size_t)j * Q::NL, r);
+    rr_store(out + (size_t)j * rr_stride<Q>(), rr_canon(r));
 }
 // fin = R_rr mod m (inverse == 0) or n^-1 in Montgomery R_rr form (from the 32-bit ninv)
 template <class Fr>
@@ -163,7 +195,7 @@ __global__ void k_ntt_fin_rr(const uint32_t* __restrict__ ninv32, uint32_t* __re
     } else {
         rr_one(r);
     }
-    rr_store(out, r);
+    rr_store(out, rr_canon(r));
 }
 
 // out[j] = w^(j * mult) in the reduced radix, straight from the exponent (the boundary table tA)
@@ -184,17 +216,18 @@ __global__ void k_ntt_table_rr_pow(uint32_t* __restrict__ out, uint32_t count, i
     }
     Frr<Q, 1, 2> r;
     rr_from_mont32_words<Q>(r, acc.v);
-    rr_store(out + (size_t)j * Q::NL, r);
+    rr_store(out + (size_t)j * rr_stride<Q>(), rr_canon(r));
 }
 
 // w^e for e < 2^27 from the three 512-entry tables
 template <class Q>
 BLZ_DEV void tw_pow_rr(Frr<Q, 1, 2>& r, const NttTablesRR& T, uint32_t e) {
-    Frr<Q, 1, 2> a;
-    rr_load(r, T.t0 + (size_t)(e & 511u) * Q::NL);
+    constexpr uint32_t ES = rr_stride<Q>();
+    Frr<Q, 1, 1> a;
+    rr_load(r, T.t0 + (size_t)(e & 511u) * ES);
     const uint32_t e1 = (e >> 9) & 511u, e2 = e >> 18;
-    if (e1) { rr_load(a, T.t1 + (size_t)e1 * Q::NL); rr_mul(r, r, a); }
-    if (e2) { rr_load(a, T.t2 + (size_t)e2 * Q::NL); rr_mul(r, r, a); }
+    if (e1) { rr_load(a, T.t1 + (size_t)e1 * ES); rr_mul(r, r, a); }
+    if (e2) { rr_load(a, T.t2 + (size_t)e2 * ES); rr_mul(r, r, a); }
 }
 
 constexpr int NR_COLS_LOG = 2;
@@ -205,8 +238,8 @@ template <class Fr, int PASS>
 __global__ __launch_bounds__(NR_THREADS, 2) void k_ntt512_rr(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, NttGeom g,
                                                             NttTablesRR T) {
     using Q = typename Fr::RR;
-    constexpr uint32_t NL = Q::NL;
-    constexpr uint32_t RS = NR_COLS * NL;   // tile row stride in dwords (40: the 32-bit kernel's 4 x 8 + 8)
+    constexpr uint32_t ES = rr_stride<Q>();  // element stride in LDS and in the tables (dwords)
+    constexpr uint32_t RS = NR_COLS * ES;    // tile row stride in dwords (40: the 32-bit kernel's 4 x 8 + 8)
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t A = 1u << g.logA, B = 1u << g.logB, C = 1u << g.logC;
     uint64_t col_base, fixed, in_base, in_rstride, in_cstride;
@@ -214,8 +247,16 @@ __global__ __launch_bounds__(NR_THREADS, 2) void k_ntt512_rr(const uint32_t* __r
     const uint32_t col = threadIdx.x & (NR_COLS - 1), n2 = threadIdx.x >> NR_COLS_LOG;
     if (PASS == 1) {   // rows i2 (stride AB), cols i0 (stride 1), fixed i1
         const uint64_t tiles_per = A >> NR_COLS_LOG;
-        fixed = tile / tiles_per;
-        col_base = (tile % tiles_per) << NR_COLS_LOG;
+        if (T.swz) {
+            // tiles in flight together differ in the low 7 bits of i1 first (16 KiB apart) and only then in the column
+            // group (128 B apart): a tile's 512 rows are 8 MiB apart, so neighbours in the column alone would put the
+            // whole chip on a 64 KiB window of every row - a few HBM channels - at any moment (pass 1: 6.9 -> 6.4 ms)
+            fixed = (tile & 127u) | ((tile >> 14) << 7);
+            col_base = ((tile >> 7) & 127u) << NR_COLS_LOG;
+        } else {
+            fixed = tile / tiles_per;
+            col_base = (tile % tiles_per) << NR_COLS_LOG;
+        }
         in_base = col_base + (uint64_t)A * fixed;
         in_rstride = (uint64_t)A * B;
         in_cstride = 1;
@@ -235,14 +276,15 @@ __global__ __launch_bounds__(NR_THREADS, 2) void k_ntt512_rr(const uint32_t* __r
         in_cstride = (uint64_t)A * B;
     }
     const uint32_t* wp = T.wpass[PASS - 1];  // w512^j, j < 512
-    using W = Frr<Q, 1, 2>;
-    W w1, w2, w3;
-    rr_load(w1, wp + 64 * NL);
-    rr_load(w2, wp + 128 * NL);
-    rr_load(w3, wp + 192 * NL);
+    using WT = Frr<Q, 1, 1>;   // table entries are canonical
+    using W = Frr<Q, 1, 2>;    // stepped twiddles
+    WT w1, w2, w3;
+    rr_load(w1, wp + 64 * ES);
+    rr_load(w2, wp + 128 * ES);
+    rr_load(w3, wp + 192 * ES);
 
     // ---- step 1: 8-point DFTs over n1 (rows 64 n1 + n2), straight from global memory.  The words on the wire are
-    // any 256-bit values (< 4m); between passes they are < 2m.
+    // values < 4m (any 256-bit value for BLS12-381); between passes they are < 2m.
     constexpr int BR[8] = {0, 4, 2, 6, 1, 5, 3, 7};
     constexpr int VIN1 = 4;
     Frr<Q, 1, VIN1> a1[8];
@@ -254,48 +296,36 @@ __global__ __launch_bounds__(NR_THREADS, 2) void k_ntt512_rr(const uint32_t* __r
         rr_from_words<Q>(a1[j], x.v);
     }
     auto o1 = dft8_rr<Q>(a1, w1, w2, w3);
-    constexpr int VS1 = decltype(o1)::maxv;   // an un-multiplied output is only carry-propagated: it keeps its value bound
-    BLZ_RR_FOR8(o1, {
-        Frr<Q, 1, VS1> y;
-        if (K != 0 && n2 != 0) {  // * w512^(n2 k1)
-            W w, t;
-            rr_load(w, wp + (size_t)(n2 * K) * NL);
-            rr_mul(t, X, w);
-            y = rr_as<1, VS1>(t);
-        } else {
-            y = rr_as<1, VS1>(rr_norm(X));
-        }
-        rr_lds_store(lds, (64u * K + n2) * RS + col * NL, y);
+    BLZ_RR_FOR8(o1, {   // * w512^(n2 k1): every output, w^0 included - the product is what renormalises it
+        WT w;
+        W t;
+        rr_load(w, wp + (size_t)(n2 * K) * ES);
+        rr_mul_n(t, X, w);
+        rr_lds_store(lds, (64u * K + n2) * RS + col * ES, t);
     })
     __syncthreads();
     // ---- step 2a: lane (k1, n2', col): 8-point DFTs over n1' (rows 64 k1 + 8 n1' + n2')
     const uint32_t k1 = n2 >> 3, n2p = n2 & 7u;
-    Frr<Q, 1, VS1> a2[8];
+    W a2[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) rr_lds_load(a2[j], lds, (64u * k1 + 8u * BR[j] + n2p) * RS + col * NL);
+    for (int j = 0; j < 8; ++j) rr_lds_load(a2[j], lds, (64u * k1 + 8u * BR[j] + n2p) * RS + col * ES);
     auto o2 = dft8_rr<Q>(a2, w1, w2, w3);
-    constexpr int VS2 = decltype(o2)::maxv;
     __syncthreads();
-    BLZ_RR_FOR8(o2, {
-        Frr<Q, 1, VS2> y;
-        if (K != 0 && n2p != 0) {  // * w64^(n2' k1') = w512^(8 n2' k1')
-            W w, t;
-            rr_load(w, wp + (size_t)(8u * n2p * K) * NL);
-            rr_mul(t, X, w);
-            y = rr_as<1, VS2>(t);
-        } else {
-            y = rr_as<1, VS2>(rr_norm(X));
-        }
-        rr_lds_store(lds, (64u * k1 + 8u * K + n2p) * RS + col * NL, y);
+    BLZ_RR_FOR8(o2, {   // * w64^(n2' k1') = w512^(8 n2' k1')
+        WT w;
+        W t;
+        rr_load(w, wp + (size_t)(8u * n2p * K) * ES);
+        rr_mul_n(t, X, w);
+        rr_lds_store(lds, (64u * k1 + 8u * K + n2p) * RS + col * ES, t);
     })
     __syncthreads();
     // ---- step 2b: lane (k1, k1', col): 8-point DFTs over n2' (rows 64 k1 + 8 k1' + n2'); outputs k = k1 + 8 k1' + 64 k2'
     // leave with the inter-pass twiddle (passes 1, 2) or the closing factor (pass 3), which also brings them back
     // below 2m for the 32-byte word
     const uint32_t k1p = n2 & 7u;
-    Frr<Q, 1, VS2> a3[8];
+    W a3[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) rr_lds_load(a3[j], lds, (64u * k1 + 8u * k1p + BR[j]) * RS + col * NL);
+    for (int j = 0; j < 8; ++j) rr_lds_load(a3[j], lds, (64u * k1 + 8u * k1p + BR[j]) * RS + col * ES);
     auto o3 = dft8_rr<Q>(a3, w1, w2, w3);
     const uint32_t kb = k1 + 8u * k1p;  // output row of x_(k2') is kb + 64 k2'
     // Boundary factors.  Between passes 1 and 2 every element owes w^(k2 (i0 + A i1)), between 2 and 3 w^(C i0 k1).
@@ -322,9 +352,9 @@ __global__ __launch_bounds__(NR_THREADS, 2) void k_ntt512_rr(const uint32_t* __r
     }
     BLZ_RR_FOR8(o3, {
         const uint32_t row = kb + 64u * K;
-        if (PASS == 1 && split) rr_load(w, T.tA + (size_t)(row * (uint32_t)fixed) * NL);   // w^(A i1 k2)
+        if (PASS == 1 && split) rr_load(w, T.tA + (size_t)(row * (uint32_t)fixed) * ES);   // w^(A i1 k2)
         W t;
-        rr_mul(t, X, w);
+        rr_mul_n(t, X, w);
         Fp<Fr> y;
         rr_to_words<Q>(y.v, t);
         uint64_t oaddr;

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(64) void k_test_field(int op, const uint32_t* a, co
                 rr_to_mont_from_words<Q>(yr, y.v);
                 if (op == 10) rr_mul(rr, xr, yr);
                 else if (op == 11) rr_sqr(rr, xr);
-                else if (op == 12) rr_mul2(rr, xr, yr, rr_add(xr, yr), rr_sub<2>(xr, yr));   // x y + (x + y)(x - y)
+                else if (op == 12) rr_mul2(rr, xr, yr, rr_norm(rr_add(xr, yr)), rr_sub<2>(xr, yr));   // x y + (x + y)(x - y)
                 else if (op == 13) rr_mul(rr, rr_norm(rr_sub_twice<2>(rr_sub<2>(xr, yr), yr)), yr);  // (x - 3y) y
                 else {  // 1 if x == y (exact test behind the cheap filter), else 0; Montgomery one / zero
                     const auto d = rr_sub<2>(xr, yr);

@@ -34,7 +34,7 @@ def test_field_ops(gpu, curve, field):
     if field == 0 or curve != "BLS381":   # lazy-range fields have the fused sum of two products (ec.cuh's Y3)
         ops[5] = lambda x, y: (x * y + (x + y) * (x - y)) % m
         ops[6] = lambda x, y: (x * y - (x + y) * (x - y)) % m
-    if field == 1 or curve != "BN254":   # reduced-radix twins: the BLS base fields (14 x 28 bits), every scalar field (10 x 27)
+    if field == 1 or curve != "BN254":   # reduced-radix twins: the BLS base fields (14 x 28 bits), every scalar field (9 x 29)
         ops[10] = lambda x, y: x * y % m
         ops[11] = lambda x, y: x * x % m
         ops[12] = lambda x, y: (x * y + (x + y) * (x - y)) % m

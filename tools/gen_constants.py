@@ -103,10 +103,13 @@ def rr_struct(name, m, n32, B, NL):
 # or 10 x 28 bits, which is no cheaper than 8 x 32 with carries: it stays on field.cuh)
 # BN254's base field stays on field.cuh: measured on 10 x 27 bits its bucket accumulation takes the same 60 ms at 2^26
 # (81 ms at pf = 8) as on 8 x 32 - with 64-byte points the kernel waits for its 805 M random gathers, not for the multiplier.
-# The scalar fields (NTT): 10 x 27 bits = 270 bits.  15-17 bits of value head-room and 5 spare bits per limb keep a
-# whole 8-point DFT (three butterfly levels) free of carries AND of normalisations; 9 x 29 bits would be 21 % fewer
-# multiply-adds per product but needs a carry propagation per butterfly level, which costs more than it saves.
-RR = {"Fq_BLS377": (28, 14), "Fq_BLS381": (28, 14), "Fr_BLS377": (27, 10), "Fr_BLS381": (27, 10), "Fr_BN254": (27, 10)}
+# The scalar fields (NTT): 9 x 29 bits = 261 bits: 162 multiply-adds per product (10 x 27 bits: 200).  The price is
+# a tight lazy range - 3 spare bits per limb (limbs < 8 x 2^29) and 6-8 bits of value head-room (values < 64 m for
+# BLS12-381) - so the 8-point DFT of ntt_rr.cuh carry-propagates the three sums it subtracts from, multiplies every
+# output (w^0 = one included: a product is what brings a value back under 2m), and its tables are canonical.  All of
+# it is checked at compile time by the bounds in the Frr type.  (Round 2 first ran 10 x 27, whose butterflies need no
+# normalisation at all: 20.1 ms at 2^27; 9 x 29: see DESIGN.md section 4.)
+RR = {"Fq_BLS377": (28, 14), "Fq_BLS381": (28, 14), "Fr_BLS377": (29, 9), "Fr_BLS381": (29, 9), "Fr_BN254": (29, 9)}
 
 
 def main():
