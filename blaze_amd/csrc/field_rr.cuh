@@ -251,6 +251,35 @@ BLZ_DEV Frr<Q, 1, V> rr_norm(const Frr<Q, F, V>& a) {
     return r;
 }
 
+// x < V m  ->  the same residue below 2m, normalised, WITHOUT a product: one quotient digit estimated from the top limb,
+// q = floor(x_top MU / 2^32) with MU = floor(2^32 / (m_top + 1)), then x - q m limb by limb.  q never exceeds
+// floor(x / m) and falls short of it by less than (V + 1) / m_top + x_top / 2^32 <= 1/2, i.e. by at most 1.
+// NL multiply-adds + ~8 NL plain instructions, against 2 NL^2 multiply-adds for a product by one: the way an 8-point
+// DFT's un-twiddled output (and a forward transform's last output) gets back into the lazy range.
+template <class Q, int F, int V>
+BLZ_DEV Frr<Q, 1, 2> rr_reduce2m(const Frr<Q, F, V>& x) {
+    constexpr int NL = Q::NL, B = Q::B;
+    // the two error terms of the estimate, each held below 1/4
+    static_assert(4ull * (V + 1) <= Q::MOD[NL - 1], "top limb of m too short for the quotient estimate");
+    static_assert((V + 1ull) * (Q::MOD[NL - 1] + 1ull) <= (1ull << 30), "x_top too large for the 32-bit reciprocal");
+    const Frr<Q, 1, V> a = rr_norm(x);
+    constexpr uint32_t MU = (uint32_t)((1ull << 32) / (Q::MOD[NL - 1] + 1ull));
+    const uint32_t q = __umulhi(a.v[NL - 1], MU);
+    Frr<Q, 1, 2> r;
+    uint64_t p = 0;
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < NL - 1; ++i) {
+        p = (uint64_t)q * Q::MOD[i] + (p >> B);           // limb i of q m, in the low B bits
+        const uint32_t d = a.v[i] - ((uint32_t)p & Q::MASK) - borrow;
+        borrow = d >> 31;                                 // both terms are < 2^B <= 2^31: negative <=> bit 31
+        r.v[i] = d & Q::MASK;
+    }
+    p = (uint64_t)q * Q::MOD[NL - 1] + (p >> B);
+    r.v[NL - 1] = a.v[NL - 1] - (uint32_t)p - borrow;
+    return r;
+}
+
 // ---- conversions -----------------------------------------------------------------------------------
 // plain integer in 32-bit words (any value < 2^(32 N32)) -> B-bit limbs, normalised
 template <class Q, int V>

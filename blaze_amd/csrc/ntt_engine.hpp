@@ -19,7 +19,7 @@ struct NttTablesRR {
     uint32_t* t0;
     uint32_t* t1;
     uint32_t* t2;
-    uint32_t* fin;   // closing factor of the last pass: R_rr mod m (forward: x * 1) or n^-1 R_rr (inverse)
+    uint32_t* fin;   // closing factor of the last pass: n^-1 R_rr (inverse) or nullptr (forward: no product)
     uint32_t* tA;    // w^(A e), e < 2^18 (n / 512 entries, 10 MiB), or nullptr: the boundary factor after pass 1 that
                      // does not depend on the column, read instead of stepped (2^27 transforms only; ntt_rr.cuh)
     uint32_t swz;    // 1: pass 1 walks its tiles in the channel-spreading order (2^27 transforms)

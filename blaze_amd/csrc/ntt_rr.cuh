@@ -7,8 +7,9 @@
 //     u + (2^J m - v) limb by limb, with the multiple of m in borrow form (tools/gen_constants.py).  The 3 spare
 //     bits per limb and the 6-8 spare bits of R_rr / m are a tight budget, so the subtrahend is always a
 //     normalised value (three of an 8-point DFT's twelve are sums and get a carry propagation first), every DFT
-//     output leaves through a product (w^0 = one included: that is what brings its value back under 2m), and
-//     the twiddle tables are canonical (< m);
+//     twiddled output leaves through a product, which brings its value back under 2m, an un-twiddled one (and a
+//     forward transform's last output) through a one-digit quotient reduction (rr_reduce2m), and the twiddle
+//     tables are canonical (< m);
 //   * every intermediate's limb and value bounds are part of its type, so the compiler proves that no 32-bit
 //     limb and no 64-bit column sum can overflow anywhere in the three DFT steps.
 // Data in HBM stay 32-byte words (canonical on the wire, < 2m between passes); tile elements in LDS and table
@@ -182,7 +183,7 @@ __global__ void k_ntt_table_to_rr(const uint32_t* __restrict__ in, uint32_t* __r
     rr_from_mont32_words<Q>(r, w.v);
     rr_store(out + (size_t)j * rr_stride<Q>(), rr_canon(r));
 }
-// fin = R_rr mod m (inverse == 0) or n^-1 in Montgomery R_rr form (from the 32-bit ninv)
+// fin = n^-1 in Montgomery R_rr form (from the 32-bit ninv); forward transforms have no closing factor
 template <class Fr>
 __global__ void k_ntt_fin_rr(const uint32_t* __restrict__ ninv32, uint32_t* __restrict__ out) {
     using Q = typename Fr::RR;
@@ -296,11 +297,15 @@ __global__ __launch_bounds__(NR_THREADS, 2) void k_ntt512_rr(const uint32_t* __r
         rr_from_words<Q>(a1[j], x.v);
     }
     auto o1 = dft8_rr<Q>(a1, w1, w2, w3);
-    BLZ_RR_FOR8(o1, {   // * w512^(n2 k1): every output, w^0 included - the product is what renormalises it
-        WT w;
+    BLZ_RR_FOR8(o1, {   // * w512^(n2 k1); the un-twiddled output (k1 = 0) is brought below 2m without a product
         W t;
-        rr_load(w, wp + (size_t)(n2 * K) * ES);
-        rr_mul_n(t, X, w);
+        if constexpr (K == 0) {
+            t = rr_reduce2m(X);
+        } else {
+            WT w;
+            rr_load(w, wp + (size_t)(n2 * K) * ES);
+            rr_mul_n(t, X, w);
+        }
         rr_lds_store(lds, (64u * K + n2) * RS + col * ES, t);
     })
     __syncthreads();
@@ -312,10 +317,14 @@ __global__ __launch_bounds__(NR_THREADS, 2) void k_ntt512_rr(const uint32_t* __r
     auto o2 = dft8_rr<Q>(a2, w1, w2, w3);
     __syncthreads();
     BLZ_RR_FOR8(o2, {   // * w64^(n2' k1') = w512^(8 n2' k1')
-        WT w;
         W t;
-        rr_load(w, wp + (size_t)(8u * n2p * K) * ES);
-        rr_mul_n(t, X, w);
+        if constexpr (K == 0) {
+            t = rr_reduce2m(X);
+        } else {
+            WT w;
+            rr_load(w, wp + (size_t)(8u * n2p * K) * ES);
+            rr_mul_n(t, X, w);
+        }
         rr_lds_store(lds, (64u * k1 + 8u * K + n2p) * RS + col * ES, t);
     })
     __syncthreads();
@@ -347,14 +356,15 @@ __global__ __launch_bounds__(NR_THREADS, 2) void k_ntt512_rr(const uint32_t* __r
         const uint64_t i0 = col_base + col;
         tw_pow_rr<Q>(w, T, (uint32_t)((((uint64_t)kb << g.logC) + (split ? fixed : 0)) * i0));
         tw_pow_rr<Q>(step, T, (uint32_t)((64u * i0) << g.logC));
-    } else {
-        rr_load(w, T.fin);
+    } else if (T.fin) {
+        rr_load(w, T.fin);   // inverse transform: n^-1; a forward transform closes with the product-free reduction
     }
     BLZ_RR_FOR8(o3, {
         const uint32_t row = kb + 64u * K;
         if (PASS == 1 && split) rr_load(w, T.tA + (size_t)(row * (uint32_t)fixed) * ES);   // w^(A i1 k2)
         W t;
-        rr_mul_n(t, X, w);
+        if (PASS == 3 && !T.fin) t = rr_reduce2m(X);
+        else rr_mul_n(t, X, w);
         Fp<Fr> y;
         rr_to_words<Q>(y.v, t);
         uint64_t oaddr;

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(64) void k_test_field(int op, const uint32_t* a, co
                 fp_zero(r);
             }
             break;
-        case 10: case 11: case 12: case 13: case 14:
+        case 10: case 11: case 12: case 13: case 14: case 15:
             // the reduced-radix twin (field_rr.cuh): product, square, fused sum of products on lazy operands,
             // carry propagation, zero tests; operands go in through the wire-word conversion and come back
             // through the 32-bit Montgomery form, so both conversions are under test as well
@@ -46,6 +46,10 @@ __global__ __launch_bounds__(64) void k_test_field(int op, const uint32_t* a, co
                 else if (op == 11) rr_sqr(rr, xr);
                 else if (op == 12) rr_mul2(rr, xr, yr, rr_norm(rr_add(xr, yr)), rr_sub<2>(xr, yr));   // x y + (x + y)(x - y)
                 else if (op == 13) rr_mul(rr, rr_norm(rr_sub_twice<2>(rr_sub<2>(xr, yr), yr)), yr);  // (x - 3y) y
+                else if (op == 15) {   // x - 3y + 12m brought below 2m by the quotient-digit reduction; then x (x - 3y)
+                    const auto t = rr_reduce2m(rr_sub_twice<2>(rr_sub<2>(xr, yr), yr));
+                    rr_mul(rr, t, xr);
+                }
                 else {  // 1 if x == y (exact test behind the cheap filter), else 0; Montgomery one / zero
                     const auto d = rr_sub<2>(xr, yr);
                     const bool eq = rr_maybe_equal(xr, yr) && rr_is_zero(d);

@@ -229,8 +229,9 @@ int blz_synth_field_elements(int device_id, void* d_out, uint64_t n, uint64_t se
  * Run the device field / group primitives on arrays so tests can compare them one by one with the
  * CPU oracle.  Host pointers; canonical little-endian encodings.
  *   fq ops (field = 0: Fq, 1: Fr): 0 mul, 1 add, 2 sub, 3 inverse(a), 4 sqr(a), 5/6 a b +- (a + b)(a - b);
- *     reduced-radix twin of the BLS base fields (all-zero output for other fields): 10 mul, 11 sqr,
- *     12 a b + (a + b)(a - b), 13 (a - 3b) b, 14 [a == b]
+ *     reduced-radix twin of the BLS base fields and of every scalar field (all-zero output for BN254 Fq):
+ *     10 mul, 11 sqr, 12 a b + (a + b)(a - b), 13 (a - 3b) b, 14 [a == b], 15 a (a - 3b) through the
+ *     product-free reduction of a lazy value
  *   ec ops: 0 P+Q (mixed, P as accumulator), 1 2P, 2 P+Q (full XYZZ add), 3 P-Q (mixed, negated),
  *     4 / 5 P+Q / P-Q through the reduced-radix mixed add (BLS curves); 6 / 7 P+Q / Q-P with both operands
  *     affine (the first addition of a bucket run)

@@ -40,6 +40,7 @@ def test_field_ops(gpu, curve, field):
         ops[12] = lambda x, y: (x * y + (x + y) * (x - y)) % m
         ops[13] = lambda x, y: (x - 3 * y) * y % m
         ops[14] = lambda x, y: 1 if x == y else 0
+        ops[15] = lambda x, y: (x - 3 * y) * x % m
     for op, fn in ops.items():
         cnt = n if op != 3 else 200  # inversion is slow on one lane; sample
         out = C.create_string_buffer(cnt * nb)
