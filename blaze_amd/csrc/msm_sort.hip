@@ -21,7 +21,10 @@
 
 namespace blz {
 
-constexpr int SORT_THREADS = 1024;
+#ifndef BLZ_SORT_THREADS
+#define BLZ_SORT_THREADS 1024
+#endif
+constexpr int SORT_THREADS = BLZ_SORT_THREADS;
 constexpr int FINE_THREADS = 512;
 constexpr int SORT_UNROLL = 4;
 
@@ -181,8 +184,14 @@ __global__ __launch_bounds__(SORT_THREADS) void k_coarse_scatter(const uint32_t*
 // scalars per lane in registers and walks the windows: per window its entries are ranked with an LDS
 // histogram over the window's 2^ch bins, laid out bin-major in an LDS stage, and copied out slot-major,
 // so consecutive lanes write consecutive addresses of a bin's run (8 entries = 64 B on average).
-constexpr int CS_THREADS = 512;
-constexpr int CS_T = 16;
+#ifndef BLZ_CS_THREADS
+#define BLZ_CS_THREADS 512
+#endif
+#ifndef BLZ_CS_T
+#define BLZ_CS_T 16
+#endif
+constexpr int CS_THREADS = BLZ_CS_THREADS;
+constexpr int CS_T = BLZ_CS_T;
 constexpr int CS_PTS = CS_THREADS * CS_T;  // 8192 points per block: 64 KiB of staging
 
 template <int SW>
@@ -364,8 +373,14 @@ __global__ __launch_bounds__(FINE_THREADS) void k_fine_count(const uint16_t* __r
 // entries of a bucket's run, and neighbouring buckets' runs are neighbours in memory too, so a store
 // instruction touches a handful of lines instead of 64 (one-lane-per-bucket copy-out: 5.0 ms; the
 // unstaged version wrote 17.6 GB for 3.2 GB of entries in the WRITE_SIZE counter).
-constexpr int FS_THREADS = 1024;
-constexpr int FS_PER_THREAD = 24;
+#ifndef BLZ_FS_THREADS
+#define BLZ_FS_THREADS 1024
+#endif
+#ifndef BLZ_FS_PER_THREAD
+#define BLZ_FS_PER_THREAD 24
+#endif
+constexpr int FS_THREADS = BLZ_FS_THREADS;
+constexpr int FS_PER_THREAD = BLZ_FS_PER_THREAD;
 constexpr int FS_ROUND = FS_THREADS * FS_PER_THREAD;  // up to 24576 entries: 6 bytes of staging each
 
 __global__ __launch_bounds__(FS_THREADS) void k_fine_scatter(const uint32_t* __restrict__ inter_idx, const uint16_t* __restrict__ inter_fine,
@@ -404,13 +419,8 @@ __global__ __launch_bounds__(FS_THREADS) void k_fine_scatter(const uint32_t* __r
         // exclusive scan of hist (each lane owns per_thr_bins consecutive buckets) + global reservation
         {
             uint32_t b0 = threadIdx.x * per_thr_bins;
-            uint32_t loc[4];
             uint32_t sum = 0;
-            for (uint32_t q = 0; q < per_thr_bins; ++q) {
-                uint32_t v = (b0 + q) < nf ? hist[b0 + q] : 0;
-                loc[q] = v;
-                sum += v;
-            }
+            for (uint32_t q = 0; q < per_thr_bins; ++q) sum += (b0 + q) < nf ? hist[b0 + q] : 0;
             uint32_t incl = sum;
             for (int o = 1; o < 64; o <<= 1) {
                 uint32_t t2 = __shfl_up(incl, o, 64);
@@ -423,7 +433,7 @@ __global__ __launch_bounds__(FS_THREADS) void k_fine_scatter(const uint32_t* __r
             uint32_t run = wbase + incl - sum;
             for (uint32_t q = 0; q < per_thr_bins; ++q) {
                 if ((b0 + q) < nf) {
-                    uint32_t v = loc[q];
+                    uint32_t v = hist[b0 + q];   // only this lane touches its buckets between the barriers
                     hist[b0 + q] = run;
                     gbase[b0 + q] = v ? atomicAdd(&cur[b0 + q], v) : 0u;
                     run += v;
