@@ -1,6 +1,7 @@
 // The 512-point NTT pass (k_ntt512 of ntt_impl.cuh) on the reduced-radix scalar field: 9 limbs of 29 bits
 // (field_rr.cuh; curve_constants.h Fr_*_RR).  Same decomposition (512 = 8 * 8 * 8, a lane holds 8 elements, two
-// LDS exchanges per pass, inter-pass twiddle stepped along the lane's outputs), different arithmetic:
+// LDS exchanges per pass - the first across the block, the second inside a wave - inter-pass twiddle stepped along the
+// lane's outputs), different arithmetic:
 //   * a field product is 162 v_mad_u64_u32 (+ 17 shifts, 9 quotient digits) instead of 128 x (v_mad_u64_u32 +
 //     v_addc_co_u32);
 //   * a butterfly is 27 plain 32-bit adds / subs - no carry chain, no compare, no select: u - v is
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(NR_THREADS, 2) void k_ntt512_rr(const uint32_t* __r
 #pragma unroll
     for (int j = 0; j < 8; ++j) rr_lds_load(a2[j], lds, (64u * k1 + 8u * BR[j] + n2p) * RS + col * ES);
     auto o2 = dft8_rr<Q>(a2, w1, w2, w3);
-    __syncthreads();
+    // no barrier: the lane overwrites exactly the 8 elements it has just read (rows 64 k1 + 8 j + n2', its column)
     BLZ_RR_FOR8(o2, {   // * w64^(n2' k1') = w512^(8 n2' k1')
         W t;
         if constexpr (K == 0) {
@@ -327,7 +328,11 @@ __global__ __launch_bounds__(NR_THREADS, 2) void k_ntt512_rr(const uint32_t* __r
         }
         rr_lds_store(lds, (64u * k1 + 8u * K + n2p) * RS + col * ES, t);
     })
-    __syncthreads();
+    // the second exchange stays inside the 32 lanes that share k1 (n2 = 8 k1 + 0..7, four columns): one wave, whose LDS
+    // operations complete in order - a wave-level fence instead of a block barrier
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // ---- step 2b: lane (k1, k1', col): 8-point DFTs over n2' (rows 64 k1 + 8 k1' + n2'); outputs k = k1 + 8 k1' + 64 k2'
     // leave with the inter-pass twiddle (passes 1, 2) or the closing factor (pass 3), which also brings them back
     // below 2m for the 32-byte word
