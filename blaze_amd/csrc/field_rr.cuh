@@ -130,13 +130,44 @@ template <int NL, int K> BLZ_DEV void rr_sq_c(uint64_t& acc, const uint32_t (&a)
 #define BLZ_RR_AB rr_ab
 #define BLZ_RR_SQ rr_sq
 #endif
+// the plain product's columns: caller's products and reduction products in one asm statement where the operand count
+// allows (rr_gen.inc rr_fused_ok), then the column's tail as in rr_column
+template <class Q, int K>
+BLZ_DEV void rr_column_mul(uint64_t& acc, uint32_t (&q)[Q::NL], uint32_t (&t)[Q::NL], const uint32_t (&a)[Q::NL],
+                           const uint32_t (&b)[Q::NL]) {
+    constexpr int NL = Q::NL;
+#if BLZ_RR_PLAIN || defined(BLZ_RR_NO_FUSE)
+    rr_column<Q, K>(acc, q, t, [&](auto k, uint64_t& c) { BLZ_RR_AB<NL, decltype(k)::value>(c, a, b); });
+#else
+    if constexpr (rr_fused_ok(NL, K)) {
+        rr_abqm<NL, K>(acc, a, b, q, Q::MOD);
+        if constexpr (K < NL) {
+            q[K] = ((uint32_t)acc * Q::N0) & Q::MASK;
+            acc = (uint64_t)q[K] * Q::MOD[0] + acc;
+        } else {
+            t[K - NL] = (uint32_t)acc & Q::MASK;
+        }
+        acc >>= Q::B;
+    } else {
+        rr_column<Q, K>(acc, q, t, [&](auto k, uint64_t& c) { BLZ_RR_AB<NL, decltype(k)::value>(c, a, b); });
+    }
+#endif
+}
+template <class Q, int... Ks>
+BLZ_DEV void rr_columns_mul(Frr<Q, 1, 2>& r, const uint32_t (&a)[Q::NL], const uint32_t (&b)[Q::NL], std::integer_sequence<int, Ks...>) {
+    uint32_t q[Q::NL], t[Q::NL];
+    uint64_t acc = 0;
+    (rr_column_mul<Q, Ks>(acc, q, t, a, b), ...);
+    t[Q::NL - 1] = (uint32_t)acc;
+#pragma unroll
+    for (int i = 0; i < Q::NL; ++i) r.v[i] = t[i];
+}
 // r = a b / Rrr  (mod m)
 template <class Q, int Fa, int Va, int Fb, int Vb>
 BLZ_DEV void rr_mul(Frr<Q, 1, 2>& r, const Frr<Q, Fa, Va>& a, const Frr<Q, Fb, Vb>& b) {
     static_assert(rr_cols_ok<Q>(Fa * Fb), "column sum would overflow 64 bits: normalise an operand");
     static_assert(rr_vals_ok<Q>(Va * Vb), "product would leave the lazy value range");
-    rr_columns<Q>(r, [&](auto k, uint64_t& acc) { BLZ_RR_AB<Q::NL, decltype(k)::value>(acc, a.v, b.v); },
-                  std::make_integer_sequence<int, 2 * Q::NL - 1>{});
+    rr_columns_mul<Q>(r, a.v, b.v, std::make_integer_sequence<int, 2 * Q::NL - 1>{});
 }
 // r = a^2 / Rrr: the off-diagonal products once, against the doubled operand
 template <class Q, int Fa, int Va>
