@@ -87,7 +87,7 @@ int ntt_setup(blz_ntt* h) {
     int lb = (l - la) > 9 ? 9 : (l - la);
     int lc = l - la - lb;
     if (lc > 9) return fail(BLZ_ERR_INVALID_PARAM, "log_size %d not supported (max 27)", l);
-    h->geom = NttGeom{la, lb, lc, l};
+    h->geom = NttGeom{la, lb, lc, l, lc ? 1 : lb ? 2 : 3};
     // columns per tile: LDS = radix * (COLS + 1) * 32 B <= 160 KiB, and COLS <= extent of the column index
     auto pick = [](int lr, int lcols_avail) {
         int c = 17 - 5 - lr;  // log2(128 KiB / 32 B / radix)

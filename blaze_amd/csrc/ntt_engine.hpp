@@ -30,6 +30,7 @@ constexpr size_t NTT_RR_TABLE_BYTES = (6 * 512 + 1) * NTT_RR_ENTRY_DWORDS * 4;
 
 struct NttGeom {
     int logA, logB, logC, logn;
+    int wire_pass;   // the pass that reads the caller's words (1, 2 or 3): the first one that runs
 };
 
 // per-field entry points.  Field ids follow enum blz_curve: the scalar field Fr of that curve.

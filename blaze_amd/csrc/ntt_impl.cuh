@@ -84,6 +84,16 @@ struct NttOps<Fp<Fr>> {
     static BLZ_DEV void canon(E& a) {
         if constexpr (Fr::LAZY) fp_reduce(a); else fp_canon_wide(a);
     }
+    // A word off the wire is canonical by contract; any other 32-byte value is still a residue and is brought into
+    // [0, 2m) by a product with one (x < 2^256 = R and one < m: the result is < 2m).  The top-limb test lets every
+    // word >= m through to the product and almost no canonical one.
+    static BLZ_DEV void wire_in(E& x) {
+        if (__builtin_expect(x.v[Fr::N - 1] >= Fr::MOD[Fr::N - 1], 0)) {
+            E one;
+            fp_one(one);
+            mul(x, x, one);
+        }
+    }
 };
 
 constexpr int NTT_THREADS = 1024;  // 4 waves per SIMD: the 128-147 KiB tile allows one block per CU
@@ -142,6 +152,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const uint32_t* __rest
         else { col = e & (COLS - 1); row = e >> cols_log; }         // contiguous along cols
         E x;
         fp_load(x, in + (in_base + row * in_rstride + col * in_cstride) * 8);
+        if (PASS == g.wire_pass) NttOps<E>::wire_in(x);
         uint32_t rrow = lr ? (__brev(row) >> (32 - lr)) : 0;
         lds_store(lds, rrow * RS + col * 8, x);
     }
@@ -315,6 +326,7 @@ __global__ __launch_bounds__(N8_THREADS, 2) void k_ntt512(const uint32_t* __rest
     for (int j = 0; j < 8; ++j) {
         uint32_t row = 64u * BR8[j] + n2;
         fp_load(a[j], in + (in_base + row * in_rstride + col * in_cstride) * 8);
+        if (PASS == g.wire_pass) NttOps<E>::wire_in(a[j]);
     }
     dft8(a, w1, w2, w3);
 #pragma unroll

@@ -286,9 +286,10 @@ __global__ __launch_bounds__(NR_THREADS, 2) void k_ntt512_rr(const uint32_t* __r
     rr_load(w3, wp + 192 * ES);
 
     // ---- step 1: 8-point DFTs over n1 (rows 64 n1 + n2), straight from global memory.  The words on the wire are
-    // values < 4m (any 256-bit value for BLS12-381); between passes they are < 2m.
+    // any 256-bit value (canonical on the wire by contract; a stray one is still reduced correctly); between passes
+    // they are < 2m.
     constexpr int BR[8] = {0, 4, 2, 6, 1, 5, 3, 7};
-    constexpr int VIN1 = 4;
+    constexpr int VIN1 = 1 << (32 * Q::N32 + 1 - Q::BITS);   // 2^256 < VIN1 m: 4 (BLS12-381), 8 (BN254), 16 (BLS12-377)
     Frr<Q, 1, VIN1> a1[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {

@@ -188,7 +188,8 @@ int blz_ntt_new_field(int device_id, int field, int log_size, int inverse, blz_n
 void blz_ntt_free(blz_ntt* h);
 /* NTTClient::initialize(NttInit{}) (ntt_api.rs:37-56) */
 int blz_ntt_initialize(blz_ntt* h);
-/* NTTClient::set_data(NTTInput{buf_host, data}) (ntt_api.rs:72-87): data = 2^log_size x 32 B LE */
+/* NTTClient::set_data(NTTInput{buf_host, data}) (ntt_api.rs:72-87): data = 2^log_size x 32 B LE, canonical field
+ * elements; a word >= r is taken as the residue it represents (the output is canonical either way) */
 int blz_ntt_set_data(blz_ntt* h, size_t buf_host, const uint8_t* data, size_t len);
 int blz_ntt_set_data_device(blz_ntt* h, size_t buf_host, const void* d_data, size_t len);
 /* NTTClient::start_process(Some(buf_kernel)) (ntt_api.rs:58-70): in-place transform of that buffer */

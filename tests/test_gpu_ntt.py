@@ -259,6 +259,34 @@ def test_other_scalar_fields(gpu, orc, field, logn):
     inv.close()
 
 
+@pytest.mark.parametrize("field", ["BLS381", "BLS377", "BN254"])
+@pytest.mark.parametrize("logn", [9, 18, 20])
+def test_non_canonical_words(gpu, orc, field, logn):
+    """The wire format is canonical by contract, but any 256-bit word is a residue: x + k r (as large as 32 bytes
+    hold, the all-ones word included) must transform like x - on the radix-2 kernel (2^9) and on the reduced-radix
+    512-point kernel whose first step types its input as "< 2^256" (2^18: pass 2 reads the wire; 2^20: pass 1 generic)."""
+    r = pyref.CURVES[field]["r"]
+    rng = random.Random(77 + logn)
+    n = 1 << logn
+    kmax = ((1 << 256) - 1) // r
+    base = []
+    for i in range(1024):
+        x = rng.randrange(r)
+        k = rng.randrange(kmax + 1)
+        if x + k * r >= 1 << 256:
+            k -= 1
+        base.append((x, x + k * r))
+    base.append(((1 << 256) - 1 - kmax * r, (1 << 256) - 1))
+    base.append((0, kmax * r))
+    canon = b"".join(base[(i * 5 + i // 1024) % len(base)][0].to_bytes(32, "little") for i in range(n))
+    stray = b"".join(base[(i * 5 + i // 1024) % len(base)][1].to_bytes(32, "little") for i in range(n))
+    cl = NTTClient(NTT.Ntt, DriverClient(0), log_size=logn, field=field)
+    want = bytes(orc.ntt(field, canon, logn, threads=16))
+    assert _ntt(cl, canon) == want
+    assert _ntt(cl, stray, buf=1) == want
+    cl.close()
+
+
 def test_other_fields_large_and_limits(gpu, orc):
     """2^24 over BN254 Fr by properties + spot coefficients; BN254's two-adicity is 28, so 2^27 exists;
     sizes beyond a field's two-adicity are refused."""
