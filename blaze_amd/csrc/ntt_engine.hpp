@@ -22,11 +22,12 @@ struct NttTablesRR {
     uint32_t* fin;   // closing factor of the last pass: n^-1 R_rr (inverse) or nullptr (forward: no product)
     uint32_t* tA;    // w^(A e), e < 2^18 (n / 512 entries, 10 MiB), or nullptr: the boundary factor after pass 1 that
                      // does not depend on the column, read instead of stepped (2^27 transforms only; ntt_rr.cuh)
+    uint32_t* ts2;   // w^(64 C i0), i0 < 512: the step of pass 2's boundary factor along a lane's rows (one per column)
     uint32_t swz;    // 1: pass 1 walks its tiles in the channel-spreading order (2^27 transforms)
 };
 constexpr size_t NTT_RR_BOUNDARY_ENTRIES = (size_t)1 << 18;
 constexpr size_t NTT_RR_ENTRY_DWORDS = 10;
-constexpr size_t NTT_RR_TABLE_BYTES = (6 * 512 + 1) * NTT_RR_ENTRY_DWORDS * 4;
+constexpr size_t NTT_RR_TABLE_BYTES = (7 * 512 + 1) * NTT_RR_ENTRY_DWORDS * 4;
 
 struct NttGeom {
     int logA, logB, logC, logn;

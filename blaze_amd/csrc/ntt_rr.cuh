@@ -361,7 +361,7 @@ __global__ __launch_bounds__(NR_THREADS, 2) void k_ntt512_rr(const uint32_t* __r
         // x(i0, k1 = row, k2) *= w^(C i0 row)   [split: * w^(i0 k2) as well; k2 = fixed]
         const uint64_t i0 = col_base + col;
         tw_pow_rr<Q>(w, T, (uint32_t)((((uint64_t)kb << g.logC) + (split ? fixed : 0)) * i0));
-        tw_pow_rr<Q>(step, T, (uint32_t)((64u * i0) << g.logC));
+        rr_load(step, T.ts2 + (size_t)i0 * ES);   // w^(64 C i0)
     } else if (T.fin) {
         rr_load(w, T.fin);   // inverse transform: n^-1; a forward transform closes with the product-free reduction
     }
