@@ -259,6 +259,16 @@ def main():
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                 "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": round(acc_avg_ms, 3),
                 "pipeline_ms": round(statistics.mean(total_ms), 3)}
+    # The resource this kernel actually saturates, beside the prescribed HBM figure: 32-bit integer multiply issue.
+    # One bucket addition (mixed XYZZ add on 14 x 28-bit limbs) is 3542 v_mad_u64_u32; a launch does one addition per
+    # non-zero window digit (255-bit scalars in 12 occupied windows at this size).  The peak is the chip's measured
+    # rate for that instruction (profiles/r01_mac_issue_microbench.txt, profiles/r02_mul_variants.txt).
+    if CURVE in ("BLS381", "BLS377") and LOG_N >= 24:
+        occupied = -(-(255 if CURVE == "BLS381" else 253) // int(api["window_bits"]))
+        mads = n_loc * occupied * 3542
+        roofline["integer_issue"] = {"unit": "v_mad_u64_u32 lane-ops/s", "achieved": round(mads / (acc_avg_ms * 1e-3), 0),
+                                     "peak": 3.1e13, "frac": round(mads / (acc_avg_ms * 1e-3) / 3.1e13, 4),
+                                     "multiply_adds_per_launch": mads}
 
     # ---- NTT 2^27 latency (replica per rank; rank 0 reports), timed like benches/ntt_bench.rs:34-39
     # minus the 100 ms sleep of reset(): initialize + start_process + wait_result on a resident buffer
