@@ -199,6 +199,56 @@ def test_full_size_2e27_every_output(gpu, orc):
     inv.close(); d_in.free(); d_y.free()
 
 
+@pytest.mark.parametrize("field", ["BLS377", "BN254"])
+def test_full_size_2e27_other_fields(gpu, orc, field):
+    """2^27 over the other two scalar fields: the only size at which their pass 1 runs the 512-point reduced-radix
+    kernel with its boundary table (and their wider input bound, 16 m / 8 m).  X[0] = sum x, sum_k X[k] = n x[0],
+    spot coefficients against the O(n) evaluation oracle, inverse(forward(x)) == x on the device."""
+    import numpy as np
+    logn = 27
+    n = 1 << logn
+    r = pyref.CURVES[field]["r"]
+    rng = np.random.default_rng(27 + len(field))
+    x = rng.integers(0, 256, size=32 * n, dtype=np.uint8)
+    x[31::32] &= 0x0F          # < 2^252 < r: canonical in both fields
+    cl = NTTClient(NTT.Ntt, DriverClient(0), log_size=logn, field=field)
+    cl.set_data(NTTInput(0, x))
+    cl.initialize(NttInit())
+    cl.start_process(0)
+    cl.wait_result()
+    y = np.frombuffer(cl.result(0), dtype=np.uint8)
+
+    def elem(arr, i):
+        return int.from_bytes(arr[32 * i: 32 * i + 32].tobytes(), "little")
+
+    def field_sum(arr):
+        limbs = arr.view(np.uint64).reshape(-1, 4)
+        tot = 0
+        for j in range(4):
+            lo = int((limbs[:, j] & np.uint64(0xFFFFFFFF)).sum(dtype=np.uint64))
+            hi = int((limbs[:, j] >> np.uint64(32)).sum(dtype=np.uint64))
+            tot += (lo + (hi << 32)) << (64 * j)
+        return tot % r
+
+    assert elem(y, 0) == field_sum(x)
+    assert field_sum(y) == (n * elem(x, 0)) % r
+    for k in (1, 87654321, n - 1):
+        got = elem(y, k)
+        assert got < r
+        assert got == orc.ntt_eval_at(field, x, logn, k), k
+    inv = NTTClient(NTT.Ntt, DriverClient(0), log_size=logn, inverse=True, field=field)
+    d_y = DeviceBuffer(0, 32 * n)
+    cl.result_device(0, d_y)
+    cl.close()
+    inv.set_data(NTTInput(0, d_y))
+    inv.initialize(NttInit())
+    inv.start_process(0)
+    inv.wait_result()
+    z = np.frombuffer(inv.result(0), dtype=np.uint8)
+    assert np.array_equal(z, x), "inverse(forward(x)) != x at 2^27"
+    inv.close(); d_y.free()
+
+
 @pytest.mark.parametrize("logn", [3, 11, 19])
 def test_inverse_transform(gpu, orc, logn):
     """the inverse direction (omega^-1, scaled by n^-1), against the oracle and
