@@ -199,6 +199,30 @@ def test_full_size_2e27_every_output(gpu, orc):
     inv.close(); d_in.free(); d_y.free()
 
 
+def test_random_sizes_fields_directions(gpu, orc):
+    """A seeded walk over (field, size, direction, buffer) on long-lived clients: every combination of kernel
+    families (radix-2 passes, 512-point reduced-radix passes) and table sets gets used more than once per client."""
+    import numpy as np
+    rng = random.Random(20260)
+    clients = {}
+    for it in range(36):
+        field = rng.choice(["BLS381", "BLS377", "BN254"])
+        logn = rng.choice([1, 4, 9, 10, 14, 17, 18, 19, 21, 22])
+        inv = rng.random() < 0.35
+        key = (field, logn, inv)
+        if key not in clients:
+            clients[key] = NTTClient(NTT.Ntt, DriverClient(0), log_size=logn, inverse=inv, field=field)
+        cl = clients[key]
+        n = 1 << logn
+        x = np.random.default_rng(rng.randrange(1 << 30)).integers(0, 256, size=32 * n, dtype=np.uint8)
+        x[31::32] &= 0x0F          # < 2^252: canonical in all three fields
+        buf = rng.randrange(2)
+        got = _ntt(cl, x.tobytes(), buf=buf)
+        assert got == bytes(orc.ntt(field, x.tobytes(), logn, inverse=inv, threads=16)), (it, field, logn, inv, buf)
+    for cl in clients.values():
+        cl.close()
+
+
 @pytest.mark.parametrize("field", ["BLS377", "BN254"])
 def test_full_size_2e27_other_fields(gpu, orc, field):
     """2^27 over the other two scalar fields: the only size at which their pass 1 runs the 512-point reduced-radix
