@@ -86,6 +86,15 @@ class NTTClient(DriverPrimitive[NTT, NttInit, NTTInput, bytes]):
         check(lib().blz_ntt_result(self._h, buf_num, p, self.nbytes))
         return out
 
+    def result_into(self, buf_num: int, out) -> None:
+        """result() into a caller-owned writable buffer (bytearray, numpy array ...) of 32 * n bytes: a host that
+        keeps its output vector between transforms does not pay the first-touch page faults of a fresh 4 GiB
+        allocation on every call (the C ABI takes the caller's pointer anyway)."""
+        p, nb, _k = buf_ptr(out)
+        if nb != self.nbytes:
+            raise ValueError(f"result buffer holds {nb} bytes, the transform has {self.nbytes}")
+        check(lib().blz_ntt_result(self._h, buf_num, p, self.nbytes))
+
     def result_device(self, buf_num: int, dst: DeviceBuffer) -> None:
         check(lib().blz_ntt_result_device(self._h, buf_num, dst.ptr, dst.nbytes))
 
