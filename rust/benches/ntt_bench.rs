@@ -1,46 +1,49 @@
-//! `/root/reference/benches/ntt_bench.rs:7-47`: initialize + start_process + wait_result (+ reset) on a resident
-//! buffer.  FNAME names a file of 2^27 x 32 bytes; without it a zero vector is transformed (the timing does not
-//! depend on the values).
-use criterion::*;
-use ingo_blaze::{driver_client::*, ingo_ntt::*};
-use std::{env, fs::File, io::Read};
+//! 2^27 NTT latency on a resident buffer, the measurement `/root/reference/benches/ntt_bench.rs:7-47` makes:
+//! per sample one `initialize` + `start_process` + `wait_result` (the reference's 100 ms `reset()` sleep has no
+//! counterpart here).  The input comes from the file named by FNAME (2^27 x 32 bytes) or, without it, is a
+//! counter pattern - the kernels' timing does not depend on the values.  Besides criterion's wall-clock figure
+//! the device-side time of the last transform (HIP events on the kernel's stream) is logged.
+use criterion::{criterion_group, criterion_main, Criterion};
+use ingo_blaze::driver_client::{CardType, DriverClient, DriverConfig, DriverPrimitive};
+use ingo_blaze::ingo_ntt::{NTTClient, NTTInput, NttInit, NTT, NTT_LOG_SIZE, NTT_WORD_SIZE};
 
-fn bench_ntt_calc(c: &mut Criterion) {
-    let _ = env_logger::try_init();
-    let id = env::var("ID").unwrap_or_else(|_| 0.to_string());
-    let mut in_vec: Vec<u8> = Default::default();
-    match env::var("FNAME") {
-        Ok(fname) => {
-            let mut f = File::open(fname).expect("no file found");
-            let _ = f.read_to_end(&mut in_vec);
-        }
-        Err(_) => in_vec = vec![0u8; NTT_WORD_SIZE << NTT_LOG_SIZE],
+const RESIDENT_BUFFER: usize = 0;
+
+fn input_vector() -> Vec<u8> {
+    if let Ok(path) = std::env::var("FNAME") {
+        return std::fs::read(&path).unwrap_or_else(|e| panic!("cannot read {path}: {e}"));
     }
-    let buf_host = 0;
-    let buf_kernel = 0;
-    let dclient = DriverClient::new(&id, DriverConfig::driver_client_cfg(CardType::C1100));
-    let driver = NTTClient::new(NTT::Ntt, dclient);
-    driver.set_data(NTTInput { buf_host, data: in_vec }).unwrap();
-    let _ = driver.driver_client.initialize_cms();
-    let _ = driver.driver_client.reset_sensor_data();
+    let words = 1usize << NTT_LOG_SIZE;
+    let mut v = vec![0u8; words * NTT_WORD_SIZE];
+    for (i, w) in v.chunks_exact_mut(NTT_WORD_SIZE).enumerate() {
+        w[..8].copy_from_slice(&(i as u64).to_le_bytes());   // canonical: far below r
+    }
+    v
+}
 
-    let mut group = c.benchmark_group("NTT computation");
-    group.bench_function("NTT", |b| {
+fn ntt_latency(c: &mut Criterion) {
+    let _ = env_logger::try_init();
+    let card = std::env::var("ID").unwrap_or_else(|_| "0".into());
+    let client = NTTClient::new(NTT::Ntt, DriverClient::new(&card, DriverConfig::driver_client_cfg(CardType::C1100)));
+    client
+        .set_data(NTTInput { buf_host: RESIDENT_BUFFER, data: input_vector() })
+        .expect("set_data");
+
+    c.benchmark_group("NTT computation").bench_function("NTT", |b| {
         b.iter(|| {
-            let _ = driver.initialize(NttInit {});
-            let _ = driver.start_process(Some(buf_kernel));
-            let _ = driver.wait_result();
-            let _ = driver.driver_client.reset();
+            client.initialize(NttInit {}).expect("initialize");
+            client.start_process(Some(RESIDENT_BUFFER)).expect("start_process");
+            client.wait_result().expect("wait_result");
         })
     });
-    group.finish();
-    let res = driver.result(Some(buf_kernel)).unwrap();
-    log::info!("NTT result: {:?} bytes, last kernel {:?} ms", res.unwrap().len(), driver.last_kernel_ms());
+
+    let out = client.result(Some(RESIDENT_BUFFER)).expect("result").expect("a transform has run");
+    log::info!("transformed {} bytes; device time of the last transform: {:?} ms", out.len(), client.last_kernel_ms());
 }
 
 criterion_group! {
     name = benches;
     config = Criterion::default().sample_size(10);
-    targets = bench_ntt_calc
+    targets = ntt_latency
 }
 criterion_main!(benches);

@@ -73,10 +73,13 @@ impl DriverClient {
     }
 }
 
-/// Return code of the C ABI -> the reference's error enum (`/root/reference/src/error.rs:6-32`, same order).
+/// Return code of the C ABI -> `Result`: the variant comes from `DriverClientError::from_code`, its payload from the
+/// library's thread-local last message.
 pub(crate) fn check(rc: std::os::raw::c_int) -> Result<()> {
-    use DriverClientError::*;
-    let msg = || unsafe {
+    if rc == 0 {
+        return Ok(());
+    }
+    let detail = unsafe {
         let p = hip_ffi::blz_last_error_message();
         if p.is_null() {
             String::new()
@@ -84,16 +87,5 @@ pub(crate) fn check(rc: std::os::raw::c_int) -> Result<()> {
             std::ffi::CStr::from_ptr(p).to_string_lossy().into_owned()
         }
     };
-    let io = |m: String| std::io::Error::new(std::io::ErrorKind::Other, m);
-    match rc {
-        0 => Ok(()),
-        1 => Err(WriteError { offset: msg(), source: io(msg()) }),
-        2 => Err(ReadError { offset: msg(), source: io(msg()) }),
-        3 => Err(HBICAPNotReady),
-        4 => Err(InvalidPrimitiveParam),
-        5 => Err(CsvError(csv::Error::from(io(msg())))),
-        6 => Err(LoadFailed { path: msg() }),
-        7 => Err(FileError(io(msg()))),
-        _ => Err(Unknown),
-    }
+    Err(DriverClientError::from_code(rc as i32, detail))
 }

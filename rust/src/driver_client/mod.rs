@@ -1,8 +1,9 @@
-//! `/root/reference/src/driver_client/mod.rs:1-7` with the register map (`dclient_code`) gone: the transport is
-//! the C ABI of libblaze_hip, one function per `DriverPrimitive` method.
-mod dclient;
-mod dclient_cfg;
-pub(crate) mod hip_ffi;
+//! The device handle (`DriverClient`), the `DriverPrimitive` trait every primitive implements, and the card
+//! configuration type kept for source compatibility.  `hip_ffi` holds the `extern "C"` declarations of
+//! `include/blaze_hip.h`: the transport that replaces the reference's XDMA register map.
+pub use self::dclient::*;
+pub use self::dclient_cfg::{CardType, DriverConfig};
 
-pub use dclient::*;
-pub use dclient_cfg::{CardType, DriverConfig};
+pub(crate) mod hip_ffi;
+mod dclient_cfg;
+mod dclient;

@@ -1,6 +1,8 @@
-//! `/root/reference/src/ingo_msm/mod.rs`: same re-exports; the register map (`msm_hw_code`) is gone.
-mod msm_api;
-mod msm_cfg;
+//! MSM primitive: `MSMClient` and its parameter / input / result types (`msm_api`), curve and memory-mode enums
+//! (`msm_cfg`).  The reference's module of the same name also carries the FPGA register map; here the transport is
+//! the C ABI, so there is nothing else to export.
+pub use self::msm_api::*;
+pub use self::msm_cfg::{Curve, PointMemoryType};
 
-pub use msm_api::*;
-pub use msm_cfg::{Curve, PointMemoryType};
+mod msm_cfg;
+mod msm_api;

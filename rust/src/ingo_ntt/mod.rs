@@ -1,5 +1,6 @@
-//! `/root/reference/src/ingo_ntt/mod.rs`: `ntt_data` (the 16-bank wire permutation) and `ntt_hw_code` are not
-//! needed on the host: the device buffer is flat (the permutation exists as device kernels for bank files).
-mod ntt_api;
+//! NTT primitive: `NTTClient`, `NTTInput`, `NttInit`, `NTT` and the size constants.  The device buffer is flat, so
+//! the host-side 16-bank permutation of the reference (`ntt_data`) has no counterpart in this crate; the permutation
+//! exists as device kernels (`blz_ntt_banks_*`) for files already in bank order.
+pub use self::ntt_api::*;
 
-pub use ntt_api::*;
+mod ntt_api;

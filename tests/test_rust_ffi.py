@@ -80,12 +80,17 @@ def test_error_codes_are_all_mapped():
     hdr = open(os.path.join(ROOT, "include", "blaze_hip.h")).read()
     codes = {int(v): k for k, v in re.findall(r"(BLZ_ERR_\w+)\s*=\s*(\d+)", hdr)}
     assert sorted(codes) == list(range(1, 9))
-    dcl = open(os.path.join(ROOT, "rust", "src", "driver_client", "dclient.rs")).read()
-    arms = dict(re.findall(r"^\s*(\d+) => Err\((\w+)", dcl, flags=re.M))
+    # the crate maps codes in one place (error.rs from_code / code) and check() in dclient.rs goes through it
+    err = open(os.path.join(ROOT, "rust", "src", "error.rs")).read()
+    arms = dict(re.findall(r"^\s*(\d+) => Self::(\w+)", err, flags=re.M))
+    back = {v: k for k, v in re.findall(r"^\s*Self::(\w+)[^=\n]*=> (\d+),", err, flags=re.M)}
     want = {1: "WriteError", 2: "ReadError", 3: "HBICAPNotReady", 4: "InvalidPrimitiveParam", 5: "CsvError", 6: "LoadFailed", 7: "FileError"}
     for code, variant in want.items():
         assert arms.get(str(code)) == variant, (code, arms.get(str(code)))
-    assert "_ => Err(Unknown)" in dcl
+        assert back.get(str(code)) == variant, (code, back.get(str(code)))
+    assert "_ => Self::Unknown" in err and back.get("8") == "Unknown"
+    dcl = open(os.path.join(ROOT, "rust", "src", "driver_client", "dclient.rs")).read()
+    assert "DriverClientError::from_code(" in dcl
     # the Python mirror agrees
     from blaze_amd._lib import DriverClientError
     assert DriverClientError.VARIANTS == {**want, 8: "Unknown"}
