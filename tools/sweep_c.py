@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Dev tool: sweep the window size c (BLAZE_MSM_C) per problem size and print the device pipeline time."""
-import sys, os, subprocess, json
+"""Dev tool: sweep the window size c (BLAZE_MSM_C: uniform windows) per problem size against the planner's own choice
+(mixed widths); prints the throughput-relevant part of the device pipeline (sort + accumulation + bucket reduce; the
+finish step hides under the next task) and the full latency."""
+import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import blaze_amd
 from blaze_amd import DeviceBuffer
@@ -12,14 +14,18 @@ for logn in [int(x) for x in sys.argv[1:]]:
     dp = DeviceBuffer(0, n * 96); ds = DeviceBuffer(0, n * 32)
     blaze_amd.lib().blz_synth_points(0, 1, dp.ptr, n, 1, 0); blaze_amd.lib().blz_synth_scalars(0, 1, ds.ptr, n, 7)
     row = []
-    for c in range(max(8, logn - 7), min(23, logn - 2) + 1):
-        os.environ["BLAZE_MSM_C"] = str(c)
+    for c in [0] + list(range(max(8, logn - 7), min(23, logn - 2) + 1)):
+        if c:
+            os.environ["BLAZE_MSM_C"] = str(c)
+        else:
+            os.environ.pop("BLAZE_MSM_C", None)
         cl = MSMClient(MSMInit(PointMemoryType.DMA, False, Curve.BLS381), dc)
-        best = 1e9
+        best = (1e9, 1e9)
         for rep in range(3):
             p = MSMParams(n, None); cl.initialize(p); cl.start_process(); cl.set_data(MSMInput(dp, ds, p)); cl.wait_result(); cl.result()
-            best = min(best, cl.get_api()["total_ms"])
-        row.append((c, round(best, 2)))
+            a = cl.get_api()
+            best = min(best, (a["sort_ms"] + a["phase1_accumulate_ms"] + a["phase2_reduce_ms"], a["total_ms"]))
+        row.append(("plan" if c == 0 else c, round(best[0], 2), round(best[1], 2)))
         cl.close()
     print(f"2^{logn}:", row, "best", min(row, key=lambda t: t[1]), flush=True)
     dp.free(); ds.free()
