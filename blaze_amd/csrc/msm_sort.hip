@@ -21,6 +21,12 @@
 
 namespace blz {
 
+// wave priority of the sort kernels (0..3): raised when they are meant to run underneath another kernel
+#ifndef BLZ_SORT_PRIO
+#define BLZ_SORT_PRIO 0
+#endif
+#define BLZ_SORT_SETPRIO() do { if (BLZ_SORT_PRIO) __builtin_amdgcn_s_setprio(BLZ_SORT_PRIO); } while (0)
+
 #ifndef BLZ_SORT_THREADS
 #define BLZ_SORT_THREADS 1024
 #endif
@@ -47,6 +53,7 @@ __device__ __forceinline__ int next_digit(ScalarWords<SW>& sw, const SortGeom& g
 template <int SW>
 __global__ __launch_bounds__(SORT_THREADS) void k_coarse_count(const uint32_t* __restrict__ scalars, uint32_t npts, SortGeom g,
                                                                uint32_t* __restrict__ coarse_count) {
+    BLZ_SORT_SETPRIO();
     extern __shared__ __attribute__((aligned(16))) uint32_t sh[];
     for (uint32_t i = threadIdx.x; i < g.NC; i += SORT_THREADS) sh[i] = 0;
     __syncthreads();
@@ -85,6 +92,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_coarse_count(const uint32_t* _
 // exclusive scan of coarse_count[NC] -> coarse_off[NC+1]; coarse_count becomes the scatter cursor
 __global__ __launch_bounds__(1024) void k_coarse_scan(uint32_t* __restrict__ coarse_count, uint32_t NC,
                                                       uint32_t* __restrict__ coarse_off) {
+    BLZ_SORT_SETPRIO();
     __shared__ uint32_t sh[1024];
     __shared__ uint32_t carry_sh;
     if (threadIdx.x == 0) carry_sh = 0;
@@ -117,6 +125,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_coarse_scatter(const uint32_t*
                                                                  uint32_t* __restrict__ coarse_cursor,
                                                                  uint32_t* __restrict__ inter_idx,
                                                                  uint16_t* __restrict__ inter_fine) {
+    BLZ_SORT_SETPRIO();
     extern __shared__ __attribute__((aligned(16))) uint32_t sh[];
     for (uint32_t i = threadIdx.x; i < g.NC; i += SORT_THREADS) sh[i] = 0;
     __syncthreads();
@@ -199,6 +208,7 @@ __global__ __launch_bounds__(CS_THREADS) void k_coarse_scatter_staged(const uint
                                                                       SortGeom g, uint32_t* __restrict__ coarse_cursor,
                                                                       uint32_t* __restrict__ inter_idx,
                                                                       uint16_t* __restrict__ inter_fine) {
+    BLZ_SORT_SETPRIO();
     extern __shared__ __attribute__((aligned(16))) uint32_t sh[];
     const uint32_t nbmax = 1u << g.chmax;
     uint32_t* hist = sh;              // [nb] counts of this window
@@ -294,19 +304,24 @@ __global__ __launch_bounds__(CS_THREADS) void k_coarse_scatter_staged(const uint
 // the device (one block), no host round trip: the launch uses the bound entries/SLICE + NC.
 constexpr uint32_t SLICE = 65536;
 
-__global__ __launch_bounds__(1024) void k_slice_map(const uint32_t* __restrict__ coarse_off, uint32_t NC,
+#ifndef BLZ_SLICEMAP_THREADS
+#define BLZ_SLICEMAP_THREADS 1024
+#endif
+constexpr int SLICEMAP_THREADS = BLZ_SLICEMAP_THREADS;
+__global__ __launch_bounds__(SLICEMAP_THREADS) void k_slice_map(const uint32_t* __restrict__ coarse_off, uint32_t NC,
                                                     uint2* __restrict__ slice_map, uint32_t* __restrict__ nslices) {
-    __shared__ uint32_t sh[1024];
+    BLZ_SORT_SETPRIO();
+    __shared__ uint32_t sh[SLICEMAP_THREADS];
     __shared__ uint32_t carry_sh;
     if (threadIdx.x == 0) carry_sh = 0;
     __syncthreads();
-    for (uint32_t base = 0; base < NC; base += 1024) {
+    for (uint32_t base = 0; base < NC; base += SLICEMAP_THREADS) {
         uint32_t i = base + threadIdx.x;
         uint32_t size = i < NC ? coarse_off[i + 1] - coarse_off[i] : 0;
         uint32_t v = (size + SLICE - 1) / SLICE;
         sh[threadIdx.x] = v;
         __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {
+        for (int o = 1; o < SLICEMAP_THREADS; o <<= 1) {
             uint32_t t = threadIdx.x >= (uint32_t)o ? sh[threadIdx.x - o] : 0;
             __syncthreads();
             sh[threadIdx.x] += t;
@@ -316,7 +331,7 @@ __global__ __launch_bounds__(1024) void k_slice_map(const uint32_t* __restrict__
         uint32_t first = carry + incl - v;
         for (uint32_t j = 0; j < v; ++j) slice_map[first + j] = make_uint2(i, j);
         __syncthreads();
-        if (threadIdx.x == 1023) carry_sh = carry + incl;
+        if (threadIdx.x == SLICEMAP_THREADS - 1) carry_sh = carry + incl;
         __syncthreads();
     }
     if (threadIdx.x == 0) *nslices = carry_sh;
@@ -338,6 +353,7 @@ __device__ __forceinline__ bool slice_range(const uint32_t* coarse_off, const ui
 __global__ __launch_bounds__(FINE_THREADS) void k_fine_count(const uint16_t* __restrict__ inter_fine, const uint32_t* __restrict__ coarse_off,
                                                              const uint2* __restrict__ slice_map, const uint32_t* __restrict__ nslices,
                                                              int cl, uint32_t* __restrict__ count) {
+    BLZ_SORT_SETPRIO();
     extern __shared__ __attribute__((aligned(16))) uint32_t sh[];
     const uint32_t nf = 1u << cl;
     uint32_t k, lo, hi;
@@ -388,6 +404,7 @@ __global__ __launch_bounds__(FS_THREADS) void k_fine_scatter(const uint32_t* __r
                                                              const uint2* __restrict__ slice_map, const uint32_t* __restrict__ nslices,
                                                              int cl, uint32_t round_cap,
                                                              uint32_t* __restrict__ cursor, uint32_t* __restrict__ entries) {
+    BLZ_SORT_SETPRIO();
     extern __shared__ __attribute__((aligned(16))) uint32_t sh[];
     const uint32_t nf = 1u << cl;
     uint32_t* hist = sh;             // [nf]  counts, then first stage slot of the bucket
@@ -530,7 +547,7 @@ int msm_sort_lds(MsmEngine& E, const void* d_scalars, uint32_t npts, int sbits) 
     BLZ_TRY(E.slice_map.reserve(((size_t)max_slices + 2) * 8));
     uint2* slice_map = E.slice_map.as<uint2>() + 1;             // element 0 holds the slice count
     uint32_t* nslices = E.slice_map.as<uint32_t>();
-    hipLaunchKernelGGL(k_slice_map, dim3(1), dim3(1024), 0, st, coarse_off, g.NC, slice_map, nslices);
+    hipLaunchKernelGGL(k_slice_map, dim3(1), dim3(SLICEMAP_THREADS), 0, st, coarse_off, g.NC, slice_map, nslices);
     E.sort_slices = max_slices;
     E.sort_cl = g.cl;
     E.sort_nc = g.NC;
