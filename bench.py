@@ -12,6 +12,13 @@ N > 1 the SAME 2^26 job is sharded by contiguous element chunk over the N GPUs o
 scaling): each rank runs its shard, one all-gather of the 144-byte partials (RCCL), every rank adds
 them in rank order.  value = MSMs per second, whole job.
 
+N > 1 cannot hang: the timed loop exchanges the partials through torch.distributed (the process group
+the launcher's rendezvous already brought up); the exchange inside the library (blz_msm_comm_init /
+blz_msm_all_gather_combine: a second RCCL communicator on the handle's own stream) is tried AFTER the
+headline is measured and reported as the extra key `exchange_native`; every bring-up and every phase
+runs under a deadline, and a rank whose deadline expires prints what it was waiting for and exits
+non-zero (an exit, never a re-exec).
+
 With --gpus N > 1 and no WORLD_SIZE in the environment the script starts the N ranks itself (a child
 `torch.distributed.run`, before this process touches the GPU) and relays their output.
 
@@ -72,6 +79,88 @@ def host_threads() -> int:
     return n
 
 
+class Watchdog:
+    """A deadline around phases that can block for ever on a peer that died (rendezvous, collectives, a wedged
+    kernel).  On expiry the rank says what it was waiting for and exits with status 3: the launcher then tears the
+    other ranks down.  os._exit, never an exec: this process has initialised the GPU."""
+
+    def __init__(self, rank):
+        self.rank, self.timer = rank, None
+
+    def arm(self, seconds, what):
+        import threading
+
+        self.disarm()
+
+        def fire():
+            print(f"[bench rank {self.rank}] DEADLINE: {what} did not complete within {seconds} s; exiting 3", file=sys.stderr, flush=True)
+            os._exit(3)
+
+        self.timer = threading.Timer(seconds, fire)
+        self.timer.daemon = True
+        self.timer.start()
+
+    def disarm(self):
+        if self.timer is not None:
+            self.timer.cancel()
+            self.timer = None
+
+
+class SclkSampler:
+    """Shader clock of this rank's GPU while the timed steps run, read from the driver's sysfs table
+    (pp_dpm_sclk marks the current level with '*'); None when the box does not expose it."""
+
+    def __init__(self, torch, dev):
+        import glob
+
+        self.path, self.samples, self.stop_flag, self.thread = None, [], False, None
+        try:
+            pr = torch.cuda.get_device_properties(dev)
+            cand = "/sys/bus/pci/devices/%04x:%02x:%02x.0/pp_dpm_sclk" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            if os.path.exists(cand):
+                self.path = cand
+        except Exception:
+            pass
+        if self.path is None:
+            found = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+            if len(found) == 1:
+                self.path = found[0]
+
+    def _read(self):
+        for ln in open(self.path).read().splitlines():
+            if ln.rstrip().endswith("*"):
+                return float(ln.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+        return None
+
+    def start(self):
+        import threading
+
+        if self.path is None:
+            return
+
+        def loop():
+            while not self.stop_flag:
+                try:
+                    v = self._read()
+                    if v:
+                        self.samples.append(v)
+                except Exception:
+                    return
+                time.sleep(0.05)
+
+        self.thread = threading.Thread(target=loop, daemon=True)
+        self.thread.start()
+
+    def stop(self):
+        self.stop_flag = True
+        if self.thread is not None:
+            self.thread.join(timeout=1.0)
+        if not self.samples:
+            return None
+        return {"min": min(self.samples), "mean": round(statistics.mean(self.samples), 1), "max": max(self.samples),
+                "samples": len(self.samples), "source": "pp_dpm_sclk (driver sysfs), sampled every 50 ms over the timed steps"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -80,6 +169,7 @@ def main():
     ap.add_argument("--no-ntt", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the result check (profiling runs only)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the reference-semantics legs (hbm_flow, config2_dma)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -93,20 +183,40 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the flag disagree")
     dist = None
-    if world > 1:
+    wd = Watchdog(rank)
+    # BLAZE_BENCH_FORCE_EXCHANGE=1: a one-rank job still goes through the process group and both exchanges (what the
+    # single-GPU box can exercise of the N > 1 path: torch imported first, torch's NCCL process group alive, then the
+    # library's own communicator next to it)
+    force_exchange = os.environ.get("BLAZE_BENCH_FORCE_EXCHANGE") == "1"
+    multi = world > 1 or force_exchange
+    if multi:
+        import datetime
+
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            import socket
+
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(so.getsockname()[1])
         # "nccl" is RCCL on ROCm (xGMI between the GPUs of the node).  BLAZE_BENCH_BACKEND=gloo with
         # BLAZE_BENCH_ONE_GPU=1 lets the sharded path be exercised by several ranks on a 1-GPU box.
         backend = os.environ.get("BLAZE_BENCH_BACKEND", "nccl")
         if os.environ.get("BLAZE_BENCH_ONE_GPU") == "1":
             local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        t_pg = int(os.environ.get("BLAZE_BENCH_PG_TIMEOUT_S", "180"))
+        wd.arm(t_pg + 30, "process-group rendezvous + first collective")
+        dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=t_pg))
+        probe = torch.ones(1, dtype=torch.int32, device=torch.device("cuda", local_rank) if backend == "nccl" else "cpu")
+        dist.all_reduce(probe)               # the communicator is built lazily: build it here, under the deadline
+        assert int(probe.item()) == world
+        wd.disarm()
     dev = local_rank
     tdev = torch.device("cuda", dev)
-    gather_dev = tdev if (world == 1 or dist.get_backend() == "nccl") else None
+    gather_dev = tdev if (not multi or dist.get_backend() == "nccl") else None
 
     import blaze_amd
     from blaze_amd import DeviceBuffer
@@ -147,23 +257,11 @@ def main():
     # overlaps the sort + accumulation of the next.  BLAZE_BENCH_QUEUE=1 runs strictly one at a time.
     queue = max(1, min(2, int(os.environ.get("BLAZE_BENCH_QUEUE", "2"))))
 
-    # N > 1: the exchange runs inside the library (blz_msm_all_gather_combine: RCCL all-gather on the handle's
-    # own stream + rank-ordered add); the communicator id travels over the torch.distributed process group.  If
-    # any rank cannot bring the native communicator up, every rank uses the torch.distributed all-gather instead.
-    exchange = "none"
-    if world > 1:
-        native_ok = 0
-        if os.environ.get("BLAZE_BENCH_EXCHANGE", "native") == "native" and dist.get_backend() == "nccl":
-            try:
-                ids = [MSMClient.comm_unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(ids, src=0)
-                client.comm_init(rank, world, ids[0])
-                native_ok = 1
-            except Exception as e:   # noqa: BLE001 - any failure means "use the fallback", on every rank
-                print(f"[bench rank {rank}] native RCCL exchange unavailable: {e}", file=sys.stderr, flush=True)
-        flag = torch.tensor([native_ok], dtype=torch.int32, device=gather_dev if gather_dev is not None else "cpu")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        exchange = "library (ncclAllGather + k_combine_partials)" if int(flag.item()) == 1 else "torch.distributed all_gather + combine_partials"
+    # N > 1: the timed loop exchanges the partials over the process group that already exists (one all-gather of
+    # 144 bytes per MSM, off the critical path: two tasks are in flight) + the device combine.  The library's own
+    # exchange (a second RCCL communicator) is measured after the headline, as `exchange_native`.
+    exchange = "torch.distributed all_gather + combine_partials (device)" if multi else "none"
+    last_partial = [None]
 
     def submit():
         client.initialize(params)
@@ -174,11 +272,9 @@ def main():
         client.wait_result()
         part = client.result().result
         api = client.get_api()  # HIP-event timers recorded on the streams the kernels run on
-        if world > 1:
-            if exchange.startswith("library"):
-                part = client.all_gather_combine(part)
-            else:
-                part = sharded_msm(part, client.combine_partials, dist, gather_dev)
+        if multi:
+            last_partial[0] = part
+            part = sharded_msm(part, client.combine_partials, dist, gather_dev)
         return part, api
 
     def run_steps(k):
@@ -195,23 +291,38 @@ def main():
         return out
 
     def fence():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize(tdev)
 
+    t_run = int(os.environ.get("BLAZE_BENCH_RUN_TIMEOUT_S", "900"))
+    wd.arm(t_run, f"warm-up + {args.steps} timed steps")
     run_steps(args.warmup)
     fence()
+    sclk = SclkSampler(torch, dev)
+    sclk.start()
     t0 = time.perf_counter()
     done = run_steps(args.steps)
     fence()
     dt = time.perf_counter() - t0
+    sclk_rec = sclk.stop()
     res, api = done[-1]
     accum_ms = [a["accumulate_kernel_ms"] for _, a in done]
     total_ms = [a["total_ms"] for _, a in done]
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], dtype=torch.float64, device=gather_dev if gather_dev is not None else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    wd.disarm()
+    # the multiply-add issue rate of THIS chip at its clocks of this moment (50 ms of independent v_mad_u64_u32
+    # chains on every SIMD, right behind the timed steps): what roofline.integer_issue is priced against
+    calib = None
+    try:
+        cal = (C.c_double * 4)()
+        check(L.blz_calib_mad_rate(dev, 50, cal))
+        calib = {"mad_lane_ops_per_s": cal[0], "kernel_ms": round(cal[1], 3), "nominal_clock_mhz": cal[2]}
+    except Exception as e:   # noqa: BLE001 - a measurement aid, never fatal
+        print(f"[bench rank {rank}] mad-rate calibration failed: {e}", file=sys.stderr, flush=True)
     ms_per_step = dt / args.steps * 1e3
     value = args.steps / dt
 
@@ -237,38 +348,189 @@ def main():
                 raise SystemExit(f"bench: the timed MSM result is WRONG (got {res.hex()[:32]}..., expected {exp.hex()[:32]}...)")
             check_rec = {"ok": True, "method": "result == (sum_i s_i (i+1) mod r) G over all 2^%d scalars, CPU oracle, %.1f s"
                          % (LOG_N, time.perf_counter() - t1)}
-        if world > 1:
+        if multi:
+            wd.arm(300, "barrier after the result check")
             dist.barrier()
+            wd.disarm()
+
+    # ---- the library's own exchange, after the fact: RCCL resolved at run time inside
+    # libblaze_hip, a communicator per handle, ncclAllGather on the handle's stream + k_combine_partials.  Nothing
+    # here can hang the job: "is RCCL loadable" is agreed on first, rank 0 ALWAYS broadcasts (an id or None), the
+    # bring-up has its own deadline inside the library (BLAZE_COMM_TIMEOUT_MS), the exchange is a bounded wait, and
+    # the watchdog stands behind all of it.
+    native = None
+    if multi and os.environ.get("BLAZE_BENCH_EXCHANGE", "native") == "native":
+        wd.arm(240, "native RCCL exchange (bring-up + 5 exchanges)")
+        fdev = gather_dev if gather_dev is not None else "cpu"
+        err = None
+        try:
+            my_id = MSMClient.comm_unique_id()          # loads librccl through the library; every rank tries
+            ok = 1
+        except Exception as e:   # noqa: BLE001
+            my_id, ok, err = None, 0, f"RCCL not loadable: {e}"
+        flag = torch.tensor([ok if dist.get_backend() == "nccl" else 0], dtype=torch.int32, device=fdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            ids = [my_id if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)      # unconditional on every rank
+            try:
+                client.comm_init(rank, world, ids[0])
+                ok = 1
+            except Exception as e:   # noqa: BLE001
+                ok, err = 0, f"comm_init: {e}"
+            flag = torch.tensor([ok], dtype=torch.int32, device=fdev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                try:
+                    my_part = last_partial[0]
+                    outs, tms = [], []
+                    for _ in range(5):
+                        t1 = time.perf_counter()
+                        outs.append(client.all_gather_combine(my_part))
+                        tms.append((time.perf_counter() - t1) * 1e3)
+                    same = all(o == res for o in outs)
+                    native = {"ok": bool(same), "ms": round(statistics.median(tms), 3), "error": None if same else "result differs from the torch.distributed exchange",
+                              "what": "blz_msm_all_gather_combine: ncclAllGather on the handle's stream + k_combine_partials, median of 5"}
+                except Exception as e:   # noqa: BLE001
+                    native = {"ok": False, "ms": None, "error": f"all_gather_combine: {e}"}
+            else:
+                native = {"ok": False, "ms": None, "error": err or "comm_init failed on another rank"}
+        else:
+            native = {"ok": False, "ms": None, "error": err or ("process group backend is not nccl" if dist.get_backend() != "nccl" else "RCCL not loadable on another rank")}
+        agree = torch.tensor([1 if native["ok"] else 0], dtype=torch.int32, device=fdev)
+        dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+        if native["ok"] and int(agree.item()) == 0:
+            native = {"ok": False, "ms": native["ms"], "error": "the exchange failed on another rank"}
+        wd.disarm()
 
     # ---- roofline of the dominant kernel (k_accumulate: one launch covers this rank's whole shard)
     acc_avg_ms = statistics.mean(accum_ms)
     algo_bytes = n_loc * MSM_BYTES_PER_ELEM
     achieved = algo_bytes / (acc_avg_ms * 1e-3) / 1e9
-    traffic = None
+    traffic, traffic_dropped = None, None
     tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tf):
         try:
             rec = json.load(open(tf)).get(f"k_accumulate_2e{LOG_N}_{CURVE}")
             # the PMC passes cannot run inside this process; the record is only quoted while the kernel it was
             # taken on is the kernel being timed (same duration within 10 %), else it is stale and dropped
-            if rec and world == 1 and abs(acc_avg_ms - rec.get("kernel_ms_at_measurement", acc_avg_ms)) <= 0.10 * acc_avg_ms:
-                traffic = rec["hbm_bytes_per_launch"]
-        except Exception:
-            traffic = None
+            if rec and world == 1:
+                rec_ms = rec.get("kernel_ms_at_measurement", acc_avg_ms)
+                if abs(acc_avg_ms - rec_ms) <= 0.10 * acc_avg_ms:
+                    traffic = rec["hbm_bytes_per_launch"]
+                else:
+                    traffic_dropped = f"kernel {acc_avg_ms:.1f} ms here vs {rec_ms:.1f} ms when the counters were read (> 10 %)"
+            elif world == 1:
+                traffic_dropped = "no counter record for this workload in profiles/pmc_traffic.json"
+            else:
+                traffic_dropped = "counters were read on the 1-GPU workload only"
+        except Exception as e:   # noqa: BLE001
+            traffic, traffic_dropped = None, f"profiles/pmc_traffic.json unreadable: {e}"
+    else:
+        traffic_dropped = "profiles/pmc_traffic.json missing"
     roofline = {"bound": "hbm", "kernel": "k_accumulate", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                 "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": round(acc_avg_ms, 3),
                 "pipeline_ms": round(statistics.mean(total_ms), 3)}
+    if traffic is None:
+        roofline["traffic_dropped"] = traffic_dropped
     # The resource this kernel actually saturates, beside the prescribed HBM figure: 32-bit integer multiply issue.
     # One bucket addition (mixed XYZZ add on 14 x 28-bit limbs) is 3542 v_mad_u64_u32; a launch does one addition per
-    # non-zero window digit (255-bit scalars in 12 occupied windows at this size).  The peak is the chip's measured
-    # rate for that instruction (profiles/r01_mac_issue_microbench.txt, profiles/r02_mul_variants.txt).
+    # non-zero window digit (255-bit scalars in 12 occupied windows at this size).  The peak is that instruction's
+    # rate on THIS chip, measured by the calibration kernel right behind the timed steps (blz_calib_mad_rate); the
+    # constant of the builder's boxes (3.1e13, profiles/r02_mul_variants.txt) is kept beside it for comparison.
     if CURVE in ("BLS381", "BLS377") and LOG_N >= 24:
         occupied = -(-(255 if CURVE == "BLS381" else 253) // int(api["window_bits"]))
         mads = n_loc * occupied * 3542
+        peak = calib["mad_lane_ops_per_s"] if calib else 3.1e13
         roofline["integer_issue"] = {"unit": "v_mad_u64_u32 lane-ops/s", "achieved": round(mads / (acc_avg_ms * 1e-3), 0),
-                                     "peak": 3.1e13, "frac": round(mads / (acc_avg_ms * 1e-3) / 3.1e13, 4),
-                                     "multiply_adds_per_launch": mads}
+                                     "peak": round(peak, 0), "frac": round(mads / (acc_avg_ms * 1e-3) / peak, 4),
+                                     "peak_source": "calibration kernel on this device, this run (50 ms of independent multiply-add chains, "
+                                                    "4 waves per SIMD)" if calib else "constant measured on another box",
+                                     "peak_reference_boxes": 3.1e13, "multiply_adds_per_launch": mads}
+    clock = {"nominal_mhz": calib["nominal_clock_mhz"] if calib else None, "sclk_mhz_timed_steps": sclk_rec,
+             "mad_calibration": calib}
+
+    # ---- the reference's own flows, timed as the reference runs them (extra keys, never the headline value)
+    hbm_flow = cfg2 = None
+    if rank == 0 and world == 1 and not multi and not args.no_extras and hbm_mode:
+        # (1) tests/integration_msm_hbm.rs:57-100: bases resident in the card's memory (loaded once), the SCALARS
+        # come from a host Vec<u8> with every task; two tasks in flight like the headline.  The 2 GiB host -> device
+        # copy of task k+1 runs under the accumulation of task k (copy stream + two staging sets).
+        sc_host = d_sc.download()
+        k_hf = max(3, min(args.steps, 6))
+
+        def submit_host():
+            client.initialize(params)
+            client.start_process()
+            client.set_data(MSMInput(None, sc_host, params))
+
+        def run_host(k):
+            out, pending = [], 0
+            for _ in range(k):
+                submit_host()
+                pending += 1
+                if pending >= queue:
+                    client.wait_result()
+                    out.append(client.result().result)
+                    pending -= 1
+            while pending:
+                client.wait_result()
+                out.append(client.result().result)
+                pending -= 1
+            return out
+
+        wd.arm(600, "hbm_flow leg")
+        run_host(2)
+        torch.cuda.synchronize(tdev)
+        t1 = time.perf_counter()
+        outs = run_host(k_hf)
+        torch.cuda.synchronize(tdev)
+        t_hf = (time.perf_counter() - t1) / k_hf * 1e3
+        wd.disarm()
+        ok_hf = all(o == res for o in outs)
+        if not ok_hf:
+            raise SystemExit("bench: hbm_flow result differs from the (checked) headline result")
+        hbm_flow = {"ms_per_msm": round(t_hf, 3), "msm_per_s": round(1e3 / t_hf, 4), "msms": k_hf, "tasks_in_flight": queue,
+                    "what": f"2^{LOG_N} BLS12-381: bases in the device arena, scalars from pageable host memory every task "
+                            "(tests/integration_msm_hbm.rs:57-100); PCIe-inclusive, never the headline value",
+                    "result_check": {"ok": True, "method": "bytes equal the headline result (same scalars), which the oracle checked"}}
+        del sc_host
+        # (2) config 2, tests/integration_msm.rs:149-207 with the timers of :338-355: 2^22 elements, points AND scalars
+        # handed over as host buffers through set_data (DMA mode), one task at a time
+        n2 = min(1 << 22, n_loc)
+        p2, s2 = d_pts.download(n2 * 96), d_sc.download(n2 * 32)
+        c2 = MSMClient(MSMInit(PointMemoryType.DMA, False, Curve[CURVE]), DriverClient(dev))
+        prm2 = MSMParams(n2, None)
+        runs = []
+        wd.arm(600, "config2_dma leg")
+        for i in range(2 + 5):
+            t1 = time.perf_counter()
+            c2.initialize(prm2)
+            c2.start_process()
+            c2.set_data(MSMInput(p2, s2, prm2))
+            t2 = time.perf_counter()
+            c2.wait_result()
+            r2 = c2.result().result
+            t3 = time.perf_counter()
+            if i >= 2:
+                runs.append(((t2 - t1) * 1e3, (t3 - t2) * 1e3, (t3 - t1) * 1e3))
+        wd.disarm()
+        c2.close()
+        chk2 = None
+        if not args.no_check:
+            import oracle
+
+            k2 = oracle.index_weighted_sum(CURVE, s2, n2, 0, threads=min(64, host_threads()))
+            if r2 != oracle.result_from_affine(CURVE, oracle.generator_mul(CURVE, k2)):
+                raise SystemExit("bench: the config2_dma result is WRONG")
+            chk2 = {"ok": True, "method": "result == (sum_i s_i (i+1) mod r) G over the 2^22 scalars, CPU oracle"}
+        med = [round(statistics.median(x), 3) for x in zip(*runs)]
+        cfg2 = {"dur_set_data_ms": med[0], "dur_wait_result_ms": med[1], "dur_full_ms": med[2], "samples": len(runs),
+                "what": f"config 2: {n2} BLS12-381 elements, host points + scalars through set_data (DMA mode), one task at a time, "
+                        "timers as tests/integration_msm.rs:338-355; PCIe-inclusive",
+                "result_check": chk2}
+        del p2, s2
 
     # ---- NTT 2^27 latency (replica per rank; rank 0 reports), timed like benches/ntt_bench.rs:34-39
     # minus the 100 ms sleep of reset(): initialize + start_process + wait_result on a resident buffer
@@ -372,14 +634,21 @@ def main():
                        "elements": n, "elements_per_gpu": n_loc, "parallelism": f"shard{world}" if world > 1 else "single", "exchange": exchange, "tasks_in_flight": queue,
                        "window_bits": int(api["window_bits"]), "windows": int(api["windows"])},
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_ref_semantics": cpu_ref, "result_check": check_rec,
-            "ntt_2e27": ntt,
+            "ntt_2e27": ntt, "clock": clock, "exchange_native": native, "hbm_flow": hbm_flow, "config2_dma": cfg2,
             "phases_ms": {k: round(v, 3) for k, v in api.items() if k.endswith("_ms")},
         }
         if os.environ.get("BLAZE_BENCH_EMIT_RESULT") == "1":
             line["result_hex"] = res.hex()
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if multi:
+        wd.arm(120, "process-group teardown")
         dist.destroy_process_group()
+        wd.disarm()
+        if native is not None and not native["ok"]:
+            # a bring-up thread abandoned inside RCCL must not keep the interpreter from exiting
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(0)
 
 
 if __name__ == "__main__":

@@ -63,6 +63,8 @@ _SIGS = {
     "blz_comm_unique_id": (C.c_int, [_u8p]),
     "blz_msm_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _u8p]),
     "blz_msm_all_gather_combine": (C.c_int, [C.c_void_p, _u8p, _u8p, C.c_size_t]),
+    "blz_msm_comm_init_all": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "blz_msm_all_gather_combine_all": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, _u8p, _u8p, C.c_size_t]),
     "blz_msm_comm_free": (C.c_int, [C.c_void_p]),
     "blz_msm_precompute_bases_device": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64]),
     "blz_msm_combine_partials": (C.c_int, [C.c_void_p, _u8p, C.c_size_t, _u8p, C.c_size_t]),
@@ -90,6 +92,10 @@ _SIGS = {
     "blz_synth_scalars_at": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]),
     "blz_synth_points": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_int, C.c_uint64]),
     "blz_synth_field_elements": (C.c_int, [C.c_int, C.c_void_p, C.c_uint64, C.c_uint64]),
+    "blz_calib_mad_rate": (C.c_int, [C.c_int, C.c_uint32, C.POINTER(C.c_double)]),
+    "blz_test_msm_stall": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "blz_test_ntt_stall": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "blz_test_stall_release": (C.c_int, [C.c_void_p]),
     "blz_test_field_op": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _u8p, _u8p, _u8p, C.c_size_t]),
     "blz_test_ec_op": (C.c_int, [C.c_int, C.c_int, C.c_int, _u8p, _u8p, _u8p, _u8p, _u8p, C.c_size_t]),
 }

@@ -49,10 +49,22 @@ int arena_write(int device_id, uint64_t pos, const void* src, size_t len, bool s
     Arena& A = arena_for(device_id);
     std::lock_guard<std::mutex> lk(A.mu);
     const uint64_t end = pos + len;
-    // extents the write overlaps or touches
+    // extents the write overlaps or touches.  An extent shared with other processes (attached here, or exported from
+    // here) is READ-ONLY: every process converts the bytes into a private Montgomery shadow and tracks staleness
+    // locally, so a write on either side would leave the other side's shadow silently stale; a write that merely
+    // touches such an extent starts a new extent of this process.
     std::vector<size_t> hit;
     for (size_t i = 0; i < A.ext.size(); ++i) {
         const ArenaExtent& x = A.ext[i];
+        if (x.imported || x.exported) {
+            // the same rule on both sides of an export: the attachers keep private Montgomery shadows of these bytes and
+            // map this very allocation, so after blz_arena_export the bytes are frozen for the holder as well
+            if (pos < x.start + x.len && x.start < end)
+                return fail(BLZ_ERR_WRITE, "arena: [%llu, +%zu) overlaps an extent that is %s, which makes it read-only "
+                            "(release the arena to load new bases)", (unsigned long long)pos, len,
+                            x.imported ? "attached from another process" : "exported to other processes");
+            continue;
+        }
         if (pos <= x.start + x.len && x.start <= end) hit.push_back(i);
     }
     ArenaExtent* e = nullptr;
@@ -68,8 +80,6 @@ int arena_write(int device_id, uint64_t pos, const void* src, size_t len, bool s
         uint64_t nstart = pos, nend = end;
         for (size_t i : hit) {
             const ArenaExtent& x = A.ext[i];
-            if (x.imported)
-                return fail(BLZ_ERR_WRITE, "arena: a write beyond an attached (imported) extent cannot extend it");
             if (x.start < nstart) nstart = x.start;
             if (x.start + x.len > nend) nend = x.start + x.len;
         }
@@ -103,11 +113,11 @@ int arena_write(int device_id, uint64_t pos, const void* src, size_t len, bool s
     mark_dirty(*e, pos - e->start, end - e->start);
     char* dst = (char*)e->raw + (pos - e->start);
     hipError_t he = hipMemcpyAsync(dst, src, len, src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st);
-    if (he == hipSuccess) he = hipStreamSynchronize(st);
     if (he != hipSuccess)
         return fail(BLZ_ERR_WRITE, "arena write of %zu bytes at offset %llu failed: %s", len, (unsigned long long)pos,
                     hipGetErrorString(he));
-    return BLZ_OK;
+    // the copy is ordered on the caller's main stream, behind its tasks in flight: a bounded wait (common.hpp)
+    return sync_stream_bounded(st, "load_data_to_hbm: copy into the arena");
 }
 
 // registry file: magic, count, then per extent {start, len, hipIpcMemHandle_t}
@@ -146,6 +156,7 @@ int blz_arena_export(int device_id, const char* path) {
         r.start = x.start;
         r.len = x.len;
         BLZ_HIP(hipIpcGetMemHandle(&r.handle, x.raw), BLZ_ERR_UNKNOWN);
+        x.exported = true;
         recs.push_back(r);
     }
     std::string tmp = std::string(path) + ".tmp";
@@ -175,16 +186,27 @@ int blz_arena_attach(int device_id, const char* path) {
     if (!ok) return fail(BLZ_ERR_FILE, "arena attach: %s is not an arena registry", path);
     Arena& A = arena_for(device_id);
     std::lock_guard<std::mutex> lk(A.mu);
-    for (const RegistryRecord& r : recs) {
+    // all or nothing: overlaps are checked before anything is mapped, and a failed open unmaps what this call mapped
+    for (const RegistryRecord& r : recs)
         for (const ArenaExtent& x : A.ext)
             if (r.start < x.start + x.len && x.start < r.start + r.len)
                 return fail(BLZ_ERR_INVALID_PARAM, "arena attach: [%llu, +%llu) overlaps an extent of this process",
                             (unsigned long long)r.start, (unsigned long long)r.len);
+    const size_t before = A.ext.size();
+    for (const RegistryRecord& r : recs) {
         ArenaExtent n;
         n.start = r.start;
         n.len = n.cap = (size_t)r.len;
         n.imported = true;
-        BLZ_HIP(hipIpcOpenMemHandle(&n.raw, r.handle, hipIpcMemLazyEnablePeerAccess), BLZ_ERR_UNKNOWN);
+        hipError_t he = hipIpcOpenMemHandle(&n.raw, r.handle, hipIpcMemLazyEnablePeerAccess);
+        if (he != hipSuccess) {
+            while (A.ext.size() > before) {
+                arena_free_extent(A.ext.back());
+                A.ext.pop_back();
+            }
+            return fail(BLZ_ERR_UNKNOWN, "arena attach: hipIpcOpenMemHandle of [%llu, +%llu) failed: %s (nothing was attached)",
+                        (unsigned long long)r.start, (unsigned long long)r.len, hipGetErrorString(he));
+        }
         n.dirty_lo = 0;
         n.dirty_hi = n.len;   // this process has no shadow of it yet
         A.ext.push_back(n);

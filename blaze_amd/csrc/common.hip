@@ -1,7 +1,9 @@
 // Error convention, device selection and the per-device arena of libblaze_hip.
 #include "common.hpp"
 
+#include <chrono>
 #include <cstdlib>
+#include <thread>
 
 namespace blz {
 
@@ -42,6 +44,68 @@ int use_device(int device_id) {
     return BLZ_OK;
 }
 
+int wait_timeout_ms() {
+    const char* s = getenv("BLAZE_WAIT_TIMEOUT_MS");
+    int v = s && *s ? atoi(s) : 120000;
+    return v > 0 ? v : 120000;
+}
+
+static thread_local bool g_wait_timed_out = false;
+bool wait_timed_out() { return g_wait_timed_out; }
+void wait_clear() { g_wait_timed_out = false; }
+
+// poll `query` (hipSuccess = done, hipErrorNotReady = pending) against the deadline.  The first 200 us spin
+// (a small task's tail is a few hundred microseconds: a sleeping wait would double its latency), then 50 us naps.
+template <class Q>
+static int bounded_wait(Q&& query, const char* what) {
+    g_wait_timed_out = false;
+    const auto t0 = std::chrono::steady_clock::now();
+    const int limit_ms = wait_timeout_ms();
+    for (;;) {
+        hipError_t e = query();
+        if (e == hipSuccess) return BLZ_OK;
+        if (e != hipErrorNotReady) {
+            (void)hipGetLastError();
+            return fail(BLZ_ERR_UNKNOWN, "%s failed: %s", what, hipGetErrorString(e));
+        }
+        const auto dt = std::chrono::steady_clock::now() - t0;
+        if (dt > std::chrono::milliseconds(limit_ms)) {
+            g_wait_timed_out = true;
+            return fail(BLZ_ERR_UNKNOWN, "%s timed out after %d ms (BLAZE_WAIT_TIMEOUT_MS): the device task did not complete; "
+                        "the handle accepts only reset / free now", what, limit_ms);
+        }
+        if (dt < std::chrono::microseconds(200)) std::this_thread::yield();
+        else std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+}
+int sync_event_bounded(hipEvent_t ev, const char* what) {
+    return bounded_wait([ev] { return hipEventQuery(ev); }, what);
+}
+int sync_stream_bounded(hipStream_t st, const char* what) {
+    return bounded_wait([st] { return hipStreamQuery(st); }, what);
+}
+
+__global__ void k_stall(uint32_t* flag, uint64_t max_ticks) {
+    const uint64_t t0 = wall_clock64();
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u && wall_clock64() - t0 < max_ticks)
+        __builtin_amdgcn_s_sleep(127);
+}
+
+int launch_stall(hipStream_t st, uint32_t max_ms, void** token) {
+    if (!token) return fail(BLZ_ERR_INVALID_PARAM, "null token");
+    if (max_ms == 0 || max_ms > 30000) return fail(BLZ_ERR_INVALID_PARAM, "stall cap must be 1..30000 ms");
+    int dev = 0, khz = 0;
+    BLZ_HIP(hipGetDevice(&dev), BLZ_ERR_UNKNOWN);
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000;   // 100 MHz
+    uint32_t* flag = nullptr;
+    BLZ_HIP(hipHostMalloc((void**)&flag, 64), BLZ_ERR_UNKNOWN);
+    *flag = 1u;
+    hipLaunchKernelGGL(k_stall, dim3(1), dim3(1), 0, st, flag, (uint64_t)max_ms * (uint64_t)khz);
+    BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
+    *token = flag;
+    return BLZ_OK;
+}
+
 int ensure_dynamic_lds(const void* kernel, int bytes) {
     static std::mutex mu;
     static std::map<std::pair<int, const void*>, int> done;   // (device, kernel) -> bytes granted
@@ -64,6 +128,12 @@ const char* blz_last_error_message(void) { return blz::g_err; }
 int blz_device_count(void) { return blz::device_count(); }
 size_t blz_point_size(int curve) { return curve == BLZ_BN254 ? 64 : (curve == BLZ_BLS377 || curve == BLZ_BLS381) ? 96 : 0; }
 size_t blz_result_size(int curve) { return curve == BLZ_BN254 ? 96 : (curve == BLZ_BLS377 || curve == BLZ_BLS381) ? 144 : 0; }
+
+int blz_test_stall_release(void* token) {
+    if (!token) return blz::fail(BLZ_ERR_INVALID_PARAM, "null token");
+    __atomic_store_n((uint32_t*)token, 0u, __ATOMIC_RELEASE);
+    return BLZ_OK;
+}
 
 int blz_device_malloc(int device_id, size_t bytes, void** out) {
     if (!out) return blz::fail(BLZ_ERR_INVALID_PARAM, "null out");

@@ -58,6 +58,22 @@ int device_count();
 // of /dev/xdma{id}_*: src/utils.rs:74)
 int use_device(int device_id);
 
+// Bounded waits ("failure detection": the reference's wait_result spins on a status register for ever,
+// msm_api.rs:222-238 / ntt_api.rs:89-108).  Every host-side wait for device work polls against a deadline of
+// BLAZE_WAIT_TIMEOUT_MS (default 120 000; read at each wait) and returns BLZ_ERR_UNKNOWN with a message when it
+// expires; wait_timed_out() then tells the caller that the failure was the deadline, not a HIP error, so the handle
+// can refuse further work until reset.
+int wait_timeout_ms();
+int sync_event_bounded(hipEvent_t ev, const char* what);
+int sync_stream_bounded(hipStream_t st, const char* what);
+bool wait_timed_out();   // the last sync_*_bounded of this thread ended on its deadline
+void wait_clear();       // forget it (before a call that may fail without ever reaching a wait)
+
+// Test hook behind blz_test_*_stall: a one-lane kernel on `st` that spins until the host clears *token (pinned host
+// memory, leaked on purpose: nobody knows when the kernel has read it for the last time) or max_ms have passed on the
+// device's wall clock - the cap keeps a failing test from wedging the GPU for good.
+int launch_stall(hipStream_t st, uint32_t max_ms, void** token);
+
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (current device, kernel): the opt-in for more than
 // 64 KiB of dynamic LDS is per device, and a host may open clients on several devices of one process.
 int ensure_dynamic_lds(const void* kernel, int bytes);
@@ -102,7 +118,9 @@ struct ArenaExtent {
     uint64_t start = 0;
     size_t len = 0, cap = 0;     // bytes written / allocated (appends within cap are in place)
     void* raw = nullptr;
-    bool imported = false;       // opened from another process's export (hipIpcOpenMemHandle): fixed size
+    bool imported = false;       // opened from another process's export (hipIpcOpenMemHandle): fixed size, read-only
+    bool exported = false;       // other processes map this allocation (blz_arena_export): frozen - it must neither
+                                 // move (grow) nor change under their private Montgomery shadows
     // shadow
     void* mont = nullptr;
     size_t mont_bytes = 0;
@@ -110,6 +128,7 @@ struct ArenaExtent {
     uint32_t mont_phase = 0;
     uint64_t dirty_lo = 0, dirty_hi = 0;   // byte span (relative to start) whose points are stale in the shadow
     hipEvent_t shadow_ready = nullptr;     // recorded after the last conversion; consumers on other streams wait
+    bool shadow_recorded = false;          // shadow_ready has been recorded at least once since the shadow was (re)built
 };
 struct Arena {
     std::mutex mu;

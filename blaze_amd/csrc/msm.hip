@@ -411,11 +411,15 @@ int MsmEngine::init(int device_id, int curve_id) {
     return BLZ_OK;
 }
 
-void MsmEngine::destroy() {
-    if (!stream) return;
+bool MsmEngine::destroy() {
+    if (!stream) return true;
     (void)hipSetDevice(device);
-    (void)hipStreamSynchronize(stream);
-    (void)hipStreamSynchronize(tail_stream);
+    if (sync_stream_bounded(stream, "free: main stream") != BLZ_OK || sync_stream_bounded(tail_stream, "free: tail stream") != BLZ_OK) {
+        // work that never completes still references the buffers: freeing them would block (or fault); leak them
+        BLZ_LOG(0, "MSM engine freed while its device work is wedged: workspace and streams are leaked");
+        stream = tail_stream = aux_stream = nullptr;
+        return false;
+    }
     for (DevBuf* b : {&count, &off, &unit_off, &unit_bucket, &unit_order, &lenhist, &coarse, &inter, &slice_map, &entries,
                       &partial, &blocksums, &stats, &result})
         b->release();
@@ -436,6 +440,7 @@ void MsmEngine::destroy() {
     (void)hipStreamDestroy(tail_stream);
     (void)hipStreamDestroy(aux_stream);
     stream = tail_stream = aux_stream = nullptr;
+    return true;
 }
 
 bool MsmEngine::can_accept() const {
@@ -446,8 +451,9 @@ bool MsmEngine::can_accept() const {
 
 int MsmEngine::sync_all() {
     BLZ_TRY(use_device(device));
-    BLZ_HIP(hipStreamSynchronize(stream), BLZ_ERR_UNKNOWN);
-    BLZ_HIP(hipStreamSynchronize(tail_stream), BLZ_ERR_UNKNOWN);
+    BLZ_TRY(sync_stream_bounded(stream, "reset: main stream"));
+    BLZ_TRY(sync_stream_bounded(tail_stream, "reset: tail stream"));
+    BLZ_TRY(sync_stream_bounded(aux_stream, "reset: exchange stream"));
     for (auto& S : slots) S.busy = false;
     return BLZ_OK;
 }
@@ -538,7 +544,8 @@ int MsmEngine::finish(int slot, uint8_t* out) {
     BLZ_TRY(use_device(device));
     if (slot < 0 || slot >= MSM_QUEUE_DEPTH || !slots[slot].busy) return fail(BLZ_ERR_INVALID_PARAM, "no task in slot %d", slot);
     MsmSlot& S = slots[slot];
-    BLZ_HIP(hipEventSynchronize(S.ev_done), BLZ_ERR_UNKNOWN);
+    // bounded: a wedged kernel must not hang the host for ever (common.hpp); on expiry the slot stays busy
+    BLZ_TRY(sync_event_bounded(S.ev_done, "wait_result: MSM task"));
     S.busy = false;
     if (S.plan.c) {
         BLZ_LOG(2, "msm: units=%u max_bucket=%u entries=%u", S.stats_h[0], S.stats_h[1], S.stats_h[2]);

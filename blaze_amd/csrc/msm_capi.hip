@@ -1,6 +1,11 @@
 // C ABI of the MSM primitive: the DriverPrimitive call sequence of src/ingo_msm/msm_api.rs
 // (initialize -> start_process -> set_data -> wait_result -> result) over the device pipeline.
+#include <chrono>
+#include <condition_variable>
 #include <deque>
+#include <functional>
+#include <memory>
+#include <thread>
 
 #include "msm_engine.hpp"
 #include "rccl_dyn.hpp"
@@ -39,6 +44,9 @@ struct blz_msm {
     bool staged_from_arena = false;
     uint64_t staged_arena_pos = 0;
     MsmEngine eng;
+    // a wait ran into its deadline (BLAZE_WAIT_TIMEOUT_MS): device work of this handle may never complete, so nothing
+    // new is queued behind it; reset (which waits, bounded, for the streams to drain) or free are the ways out
+    bool wedged = false;
     // multi-GPU exchange (blz_msm_comm_*): one communicator rank per handle
     ncclComm_t comm = nullptr;
     int comm_rank = 0, comm_size = 0;
@@ -46,6 +54,23 @@ struct blz_msm {
 };
 
 namespace {
+
+#define BLZ_LIVE(h)                                                                                              \
+    do {                                                                                                         \
+        if ((h)->wedged)                                                                                         \
+            return fail(BLZ_ERR_UNKNOWN, "handle is wedged: an earlier wait timed out (BLAZE_WAIT_TIMEOUT_MS); only " \
+                                         "reset / free are accepted");                                           \
+    } while (0)
+// a bounded wait of this handle: remember a deadline expiry
+#define BLZ_WAIT(h, expr)                          \
+    do {                                           \
+        wait_clear();                              \
+        int rc__ = (expr);                         \
+        if (rc__ != BLZ_OK) {                      \
+            if (wait_timed_out()) (h)->wedged = true; \
+            return rc__;                           \
+        }                                          \
+    } while (0)
 
 size_t point_size(const blz_msm* h) { return blz_point_size(h->curve); }
 size_t result_size(const blz_msm* h) { return blz_result_size(h->curve); }
@@ -77,8 +102,14 @@ int arena_points_mont(blz_msm* h, uint64_t pos, uint32_t npts, const void** out)
         e->mont_phase = phase;
         e->dirty_lo = 0;
         e->dirty_hi = e->len;
+        e->shadow_recorded = false;   // (the device was drained above: nothing recorded earlier is still running)
     }
     if (!e->shadow_ready) BLZ_HIP(hipEventCreateWithFlags(&e->shadow_ready, hipEventDisableTiming), BLZ_ERR_UNKNOWN);
+    // Conversions are chained through ONE event: whoever touches the shadow next - to read it or to convert another
+    // span - first orders its stream behind the last conversion recorded, whichever handle enqueued it.  (Without the
+    // wait in the dirty branch, handle B converting a small appended span re-recorded the event while handle A's
+    // full-extent conversion was still running on A's stream, and B's task read points A had not written yet.)
+    if (e->shadow_recorded) BLZ_HIP(hipStreamWaitEvent(h->eng.stream, e->shadow_ready, 0), BLZ_ERR_UNKNOWN);
     if (e->dirty_lo < e->dirty_hi) {
         // only the points the written span touches
         uint64_t lo = e->dirty_lo > phase ? (e->dirty_lo - phase) / ps : 0;
@@ -87,9 +118,8 @@ int arena_points_mont(blz_msm* h, uint64_t pos, uint32_t npts, const void** out)
         if (lo < hi)
             BLZ_TRY(h->eng.points_to_mont((const char*)e->raw + phase + lo * ps, (char*)e->mont + lo * mp, (uint32_t)(hi - lo)));
         BLZ_HIP(hipEventRecord(e->shadow_ready, h->eng.stream), BLZ_ERR_UNKNOWN);
+        e->shadow_recorded = true;
         e->dirty_lo = e->dirty_hi = 0;
-    } else {
-        BLZ_HIP(hipStreamWaitEvent(h->eng.stream, e->shadow_ready, 0), BLZ_ERR_UNKNOWN);
     }
     *out = (const char*)e->mont + (pos - e->start - phase) / ps * mp;
     return BLZ_OK;
@@ -118,6 +148,7 @@ int launch_if_ready(blz_msm* h) {
 int stage_common(blz_msm* h, bool have_points, const void* points, size_t points_len, const void* scalars,
                  size_t scalars_len, uint32_t n, int has_hbm, uint64_t hbm_addr, uint64_t hbm_off, bool on_device) {
     if (!h) return fail(BLZ_ERR_INVALID_PARAM, "null handle");
+    BLZ_LIVE(h);
     BLZ_TRY(use_device(h->device));
     if (!have_points && !has_hbm) return BLZ_OK;  // reference: falls through every branch (msm_api.rs:163-216)
     if (!scalars && n) return fail(BLZ_ERR_INVALID_PARAM, "null scalars");
@@ -154,7 +185,7 @@ int stage_common(blz_msm* h, bool have_points, const void* points, size_t points
 
     if (have_points && has_hbm) {
         // msm_api.rs:203-206: load_data_to_hbm(points, addr, offset) first
-        BLZ_TRY(arena_write(h->device, hbm_addr + hbm_off, points, points_len, on_device, st));
+        BLZ_WAIT(h, arena_write(h->device, hbm_addr + hbm_off, points, points_len, on_device, st));
         h->bases_from_hbm = true;
         h->hbm_addr = hbm_addr;
     }
@@ -181,7 +212,7 @@ int stage_common(blz_msm* h, bool have_points, const void* points, size_t points
         } else {
             BLZ_TRY(h->points_raw[set].reserve(want_pts ? want_pts : 16));
             if (want_pts) BLZ_HIP(hipMemcpyAsync(h->points_raw[set].p, points, want_pts, hipMemcpyHostToDevice, cst), BLZ_ERR_WRITE);
-            BLZ_HIP(hipStreamSynchronize(cst), BLZ_ERR_WRITE);
+            BLZ_WAIT(h, sync_stream_bounded(cst, "set_data: host -> device copy of the points"));
             BLZ_TRY(h->eng.points_to_mont(h->points_raw[set].p, h->points_mont.p, npts));
         }
         h->d_points_mont = h->points_mont.p;
@@ -193,8 +224,9 @@ int stage_common(blz_msm* h, bool have_points, const void* points, size_t points
         BLZ_TRY(h->scalars_buf[set].reserve(scalars_len ? scalars_len : 16));
         if (scalars_len) BLZ_HIP(hipMemcpyAsync(h->scalars_buf[set].p, scalars, scalars_len, hipMemcpyHostToDevice, cst), BLZ_ERR_WRITE);
         h->d_scalars = h->scalars_buf[set].p;
-        // the caller may drop its buffers as soon as we return (set_data is synchronous: utils.rs:71)
-        BLZ_HIP(hipStreamSynchronize(cst), BLZ_ERR_WRITE);
+        // the caller may drop its buffers as soon as we return (set_data is synchronous: utils.rs:71).  The copy waits
+        // for the staging set's previous user (set_free, two tasks back): bounded like every wait
+        BLZ_WAIT(h, sync_stream_bounded(cst, "set_data: host -> device copy of the scalars"));
     }
     h->staged_n = n;
     h->data_ready = true;
@@ -235,7 +267,10 @@ void blz_msm_free(blz_msm* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->comm) (void)blz_msm_comm_free(h);
-    h->eng.destroy();
+    if (!h->eng.destroy() || sync_stream_bounded(h->copy_stream, "free: copy stream") != BLZ_OK) {
+        delete h;   // wedged device work may still touch the staging buffers: they are leaked, not freed
+        return;
+    }
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     for (int i = 0; i < 2; ++i) {
         h->scalars_buf[i].release();
@@ -275,6 +310,7 @@ int blz_msm_loaded_binary_parameters(blz_msm* h, uint32_t out[2]) {
 
 int blz_msm_initialize(blz_msm* h, uint32_t nof_elements, int has_hbm, uint64_t hbm_addr, uint64_t hbm_off) {
     if (!h) return fail(BLZ_ERR_INVALID_PARAM, "null handle");
+    BLZ_LIVE(h);
     (void)hbm_off;  // msm_api.rs:84: only hbm_point_addr.0 is programmed
     if (h->mem_type == BLZ_DMA && !has_hbm) {
         h->bases_from_hbm = false;  // BASES_SOURCE = 0 (msm_api.rs:75-81)
@@ -291,6 +327,7 @@ int blz_msm_initialize(blz_msm* h, uint32_t nof_elements, int has_hbm, uint64_t 
 
 int blz_msm_start_process(blz_msm* h) {
     if (!h) return fail(BLZ_ERR_INVALID_PARAM, "null handle");
+    BLZ_LIVE(h);
     if (!h->initialized) return fail(BLZ_ERR_INVALID_PARAM, "start_process before initialize");
     if (h->armed) return fail(BLZ_ERR_INVALID_PARAM, "a task is already queued and waits for data");
     h->armed = true;
@@ -318,17 +355,25 @@ int blz_msm_set_data_device(blz_msm* h, const void* d_points, size_t points_len,
 
 int blz_msm_wait_result(blz_msm* h) {
     if (!h) return fail(BLZ_ERR_INVALID_PARAM, "null handle");
+    BLZ_LIVE(h);
     if (h->in_flight.empty()) {
         if (!h->results.empty()) return BLZ_OK;  // RESULT_VALID already set
         return fail(BLZ_ERR_INVALID_PARAM, "wait_result with no task in flight (the reference would spin forever)");
     }
-    // tasks complete in submission order: wait for the oldest, move its bytes to the result queue
+    // tasks complete in submission order: wait for the oldest, move its bytes to the result queue.  The wait is
+    // bounded (BLAZE_WAIT_TIMEOUT_MS; the reference polls RESULT_VALID without a deadline, msm_api.rs:222-238): on
+    // expiry the task stays queued, the handle turns reset-only and the error is Unknown.
     blz_msm::Pending p = h->in_flight.front();
-    h->in_flight.pop_front();
     blz_msm::Res r;
     r.bytes.resize(result_size(h));
     r.label = p.label;
-    int rc = h->eng.finish(p.slot, r.bytes.data());
+    wait_clear();
+    const int rc = h->eng.finish(p.slot, r.bytes.data());
+    if (rc != BLZ_OK && wait_timed_out()) {
+        h->wedged = true;
+        return rc;
+    }
+    h->in_flight.pop_front();
     if (rc != BLZ_OK) return rc;
     h->results.push_back(std::move(r));
     return BLZ_OK;
@@ -348,7 +393,8 @@ int blz_msm_result(blz_msm* h, uint8_t* out, size_t out_cap, size_t* out_len, ui
 
 int blz_msm_load_data_to_hbm(blz_msm* h, const uint8_t* points, size_t len, uint64_t addr, uint64_t off) {
     if (!h || (!points && len)) return fail(BLZ_ERR_INVALID_PARAM, "null argument");
-    BLZ_TRY(arena_write(h->device, addr + off, points, len, false, h->eng.stream));
+    BLZ_LIVE(h);
+    BLZ_WAIT(h, arena_write(h->device, addr + off, points, len, false, h->eng.stream));
     h->bases_from_hbm = true;  // msm_api.rs:301-311 flips BASES_SOURCE and programs the address
     h->hbm_addr = addr;
     return BLZ_OK;
@@ -356,7 +402,8 @@ int blz_msm_load_data_to_hbm(blz_msm* h, const uint8_t* points, size_t len, uint
 
 int blz_msm_load_data_to_hbm_device(blz_msm* h, const void* d_points, size_t len, uint64_t addr, uint64_t off) {
     if (!h || (!d_points && len)) return fail(BLZ_ERR_INVALID_PARAM, "null argument");
-    BLZ_TRY(arena_write(h->device, addr + off, d_points, len, true, h->eng.stream));
+    BLZ_LIVE(h);
+    BLZ_WAIT(h, arena_write(h->device, addr + off, d_points, len, true, h->eng.stream));
     h->bases_from_hbm = true;
     h->hbm_addr = addr;
     return BLZ_OK;
@@ -392,7 +439,11 @@ int blz_msm_is_engine_ready(blz_msm* h, uint32_t* out) {
 int blz_msm_reset(blz_msm* h) {
     if (!h) return fail(BLZ_ERR_INVALID_PARAM, "null handle");
     BLZ_TRY(use_device(h->device));
+    // waits (bounded) until every stream of the handle has drained; a handle whose device work still does not
+    // complete stays wedged and reset fails with Unknown again
+    BLZ_TRY(sync_stream_bounded(h->copy_stream, "reset: copy stream"));
     BLZ_TRY(h->eng.sync_all());
+    h->wedged = false;
     h->armed = h->data_ready = false;
     h->in_flight.clear();
     h->results.clear();
@@ -427,7 +478,9 @@ int blz_msm_plan(int curve, uint32_t nof_elements, int is_precompute, uint32_t o
 int blz_msm_combine_partials(blz_msm* h, const uint8_t* partials, size_t count, uint8_t* out, size_t out_cap) {
     if (!h || !out || (!partials && count)) return fail(BLZ_ERR_INVALID_PARAM, "null argument");
     if (out_cap < result_size(h)) return fail(BLZ_ERR_INVALID_PARAM, "result buffer too small");
-    return h->eng.combine_partials(partials, count, out, false);
+    BLZ_LIVE(h);
+    BLZ_WAIT(h, h->eng.combine_partials(partials, count, out, false));
+    return BLZ_OK;
 }
 
 // ---- multi-GPU exchange: RCCL all-gather of the per-rank partial results + rank-ordered add
@@ -448,6 +501,41 @@ int blz_comm_unique_id(uint8_t out[BLZ_COMM_ID_BYTES]) {
     return BLZ_OK;
 }
 
+// Communicator bring-up is a rendezvous: ncclCommInitRank returns when EVERY rank has called it, and for ever never
+// if one of them died on the way.  It therefore runs on a helper thread and the caller waits for it against
+// BLAZE_COMM_TIMEOUT_MS (default 60 000); on expiry the call fails with Unknown and the helper - parked inside RCCL - is
+// abandoned (it owns its state through the shared_ptr and never touches the handle).
+struct CommJob {
+    std::mutex mu;
+    std::condition_variable cv;
+    bool done = false;
+    int rc = BLZ_OK;
+    std::string err;
+    std::vector<ncclComm_t> comms;
+};
+static int comm_timeout_ms() {
+    const char* s = getenv("BLAZE_COMM_TIMEOUT_MS");
+    int v = s && *s ? atoi(s) : 60000;
+    return v > 0 ? v : 60000;
+}
+static int run_comm_job(std::shared_ptr<CommJob> job, std::function<int(CommJob&)> fn, const char* what) {
+    std::thread([job, fn] {
+        int rc = fn(*job);
+        std::lock_guard<std::mutex> lk(job->mu);
+        job->rc = rc;
+        if (rc != BLZ_OK) job->err = blz_last_error_message();   // the message lives in the helper's thread-local buffer
+        job->done = true;
+        job->cv.notify_all();
+    }).detach();
+    std::unique_lock<std::mutex> lk(job->mu);
+    const int limit = comm_timeout_ms();
+    if (!job->cv.wait_for(lk, std::chrono::milliseconds(limit), [&] { return job->done; }))
+        return fail(BLZ_ERR_UNKNOWN, "%s did not complete within %d ms (BLAZE_COMM_TIMEOUT_MS): a peer rank never arrived, or "
+                    "RCCL cannot reach it; the bring-up thread is abandoned", what, limit);
+    if (job->rc != BLZ_OK) return fail(job->rc, "%s", job->err.c_str());
+    return BLZ_OK;
+}
+
 int blz_msm_comm_init(blz_msm* h, int rank, int nranks, const uint8_t id_bytes[BLZ_COMM_ID_BYTES]) {
     if (!h || !id_bytes) return fail(BLZ_ERR_INVALID_PARAM, "null argument");
     if (nranks < 1 || rank < 0 || rank >= nranks) return fail(BLZ_ERR_INVALID_PARAM, "rank %d of %d", rank, nranks);
@@ -457,18 +545,65 @@ int blz_msm_comm_init(blz_msm* h, int rank, int nranks, const uint8_t id_bytes[B
     BLZ_TRY(use_device(h->device));
     ncclUniqueId id;
     memcpy(&id, id_bytes, sizeof(id));
-    BLZ_NCCL(api, api->CommInitRank(&h->comm, nranks, id, rank));   // collective: every rank calls it
+    auto job = std::make_shared<CommJob>();
+    job->comms.assign(1, nullptr);
+    const int dev = h->device;
+    char what[96];
+    snprintf(what, sizeof(what), "ncclCommInitRank (rank %d of %d)", rank, nranks);
+    BLZ_TRY(run_comm_job(job, [api, dev, id, rank, nranks](CommJob& j) -> int {
+        BLZ_HIP(hipSetDevice(dev), BLZ_ERR_FILE);
+        BLZ_NCCL(api, api->CommInitRank(&j.comms[0], nranks, id, rank));   // collective: every rank calls it
+        return BLZ_OK;
+    }, what));
+    h->comm = job->comms[0];
     h->comm_rank = rank;
     h->comm_size = nranks;
     return h->comm_buf.reserve((size_t)(nranks + 1) * result_size(h) + 64);
 }
 
-int blz_msm_all_gather_combine(blz_msm* h, const uint8_t* partial, uint8_t* out, size_t out_cap) {
-    if (!h || !partial || !out) return fail(BLZ_ERR_INVALID_PARAM, "null argument");
-    if (!h->comm) return fail(BLZ_ERR_INVALID_PARAM, "all_gather_combine before comm_init");
-    if (out_cap < result_size(h)) return fail(BLZ_ERR_INVALID_PARAM, "result buffer too small");
+// One process driving several devices (the "management layer" of README.md:20-22 as a single host thread): one
+// handle per device, rank i = handles[i].  The n bring-ups are one RCCL group (ncclGroupStart / End), because n
+// sequential ncclCommInitRank calls from one thread would each wait for the ones that thread has not made yet.
+int blz_msm_comm_init_all(blz_msm* const* handles, int n) {
+    if (!handles || n < 1) return fail(BLZ_ERR_INVALID_PARAM, "no handles");
+    for (int i = 0; i < n; ++i) {
+        if (!handles[i]) return fail(BLZ_ERR_INVALID_PARAM, "null handle %d", i);
+        if (handles[i]->comm) return fail(BLZ_ERR_INVALID_PARAM, "communicator already initialised on handle %d", i);
+        if (handles[i]->curve != handles[0]->curve) return fail(BLZ_ERR_INVALID_PARAM, "handles of different curves");
+        for (int k = 0; k < i; ++k)
+            if (handles[k]->device == handles[i]->device)
+                return fail(BLZ_ERR_INVALID_PARAM, "handles %d and %d share device %d (RCCL: one rank per device)", k, i, handles[i]->device);
+    }
     const RcclApi* api = rccl_api();
     if (!api) return BLZ_ERR_LOAD_FAILED;
+    auto job = std::make_shared<CommJob>();
+    job->comms.assign((size_t)n, nullptr);
+    std::vector<int> devs;
+    for (int i = 0; i < n; ++i) devs.push_back(handles[i]->device);
+    BLZ_TRY(run_comm_job(job, [api, devs, n](CommJob& j) -> int {
+        ncclUniqueId id;
+        BLZ_NCCL(api, api->GetUniqueId(&id));
+        BLZ_NCCL(api, api->GroupStart());
+        for (int i = 0; i < n; ++i) {
+            if (hipSetDevice(devs[i]) != hipSuccess) { (void)api->GroupEnd(); return fail(BLZ_ERR_FILE, "hipSetDevice(%d) failed", devs[i]); }
+            ncclResult_t r = api->CommInitRank(&j.comms[i], n, id, i);
+            if (r != ncclSuccess) { (void)api->GroupEnd(); return fail(BLZ_ERR_UNKNOWN, "ncclCommInitRank(rank %d) failed: %s", i, api->GetErrorString(r)); }
+        }
+        BLZ_NCCL(api, api->GroupEnd());
+        return BLZ_OK;
+    }, "ncclCommInitRank group (single process)"));
+    for (int i = 0; i < n; ++i) {
+        handles[i]->comm = job->comms[i];
+        handles[i]->comm_rank = i;
+        handles[i]->comm_size = n;
+        BLZ_TRY(use_device(handles[i]->device));
+        BLZ_TRY(handles[i]->comm_buf.reserve((size_t)(n + 1) * result_size(handles[i]) + 64));
+    }
+    return BLZ_OK;
+}
+
+// enqueue this handle's half of the exchange on its exchange stream (no host wait)
+static int enqueue_all_gather(blz_msm* h, const RcclApi* api, const uint8_t* partial, uint8_t** recv_out) {
     BLZ_TRY(use_device(h->device));
     // own stream: the exchange must not queue behind the next task's accumulation on the main stream
     hipStream_t st = h->eng.aux_stream;
@@ -477,7 +612,53 @@ int blz_msm_all_gather_combine(blz_msm* h, const uint8_t* partial, uint8_t* out,
     uint8_t* recv = send + ((rs + 63) / 64) * 64;
     BLZ_HIP(hipMemcpyAsync(send, partial, rs, hipMemcpyHostToDevice, st), BLZ_ERR_WRITE);
     BLZ_NCCL(api, api->AllGather(send, recv, rs, ncclUint8, h->comm, st));
-    return h->eng.combine_partials(recv, (size_t)h->comm_size, out, true);   // rank order = buffer order
+    *recv_out = recv;
+    return BLZ_OK;
+}
+
+int blz_msm_all_gather_combine(blz_msm* h, const uint8_t* partial, uint8_t* out, size_t out_cap) {
+    if (!h || !partial || !out) return fail(BLZ_ERR_INVALID_PARAM, "null argument");
+    BLZ_LIVE(h);
+    if (!h->comm) return fail(BLZ_ERR_INVALID_PARAM, "all_gather_combine before comm_init");
+    if (out_cap < result_size(h)) return fail(BLZ_ERR_INVALID_PARAM, "result buffer too small");
+    const RcclApi* api = rccl_api();
+    if (!api) return BLZ_ERR_LOAD_FAILED;
+    uint8_t* recv = nullptr;
+    BLZ_TRY(enqueue_all_gather(h, api, partial, &recv));
+    // rank order = buffer order; the wait inside is bounded (a peer that never joins the all-gather: Unknown, wedged)
+    BLZ_WAIT(h, h->eng.combine_partials(recv, (size_t)h->comm_size, out, true));
+    return BLZ_OK;
+}
+
+// The exchange for the handles of blz_msm_comm_init_all, from the one thread that drives them: partials and out hold
+// n x result_size bytes in handle order; every handle's sum is written (identical bytes).  All n all-gathers are
+// enqueued as one RCCL group before any of them is waited for.
+int blz_msm_all_gather_combine_all(blz_msm* const* handles, int n, const uint8_t* partials, uint8_t* out, size_t out_cap) {
+    if (!handles || n < 1 || !partials || !out) return fail(BLZ_ERR_INVALID_PARAM, "null argument");
+    const RcclApi* api = rccl_api();
+    if (!api) return BLZ_ERR_LOAD_FAILED;
+    for (int i = 0; i < n; ++i) {
+        if (!handles[i] || !handles[i]->comm || handles[i]->comm_size != n || handles[i]->comm_rank != i)
+            return fail(BLZ_ERR_INVALID_PARAM, "handle %d is not rank %d of a %d-rank communicator (blz_msm_comm_init_all)", i, i, n);
+        BLZ_LIVE(handles[i]);
+    }
+    const size_t rs = result_size(handles[0]);
+    if (out_cap < rs * (size_t)n) return fail(BLZ_ERR_INVALID_PARAM, "result buffer too small: %zu < %zu", out_cap, rs * (size_t)n);
+    std::vector<uint8_t*> recv((size_t)n, nullptr);
+    BLZ_NCCL(api, api->GroupStart());
+    for (int i = 0; i < n; ++i) {
+        int rc = enqueue_all_gather(handles[i], api, partials + (size_t)i * rs, &recv[i]);
+        if (rc != BLZ_OK) { (void)api->GroupEnd(); return rc; }
+    }
+    BLZ_NCCL(api, api->GroupEnd());
+    for (int i = 0; i < n; ++i) BLZ_WAIT(handles[i], handles[i]->eng.combine_partials(recv[i], (size_t)n, out + (size_t)i * rs, true));
+    return BLZ_OK;
+}
+
+int blz_test_msm_stall(blz_msm* h, uint32_t max_ms, void** token) {
+    if (!h) return fail(BLZ_ERR_INVALID_PARAM, "null handle");
+    BLZ_TRY(use_device(h->device));
+    return launch_stall(h->eng.stream, max_ms, token);
 }
 
 int blz_msm_comm_free(blz_msm* h) {
@@ -486,8 +667,9 @@ int blz_msm_comm_free(blz_msm* h) {
     const RcclApi* api = rccl_api();
     if (api) {
         (void)hipSetDevice(h->device);
-        (void)hipStreamSynchronize(h->eng.aux_stream);
-        (void)api->CommDestroy(h->comm);
+        // a communicator whose exchange never completed cannot be destroyed gracefully (ncclCommDestroy waits for it)
+        if (sync_stream_bounded(h->eng.aux_stream, "comm_free: exchange stream") == BLZ_OK) (void)api->CommDestroy(h->comm);
+        else if (api->CommAbort) (void)api->CommAbort(h->comm);
     }
     h->comm = nullptr;
     h->comm_size = 0;

@@ -63,7 +63,7 @@ struct MsmEngine {
     void* sort_inter_fine = nullptr;  // u16 fine digits of the sort intermediate (second half of `inter`)
 
     int init(int device_id, int curve_id);
-    void destroy();
+    bool destroy();   // false: the streams never drained (wedged device work): everything was leaked instead of freed
     // device result bytes of slot s / scratch of combine_partials inside `result`
     uint32_t* slot_result(int s) { return result.as<uint32_t>() + (size_t)s * 64; }
     bool can_accept() const;

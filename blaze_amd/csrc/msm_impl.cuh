@@ -536,10 +536,12 @@ int run_tail_t(MsmEngine& E, const void* d_pts, uint32_t U) {
         const uint32_t maxunits = (P.npts + P.L - 1) / P.L;   // a bucket holds at most one entry per point
         uint64_t full_bound = (uint64_t)P.npts * P.W / P.L + 1;  // units of length L: at most entries / L
         if (full_bound > U) full_bound = U;
-        for (uint32_t stride = 1; stride < maxunits; stride *= 16)
+        // (64-bit stride: with BLAZE_MSM_L < 8 and close to 2^31 points, maxunits exceeds 2^28 and a u32 stride would
+        // wrap to 0 - an endless launch loop)
+        for (uint64_t stride = 1; stride < maxunits; stride *= 16)
             hipLaunchKernelGGL(k_combine_units<F>, dim3((uint32_t)((full_bound / 16 + 1) * 4 / 128 + 1)), dim3(128), 0, st,
                                E.unit_off.as<uint32_t>(), E.unit_bucket.as<uint32_t>(), E.unit_order.as<uint32_t>(),
-                               E.lenhist.as<uint32_t>() + P.L, E.stats.as<uint32_t>(), P.L, stride, E.partial.as<uint32_t>());
+                               E.lenhist.as<uint32_t>() + P.L, E.stats.as<uint32_t>(), P.L, (uint32_t)stride, E.partial.as<uint32_t>());
         BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
     }
     BLZ_HIP(hipEventRecord(S.ev[2], st), BLZ_ERR_UNKNOWN);
@@ -639,10 +641,10 @@ int combine_t(MsmEngine& E, const uint8_t* partials, size_t count, uint8_t* out,
     hipLaunchKernelGGL(k_combine_partials<F>, dim3(1), dim3(64), 0, st, d_in, (uint32_t)count, d_out);
     BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
     BLZ_HIP(hipMemcpyAsync(E.combine_h, d_out, rs, hipMemcpyDeviceToHost, st), BLZ_ERR_READ);
-    BLZ_HIP(hipStreamSynchronize(st), BLZ_ERR_UNKNOWN);
-    memcpy(out, E.combine_h, rs);
-    tmp.release();
-    return BLZ_OK;
+    const int rc = sync_stream_bounded(st, on_device ? "all_gather_combine: exchange + combine" : "combine_partials");
+    if (rc == BLZ_OK) memcpy(out, E.combine_h, rs);
+    if (rc == BLZ_OK || !wait_timed_out()) tmp.release();   // (a wedged stream may still read it: leak rather than block)
+    return rc;
 }
 
 template <class F>

@@ -65,7 +65,24 @@ struct blz_ntt {
     bool in_flight = false;
     int in_flight_buf = -1;   // buffer under transform while in_flight
     float last_ms = 0.f;
+    bool wedged = false;      // a wait ran into BLAZE_WAIT_TIMEOUT_MS: only reset / free are accepted (common.hpp)
 };
+
+#define BLZ_NTT_LIVE(h)                                                                                          \
+    do {                                                                                                         \
+        if ((h)->wedged)                                                                                         \
+            return fail(BLZ_ERR_UNKNOWN, "handle is wedged: an earlier wait timed out (BLAZE_WAIT_TIMEOUT_MS); only " \
+                                         "reset / free are accepted");                                           \
+    } while (0)
+#define BLZ_NTT_WAIT(h, expr)                      \
+    do {                                           \
+        blz::wait_clear();                         \
+        int rc__ = (expr);                         \
+        if (rc__ != BLZ_OK) {                      \
+            if (blz::wait_timed_out()) (h)->wedged = true; \
+            return rc__;                           \
+        }                                          \
+    } while (0)
 
 namespace {
 
@@ -185,7 +202,12 @@ int blz_ntt_new_field(int device_id, int field, int log_size, int inverse, blz_n
 void blz_ntt_free(blz_ntt* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->stream && (sync_stream_bounded(h->stream, "free: NTT stream") != BLZ_OK ||
+                      sync_stream_bounded(h->copy_stream, "free: NTT copy stream") != BLZ_OK)) {
+        BLZ_LOG(0, "NTT handle freed while its device work is wedged: buffers and streams are leaked");
+        delete h;
+        return;
+    }
     h->buf[0].release(); h->buf[1].release(); h->scratch.release(); h->tables.release(); h->tables_rr.release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -203,6 +225,7 @@ static int ntt_set_data_common(blz_ntt* h, size_t buf_host, const void* data, si
     if (!h || !data) return fail(BLZ_ERR_INVALID_PARAM, "null argument");
     if (buf_host > 1) return fail(BLZ_ERR_INVALID_PARAM, "buf_host must be 0 or 1");
     if (len != ntt_bytes(h)) return fail(BLZ_ERR_INVALID_PARAM, "data length %zu != %zu", len, ntt_bytes(h));
+    BLZ_NTT_LIVE(h);
     if (h->in_flight && h->in_flight_buf == (int)buf_host)
         return fail(BLZ_ERR_INVALID_PARAM, "buffer %zu is being transformed; call wait_result first", buf_host);
     BLZ_TRY(use_device(h->device));
@@ -211,7 +234,7 @@ static int ntt_set_data_common(blz_ntt* h, size_t buf_host, const void* data, si
     // blocking, and a device-to-device hipMemcpy alone is not ordered against other streams.
     BLZ_HIP(hipMemcpyAsync(h->buf[buf_host].p, data, len, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
                            h->copy_stream), BLZ_ERR_WRITE);
-    BLZ_HIP(hipStreamSynchronize(h->copy_stream), BLZ_ERR_WRITE);
+    BLZ_NTT_WAIT(h, sync_stream_bounded(h->copy_stream, "set_data: copy into the NTT buffer"));
     return BLZ_OK;
 }
 
@@ -225,6 +248,7 @@ int blz_ntt_set_data_device(blz_ntt* h, size_t buf_host, const void* d_data, siz
 int blz_ntt_start_process(blz_ntt* h, size_t buf_kernel) {
     if (!h) return fail(BLZ_ERR_INVALID_PARAM, "null handle");
     if (buf_kernel > 1) return fail(BLZ_ERR_INVALID_PARAM, "buf_kernel must be 0 or 1");
+    BLZ_NTT_LIVE(h);
     if (h->in_flight) return fail(BLZ_ERR_INVALID_PARAM, "a transform is already running; call wait_result first");
     BLZ_TRY(use_device(h->device));
     void* b = h->buf[buf_kernel].p;
@@ -246,9 +270,11 @@ int blz_ntt_start_process(blz_ntt* h, size_t buf_kernel) {
 
 int blz_ntt_wait_result(blz_ntt* h) {
     if (!h) return fail(BLZ_ERR_INVALID_PARAM, "null handle");
+    BLZ_NTT_LIVE(h);
     if (!h->in_flight) return fail(BLZ_ERR_INVALID_PARAM, "wait_result with no transform in flight");
     BLZ_TRY(use_device(h->device));
-    BLZ_HIP(hipStreamSynchronize(h->stream), BLZ_ERR_UNKNOWN);
+    // bounded (BLAZE_WAIT_TIMEOUT_MS): the reference polls the status register without a deadline (ntt_api.rs:89-108)
+    BLZ_NTT_WAIT(h, sync_event_bounded(h->ev1, "wait_result: NTT"));
     (void)hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1);
     h->in_flight = false;
     return BLZ_OK;
@@ -260,10 +286,11 @@ static int ntt_result_common(blz_ntt* h, size_t buf, void* out, size_t out_cap, 
     if (h->in_flight && h->in_flight_buf == (int)buf)
         return fail(BLZ_ERR_INVALID_PARAM, "buffer %zu is being transformed; call wait_result first", buf);
     if (out_cap < ntt_bytes(h)) return fail(BLZ_ERR_INVALID_PARAM, "output buffer too small");
+    BLZ_NTT_LIVE(h);
     BLZ_TRY(use_device(h->device));
     BLZ_HIP(hipMemcpyAsync(out, h->buf[buf].p, ntt_bytes(h), on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
                            h->copy_stream), BLZ_ERR_READ);
-    BLZ_HIP(hipStreamSynchronize(h->copy_stream), BLZ_ERR_READ);
+    BLZ_NTT_WAIT(h, sync_stream_bounded(h->copy_stream, "result: copy out of the NTT buffer"));
     return BLZ_OK;
 }
 int blz_ntt_result(blz_ntt* h, size_t buf, uint8_t* out, size_t out_cap) { return ntt_result_common(h, buf, out, out_cap, false); }
@@ -272,9 +299,17 @@ int blz_ntt_result_device(blz_ntt* h, size_t buf, void* d_out, size_t out_cap) {
 int blz_ntt_reset(blz_ntt* h) {
     if (!h) return fail(BLZ_ERR_INVALID_PARAM, "null handle");
     BLZ_TRY(use_device(h->device));
-    BLZ_HIP(hipStreamSynchronize(h->stream), BLZ_ERR_UNKNOWN);
+    BLZ_TRY(sync_stream_bounded(h->stream, "reset: NTT stream"));
+    BLZ_TRY(sync_stream_bounded(h->copy_stream, "reset: NTT copy stream"));
     h->in_flight = false;
+    h->wedged = false;
     return BLZ_OK;
+}
+
+int blz_test_ntt_stall(blz_ntt* h, uint32_t max_ms, void** token) {
+    if (!h) return fail(BLZ_ERR_INVALID_PARAM, "null handle");
+    BLZ_TRY(use_device(h->device));
+    return launch_stall(h->stream, max_ms, token);
 }
 
 int blz_ntt_last_kernel_ms(blz_ntt* h, float* out) {

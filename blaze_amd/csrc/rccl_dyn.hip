@@ -40,6 +40,7 @@ const RcclApi* rccl_api() {
         lib = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
         if (lib) {
             BLZ_LOG(2, "RCCL: %s", name.c_str());
+            snprintf(api.path, sizeof(api.path), "%s", name.c_str());
             break;
         }
     }
@@ -53,7 +54,11 @@ const RcclApi* rccl_api() {
     api.CommDestroy = (decltype(api.CommDestroy))dlsym(lib, "ncclCommDestroy");
     api.AllGather = (decltype(api.AllGather))dlsym(lib, "ncclAllGather");
     api.GetErrorString = (decltype(api.GetErrorString))dlsym(lib, "ncclGetErrorString");
-    if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather || !api.GetErrorString) {
+    api.GroupStart = (decltype(api.GroupStart))dlsym(lib, "ncclGroupStart");
+    api.GroupEnd = (decltype(api.GroupEnd))dlsym(lib, "ncclGroupEnd");
+    api.CommAbort = (decltype(api.CommAbort))dlsym(lib, "ncclCommAbort");
+    if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather || !api.GetErrorString || !api.GroupStart ||
+        !api.GroupEnd) {
         state = -1;
         set_last_error("RCCL library lacks an expected entry point");
         return nullptr;

@@ -232,6 +232,25 @@ class MSMClient(DriverPrimitive[MSMInit, MSMParams, MSMInput, MSMResult]):
         check(lib().blz_msm_all_gather_combine(self._h, p, C.cast(out, C.c_void_p), len(out)))
         return out.raw
 
+    @staticmethod
+    def comm_init_all(clients) -> None:
+        """One process, one thread, one client per device: all communicator ranks as ONE RCCL group (rank i =
+        clients[i]).  The per-rank comm_init is a blocking rendezvous and cannot be called in sequence from one thread."""
+        hs = (C.c_void_p * len(clients))(*[c._h for c in clients])
+        check(lib().blz_msm_comm_init_all(hs, len(clients)))
+
+    @staticmethod
+    def all_gather_combine_all(clients, partials) -> list:
+        """The exchange for the clients of comm_init_all: partials[i] is client i's result; every client's sum comes back."""
+        rs = clients[0].msm_cfg.result_point_size
+        assert len(partials) == len(clients) and all(len(p) == rs for p in partials)
+        hs = (C.c_void_p * len(clients))(*[c._h for c in clients])
+        flat = b"".join(bytes(p) for p in partials)
+        out = C.create_string_buffer(rs * len(clients))
+        p, _n, _k = buf_ptr(flat)
+        check(lib().blz_msm_all_gather_combine_all(hs, len(clients), p, C.cast(out, C.c_void_p), len(out)))
+        return [out.raw[i * rs: (i + 1) * rs] for i in range(len(clients))]
+
     def comm_free(self) -> None:
         check(lib().blz_msm_comm_free(self._h))
 

@@ -131,6 +131,26 @@ class MSMClient : public DriverPrimitive<MSMInit, MSMParams, MSMInput, MSMResult
         check(blz_msm_all_gather_combine(h_, partial.data(), out.data(), out.size()));
         return out;
     }
+    // one thread driving one client per device: the group forms (the per-rank calls above are blocking rendezvous)
+    static void comm_init_all(const std::vector<MSMClient*>& clients) {
+        std::vector<blz_msm*> hs;
+        for (MSMClient* c : clients) hs.push_back(c->h_);
+        check(blz_msm_comm_init_all(hs.data(), (int)hs.size()));
+    }
+    static std::vector<std::vector<uint8_t>> all_gather_combine_all(const std::vector<MSMClient*>& clients,
+                                                                    const std::vector<std::vector<uint8_t>>& partials) {
+        std::vector<blz_msm*> hs;
+        std::vector<uint8_t> flat;
+        for (MSMClient* c : clients) hs.push_back(c->h_);
+        for (const auto& p : partials) flat.insert(flat.end(), p.begin(), p.end());
+        const size_t rs = clients.at(0)->result_size_;
+        if (partials.size() != clients.size() || flat.size() != rs * clients.size()) throw DriverClientError(BLZ_ERR_INVALID_PARAM, "partials");
+        std::vector<uint8_t> out(rs * clients.size());
+        check(blz_msm_all_gather_combine_all(hs.data(), (int)hs.size(), flat.data(), out.data(), out.size()));
+        std::vector<std::vector<uint8_t>> res;
+        for (size_t i = 0; i < clients.size(); ++i) res.emplace_back(out.begin() + i * rs, out.begin() + (i + 1) * rs);
+        return res;
+    }
     std::vector<uint8_t> combine_partials(const std::vector<uint8_t>& partials, size_t count) {
         std::vector<uint8_t> out(result_size_);
         check(blz_msm_combine_partials(h_, partials.data(), count, out.data(), out.size()));

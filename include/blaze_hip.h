@@ -97,7 +97,13 @@ int blz_msm_set_data_device(blz_msm* h, const void* d_points, size_t points_len,
                             uint64_t hbm_off);
 
 /* MSMClient::wait_result (msm_api.rs:222-238): block until the OLDEST task's result is valid.
- * The reference spins forever when nothing is armed; here that is BLZ_ERR_INVALID_PARAM. */
+ * The reference spins forever when nothing is armed; here that is BLZ_ERR_INVALID_PARAM.
+ * BOUNDED: the reference polls RESULT_VALID without a deadline; every host-side wait of this library (wait_result,
+ * the blocking copies of set_data / load_data_to_hbm / result, the exchange) polls against BLAZE_WAIT_TIMEOUT_MS
+ * (environment, milliseconds, default 120000).  On expiry the call returns BLZ_ERR_UNKNOWN (message: "... timed
+ * out after N ms"), the task stays queued and the handle turns RESET-ONLY: every call except blz_msm_reset /
+ * blz_msm_free / blz_msm_result (of results already collected) fails with BLZ_ERR_UNKNOWN until a reset succeeds;
+ * reset itself waits, bounded, for the handle's streams to drain.  Same for the NTT handle. */
 int blz_msm_wait_result(blz_msm* h);
 
 /* MSMClient::result (msm_api.rs:240-274): read result_point_size bytes + RESULT_LABEL, pop.
@@ -118,10 +124,12 @@ int blz_msm_get_data_from_hbm(blz_msm* h, uint8_t* out, size_t len, uint64_t add
 int blz_arena_release(int device_id);
 /* Cross-process arena (the card's HBM outlives the process that loaded it; GPU memory does not, so a holder
  * process keeps it): blz_arena_export writes one IPC handle per extent of this process to `registry_path`;
- * blz_arena_attach, in ANOTHER process, maps those extents at the same arena offsets, after which
- * hbm_point_addr / get_data_from_hbm / in-place load_data_to_hbm address the holder's bytes.  The extents live
- * as long as the holder does; an attached extent cannot be extended.  (HSA_ENABLE_IPC_MODE_LEGACY=0 where the
- * host driver only supports dmabuf IPC.) */
+ * blz_arena_attach, in ANOTHER process, maps those extents at the same arena offsets (all of them or, on any
+ * failure, none), after which hbm_point_addr / get_data_from_hbm address the holder's bytes.  Shared extents are
+ * READ-ONLY on both sides from the export on (every process keeps a private Montgomery copy of the points and
+ * tracks staleness locally): load_data_to_hbm into one returns WriteError, in the holder too; a load that only
+ * touches one starts a separate extent.  blz_arena_release un-shares.  The extents live as long as the holder
+ * does.  (HSA_ENABLE_IPC_MODE_LEGACY=0 where the host driver only supports dmabuf IPC.) */
 int blz_arena_export(int device_id, const char* registry_path);
 int blz_arena_attach(int device_id, const char* registry_path);
 
@@ -164,11 +172,20 @@ int blz_msm_combine_partials(blz_msm* h, const uint8_t* partials, size_t count, 
  *   rank 0:        blz_comm_unique_id(id); the host ships the 128 bytes to the other ranks (MPI, a file, a pipe ...)
  *   every rank:    blz_msm_comm_init(h, rank, nranks, id)                        -- collective
  *   per MSM:       blz_msm_result(h, partial ...); blz_msm_all_gather_combine(h, partial, out, cap) -- collective
- *   every rank:    blz_msm_comm_free(h)   (blz_msm_free does it too) */
+ *   every rank:    blz_msm_comm_free(h)   (blz_msm_free does it too)
+ * One process driving several devices from one thread (one handle per device, rank i = handles[i]):
+ *   once:          blz_msm_comm_init_all(handles, n)                             -- one RCCL group (ncclGroupStart/End)
+ *   per MSM:       blz_msm_all_gather_combine_all(handles, n, partials, out, cap) -- partials / out: n x result_size
+ * (blz_msm_comm_init / blz_msm_all_gather_combine are blocking rendezvous: called for several handles from ONE
+ * thread they would wait for each other - use the _all forms there.)
+ * Deadlines: the bring-up runs against BLAZE_COMM_TIMEOUT_MS (default 60000) and fails with BLZ_ERR_UNKNOWN when a
+ * peer never arrives; the exchange is a bounded wait like wait_result (BLAZE_WAIT_TIMEOUT_MS). */
 #define BLZ_COMM_ID_BYTES 128
 int blz_comm_unique_id(uint8_t out[BLZ_COMM_ID_BYTES]);
 int blz_msm_comm_init(blz_msm* h, int rank, int nranks, const uint8_t id[BLZ_COMM_ID_BYTES]);
 int blz_msm_all_gather_combine(blz_msm* h, const uint8_t* partial, uint8_t* out, size_t out_cap);
+int blz_msm_comm_init_all(blz_msm* const* handles, int n);
+int blz_msm_all_gather_combine_all(blz_msm* const* handles, int n, const uint8_t* partials, uint8_t* out, size_t out_cap);
 int blz_msm_comm_free(blz_msm* h);
 
 /* ------------------------------------------------------------------ NTT (src/ingo_ntt/ntt_api.rs) */
@@ -225,6 +242,18 @@ int blz_synth_scalars_at(int device_id, int curve, void* d_out, uint64_t n, uint
 int blz_synth_points(int device_id, int curve, void* d_out, uint64_t n, int pf, uint64_t start);
 /* NTT input: n x 32 B uniform-ish in [0, r) of BLS12-381 Fr */
 int blz_synth_field_elements(int device_id, void* d_out, uint64_t n, uint64_t seed);
+
+/* The issue rate of v_mad_u64_u32 - the instruction the MSM / NTT kernels are bound by - measured on this device at
+ * its clocks of this moment: a ~target_ms kernel of independent multiply-add chains on every SIMD.  out[0] lane-ops
+ * per second, [1] kernel ms, [2] the device's nominal clock in MHz (hipDeviceAttributeClockRate), [3] ops executed.
+ * Measurement aid of bench.py (roofline.integer_issue.peak); no reference counterpart. */
+int blz_calib_mad_rate(int device_id, uint32_t target_ms, double out[4]);
+
+/* Test hooks for the bounded waits: enqueue, on the handle's main stream, a one-lane kernel that spins until
+ * blz_test_stall_release(token) or until max_ms (1..30000) have passed on the device clock, whichever comes first. */
+int blz_test_msm_stall(blz_msm* h, uint32_t max_ms, void** token);
+int blz_test_ntt_stall(blz_ntt* h, uint32_t max_ms, void** token);
+int blz_test_stall_release(void* token);
 
 /* ------------------------------------------------------------------ test hooks (element-wise kernels)
  * Run the device field / group primitives on arrays so tests can compare them one by one with the

@@ -53,6 +53,8 @@ extern "C" {
     pub fn blz_comm_unique_id(out: *mut u8) -> c_int;
     pub fn blz_msm_comm_init(h: *mut BlzMsm, rank: c_int, nranks: c_int, id: *const u8) -> c_int;
     pub fn blz_msm_all_gather_combine(h: *mut BlzMsm, partial: *const u8, out: *mut u8, out_cap: usize) -> c_int;
+    pub fn blz_msm_comm_init_all(handles: *const *mut BlzMsm, n: c_int) -> c_int;
+    pub fn blz_msm_all_gather_combine_all(handles: *const *mut BlzMsm, n: c_int, partials: *const u8, out: *mut u8, out_cap: usize) -> c_int;
     pub fn blz_msm_comm_free(h: *mut BlzMsm) -> c_int;
     // device arena
     pub fn blz_arena_release(device_id: c_int) -> c_int;

@@ -196,6 +196,29 @@ impl MSMClient {
         check(unsafe { blz_msm_all_gather_combine(self.h, partial.as_ptr(), out.as_mut_ptr(), out.len()) })?;
         Ok(out)
     }
+    /// One process, one thread, one client per device: bring all communicator ranks up as one RCCL group
+    /// (rank i = clients[i]); the per-rank `comm_init` is a blocking rendezvous and cannot be called in sequence
+    /// from a single thread.
+    pub fn comm_init_all(clients: &[&MSMClient]) -> Result<()> {
+        let hs: Vec<*mut BlzMsm> = clients.iter().map(|c| c.h).collect();
+        check(unsafe { blz_msm_comm_init_all(hs.as_ptr(), hs.len() as c_int) })
+    }
+    /// The exchange for the clients of `comm_init_all`: `partials[i]` is client i's result; returns every
+    /// client's full sum (identical bytes).
+    pub fn all_gather_combine_all(clients: &[&MSMClient], partials: &[Vec<u8>]) -> Result<Vec<Vec<u8>>> {
+        if clients.is_empty() || partials.len() != clients.len() {
+            return Err(DriverClientError::InvalidPrimitiveParam);
+        }
+        let rs = clients[0].msm_cfg.result_point_size;
+        if partials.iter().any(|p| p.len() != rs) {
+            return Err(DriverClientError::InvalidPrimitiveParam);
+        }
+        let hs: Vec<*mut BlzMsm> = clients.iter().map(|c| c.h).collect();
+        let flat: Vec<u8> = partials.iter().flat_map(|p| p.iter().copied()).collect();
+        let mut out = vec![0u8; rs * clients.len()];
+        check(unsafe { blz_msm_all_gather_combine_all(hs.as_ptr(), hs.len() as c_int, flat.as_ptr(), out.as_mut_ptr(), out.len()) })?;
+        Ok(out.chunks(rs).map(|c| c.to_vec()).collect())
+    }
     pub fn combine_partials(&self, partials: &[u8], count: usize) -> Result<Vec<u8>> {
         if partials.len() != count * self.msm_cfg.result_point_size {
             return Err(DriverClientError::InvalidPrimitiveParam);

@@ -180,6 +180,69 @@ def test_native_exchange_single_rank(gpu, orc):
         cl.close()
 
 
+@pytest.mark.gpu
+def test_single_process_group_exchange(gpu, orc):
+    """blz_msm_comm_init_all / blz_msm_all_gather_combine_all: one host thread, one handle per device, every rank of
+    the communicator brought up inside one ncclGroupStart/End (the per-rank calls are blocking rendezvous and would
+    wait for each other when issued in sequence from one thread).  Runs with as many ranks as the box has GPUs
+    (1 on the single-GPU box: the group path with n = 1)."""
+    import blaze_amd
+    from blaze_amd.ingo_msm import MSMClient
+    from gpu_util import msm_client, run_msm
+
+    ndev = min(8, blaze_amd.lib().blz_device_count())
+    curve, n = "BLS381", 900
+    pts, sc, exp = orc.input_generator(curve, n, 1, 123)
+    pb = orc.point_bytes(curve)
+    from blaze_amd.multi_gpu import shard_range
+
+    clients = [msm_client(curve, 1, device=d) for d in range(ndev)]
+    partials = []
+    for r, cl in enumerate(clients):
+        lo, hi = shard_range(n, r, ndev)
+        partials.append(run_msm(cl, bytes(pts[lo * pb: hi * pb]), bytes(sc[lo * 32: hi * 32]), hi - lo))
+    MSMClient.comm_init_all(clients)
+    for _ in range(2):                                   # the communicators are reusable
+        outs = MSMClient.all_gather_combine_all(clients, partials)
+        assert all(o == exp for o in outs), [o.hex()[:16] for o in outs]
+    with pytest.raises(Exception):
+        MSMClient.comm_init_all(clients)                 # one communicator per handle
+    for cl in clients:
+        cl.comm_free()
+        cl.close()
+
+
+@pytest.mark.gpu
+def test_comm_init_has_a_deadline(gpu, monkeypatch):
+    """A rank that never arrives: ncclCommInitRank(rank 0 of 2) with no peer must come back with Unknown after
+    BLAZE_COMM_TIMEOUT_MS instead of blocking for ever.  Runs in a child process, because the
+    abandoned bring-up thread stays parked inside RCCL until the process exits."""
+    import subprocess
+    import textwrap
+
+    code = textwrap.dedent("""
+        import sys, time
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        from gpu_util import msm_client
+        from blaze_amd import DriverClientError
+        cl = msm_client("BLS381", 1)
+        t0 = time.perf_counter()
+        try:
+            cl.comm_init(0, 2, cl.comm_unique_id())
+        except DriverClientError as e:
+            dt = time.perf_counter() - t0
+            print("RESULT", e.variant, round(dt, 2), "did not complete within" in str(e), flush=True)
+            import os; os._exit(0)
+        print("RESULT no-error", flush=True); import os; os._exit(1)
+    """) % (ROOT, os.path.join(ROOT, "tests"))
+    env = dict(os.environ, BLAZE_COMM_TIMEOUT_MS="3000")
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    line = [l for l in p.stdout.splitlines() if l.startswith("RESULT")]
+    assert p.returncode == 0 and line, (p.stdout[-500:], p.stderr[-1500:])
+    _, variant, dt, msg_ok = line[-1].split()
+    assert variant == "Unknown" and msg_ok == "True" and 2.5 < float(dt) < 30.0, line
+
+
 def test_shard_range_partitions_exactly():
     from blaze_amd.multi_gpu import shard_range
 

@@ -381,3 +381,37 @@ def test_other_fields_large_and_limits(gpu, orc):
     with pytest.raises(DriverClientError) as ei:
         NTTClient(NTT.Ntt, DriverClient(0), log_size=28, field="BN254")   # > 27: shape limit of the 3-pass plan
     assert ei.value.variant == "InvalidPrimitiveParam"
+
+
+def test_wait_result_is_bounded(gpu, orc, monkeypatch):
+    """The reference polls the NTT status register for ever (ntt_api.rs:89-108); here wait_result has a deadline
+    (BLAZE_WAIT_TIMEOUT_MS): a stalled transform gives Unknown in bounded time, the handle is reset-only until the
+    stall ends, and the transform that was queued behind it still produced the right output."""
+    import ctypes as C
+    import time
+
+    logn = 12
+    rng = random.Random(5)
+    data = b"".join(rng.randrange(pyref.CURVES["BLS381"]["r"]).to_bytes(32, "little") for _ in range(1 << logn))
+    nc = NTTClient(NTT.Ntt, DriverClient(0), log_size=logn)
+    nc.set_data(NTTInput(0, data))
+    monkeypatch.setenv("BLAZE_WAIT_TIMEOUT_MS", "400")
+    tok = C.c_void_p()
+    blaze_amd._lib.check(blaze_amd.lib().blz_test_ntt_stall(nc._h, 20000, C.byref(tok)))
+    nc.initialize(NttInit())
+    nc.start_process(0)
+    t0 = time.perf_counter()
+    with pytest.raises(DriverClientError) as ei:
+        nc.wait_result()
+    dt = time.perf_counter() - t0
+    assert ei.value.variant == "Unknown" and "timed out" in str(ei.value) and 0.3 < dt < 5.0, (str(ei.value), dt)
+    with pytest.raises(DriverClientError) as ei:
+        nc.start_process(1)
+    assert "wedged" in str(ei.value)
+    with pytest.raises(DriverClientError):
+        nc.reset()
+    blaze_amd._lib.check(blaze_amd.lib().blz_test_stall_release(tok))
+    monkeypatch.setenv("BLAZE_WAIT_TIMEOUT_MS", "60000")
+    nc.reset()
+    assert bytes(nc.result(0)) == bytes(orc.ntt("BLS381", data, logn))   # the queued transform ran once the stall ended
+    nc.close()
