@@ -126,6 +126,13 @@ BLZ_DEV void store_xyzz(uint32_t* base, size_t idx, const XYZZ<F>& a) {
 #ifndef BLZ_ACC_RR_WAVES
 #define BLZ_ACC_RR_WAVES 2
 #endif
+// point index of an entry.  -DBLZ_GATHER_MASK=0x... (A/B builds only: WRONG RESULTS, timing experiments) confines every
+// gather to the first mask + 1 points of the table, which separates the kernel's arithmetic from its memory side.
+#ifdef BLZ_GATHER_MASK
+#define BLZ_PT_IDX(e) ((e) & 0x7fffffffu & (uint32_t)(BLZ_GATHER_MASK))
+#else
+#define BLZ_PT_IDX(e) ((e) & 0x7fffffffu)
+#endif
 template <class F>
 __global__ __launch_bounds__(128, USE_RR<F> ? BLZ_ACC_RR_WAVES : 3) void k_accumulate(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ entries,
                                                     const uint32_t* __restrict__ off, const uint32_t* __restrict__ unit_off,
@@ -151,7 +158,7 @@ __global__ __launch_bounds__(128, USE_RR<F> ? BLZ_ACC_RR_WAVES : 3) void k_accum
         uint32_t e = entries[start];
 #if BLZ_ACC_RR_WAVES == 2
         AffineRR<Q> nxt;
-        load_affine_rr<F>(nxt, pts, e & 0x7fffffffu);
+        load_affine_rr<F>(nxt, pts, BLZ_PT_IDX(e));
         uint32_t j = start;
 #ifndef BLZ_ACC_NO_AADD
         if (end - start >= 2) {
@@ -161,10 +168,10 @@ __global__ __launch_bounds__(128, USE_RR<F> ? BLZ_ACC_RR_WAVES : 3) void k_accum
             const bool neg0 = (e & 0x80000000u) != 0;
             const uint32_t e1 = entries[start + 1];
             AffineRR<Q> p1;
-            load_affine_rr<F>(p1, pts, e1 & 0x7fffffffu);
+            load_affine_rr<F>(p1, pts, BLZ_PT_IDX(e1));
             if (start + 2 < end) {
                 e = entries[start + 2];
-                load_affine_rr<F>(nxt, pts, e & 0x7fffffffu);
+                load_affine_rr<F>(nxt, pts, BLZ_PT_IDX(e));
             }
             ptrr_aadd<Q, 1>(acc, p0, neg0, p1, (e1 & 0x80000000u) != 0);
             j = start + 2;
@@ -175,14 +182,14 @@ __global__ __launch_bounds__(128, USE_RR<F> ? BLZ_ACC_RR_WAVES : 3) void k_accum
             const bool neg = (e & 0x80000000u) != 0;
             if (j + 1 < end) {
                 e = entries[j + 1];
-                load_affine_rr<F>(nxt, pts, e & 0x7fffffffu);
+                load_affine_rr<F>(nxt, pts, BLZ_PT_IDX(e));
             }
             ptrr_madd<Q, 1>(acc, cur, neg);
         }
 #else
         for (uint32_t j = start; j < end; ++j) {
             AffineRR<Q> cur;
-            load_affine_rr<F>(cur, pts, e & 0x7fffffffu);
+            load_affine_rr<F>(cur, pts, BLZ_PT_IDX(e));
             const bool neg = (e & 0x80000000u) != 0;
             if (j + 1 < end) e = entries[j + 1];
             ptrr_madd<Q, 1>(acc, cur, neg);
@@ -198,7 +205,7 @@ __global__ __launch_bounds__(128, USE_RR<F> ? BLZ_ACC_RR_WAVES : 3) void k_accum
         uint32_t e = entries[start];
         for (uint32_t j = start; j < end; ++j) {
             Affine<F> cur;
-            load_affine(cur, pts, e & 0x7fffffffu);
+            load_affine(cur, pts, BLZ_PT_IDX(e));
             const uint32_t ecur = e;
             if (j + 1 < end) e = entries[j + 1];
             if (ecur & 0x80000000u) fp_neg(cur.y, cur.y);
