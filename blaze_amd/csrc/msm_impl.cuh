@@ -21,6 +21,15 @@ constexpr int MONT_STRIDE = 2 * F::N > 16 ? 32 : 2 * F::N;  // dwords per Montgo
 // it: their Montgomery point copy holds 2 x NL limbs of B bits (x R_rr, y R_rr: 112 of the line's 128 bytes) and
 // k_accumulate converts a unit's sum to the 32-bit form once, when it stores it.
 
+// Does the reduced-radix point (2 NL limb dwords) fit the Montgomery stride?  BLS: 2 x 14 dwords in a 32-dword line.
+// BN254: 2 x 9 = 18 dwords do not fit its 64-byte half line, so the copy holds x Rrr and y Rrr (each < 2m < 2^255) as
+// 2 x 8 packed 32-bit words and a gather unpacks them into 29-bit limbs (18 alignbit / and pairs per point).
+template <class F>
+constexpr bool rr_point_packed() {
+    if constexpr (USE_RR<F>) return 2 * F::RR::NL > MONT_STRIDE<F>;
+    else return false;
+}
+
 template <class F>
 __global__ __launch_bounds__(256) void k_points_to_mont(const uint32_t* __restrict__ raw, uint32_t* __restrict__ mont,
                                                         uint32_t npts) {
@@ -31,12 +40,20 @@ __global__ __launch_bounds__(256) void k_points_to_mont(const uint32_t* __restri
     fp_load(y, raw + (size_t)p * 2 * F::N + F::N);
     if constexpr (USE_RR<F>) {
         using Q = typename F::RR;
-        static_assert(2 * Q::NL <= MONT_STRIDE<F> && Q::NL % 2 == 0, "reduced-radix point does not fit its line");
         Frr<Q, 1, 2> xr, yr;
         rr_to_mont_from_words<Q>(xr, x.v);
         rr_to_mont_from_words<Q>(yr, y.v);
-        rr_store(mont + (size_t)p * MONT_STRIDE<F>, xr);
-        rr_store(mont + (size_t)p * MONT_STRIDE<F> + Q::NL, yr);
+        if constexpr (rr_point_packed<F>()) {
+            static_assert(2 * Q::N32 <= MONT_STRIDE<F>, "packed reduced-radix point does not fit its stride");
+            rr_to_words<Q>(x.v, xr);
+            rr_to_words<Q>(y.v, yr);
+            fp_store(mont + (size_t)p * MONT_STRIDE<F>, x);
+            fp_store(mont + (size_t)p * MONT_STRIDE<F> + F::N, y);
+        } else {
+            static_assert(2 * Q::NL <= MONT_STRIDE<F> && Q::NL % 2 == 0, "reduced-radix point does not fit its line");
+            rr_store(mont + (size_t)p * MONT_STRIDE<F>, xr);
+            rr_store(mont + (size_t)p * MONT_STRIDE<F> + Q::NL, yr);
+        }
     } else {
         fp_to_mont(x, x);
         fp_to_mont(y, y);
@@ -47,24 +64,42 @@ __global__ __launch_bounds__(256) void k_points_to_mont(const uint32_t* __restri
 template <class F>
 BLZ_DEV void load_affine_rr(AffineRR<typename F::RR>& a, const uint32_t* pts, uint32_t idx) {
     using Q = typename F::RR;
-    // 2 NL dwords, 16-byte aligned: x and y share a vector load in the middle when NL is not a multiple of 4
     const uint4* q4 = reinterpret_cast<const uint4*>(pts + (size_t)idx * MONT_STRIDE<F>);
-    uint32_t w[2 * Q::NL];
-    static_assert((2 * Q::NL) % 4 == 0, "point not a whole number of 16-byte pieces");
+    if constexpr (rr_point_packed<F>()) {
+        // 2 x N32 packed words (one 64-byte half line for BN254), unpacked into limbs
+        uint32_t wx[Q::N32], wy[Q::N32];
+        static_assert(Q::N32 % 4 == 0, "packed coordinate not a whole number of 16-byte pieces");
 #pragma unroll
-    for (int i = 0; i < 2 * Q::NL / 4; ++i) {
-        uint4 v = q4[i];
-        w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+        for (int i = 0; i < Q::N32 / 4; ++i) {
+            uint4 v = q4[i];
+            wx[4 * i] = v.x; wx[4 * i + 1] = v.y; wx[4 * i + 2] = v.z; wx[4 * i + 3] = v.w;
+        }
+#pragma unroll
+        for (int i = 0; i < Q::N32 / 4; ++i) {
+            uint4 v = q4[Q::N32 / 4 + i];
+            wy[4 * i] = v.x; wy[4 * i + 1] = v.y; wy[4 * i + 2] = v.z; wy[4 * i + 3] = v.w;
+        }
+        rr_from_words<Q>(a.x, wx);
+        rr_from_words<Q>(a.y, wy);
+    } else {
+        // 2 NL dwords, 16-byte aligned: x and y share a vector load in the middle when NL is not a multiple of 4
+        uint32_t w[2 * Q::NL];
+        static_assert((2 * Q::NL) % 4 == 0, "point not a whole number of 16-byte pieces");
+#pragma unroll
+        for (int i = 0; i < 2 * Q::NL / 4; ++i) {
+            uint4 v = q4[i];
+            w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+        }
+#pragma unroll
+        for (int i = 0; i < Q::NL; ++i) { a.x.v[i] = w[i]; a.y.v[i] = w[Q::NL + i]; }
     }
-#pragma unroll
-    for (int i = 0; i < Q::NL; ++i) { a.x.v[i] = w[i]; a.y.v[i] = w[Q::NL + i]; }
 }
 
 // dwords per unit / bucket sum in `partial`: fields with a reduced-radix twin keep the sums in it (4 x 14 limbs),
 // so neither the accumulation nor the first bucket-reduce level converts anything
 template <class F>
 constexpr int partial_dwords() {
-    if constexpr (USE_RR<F>) return 4 * F::RR::NL;
+    if constexpr (USE_RR<F>) return ptrr_dwords<typename F::RR>();
     else return 4 * F::N;
 }
 // (for the few kernels that still work on 32-bit limbs: k_combine_units)
@@ -157,6 +192,11 @@ __global__ __launch_bounds__(128, USE_RR<F> ? BLZ_ACC_RR_WAVES : 3) void k_accum
         ptrr_set_inf(acc);
         uint32_t e = entries[start];
 #if BLZ_ACC_RR_WAVES == 2
+        // Two loads run ahead of the arithmetic: the POINT of entry j + 1 (28 / 16 VGPRs) and the INDEX of entry j + 2.
+        // With the index only one step ahead, every iteration stalled once for a dependent pair of loads (index, then
+        // the point it names) before its addition could start; two steps ahead the point's address is already in a
+        // register when its load is issued.
+        uint32_t en = start + 1 < end ? entries[start + 1] : 0u;   // entry after `e`
         AffineRR<Q> nxt;
         load_affine_rr<F>(nxt, pts, BLZ_PT_IDX(e));
         uint32_t j = start;
@@ -166,12 +206,13 @@ __global__ __launch_bounds__(128, USE_RR<F> ? BLZ_ACC_RR_WAVES : 3) void k_accum
             // units are ordered by length, so the lanes of a wave take this branch together
             const AffineRR<Q> p0 = nxt;
             const bool neg0 = (e & 0x80000000u) != 0;
-            const uint32_t e1 = entries[start + 1];
+            const uint32_t e1 = en;
             AffineRR<Q> p1;
             load_affine_rr<F>(p1, pts, BLZ_PT_IDX(e1));
             if (start + 2 < end) {
                 e = entries[start + 2];
                 load_affine_rr<F>(nxt, pts, BLZ_PT_IDX(e));
+                en = start + 3 < end ? entries[start + 3] : 0u;
             }
             ptrr_aadd<Q, 1>(acc, p0, neg0, p1, (e1 & 0x80000000u) != 0);
             j = start + 2;
@@ -181,8 +222,9 @@ __global__ __launch_bounds__(128, USE_RR<F> ? BLZ_ACC_RR_WAVES : 3) void k_accum
             const AffineRR<Q> cur = nxt;
             const bool neg = (e & 0x80000000u) != 0;
             if (j + 1 < end) {
-                e = entries[j + 1];
+                e = en;
                 load_affine_rr<F>(nxt, pts, BLZ_PT_IDX(e));
+                if (j + 2 < end) en = entries[j + 2];
             }
             ptrr_madd<Q, 1>(acc, cur, neg);
         }

@@ -123,6 +123,26 @@ __global__ __launch_bounds__(64) void k_test_ec(int op, const uint32_t* p, const
                 pt_set_inf(acc);
             }
             break;
+        case 8: case 9:   // the full XYZZ add / doubling on the reduced radix (first bucket-reduce level): 8 = P + Q, 9 = 2 P
+            if constexpr (USE_RR<F>) {
+                using QQ = typename F::RR;
+                if (op == 8 && !(fl & 2)) {  // de-normalise q too
+                    Fp<F> z, z2, z3;
+                    z = Q.x; fp_add(z, z, P.y);
+                    if (fp_is_zero(z)) fp_one(z);
+                    fp_sqr(z2, z); fp_mul(z3, z2, z);
+                    fp_mul(qq.x, qq.x, z2); fp_mul(qq.y, qq.y, z3); qq.zz = z2; qq.zzz = z3;
+                }
+                XYZZRR<QQ> a, b;
+                ptrr_from_xyzz32<F>(a, acc);
+                ptrr_from_xyzz32<F>(b, qq);
+                if (op == 8) ptrr_add<QQ, 2>(a, b);
+                else a = ptrr_dbl_val<QQ, 2>(a);
+                ptrr_to_xyzz32<F>(acc, a);
+            } else {
+                pt_set_inf(acc);
+            }
+            break;
         case 6: case 7:   // both operands affine (the first addition of a run, ptrr_aadd): 6 = P + Q, 7 = Q - P
             if constexpr (USE_RR<F>) {
                 using QQ = typename F::RR;

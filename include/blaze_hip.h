@@ -259,12 +259,12 @@ int blz_test_stall_release(void* token);
  * Run the device field / group primitives on arrays so tests can compare them one by one with the
  * CPU oracle.  Host pointers; canonical little-endian encodings.
  *   fq ops (field = 0: Fq, 1: Fr): 0 mul, 1 add, 2 sub, 3 inverse(a), 4 sqr(a), 5/6 a b +- (a + b)(a - b);
- *     reduced-radix twin of the BLS base fields and of every scalar field (all-zero output for BN254 Fq):
+ *     reduced-radix twin (every base field and every scalar field has one):
  *     10 mul, 11 sqr, 12 a b + (a + b)(a - b), 13 (a - 3b) b, 14 [a == b], 15 a (a - 3b) through the
  *     product-free reduction of a lazy value
  *   ec ops: 0 P+Q (mixed, P as accumulator), 1 2P, 2 P+Q (full XYZZ add), 3 P-Q (mixed, negated),
- *     4 / 5 P+Q / P-Q through the reduced-radix mixed add (BLS curves); 6 / 7 P+Q / Q-P with both operands
- *     affine (the first addition of a bucket run)
+ *     4 / 5 P+Q / P-Q through the reduced-radix mixed add; 6 / 7 P+Q / Q-P with both operands affine (the first
+ *     addition of a bucket run); 8 P+Q through the reduced-radix full add, 9 2P through its doubling (bucket reduce)
  *     points x||y; inf_flags[i] bit0: P is infinity, bit1: Q is infinity; out_inf[i]=1 if result inf */
 int blz_test_field_op(int device_id, int curve, int field, int op, const uint8_t* a, const uint8_t* b,
                       uint8_t* out, size_t n);

@@ -34,7 +34,7 @@ def test_field_ops(gpu, curve, field):
     if field == 0 or curve != "BLS381":   # lazy-range fields have the fused sum of two products (ec.cuh's Y3)
         ops[5] = lambda x, y: (x * y + (x + y) * (x - y)) % m
         ops[6] = lambda x, y: (x * y - (x + y) * (x - y)) % m
-    if field == 1 or curve != "BN254":   # reduced-radix twins: the BLS base fields (14 x 28 bits), every scalar field (9 x 29)
+    if True:   # reduced-radix twins: the BLS base fields (14 x 28 bits); BN254's base field and every scalar field (9 x 29)
         ops[10] = lambda x, y: x * y % m
         ops[11] = lambda x, y: x * x % m
         ops[12] = lambda x, y: (x * y + (x + y) * (x - y)) % m
@@ -81,13 +81,15 @@ def test_ec_ops(gpu, curve):
             return pyref.add(curve, p, q)
         if op == 1:
             return pyref.add(curve, p, p)
-        if op in (4, 6):
+        if op in (4, 6, 8):
             return pyref.add(curve, p, q)
+        if op == 9:
+            return pyref.add(curve, p, p)
         if op == 7:
             return pyref.add(curve, q, None if p is None else pyref.neg(curve, p))
         return pyref.add(curve, p, pyref.neg(curve, q))
 
-    for op in (0, 1, 2, 3) + ((4, 5, 6, 7) if curve != "BN254" else ()):
+    for op in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9):
         out = C.create_string_buffer(n * sz)
         oinf = C.create_string_buffer(n)
         rc = gpu.blz_test_ec_op(0, cid, op, pb, qb, flb, C.cast(out, C.c_void_p), C.cast(oinf, C.c_void_p), n)

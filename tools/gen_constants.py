@@ -99,17 +99,17 @@ def rr_struct(name, m, n32, B, NL):
 
 
 # reduced-radix twins: (field, B, NL)
-# (BN254's 254-bit field would take 9 x 29 bits, whose 64-bit column sums leave no room for lazy operands,
-# or 10 x 28 bits, which is no cheaper than 8 x 32 with carries: it stays on field.cuh)
-# BN254's base field stays on field.cuh: measured on 10 x 27 bits its bucket accumulation takes the same 60 ms at 2^26
-# (81 ms at pf = 8) as on 8 x 32 - with 64-byte points the kernel waits for its 805 M random gathers, not for the multiplier.
-# The scalar fields (NTT): 9 x 29 bits = 261 bits: 162 multiply-adds per product (10 x 27 bits: 200).  The price is
-# a tight lazy range - 3 spare bits per limb (limbs < 8 x 2^29) and 6-8 bits of value head-room (values < 64 m for
-# BLS12-381) - so the 8-point DFT of ntt_rr.cuh carry-propagates the three sums it subtracts from, multiplies every
-# output (w^0 = one included: a product is what brings a value back under 2m), and its tables are canonical.  All of
-# it is checked at compile time by the bounds in the Frr type.  (Round 2 first ran 10 x 27, whose butterflies need no
-# normalisation at all: 20.1 ms at 2^27; 9 x 29: see DESIGN.md section 4.)
-RR = {"Fq_BLS377": (28, 14), "Fq_BLS381": (28, 14), "Fr_BLS377": (29, 9), "Fr_BLS381": (29, 9), "Fr_BN254": (29, 9)}
+# BLS base fields: 14 x 28 bits (392 product multiply-adds, 4 spare bits per limb, 11+ bits of value head-room).
+# Every 254 / 255-bit field - the three scalar fields (2^27 NTT) and, from round 3 on, BN254's base field (bucket
+# accumulation) - takes 9 x 29 bits = 261 bits: 162 multiply-adds per product (10 x 27 bits: 200; 8 x 32 bits with a
+# carry word: 128 pairs = 256 instructions).  The price is a tight lazy range - 3 spare bits per limb (limbs < 8 x 2^29),
+# 6-8 bits of value head-room (values < 64 m ... 128 m) and 64-bit column sums that admit only sum(Fa Fb) <= 6 - so
+# lazy operands are carry-propagated before a product and accumulator coordinates are kept below 2m with the one-digit
+# quotient reduction (rr_reduce2m); all of it is checked at compile time by the bounds in the Frr type.
+# History: round 2 tried BN254's base field on 10 x 27 bits and measured the same 60 ms for its accumulation at 2^26
+# as on 8 x 32, and blamed the gathers; round 3 measured the gathers out (profiles/r03_bn254_gather_split.txt: 5 %) -
+# 200 multiply-adds simply cost what 128 multiply-add / add-carry pairs cost.
+RR = {"Fq_BLS377": (28, 14), "Fq_BLS381": (28, 14), "Fq_BN254": (29, 9), "Fr_BLS377": (29, 9), "Fr_BLS381": (29, 9), "Fr_BN254": (29, 9)}
 
 
 def main():
