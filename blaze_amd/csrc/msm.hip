@@ -126,6 +126,11 @@ __global__ __launch_bounds__(256) void k_zero(uint4* __restrict__ p, size_t n16)
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) p[i] = z;
 }
 
+// p[i] = i: the "every bucket has exactly one sum, at its own index" unit_off of slice-major tasks
+__global__ __launch_bounds__(256) void k_iota(uint32_t* __restrict__ p, uint64_t n) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) p[i] = (uint32_t)i;
+}
+
 // ------------------------------------------------------------------------------------------------
 // exclusive scan of (count, units(count)) packed in one u64: low = entries, high = units
 // ------------------------------------------------------------------------------------------------
@@ -360,11 +365,11 @@ int msm_env_int(const char* name, int dflt) {
     return s && *s ? atoi(s) : dflt;
 }
 
-static const MsmCurveOps* ops_for(int curve) {
+static const MsmCurveOps* ops_for(int curve, int repr = 0) {
     switch (curve) {
         case BLZ_BLS377: return &msm_ops_bls377();
         case BLZ_BLS381: return &msm_ops_bls381();
-        case BLZ_BN254: return &msm_ops_bn254();
+        case BLZ_BN254: return repr ? &msm_ops_bn254_w32() : &msm_ops_bn254();
     }
     return nullptr;
 }
@@ -389,16 +394,24 @@ int launch_fill_units(MsmEngine& E, uint32_t U /* upper bound of the unit count 
     return BLZ_OK;
 }
 
-int MsmEngine::init(int device_id, int curve_id) {
+int MsmEngine::init(int device_id, int curve_id, int precompute_factor) {
     device = device_id;
     curve = curve_id;
-    if (!ops_for(curve)) return fail(BLZ_ERR_INVALID_PARAM, "unknown curve %d", curve);
+    repr = 0;
+    if (curve == BLZ_BN254) {
+        // BLAZE_BN254_REPR = rr | w32 overrides the choice by precompute factor (A/B runs)
+        const char* e = getenv("BLAZE_BN254_REPR");
+        if (e && *e) repr = strcmp(e, "w32") == 0 ? 1 : 0;
+        else repr = precompute_factor > 1 ? 1 : 0;
+    }
+    if (!ops_for(curve, repr)) return fail(BLZ_ERR_INVALID_PARAM, "unknown curve %d", curve);
     BLZ_TRY(use_device(device));
     BLZ_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), BLZ_ERR_UNKNOWN);
     BLZ_HIP(hipStreamCreateWithFlags(&tail_stream, hipStreamNonBlocking), BLZ_ERR_UNKNOWN);
     BLZ_HIP(hipStreamCreateWithFlags(&aux_stream, hipStreamNonBlocking), BLZ_ERR_UNKNOWN);
     for (auto& S : slots) {
         for (auto& e : S.ev) BLZ_HIP(hipEventCreate(&e), BLZ_ERR_UNKNOWN);
+        for (auto& e : S.slice_ev) BLZ_HIP(hipEventCreate(&e), BLZ_ERR_UNKNOWN);
         BLZ_HIP(hipEventCreateWithFlags(&S.ev_l0, hipEventDisableTiming), BLZ_ERR_UNKNOWN);
         BLZ_HIP(hipEventCreateWithFlags(&S.ev_done, hipEventDisableTiming), BLZ_ERR_UNKNOWN);
         BLZ_HIP(hipHostMalloc((void**)&S.result_h, 256), BLZ_ERR_UNKNOWN);
@@ -421,11 +434,13 @@ bool MsmEngine::destroy() {
         return false;
     }
     for (DevBuf* b : {&count, &off, &unit_off, &unit_bucket, &unit_order, &lenhist, &coarse, &inter, &slice_map, &entries,
-                      &partial, &blocksums, &stats, &result})
+                      &partial, &blocksums, &stats, &result, &bucket_sums, &bucket_ident})
         b->release();
     for (auto& S : slots) {
         for (DevBuf* b : {&S.lvlA[0], &S.lvlA[1], &S.lvlC[0], &S.lvlC[1]}) b->release();
         for (auto& e : S.ev)
+            if (e) (void)hipEventDestroy(e);
+        for (auto& e : S.slice_ev)
             if (e) (void)hipEventDestroy(e);
         if (S.ev_l0) (void)hipEventDestroy(S.ev_l0);
         if (S.ev_done) (void)hipEventDestroy(S.ev_done);
@@ -460,7 +475,7 @@ int MsmEngine::sync_all() {
 
 int MsmEngine::points_to_mont(const void* d_raw, void* d_mont, uint32_t npts) {
     BLZ_TRY(use_device(device));
-    return ops_for(curve)->points_to_mont(*this, d_raw, d_mont, npts);
+    return ops_for(curve, repr)->points_to_mont(*this, d_raw, d_mont, npts);
 }
 
 static const int kScalarFieldBits[3] = {253, 255, 254};  // bit length of r (BLS12-377 / 381 / BN254)
@@ -472,7 +487,7 @@ MsmPlan MsmEngine::plan_for(uint32_t npts, int sbits) const {
 
 int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int sbits, int* slot_out) {
     BLZ_TRY(use_device(device));
-    const MsmCurveOps* ops = ops_for(curve);
+    const MsmCurveOps* ops = ops_for(curve, repr);
     MsmEngine& E = *this;
     hipStream_t st = stream;
     // slots are handed out round-robin, so results complete in submission order
@@ -501,7 +516,28 @@ int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int 
     if (P.L > (uint32_t)MAX_L) P.L = MAX_L;
     last_plan = S.plan = P;
     const uint64_t G = P.G;
-    const uint64_t max_entries = (uint64_t)npts * P.W;
+    BLZ_LOG(2, "msm plan: npts=%u sbits=%d c=%d W=%d Bw=%u G=%llu L=%u", npts, sbits, P.c, P.W, P.Bw,
+            (unsigned long long)G, P.L);
+
+    // Slice-major accumulation (BLAZE_MSM_SLICES = n; off by default).  Built to test VERDICT r02's proposal for point
+    // tables beyond the reach of the address-translation caches: the table is cut into n slices, sort + accumulation run
+    // slice by slice (every gather of a launch inside one slice), a bucket's sums are added up across slices
+    // (k_merge_buckets) and the reduce sees one sum per bucket.  Measured on config 3 (2^26 BN254 elements x 8 bases =
+    // 32 GiB, profiles/r03_bn254_slices.txt): the accumulation kernels do get faster (85 -> 75 ms with 16 slices of
+    // 2 GiB on the reduced radix) but the per-slice sorts, the short units the slices need and their combine passes
+    // cost more than that; the best total (8 slices, L = 128: 98.5 ms) stays behind the plain 32-bit-limb path (95.3 ms).
+    int nslices = 1;
+    {
+        const uint64_t table = (uint64_t)npts * mont_point_bytes(curve);
+        const int forced = msm_env_int("BLAZE_MSM_SLICES", 0);
+        if (forced > 0) nslices = forced;
+        (void)table;
+        if (nslices > MSM_MAX_SLICES) nslices = MSM_MAX_SLICES;
+        if ((uint64_t)nslices > npts) nslices = 1;
+    }
+    S.slices = nslices;
+    const uint32_t pts_per_slice = (uint32_t)(((uint64_t)npts + nslices - 1) / nslices + 15) & ~15u;   // keeps scalar slices 16-byte aligned
+    const uint64_t max_entries = (uint64_t)(nslices > 1 ? pts_per_slice : npts) * P.W;
     const uint64_t max_units = G + max_entries / P.L + 1;
     if (max_units >= (1ull << 32)) return fail(BLZ_ERR_INVALID_PARAM, "unit bound %llu exceeds 32 bits", (unsigned long long)max_units);
     const uint32_t nscan = (uint32_t)((G + 1 + SCAN_TILE - 1) / SCAN_TILE);
@@ -510,32 +546,50 @@ int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int 
     BLZ_TRY(unit_off.reserve((G + 2) * 4));
     BLZ_TRY(blocksums.reserve((size_t)nscan * 8));
     BLZ_TRY(entries.reserve(max_entries * 4));
-    BLZ_LOG(2, "msm plan: npts=%u sbits=%d c=%d W=%d Bw=%u G=%llu L=%u", npts, sbits, P.c, P.W, P.Bw,
-            (unsigned long long)G, P.L);
-
-    {
-        const size_t n16 = ((G + 1) * 4 + 15) / 16;   // the reserve below rounds the allocation up
-        hipLaunchKernelGGL(k_zero, dim3(2048), dim3(256), 0, st, (uint4*)count.p, n16);
-    }
-    BLZ_HIP(hipMemsetAsync(stats.p, 0, 64, st), BLZ_ERR_UNKNOWN);
     dim3 b256(256);
-    BLZ_TRY(msm_sort_lds(E, d_scalars, npts, sbits));
-    hipLaunchKernelGGL(k_scan_reduce, dim3(nscan), b256, 0, st, count.as<uint32_t>(), G, P.L, blocksums.as<uint64_t>(),
-                       stats.as<uint32_t>());
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, blocksums.as<uint64_t>(), nscan, stats.as<uint32_t>());
-    hipLaunchKernelGGL(k_scan_final, dim3(nscan), b256, 0, st, count.as<uint32_t>(), G, P.L, blocksums.as<uint64_t>(),
-                       off.as<uint32_t>(), unit_off.as<uint32_t>());
-    BLZ_TRY(msm_sort_lds_scatter(E));
-    BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
-    // the staged inputs (scalars, raw points) have been consumed: a later task's host -> device copies may
-    // overwrite this staging set once the caller's event has passed (msm_capi.hip's copy stream waits for it)
-    if (inputs_event) BLZ_HIP(hipEventRecord(inputs_event, st), BLZ_ERR_UNKNOWN);
-    // No host round trip: the unit count stays on the device.  Buffers and grids are sized by the bound
-    // (every bucket at most one short unit, plus entries / L full ones) and the kernels read the real count
-    // from `stats`; the host copy below is for the log line and the sanity check of finish() only.
-    BLZ_HIP(hipMemcpyAsync(S.stats_h, stats.p, 16, hipMemcpyDeviceToHost, st), BLZ_ERR_READ);
+    if (nslices > 1) {
+        const size_t sum_bytes = (size_t)ops->partial_dwords * 4;
+        BLZ_TRY(bucket_sums.reserve((G + 1) * sum_bytes));
+        BLZ_TRY(bucket_ident.reserve((G + 2) * 4));
+        hipLaunchKernelGGL(k_zero, dim3(2048), dim3(256), 0, st, (uint4*)bucket_sums.p, ((G + 1) * sum_bytes + 15) / 16);   // all-zero = infinity
+    }
     S.max_units = max_units;
-    BLZ_TRY(ops->run_tail(E, d_pts, (uint32_t)max_units));
+    for (int sl = 0; sl < nslices; ++sl) {
+        const uint32_t p0 = nslices > 1 ? (uint32_t)sl * pts_per_slice : 0u;
+        if (p0 >= npts) { S.slices = sl; break; }
+        const uint32_t np = nslices > 1 ? (npts - p0 < pts_per_slice ? npts - p0 : pts_per_slice) : npts;
+        const char* sc_s = (const char*)d_scalars + (size_t)p0 * (sbits / 8);
+        const char* pt_s = (const char*)d_pts + (size_t)p0 * mont_point_bytes(curve);
+        {
+            const size_t n16 = ((G + 1) * 4 + 15) / 16;   // the reserve above rounds the allocation up
+            hipLaunchKernelGGL(k_zero, dim3(2048), dim3(256), 0, st, (uint4*)count.p, n16);
+        }
+        BLZ_HIP(hipMemsetAsync(stats.p, 0, 64, st), BLZ_ERR_UNKNOWN);
+        BLZ_TRY(msm_sort_lds(E, sc_s, np, sbits));
+        hipLaunchKernelGGL(k_scan_reduce, dim3(nscan), b256, 0, st, count.as<uint32_t>(), G, P.L, blocksums.as<uint64_t>(),
+                           stats.as<uint32_t>());
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, blocksums.as<uint64_t>(), nscan, stats.as<uint32_t>());
+        hipLaunchKernelGGL(k_scan_final, dim3(nscan), b256, 0, st, count.as<uint32_t>(), G, P.L, blocksums.as<uint64_t>(),
+                           off.as<uint32_t>(), unit_off.as<uint32_t>());
+        BLZ_TRY(msm_sort_lds_scatter(E));
+        BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
+        // the staged inputs (scalars, raw points) have been consumed once the LAST sort has run: a later task's host ->
+        // device copies may overwrite this staging set once the caller's event has passed (msm_capi.hip's copy stream
+        // waits for it)
+        if (inputs_event && (sl + 1 == nslices || (uint64_t)p0 + np >= npts)) BLZ_HIP(hipEventRecord(inputs_event, st), BLZ_ERR_UNKNOWN);
+        // No host round trip: the unit count stays on the device.  Buffers and grids are sized by the bound
+        // (every bucket at most one short unit, plus entries / L full ones) and the kernels read the real count
+        // from `stats`; the host copy below is for the log line and the sanity check of finish() only.
+        BLZ_HIP(hipMemcpyAsync(S.stats_h, stats.p, 16, hipMemcpyDeviceToHost, st), BLZ_ERR_READ);
+        BLZ_TRY(ops->run_accumulate(E, pt_s, (uint32_t)max_units, nslices > 1 ? sl : -1));
+        if (nslices > 1) BLZ_TRY(ops->merge_buckets(E));
+    }
+    if (nslices > 1) {
+        hipLaunchKernelGGL(k_iota, dim3(1024), dim3(256), 0, st, bucket_ident.as<uint32_t>(), G + 2);
+        BLZ_TRY(ops->run_reduce(E, bucket_sums.p, bucket_ident.p));
+    } else {
+        BLZ_TRY(ops->run_reduce(E, partial.p, unit_off.p));
+    }
     S.busy = true;
     return BLZ_OK;
 }
@@ -555,7 +609,15 @@ int MsmEngine::finish(int slot, uint8_t* out) {
     float t = 0;
     (void)hipEventElapsedTime(&t, S.ev[0], S.ev[4]); last_ms[0] = t;
     last_ms[1] = 0;
-    if (S.accum_timed && S.plan.c) { (void)hipEventElapsedTime(&t, S.ev[5], S.ev[6]); last_ms[1] = t; }
+    if (S.accum_timed && S.plan.c) {
+        if (S.slices > 1) {   // slice-major task: the sum of the slices' k_accumulate launches
+            for (int i = 0; i < S.slices; ++i)
+                if (hipEventElapsedTime(&t, S.slice_ev[2 * i], S.slice_ev[2 * i + 1]) == hipSuccess) last_ms[1] += t;
+        } else {
+            (void)hipEventElapsedTime(&t, S.ev[5], S.ev[6]);
+            last_ms[1] = t;
+        }
+    }
     (void)hipEventElapsedTime(&t, S.ev[0], S.ev[1]); last_ms[2] = t;
     (void)hipEventElapsedTime(&t, S.ev[1], S.ev[2]); last_ms[3] = t;
     (void)hipEventElapsedTime(&t, S.ev[2], S.ev[3]); last_ms[4] = t;
@@ -567,7 +629,7 @@ int MsmEngine::finish(int slot, uint8_t* out) {
 
 int MsmEngine::combine_partials(const uint8_t* partials, size_t cnt, uint8_t* out, bool on_device) {
     BLZ_TRY(use_device(device));
-    return ops_for(curve)->combine(*this, partials, cnt, out, on_device);
+    return ops_for(curve, repr)->combine(*this, partials, cnt, out, on_device);
 }
 
 }  // namespace blz

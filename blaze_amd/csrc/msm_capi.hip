@@ -89,7 +89,7 @@ int arena_points_mont(blz_msm* h, uint64_t pos, uint32_t npts, const void** out)
                     (unsigned long long)pos, len, h->device);
     const uint32_t phase = (uint32_t)((pos - e->start) % ps);   // where the point grid sits inside the extent
     const size_t cap_pts = (e->cap - phase) / ps, ext_pts = (e->len - phase) / ps;
-    if (e->mont_curve != h->curve || e->mont_phase != phase || e->mont_bytes < cap_pts * mp) {
+    if (e->mont_curve != h->eng.format_id() || e->mont_phase != phase || e->mont_bytes < cap_pts * mp) {
         // another curve / grid (or the first use): a fresh shadow, everything stale
         if (e->mont) {
             BLZ_HIP(hipDeviceSynchronize(), BLZ_ERR_UNKNOWN);   // a task of another handle may still read the old one
@@ -98,7 +98,7 @@ int arena_points_mont(blz_msm* h, uint64_t pos, uint32_t npts, const void** out)
         }
         e->mont_bytes = cap_pts * mp + 16;
         BLZ_HIP(hipMalloc(&e->mont, e->mont_bytes), BLZ_ERR_UNKNOWN);
-        e->mont_curve = h->curve;
+        e->mont_curve = h->eng.format_id();   // curve and layout of the copy (BN254 has two: msm_engine.hpp `repr`)
         e->mont_phase = phase;
         e->dirty_lo = 0;
         e->dirty_hi = e->len;
@@ -248,7 +248,7 @@ int blz_msm_new(int device_id, int mem_type, int is_precompute, int curve, blz_m
     h->mem_type = mem_type;
     h->pf = is_precompute ? BLZ_PRECOMPUTE_FACTOR : BLZ_PRECOMPUTE_FACTOR_BASE;
     h->curve = curve;
-    int rc = h->eng.init(device_id, curve);
+    int rc = h->eng.init(device_id, curve, (int)h->pf);
     if (rc == BLZ_OK && hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess)
         rc = fail(BLZ_ERR_UNKNOWN, "copy stream creation failed");
     for (int i = 0; i < 2 && rc == BLZ_OK; ++i)

@@ -31,6 +31,7 @@ MsmPlan make_plan(uint32_t npts, int sbits, int ebits, int force_c);
 // levels, Horner, inversion: a few lanes for ~3 ms) runs on `tail_stream`, so it overlaps the next
 // task's sort and accumulation instead of idling the chip.  Everything the tail touches is per slot.
 constexpr int MSM_QUEUE_DEPTH = 2;
+constexpr int MSM_MAX_SLICES = 64;
 struct MsmSlot {
     // 0 start, 1 sort done, 2 accumulate done, 5..6 the accumulate kernel alone (stream);
     // 3 reduce done, 4 finish done (tail_stream)
@@ -42,6 +43,9 @@ struct MsmSlot {
     uint32_t* stats_h = nullptr;   // pinned: [0] total units, [1] max bucket count, [2] total entries (read in finish())
     uint64_t max_units = 0;        // the bound the launches of this task were sized by
     MsmPlan plan;
+    // slice-major tasks (msm.hip run()): one event pair per slice around its k_accumulate launch; finish() sums them
+    hipEvent_t slice_ev[2 * 64] = {};
+    int slices = 1;
     bool accum_timed = false;
     bool busy = false;             // enqueued, result not collected yet
 };
@@ -49,10 +53,19 @@ struct MsmSlot {
 struct MsmEngine {
     int device = 0;
     int curve = 0;
+    // Layout / arithmetic of the Montgomery point copy: 0 = the curve's default; 1 = BN254's 32-bit-limb twin
+    // (Fq_BN254_W32, msm_bn254w.hip).  BN254's 9 x 29 reduced radix wins where runs are short (pf = 1: the first
+    // addition of a run is the cheap affine + affine one, the level-0 reduce is cheaper: 2^26 in 69.7 instead of 76.9
+    // ms) and loses on the precompute shapes (pf = 8: 2^29 points, 32 GiB of bases, runs of 8192: 100.5 against 95.3 ms:
+    // faster arithmetic only exposes the translation-bound gathers - profiles/r03_bn254_*.txt), so the handle picks by
+    // precompute factor.  format_id() keys the arena's Montgomery shadows.
+    int repr = 0;
+    int format_id() const { return curve | (repr << 8); }
     hipStream_t stream = nullptr, tail_stream = nullptr, aux_stream = nullptr;  // aux: combine_partials
     MsmSlot slots[MSM_QUEUE_DEPTH];
     int cur = 0;                   // slot of the task being enqueued
     DevBuf count, off, unit_off, unit_bucket, unit_order, lenhist, coarse, inter, slice_map, entries, partial, blocksums, stats, result;
+    DevBuf bucket_sums, bucket_ident;   // slice-major tasks: running bucket sums across slices; identity unit_off for the reduce
     hipEvent_t inputs_event = nullptr;   // set by the caller of run(): recorded on `stream` once the task has read
                                          // its scalars / raw points (after the digit sort)
     uint8_t* combine_h = nullptr;  // pinned bytes of combine_partials
@@ -62,7 +75,7 @@ struct MsmEngine {
     int sort_cl = 0;
     void* sort_inter_fine = nullptr;  // u16 fine digits of the sort intermediate (second half of `inter`)
 
-    int init(int device_id, int curve_id);
+    int init(int device_id, int curve_id, int precompute_factor);
     bool destroy();   // false: the streams never drained (wedged device work): everything was leaked instead of freed
     // device result bytes of slot s / scratch of combine_partials inside `result`
     uint32_t* slot_result(int s) { return result.as<uint32_t>() + (size_t)s * 64; }
@@ -92,11 +105,19 @@ int launch_fill_units(MsmEngine& E, uint32_t units);  // unit->bucket map + leng
 struct MsmCurveOps {
     int (*points_to_mont)(MsmEngine&, const void* d_raw, void* d_mont, uint32_t npts);
     int (*emit_infinity)(MsmEngine&);
-    int (*run_tail)(MsmEngine&, const void* d_pts, uint32_t max_units);
+    // phase 1 after a digit sort: unit lists, k_accumulate, k_combine_units (at most max_units units; the real count is on
+    // the device).  slice >= 0: part of a slice-major task - only the accumulate kernel is bracketed, by the slice's events.
+    int (*run_accumulate)(MsmEngine&, const void* d_pts, uint32_t max_units, int slice);
+    // slice-major tasks: bucket_sums[g] += the slice's sum of bucket g (the leader unit of its run)
+    int (*merge_buckets)(MsmEngine&);
+    // phases 2 - 3 over bucket sums found at sums[unit_off[g]] (unit_off[g + 1] > unit_off[g], else the bucket is empty)
+    int (*run_reduce)(MsmEngine&, const void* sums, const void* unit_off);
+    int partial_dwords;   // dwords of one unit / bucket sum in `partial`
     int (*combine)(MsmEngine&, const uint8_t* partials, size_t count, uint8_t* out, bool on_device);
 };
 const MsmCurveOps& msm_ops_bls377();
 const MsmCurveOps& msm_ops_bls381();
 const MsmCurveOps& msm_ops_bn254();
+const MsmCurveOps& msm_ops_bn254_w32();
 
 }  // namespace blz

@@ -561,53 +561,95 @@ int emit_infinity_t(MsmEngine& E) {
     return BLZ_OK;
 }
 
-// phases 1-3 after the digit sort: at most U units (the real count is in E.stats on the device)
+// bucket_sums[g] += sum of bucket g in this slice (slice-major tasks, msm.hip run()).  After k_combine_units the sum of
+// a bucket's run sits in its first unit; an empty run leaves the bucket alone.
 template <class F>
-int run_tail_t(MsmEngine& E, const void* d_pts, uint32_t U) {
+__global__ __launch_bounds__(128, 2) void k_merge_buckets(const uint32_t* __restrict__ partial, const uint32_t* __restrict__ unit_off,
+                                                         uint64_t G, uint32_t* __restrict__ sums) {
+    const uint64_t g = (uint64_t)blockIdx.x * 128u + threadIdx.x;
+    if (g >= G) return;
+    const uint32_t u0 = unit_off[g], u1 = unit_off[g + 1];
+    if (u1 <= u0) return;
+    if constexpr (USE_RR<F>) {
+        using Q = typename F::RR;
+        XYZZRR<Q> a, b;
+        ptrr_load(a, sums, g);
+        ptrr_load(b, partial, u0);
+        ptrr_add<Q, 4>(a, b);
+        ptrr_store(sums, g, a);
+    } else {
+        XYZZ<F> a, b;
+        load_xyzz(a, sums, g);
+        load_xyzz(b, partial, u0);
+        pt_add_inl<F, 2>(a, b);
+        store_xyzz(sums, g, a);
+    }
+}
+
+// phase 1 after a digit sort: at most U units (the real count is in E.stats on the device)
+template <class F>
+int run_accumulate_t(MsmEngine& E, const void* d_pts, uint32_t U, int slice) {
+    hipStream_t st = E.stream;
+    MsmSlot& S = E.slots[E.cur];
+    const MsmPlan& P = E.last_plan;
+    BLZ_TRY(E.unit_bucket.reserve(((size_t)U + 1) * 4));
+    BLZ_TRY(E.partial.reserve(((size_t)U + 1) * 4 * partial_dwords<F>()));
+    if (slice <= 0) BLZ_HIP(hipEventRecord(S.ev[1], st), BLZ_ERR_UNKNOWN);   // (slice-major: the FIRST slice's sort is done)
+    S.accum_timed = true;
+    BLZ_TRY(launch_fill_units(E, U));
+    // ev5..ev6 (or the slice's pair) bracket the dominant kernel alone
+    BLZ_HIP(hipEventRecord(slice < 0 ? S.ev[5] : S.slice_ev[2 * slice], st), BLZ_ERR_UNKNOWN);
+    hipLaunchKernelGGL(k_accumulate<F>, dim3((U + 127) / 128), dim3(128), 0, st, (const uint32_t*)d_pts,
+                       E.entries.as<uint32_t>(), E.off.as<uint32_t>(), E.unit_off.as<uint32_t>(),
+                       E.unit_bucket.as<uint32_t>(), E.unit_order.as<uint32_t>(), E.stats.as<uint32_t>(), P.L,
+                       E.partial.as<uint32_t>());
+    BLZ_HIP(hipEventRecord(slice < 0 ? S.ev[6] : S.slice_ev[2 * slice + 1], st), BLZ_ERR_UNKNOWN);
+    const uint32_t maxunits = (P.npts + P.L - 1) / P.L;   // a bucket holds at most one entry per point
+    uint64_t full_bound = (uint64_t)P.npts * P.W / P.L + 1;  // units of length L: at most entries / L
+    if (full_bound > U) full_bound = U;
+    // (64-bit stride: with BLAZE_MSM_L < 8 and close to 2^31 points, maxunits exceeds 2^28 and a u32 stride would
+    // wrap to 0 - an endless launch loop)
+    for (uint64_t stride = 1; stride < maxunits; stride *= 16)
+        hipLaunchKernelGGL(k_combine_units<F>, dim3((uint32_t)((full_bound / 16 + 1) * 4 / 128 + 1)), dim3(128), 0, st,
+                           E.unit_off.as<uint32_t>(), E.unit_bucket.as<uint32_t>(), E.unit_order.as<uint32_t>(),
+                           E.lenhist.as<uint32_t>() + P.L, E.stats.as<uint32_t>(), P.L, (uint32_t)stride, E.partial.as<uint32_t>());
+    BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
+    return BLZ_OK;
+}
+
+template <class F>
+int merge_buckets_t(MsmEngine& E) {
+    const uint64_t G = E.last_plan.G;
+    hipLaunchKernelGGL(k_merge_buckets<F>, dim3((uint32_t)((G + 127) / 128)), dim3(128), 0, E.stream, E.partial.as<uint32_t>(),
+                       E.unit_off.as<uint32_t>(), G, E.bucket_sums.as<uint32_t>());
+    BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
+    return BLZ_OK;
+}
+
+// phases 2 - 3: bucket reduce over the sums at sums[unit_off[g]], then the window combine
+template <class F>
+int run_reduce_t(MsmEngine& E, const void* sums, const void* unit_off_v) {
     hipStream_t st = E.stream;
     MsmSlot& S = E.slots[E.cur];
     const MsmPlan& P = E.last_plan;
     const uint64_t G = P.G;
-    BLZ_TRY(E.unit_bucket.reserve(((size_t)U + 1) * 4));
-    BLZ_TRY(E.partial.reserve(((size_t)U + 1) * 4 * partial_dwords<F>()));
-    BLZ_HIP(hipEventRecord(S.ev[1], st), BLZ_ERR_UNKNOWN);
-
-    // ---- phase 1
-    S.accum_timed = true;
-    {
-        BLZ_TRY(launch_fill_units(E, U));
-        BLZ_HIP(hipEventRecord(S.ev[5], st), BLZ_ERR_UNKNOWN);  // ev5..ev6 bracket the dominant kernel alone
-        hipLaunchKernelGGL(k_accumulate<F>, dim3((U + 127) / 128), dim3(128), 0, st, (const uint32_t*)d_pts,
-                           E.entries.as<uint32_t>(), E.off.as<uint32_t>(), E.unit_off.as<uint32_t>(),
-                           E.unit_bucket.as<uint32_t>(), E.unit_order.as<uint32_t>(), E.stats.as<uint32_t>(), P.L,
-                           E.partial.as<uint32_t>());
-        BLZ_HIP(hipEventRecord(S.ev[6], st), BLZ_ERR_UNKNOWN);
-        const uint32_t maxunits = (P.npts + P.L - 1) / P.L;   // a bucket holds at most one entry per point
-        uint64_t full_bound = (uint64_t)P.npts * P.W / P.L + 1;  // units of length L: at most entries / L
-        if (full_bound > U) full_bound = U;
-        // (64-bit stride: with BLAZE_MSM_L < 8 and close to 2^31 points, maxunits exceeds 2^28 and a u32 stride would
-        // wrap to 0 - an endless launch loop)
-        for (uint64_t stride = 1; stride < maxunits; stride *= 16)
-            hipLaunchKernelGGL(k_combine_units<F>, dim3((uint32_t)((full_bound / 16 + 1) * 4 / 128 + 1)), dim3(128), 0, st,
-                               E.unit_off.as<uint32_t>(), E.unit_bucket.as<uint32_t>(), E.unit_order.as<uint32_t>(),
-                               E.lenhist.as<uint32_t>() + P.L, E.stats.as<uint32_t>(), P.L, (uint32_t)stride, E.partial.as<uint32_t>());
-        BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
-    }
+    const uint32_t* unit_off = (const uint32_t*)unit_off_v;
     BLZ_HIP(hipEventRecord(S.ev[2], st), BLZ_ERR_UNKNOWN);
 
     // ---- phase 2
     // level 0 is throughput-bound (2 adds per bucket): long segments; the upper levels have few
     // lanes and are latency-bound on their sequential chain: short segments, more levels
-    // (a small bucket space cannot fill the chip with 32-bucket segments: 17 x 2^15 buckets give 272
+    // (a small bucket space cannot fill the chip with long segments: 17 x 2^15 buckets give 272
     // waves for 1024 SIMDs and the level costs 32 sequential steps; shorter segments put a wave on
-    // every SIMD and the extra segment sums are absorbed by the upper levels)
-    uint32_t seg0_auto = 32;
+    // every SIMD and the extra segment sums are absorbed by the upper levels).  64 at the headline size: measured
+    // 12.2 / 10.3 / 9.1 / 8.6 ms of phase 2 for segments of 8 / 16 / 32 / 64 buckets (profiles/r03_seg_sweep.txt).
+    uint32_t seg0_auto = 64;
     while (seg0_auto > 8 && G / seg0_auto < 65536) seg0_auto >>= 1;
     const uint32_t SEG0 = (uint32_t)msm_env_int("BLAZE_MSM_SEG", (int)seg0_auto);
     const uint32_t SEGU = (uint32_t)msm_env_int("BLAZE_MSM_SEG_UPPER", 8);
     uint32_t M = P.Bw;
     int level = 0, shift = 0;
-    const uint32_t* curA = E.partial.as<uint32_t>();
+    const uint32_t* curA = (const uint32_t*)sums;
     const uint32_t* curC = nullptr;
     for (;;) {
         const uint32_t SEG = level == 0 ? SEG0 : SEGU;
@@ -621,11 +663,11 @@ int run_tail_t(MsmEngine& E, const void* d_pts, uint32_t U) {
         uint32_t nthreads = T * (uint32_t)P.Wv;
         if (level == 0) {
             if constexpr (USE_RR<F>)
-                hipLaunchKernelGGL(k_reduce_level0_rr<F>, dim3((nthreads + 63) / 64), dim3(64), 0, st, curA, E.unit_off.as<uint32_t>(), M,
+                hipLaunchKernelGGL(k_reduce_level0_rr<F>, dim3((nthreads + 63) / 64), dim3(64), 0, st, curA, unit_off, M,
                                    SEG, T, P.Wv, oA.as<uint32_t>(), oC.as<uint32_t>());
             else
                 hipLaunchKernelGGL((k_reduce_level<F, true>), dim3((nthreads + 63) / 64), dim3(64), 0, st, curA, curC,
-                                   E.unit_off.as<uint32_t>(), M, SEG, T, P.Wv, shift, oA.as<uint32_t>(), oC.as<uint32_t>());
+                                   unit_off, M, SEG, T, P.Wv, shift, oA.as<uint32_t>(), oC.as<uint32_t>());
             // the rest is a few lanes of sequential work: hand it to the tail stream, so this stream can
             // start the next task's sort while it runs
             BLZ_HIP(hipEventRecord(S.ev_l0, st), BLZ_ERR_UNKNOWN);
@@ -633,7 +675,7 @@ int run_tail_t(MsmEngine& E, const void* d_pts, uint32_t U) {
             BLZ_HIP(hipStreamWaitEvent(st, S.ev_l0, 0), BLZ_ERR_UNKNOWN);
         } else {
             hipLaunchKernelGGL((k_reduce_level<F, false>), dim3((nthreads * 4 + 63) / 64), dim3(64), 0, st, curA, curC,
-                               E.unit_off.as<uint32_t>(), M, SEG, T, P.Wv, shift, oA.as<uint32_t>(), oC.as<uint32_t>());
+                               unit_off, M, SEG, T, P.Wv, shift, oA.as<uint32_t>(), oC.as<uint32_t>());
         }
         curA = oA.as<uint32_t>();
         curC = oC.as<uint32_t>();
@@ -701,7 +743,10 @@ MsmCurveOps make_ops() {
     MsmCurveOps o;
     o.points_to_mont = &points_to_mont_t<F>;
     o.emit_infinity = &emit_infinity_t<F>;
-    o.run_tail = &run_tail_t<F>;
+    o.run_accumulate = &run_accumulate_t<F>;
+    o.merge_buckets = &merge_buckets_t<F>;
+    o.run_reduce = &run_reduce_t<F>;
+    o.partial_dwords = partial_dwords<F>();
     o.combine = &combine_t<F>;
     return o;
 }

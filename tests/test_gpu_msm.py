@@ -781,3 +781,31 @@ def test_wait_result_is_bounded(gpu, orc, monkeypatch):
     cl.reset()
     assert run_msm(cl, pts, sc, n) == exp                                # the handle is whole again
     cl.close()
+
+
+@pytest.mark.parametrize("curve,pf", [("BN254", 8), ("BN254", 1), ("BLS381", 8), ("BLS377", 1)])
+def test_slice_major_accumulation(gpu, orc, curve, pf, monkeypatch):
+    """Big point tables are accumulated slice by slice (every gather of a launch inside <= 2 GiB of the table; the
+    buckets' sums are merged across slices, msm.hip run()): automatic only for the 32 GiB table of config 3, forced
+    here at sizes the oracle checks byte for byte - ragged slice counts, slices that end up empty, hot buckets
+    (the reference harness's repeated tile), two tasks in flight."""
+    n = 5000
+    pts, sc, exp = orc.input_generator(curve, n, pf, 4100 + pf)
+    for slices in ("3", "7", "64"):
+        monkeypatch.setenv("BLAZE_MSM_SLICES", slices)
+        cl = msm_client(curve, pf)
+        assert run_msm(cl, pts, sc, n) == exp, f"{curve} pf={pf} slices={slices}"
+        # two in flight, the second with other scalars
+        sc2 = bytes(sc[32:]) + bytes(sc[:32])
+        exp2 = orc.msm_pippenger(curve, pts, sc2, n, pf, threads=4)
+        p = MSMParams(n, None)
+        cl.initialize(p); cl.start_process(); cl.set_data(MSMInput(pts, sc, p))
+        cl.initialize(p); cl.start_process(); cl.set_data(MSMInput(pts, sc2, p))
+        cl.wait_result(); assert cl.result().result == exp
+        cl.wait_result(); assert cl.result().result == exp2
+        assert cl.get_api()["accumulate_kernel_ms"] > 0
+        cl.close()
+    monkeypatch.setenv("BLAZE_MSM_SLICES", "1")
+    cl = msm_client(curve, pf)
+    assert run_msm(cl, pts, sc, n) == exp
+    cl.close()
