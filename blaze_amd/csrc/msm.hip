@@ -122,6 +122,7 @@ MsmPlan make_plan(uint32_t npts, int sbits, int ebits, int force_c) {
 
 // zero-fill (hipMemsetAsync's fill kernel took 0.7 ms for the 71 MB bucket-count array: ~100 GB/s)
 __global__ __launch_bounds__(256) void k_zero(uint4* __restrict__ p, size_t n16) {
+    __builtin_amdgcn_s_setprio(3);   // sort-stage kernel: may run underneath another task's accumulation (msm_sort3.hip)
     const uint4 z = make_uint4(0, 0, 0, 0);
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) p[i] = z;
 }
@@ -153,6 +154,7 @@ __device__ __forceinline__ uint64_t block_sum_u64(uint64_t v, uint64_t* sh) {
 
 __global__ __launch_bounds__(256) void k_scan_reduce(const uint32_t* __restrict__ count, uint64_t G, uint32_t L,
                                                      uint64_t* __restrict__ blocksums, uint32_t* __restrict__ stats) {
+    __builtin_amdgcn_s_setprio(3);   // sort-stage kernel: may run underneath another task's accumulation (msm_sort3.hip)
     __shared__ uint64_t sh[4];
     uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE;
     uint64_t acc = 0;
@@ -176,6 +178,7 @@ __global__ __launch_bounds__(256) void k_scan_reduce(const uint32_t* __restrict_
 // single block: exclusive scan of blocksums in place; totals -> stats[0] (units), stats[2] (entries)
 __global__ __launch_bounds__(1024) void k_scan_sums(uint64_t* __restrict__ blocksums, uint32_t nblocks,
                                                     uint32_t* __restrict__ stats) {
+    __builtin_amdgcn_s_setprio(3);   // sort-stage kernel: may run underneath another task's accumulation (msm_sort3.hip)
     __shared__ uint64_t sh[1024];
     __shared__ uint64_t carry_sh;
     if (threadIdx.x == 0) carry_sh = 0;
@@ -209,6 +212,7 @@ __global__ __launch_bounds__(1024) void k_scan_sums(uint64_t* __restrict__ block
 __global__ __launch_bounds__(256) void k_scan_final(uint32_t* __restrict__ count, uint64_t G, uint32_t L,
                                                     const uint64_t* __restrict__ blocksums,
                                                     uint32_t* __restrict__ off, uint32_t* __restrict__ unit_off) {
+    __builtin_amdgcn_s_setprio(3);   // sort-stage kernel: may run underneath another task's accumulation (msm_sort3.hip)
     __shared__ uint64_t sh[256];
     uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
     uint64_t v[SCAN_ITEMS];
@@ -257,6 +261,7 @@ constexpr uint32_t UNIT_GRID = 2048;
 __global__ __launch_bounds__(256) void k_fill_units(const uint32_t* __restrict__ off, const uint32_t* __restrict__ unit_off,
                                                     uint64_t G, uint32_t L, uint32_t* __restrict__ unit_bucket,
                                                     uint32_t* __restrict__ hist) {
+    __builtin_amdgcn_s_setprio(3);   // sort-stage kernel: may run underneath another task's accumulation (msm_sort3.hip)
     __shared__ uint32_t sh[MAX_L + 1];
     __shared__ uint32_t big[256], nbig;
     for (uint32_t i = threadIdx.x; i <= L; i += 256) sh[i] = 0;
@@ -291,6 +296,7 @@ __global__ __launch_bounds__(256) void k_fill_units(const uint32_t* __restrict__
 // cursor[len] = number of units strictly longer than len (descending order); one block
 __global__ __launch_bounds__(256) void k_unit_len_scan(const uint32_t* __restrict__ hist, uint32_t L,
                                                        uint32_t* __restrict__ cursor) {
+    __builtin_amdgcn_s_setprio(3);   // sort-stage kernel: may run underneath another task's accumulation (msm_sort3.hip)
     if (threadIdx.x != 0) return;
     uint32_t run = 0;
     for (int len = (int)L; len >= 0; --len) {
@@ -302,6 +308,7 @@ __global__ __launch_bounds__(256) void k_unit_len_scan(const uint32_t* __restric
 __global__ __launch_bounds__(256) void k_unit_order(const uint32_t* __restrict__ off, const uint32_t* __restrict__ unit_off,
                                                     uint64_t G, uint32_t L, uint32_t* __restrict__ cursor,
                                                     uint32_t* __restrict__ unit_order) {
+    __builtin_amdgcn_s_setprio(3);   // sort-stage kernel: may run underneath another task's accumulation (msm_sort3.hip)
     __shared__ uint32_t sh_cnt[MAX_L + 1];
     __shared__ uint32_t sh_base[MAX_L + 1];
     __shared__ uint32_t big[256], big_pos[256], nbig;
@@ -377,19 +384,20 @@ static const MsmCurveOps* ops_for(int curve, int repr = 0) {
 int launch_fill_units(MsmEngine& E, uint32_t U /* upper bound of the unit count */) {
     const uint64_t G = E.last_plan.G;
     const uint32_t L = E.last_plan.L;
-    hipStream_t st = E.stream;
-    BLZ_TRY(E.unit_order.reserve(((size_t)U + 1) * 4));
-    BLZ_TRY(E.lenhist.reserve(2 * (MAX_L + 1) * 4));
-    uint32_t* hist = E.lenhist.as<uint32_t>();
+    hipStream_t st = E.sort_st;
+    BLZ_TRY(E.sb().unit_bucket.reserve(((size_t)U + 1) * 4));
+    BLZ_TRY(E.sb().unit_order.reserve(((size_t)U + 1) * 4));
+    BLZ_TRY(E.sb().lenhist.reserve(2 * (MAX_L + 1) * 4));
+    uint32_t* hist = E.sb().lenhist.as<uint32_t>();
     uint32_t* cursor = hist + (MAX_L + 1);
     BLZ_HIP(hipMemsetAsync(hist, 0, 2 * (MAX_L + 1) * 4, st), BLZ_ERR_UNKNOWN);
     uint64_t nchunks = (G + 255) / 256;
     dim3 gg((uint32_t)(nchunks < UNIT_GRID ? nchunks : UNIT_GRID)), b(256);
-    hipLaunchKernelGGL(k_fill_units, gg, b, 0, st, E.off.as<uint32_t>(), E.unit_off.as<uint32_t>(), G, L,
-                       E.unit_bucket.as<uint32_t>(), hist);
+    hipLaunchKernelGGL(k_fill_units, gg, b, 0, st, E.sb().off.as<uint32_t>(), E.sb().unit_off.as<uint32_t>(), G, L,
+                       E.sb().unit_bucket.as<uint32_t>(), hist);
     hipLaunchKernelGGL(k_unit_len_scan, dim3(1), b, 0, st, hist, L, cursor);
-    hipLaunchKernelGGL(k_unit_order, gg, b, 0, st, E.off.as<uint32_t>(), E.unit_off.as<uint32_t>(), G, L, cursor,
-                       E.unit_order.as<uint32_t>());
+    hipLaunchKernelGGL(k_unit_order, gg, b, 0, st, E.sb().off.as<uint32_t>(), E.sb().unit_off.as<uint32_t>(), G, L, cursor,
+                       E.sb().unit_order.as<uint32_t>());
     BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
     return BLZ_OK;
 }
@@ -409,17 +417,23 @@ int MsmEngine::init(int device_id, int curve_id, int precompute_factor) {
     BLZ_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), BLZ_ERR_UNKNOWN);
     BLZ_HIP(hipStreamCreateWithFlags(&tail_stream, hipStreamNonBlocking), BLZ_ERR_UNKNOWN);
     BLZ_HIP(hipStreamCreateWithFlags(&aux_stream, hipStreamNonBlocking), BLZ_ERR_UNKNOWN);
+    BLZ_HIP(hipStreamCreateWithFlags(&sort_stream, hipStreamNonBlocking), BLZ_ERR_UNKNOWN);
+    sort_st = stream;
+    last_sort_done = nullptr;
     for (auto& S : slots) {
         for (auto& e : S.ev) BLZ_HIP(hipEventCreate(&e), BLZ_ERR_UNKNOWN);
         for (auto& e : S.slice_ev) BLZ_HIP(hipEventCreate(&e), BLZ_ERR_UNKNOWN);
         BLZ_HIP(hipEventCreateWithFlags(&S.ev_l0, hipEventDisableTiming), BLZ_ERR_UNKNOWN);
         BLZ_HIP(hipEventCreateWithFlags(&S.ev_done, hipEventDisableTiming), BLZ_ERR_UNKNOWN);
+        BLZ_HIP(hipEventCreateWithFlags(&S.ev_sorted, hipEventDisableTiming), BLZ_ERR_UNKNOWN);
+        BLZ_HIP(hipEventCreate(&S.ev_s0), BLZ_ERR_UNKNOWN);
+        BLZ_HIP(hipEventCreate(&S.ev_s1), BLZ_ERR_UNKNOWN);
         BLZ_HIP(hipHostMalloc((void**)&S.result_h, 256), BLZ_ERR_UNKNOWN);
         BLZ_HIP(hipHostMalloc((void**)&S.stats_h, 64), BLZ_ERR_UNKNOWN);
         memset(S.stats_h, 0, 64);
     }
     BLZ_HIP(hipHostMalloc((void**)&combine_h, 256), BLZ_ERR_UNKNOWN);
-    BLZ_TRY(stats.reserve(64));
+    for (auto& B : sbuf) BLZ_TRY(B.stats.reserve(64));
     BLZ_TRY(result.reserve(256 * 64));
     return BLZ_OK;
 }
@@ -427,15 +441,17 @@ int MsmEngine::init(int device_id, int curve_id, int precompute_factor) {
 bool MsmEngine::destroy() {
     if (!stream) return true;
     (void)hipSetDevice(device);
-    if (sync_stream_bounded(stream, "free: main stream") != BLZ_OK || sync_stream_bounded(tail_stream, "free: tail stream") != BLZ_OK) {
+    if (sync_stream_bounded(stream, "free: main stream") != BLZ_OK || sync_stream_bounded(tail_stream, "free: tail stream") != BLZ_OK ||
+        sync_stream_bounded(sort_stream, "free: sort stream") != BLZ_OK) {
         // work that never completes still references the buffers: freeing them would block (or fault); leak them
         BLZ_LOG(0, "MSM engine freed while its device work is wedged: workspace and streams are leaked");
-        stream = tail_stream = aux_stream = nullptr;
+        stream = tail_stream = aux_stream = sort_stream = nullptr;
         return false;
     }
-    for (DevBuf* b : {&count, &off, &unit_off, &unit_bucket, &unit_order, &lenhist, &coarse, &inter, &slice_map, &entries,
-                      &partial, &blocksums, &stats, &result, &bucket_sums, &bucket_ident})
+    for (DevBuf* b : {&coarse, &inter, &inter2, &slice_map, &partial, &blocksums, &result, &sort3_tabs, &bucket_sums, &bucket_ident})
         b->release();
+    for (auto& B : sbuf)
+        for (DevBuf* b : {&B.count, &B.off, &B.unit_off, &B.unit_bucket, &B.unit_order, &B.lenhist, &B.entries, &B.stats}) b->release();
     for (auto& S : slots) {
         for (DevBuf* b : {&S.lvlA[0], &S.lvlA[1], &S.lvlC[0], &S.lvlC[1]}) b->release();
         for (auto& e : S.ev)
@@ -444,6 +460,9 @@ bool MsmEngine::destroy() {
             if (e) (void)hipEventDestroy(e);
         if (S.ev_l0) (void)hipEventDestroy(S.ev_l0);
         if (S.ev_done) (void)hipEventDestroy(S.ev_done);
+        if (S.ev_sorted) (void)hipEventDestroy(S.ev_sorted);
+        if (S.ev_s0) (void)hipEventDestroy(S.ev_s0);
+        if (S.ev_s1) (void)hipEventDestroy(S.ev_s1);
         if (S.result_h) (void)hipHostFree(S.result_h);
         if (S.stats_h) (void)hipHostFree(S.stats_h);
         S = MsmSlot();
@@ -454,7 +473,9 @@ bool MsmEngine::destroy() {
     (void)hipStreamDestroy(stream);
     (void)hipStreamDestroy(tail_stream);
     (void)hipStreamDestroy(aux_stream);
-    stream = tail_stream = aux_stream = nullptr;
+    (void)hipStreamDestroy(sort_stream);
+    stream = tail_stream = aux_stream = sort_stream = nullptr;
+    last_sort_done = nullptr;
     return true;
 }
 
@@ -469,6 +490,7 @@ int MsmEngine::sync_all() {
     BLZ_TRY(sync_stream_bounded(stream, "reset: main stream"));
     BLZ_TRY(sync_stream_bounded(tail_stream, "reset: tail stream"));
     BLZ_TRY(sync_stream_bounded(aux_stream, "reset: exchange stream"));
+    BLZ_TRY(sync_stream_bounded(sort_stream, "reset: sort stream"));
     for (auto& S : slots) S.busy = false;
     return BLZ_OK;
 }
@@ -541,11 +563,40 @@ int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int 
     const uint64_t max_units = G + max_entries / P.L + 1;
     if (max_units >= (1ull << 32)) return fail(BLZ_ERR_INVALID_PARAM, "unit bound %llu exceeds 32 bits", (unsigned long long)max_units);
     const uint32_t nscan = (uint32_t)((G + 1 + SCAN_TILE - 1) / SCAN_TILE);
-    BLZ_TRY(count.reserve((G + 1) * 4 + 16));
-    BLZ_TRY(off.reserve((G + 2) * 4));
-    BLZ_TRY(unit_off.reserve((G + 2) * 4));
+
+    // The sort stage (digit sort, bucket / unit scans, unit lists) of this task.  When the handle's other task is still
+    // in flight - its accumulation is running or about to - the stage goes to sort_stream with the small-footprint
+    // three-level sort (msm_sort3.hip) and runs UNDERNEATH that accumulation; the accumulation of this task then starts
+    // with its sort already done.  Its outputs are per slot (SortBufs); the scratch the sorts share is protected by
+    // chaining every sort stage behind the one before (last_sort_done).  BLAZE_SORT_HIDE: 0 never, 1 when the other slot
+    // is busy (default), 2 the three-level sort always (on the main stream when there is nothing to hide under: tests).
+    SortBufs& B = sb();
+    const int hide_env = msm_env_int("BLAZE_SORT_HIDE", 1);
+    const MsmSlot& O = slots[(slot + 1) % MSM_QUEUE_DEPTH];
+    bool s3 = hide_env != 0 && nslices == 1 && msm_sort3_ok(P, sbits);
+    if (s3 && hide_env == 1) {
+        // the three-level sort gives one block a whole level-2 bin: fine for the near-uniform digits of real scalars, a
+        // cliff for inputs that pile entries into a few buckets (the reference harness repeats a 256-point tile).  The
+        // handle's last tasks say which kind it is being fed: stats_h[1] is their largest bucket.
+        const uint64_t mean = max_entries / (G ? G : 1) + 1;
+        if ((uint64_t)S.stats_h[1] > 64 * mean + 4096 || (uint64_t)O.stats_h[1] > 64 * mean + 4096) s3 = false;
+    }
+    const bool hide = s3 && O.busy;
+    const bool use_s3 = s3 && (hide || hide_env == 2);
+    S.sort_hidden = hide;
+    sort_st = hide ? sort_stream : st;
+    hipStream_t ss = sort_st;
+    if (last_sort_done) BLZ_HIP(hipStreamWaitEvent(ss, last_sort_done, 0), BLZ_ERR_UNKNOWN);
+    if (hide) {
+        // this slot's previous task must have let go of its sort outputs (its level-0 reduce read unit_off last)
+        if (S.l0_recorded) BLZ_HIP(hipStreamWaitEvent(ss, S.ev_l0, 0), BLZ_ERR_UNKNOWN);
+        BLZ_HIP(hipEventRecord(S.ev_s0, ss), BLZ_ERR_UNKNOWN);
+    }
+    BLZ_TRY(B.count.reserve((G + 1) * 4 + 16));
+    BLZ_TRY(B.off.reserve((G + 2) * 4));
+    BLZ_TRY(B.unit_off.reserve((G + 2) * 4));
     BLZ_TRY(blocksums.reserve((size_t)nscan * 8));
-    BLZ_TRY(entries.reserve(max_entries * 4));
+    BLZ_TRY(B.entries.reserve(max_entries * 4));
     dim3 b256(256);
     if (nslices > 1) {
         const size_t sum_bytes = (size_t)ops->partial_dwords * 4;
@@ -560,27 +611,38 @@ int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int 
         const uint32_t np = nslices > 1 ? (npts - p0 < pts_per_slice ? npts - p0 : pts_per_slice) : npts;
         const char* sc_s = (const char*)d_scalars + (size_t)p0 * (sbits / 8);
         const char* pt_s = (const char*)d_pts + (size_t)p0 * mont_point_bytes(curve);
-        {
+        // ---- sort stage, on ss
+        BLZ_HIP(hipMemsetAsync(B.stats.p, 0, 64, ss), BLZ_ERR_UNKNOWN);
+        if (use_s3) {
+            BLZ_TRY(msm_sort3(E, sc_s, np));   // count[] and entries[] in one go
+        } else {
             const size_t n16 = ((G + 1) * 4 + 15) / 16;   // the reserve above rounds the allocation up
-            hipLaunchKernelGGL(k_zero, dim3(2048), dim3(256), 0, st, (uint4*)count.p, n16);
+            hipLaunchKernelGGL(k_zero, dim3(2048), dim3(256), 0, ss, (uint4*)B.count.p, n16);
+            BLZ_TRY(msm_sort_lds(E, sc_s, np, sbits));
         }
-        BLZ_HIP(hipMemsetAsync(stats.p, 0, 64, st), BLZ_ERR_UNKNOWN);
-        BLZ_TRY(msm_sort_lds(E, sc_s, np, sbits));
-        hipLaunchKernelGGL(k_scan_reduce, dim3(nscan), b256, 0, st, count.as<uint32_t>(), G, P.L, blocksums.as<uint64_t>(),
-                           stats.as<uint32_t>());
-        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, blocksums.as<uint64_t>(), nscan, stats.as<uint32_t>());
-        hipLaunchKernelGGL(k_scan_final, dim3(nscan), b256, 0, st, count.as<uint32_t>(), G, P.L, blocksums.as<uint64_t>(),
-                           off.as<uint32_t>(), unit_off.as<uint32_t>());
-        BLZ_TRY(msm_sort_lds_scatter(E));
+        hipLaunchKernelGGL(k_scan_reduce, dim3(nscan), b256, 0, ss, B.count.as<uint32_t>(), G, P.L, blocksums.as<uint64_t>(),
+                           B.stats.as<uint32_t>());
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, ss, blocksums.as<uint64_t>(), nscan, B.stats.as<uint32_t>());
+        hipLaunchKernelGGL(k_scan_final, dim3(nscan), b256, 0, ss, B.count.as<uint32_t>(), G, P.L, blocksums.as<uint64_t>(),
+                           B.off.as<uint32_t>(), B.unit_off.as<uint32_t>());
+        if (!use_s3) BLZ_TRY(msm_sort_lds_scatter(E));
         BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
         // the staged inputs (scalars, raw points) have been consumed once the LAST sort has run: a later task's host ->
         // device copies may overwrite this staging set once the caller's event has passed (msm_capi.hip's copy stream
         // waits for it)
-        if (inputs_event && (sl + 1 == nslices || (uint64_t)p0 + np >= npts)) BLZ_HIP(hipEventRecord(inputs_event, st), BLZ_ERR_UNKNOWN);
+        if (inputs_event && (sl + 1 == nslices || (uint64_t)p0 + np >= npts)) BLZ_HIP(hipEventRecord(inputs_event, ss), BLZ_ERR_UNKNOWN);
         // No host round trip: the unit count stays on the device.  Buffers and grids are sized by the bound
         // (every bucket at most one short unit, plus entries / L full ones) and the kernels read the real count
-        // from `stats`; the host copy below is for the log line and the sanity check of finish() only.
-        BLZ_HIP(hipMemcpyAsync(S.stats_h, stats.p, 16, hipMemcpyDeviceToHost, st), BLZ_ERR_READ);
+        // from `stats`; the host copy below is for the log line, the sanity check of finish() and the hot-bucket guard.
+        BLZ_HIP(hipMemcpyAsync(S.stats_h, B.stats.p, 16, hipMemcpyDeviceToHost, ss), BLZ_ERR_READ);
+        BLZ_TRY(launch_fill_units(E, (uint32_t)max_units));
+        BLZ_HIP(hipEventRecord(S.ev_sorted, ss), BLZ_ERR_UNKNOWN);
+        last_sort_done = S.ev_sorted;
+        if (hide) {
+            BLZ_HIP(hipEventRecord(S.ev_s1, ss), BLZ_ERR_UNKNOWN);
+            BLZ_HIP(hipStreamWaitEvent(st, S.ev_sorted, 0), BLZ_ERR_UNKNOWN);
+        }
+        // ---- accumulation, on the main stream
         BLZ_TRY(ops->run_accumulate(E, pt_s, (uint32_t)max_units, nslices > 1 ? sl : -1));
         if (nslices > 1) BLZ_TRY(ops->merge_buckets(E));
     }
@@ -588,8 +650,9 @@ int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int 
         hipLaunchKernelGGL(k_iota, dim3(1024), dim3(256), 0, st, bucket_ident.as<uint32_t>(), G + 2);
         BLZ_TRY(ops->run_reduce(E, bucket_sums.p, bucket_ident.p));
     } else {
-        BLZ_TRY(ops->run_reduce(E, partial.p, unit_off.p));
+        BLZ_TRY(ops->run_reduce(E, partial.p, B.unit_off.p));
     }
+    S.l0_recorded = true;
     S.busy = true;
     return BLZ_OK;
 }
@@ -618,7 +681,9 @@ int MsmEngine::finish(int slot, uint8_t* out) {
             last_ms[1] = t;
         }
     }
-    (void)hipEventElapsedTime(&t, S.ev[0], S.ev[1]); last_ms[2] = t;
+    if (S.sort_hidden) (void)hipEventElapsedTime(&t, S.ev_s0, S.ev_s1);   // on sort_stream, underneath the previous task
+    else (void)hipEventElapsedTime(&t, S.ev[0], S.ev[1]);
+    last_ms[2] = t;
     (void)hipEventElapsedTime(&t, S.ev[1], S.ev[2]); last_ms[3] = t;
     (void)hipEventElapsedTime(&t, S.ev[2], S.ev[3]); last_ms[4] = t;
     (void)hipEventElapsedTime(&t, S.ev[3], S.ev[4]); last_ms[5] = t;

@@ -36,7 +36,11 @@ struct MsmSlot {
     // 0 start, 1 sort done, 2 accumulate done, 5..6 the accumulate kernel alone (stream);
     // 3 reduce done, 4 finish done (tail_stream)
     hipEvent_t ev[8] = {};
-    hipEvent_t ev_l0 = nullptr;    // stream: level-0 reduce written -> tail may start
+    hipEvent_t ev_l0 = nullptr;    // stream: level-0 reduce written -> tail may start (and this slot's sort outputs are free)
+    hipEvent_t ev_sorted = nullptr;  // the sort stage (sort, scans, unit lists) of this slot's task is complete
+    hipEvent_t ev_s0 = nullptr, ev_s1 = nullptr;  // timing of a hidden sort stage on sort_stream
+    bool sort_hidden = false;      // this task's sort ran on sort_stream
+    bool l0_recorded = false;      // ev_l0 has been recorded at least once
     hipEvent_t ev_done = nullptr;  // tail_stream: result bytes are in result_h
     DevBuf lvlA[2], lvlC[2];
     uint8_t* result_h = nullptr;   // pinned result bytes
@@ -64,7 +68,17 @@ struct MsmEngine {
     hipStream_t stream = nullptr, tail_stream = nullptr, aux_stream = nullptr;  // aux: combine_partials
     MsmSlot slots[MSM_QUEUE_DEPTH];
     int cur = 0;                   // slot of the task being enqueued
-    DevBuf count, off, unit_off, unit_bucket, unit_order, lenhist, coarse, inter, slice_map, entries, partial, blocksums, stats, result;
+    // What the digit sort of a task hands to its accumulation / reduce: one set per task slot, so that the sort of task
+    // k + 1 can run (on sort_stream, underneath task k's accumulation: msm_sort3.hip) while task k still reads its own.
+    struct SortBufs {
+        DevBuf count, off, unit_off, unit_bucket, unit_order, lenhist, entries, stats;
+    };
+    SortBufs sbuf[MSM_QUEUE_DEPTH];
+    SortBufs& sb() { return sbuf[cur]; }
+    hipStream_t sort_stream = nullptr;   // hidden sorts
+    hipStream_t sort_st = nullptr;       // the stream the CURRENT task's sort stage is being enqueued on (stream or sort_stream)
+    hipEvent_t last_sort_done = nullptr; // sorts share their scratch (coarse, inter, inter2, ...): each waits for the one before
+    DevBuf coarse, inter, inter2, slice_map, partial, blocksums, result, sort3_tabs;
     DevBuf bucket_sums, bucket_ident;   // slice-major tasks: running bucket sums across slices; identity unit_off for the reduce
     hipEvent_t inputs_event = nullptr;   // set by the caller of run(): recorded on `stream` once the task has read
                                          // its scalars / raw points (after the digit sort)
@@ -98,6 +112,10 @@ size_t mont_point_bytes(int curve);  // stride of the Montgomery point array the
 int msm_env_int(const char* name, int dflt);
 // two-level LDS-privatised digit sort (msm_sort.hip): fills count[], then (after the scan) entries[]
 int msm_sort_lds(MsmEngine& E, const void* d_scalars, uint32_t npts, int sbits);
+// three-level, small-footprint digit sort built to run underneath another task's k_accumulate (msm_sort3.hip): fills
+// count[] and entries[] of the current slot's SortBufs on E.sort_st; msm_sort3_ok: does the plan qualify
+bool msm_sort3_ok(const MsmPlan& P, int sbits);
+int msm_sort3(MsmEngine& E, const void* d_scalars, uint32_t npts);
 int msm_sort_lds_scatter(MsmEngine& E);
 int launch_fill_units(MsmEngine& E, uint32_t units);  // unit->bucket map + length-ordered unit list
 

@@ -586,22 +586,20 @@ __global__ __launch_bounds__(128, 2) void k_merge_buckets(const uint32_t* __rest
     }
 }
 
-// phase 1 after a digit sort: at most U units (the real count is in E.stats on the device)
+// phase 1 after a digit sort: at most U units (the real count is in E.sb().stats on the device)
 template <class F>
 int run_accumulate_t(MsmEngine& E, const void* d_pts, uint32_t U, int slice) {
     hipStream_t st = E.stream;
     MsmSlot& S = E.slots[E.cur];
     const MsmPlan& P = E.last_plan;
-    BLZ_TRY(E.unit_bucket.reserve(((size_t)U + 1) * 4));
     BLZ_TRY(E.partial.reserve(((size_t)U + 1) * 4 * partial_dwords<F>()));
-    if (slice <= 0) BLZ_HIP(hipEventRecord(S.ev[1], st), BLZ_ERR_UNKNOWN);   // (slice-major: the FIRST slice's sort is done)
+    if (slice <= 0) BLZ_HIP(hipEventRecord(S.ev[1], st), BLZ_ERR_UNKNOWN);   // (slice-major: the FIRST slice's sort stage is done)
     S.accum_timed = true;
-    BLZ_TRY(launch_fill_units(E, U));
     // ev5..ev6 (or the slice's pair) bracket the dominant kernel alone
     BLZ_HIP(hipEventRecord(slice < 0 ? S.ev[5] : S.slice_ev[2 * slice], st), BLZ_ERR_UNKNOWN);
     hipLaunchKernelGGL(k_accumulate<F>, dim3((U + 127) / 128), dim3(128), 0, st, (const uint32_t*)d_pts,
-                       E.entries.as<uint32_t>(), E.off.as<uint32_t>(), E.unit_off.as<uint32_t>(),
-                       E.unit_bucket.as<uint32_t>(), E.unit_order.as<uint32_t>(), E.stats.as<uint32_t>(), P.L,
+                       E.sb().entries.as<uint32_t>(), E.sb().off.as<uint32_t>(), E.sb().unit_off.as<uint32_t>(),
+                       E.sb().unit_bucket.as<uint32_t>(), E.sb().unit_order.as<uint32_t>(), E.sb().stats.as<uint32_t>(), P.L,
                        E.partial.as<uint32_t>());
     BLZ_HIP(hipEventRecord(slice < 0 ? S.ev[6] : S.slice_ev[2 * slice + 1], st), BLZ_ERR_UNKNOWN);
     const uint32_t maxunits = (P.npts + P.L - 1) / P.L;   // a bucket holds at most one entry per point
@@ -611,8 +609,8 @@ int run_accumulate_t(MsmEngine& E, const void* d_pts, uint32_t U, int slice) {
     // wrap to 0 - an endless launch loop)
     for (uint64_t stride = 1; stride < maxunits; stride *= 16)
         hipLaunchKernelGGL(k_combine_units<F>, dim3((uint32_t)((full_bound / 16 + 1) * 4 / 128 + 1)), dim3(128), 0, st,
-                           E.unit_off.as<uint32_t>(), E.unit_bucket.as<uint32_t>(), E.unit_order.as<uint32_t>(),
-                           E.lenhist.as<uint32_t>() + P.L, E.stats.as<uint32_t>(), P.L, (uint32_t)stride, E.partial.as<uint32_t>());
+                           E.sb().unit_off.as<uint32_t>(), E.sb().unit_bucket.as<uint32_t>(), E.sb().unit_order.as<uint32_t>(),
+                           E.sb().lenhist.as<uint32_t>() + P.L, E.sb().stats.as<uint32_t>(), P.L, (uint32_t)stride, E.partial.as<uint32_t>());
     BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
     return BLZ_OK;
 }
@@ -621,7 +619,7 @@ template <class F>
 int merge_buckets_t(MsmEngine& E) {
     const uint64_t G = E.last_plan.G;
     hipLaunchKernelGGL(k_merge_buckets<F>, dim3((uint32_t)((G + 127) / 128)), dim3(128), 0, E.stream, E.partial.as<uint32_t>(),
-                       E.unit_off.as<uint32_t>(), G, E.bucket_sums.as<uint32_t>());
+                       E.sb().unit_off.as<uint32_t>(), G, E.bucket_sums.as<uint32_t>());
     BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
     return BLZ_OK;
 }

@@ -499,7 +499,7 @@ static SortGeom make_geom(const MsmPlan& P) {
 
 int msm_sort_lds(MsmEngine& E, const void* d_scalars, uint32_t npts, int sbits) {
     const MsmPlan& P = E.last_plan;
-    hipStream_t st = E.stream;
+    hipStream_t st = E.sort_st;
     SortGeom g = make_geom(P);
     if (g.cl > 12 || g.NC > 24576u) return fail(BLZ_ERR_UNKNOWN, "sort geometry out of range (c=%d W=%d)", P.c, P.W);
     // points per block: enough entries per block to amortise the NC-sized LDS sweeps, enough blocks to fill the chip
@@ -552,13 +552,13 @@ int msm_sort_lds(MsmEngine& E, const void* d_scalars, uint32_t npts, int sbits) 
     E.sort_cl = g.cl;
     E.sort_nc = g.NC;
     hipLaunchKernelGGL(k_fine_count, dim3(max_slices), dim3(FINE_THREADS), (size_t)4 << g.cl, st, inter_fine, coarse_off,
-                       slice_map, nslices, g.cl, E.count.as<uint32_t>());
+                       slice_map, nslices, g.cl, E.sb().count.as<uint32_t>());
     BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
     return BLZ_OK;
 }
 
 int msm_sort_lds_scatter(MsmEngine& E) {
-    hipStream_t st = E.stream;
+    hipStream_t st = E.sort_st;
     uint32_t* coarse_off = E.coarse.as<uint32_t>() + E.sort_nc;
     BLZ_TRY(ensure_dynamic_lds((const void*)k_fine_scatter, 158 * 1024));
     // staging entries per round (6 bytes each): what is left of the LDS after the two per-bucket arrays
@@ -568,8 +568,8 @@ int msm_sort_lds_scatter(MsmEngine& E) {
     round_cap &= ~1023u;
     const size_t lds = ((size_t)2 << E.sort_cl) * 4 + (size_t)round_cap * 6;
     hipLaunchKernelGGL(k_fine_scatter, dim3(E.sort_slices), dim3(FS_THREADS), lds, st, E.inter.as<uint32_t>(), (const uint16_t*)E.sort_inter_fine, coarse_off,
-                       E.slice_map.as<uint2>() + 1, E.slice_map.as<uint32_t>(), E.sort_cl, round_cap, E.count.as<uint32_t>(),
-                       E.entries.as<uint32_t>());
+                       E.slice_map.as<uint2>() + 1, E.slice_map.as<uint32_t>(), E.sort_cl, round_cap, E.sb().count.as<uint32_t>(),
+                       E.sb().entries.as<uint32_t>());
     BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
     return BLZ_OK;
 }

@@ -1,0 +1,487 @@
+// Three-level digit sort with a small footprint, built to run UNDERNEATH another task's bucket accumulation.
+//
+// k_accumulate (2 waves x 200 VGPRs per SIMD, no LDS) leaves 112 VGPRs per SIMD, four wave slots and the whole LDS of
+// every CU idle, and ~85 % of the memory system: the digit sort of the NEXT task (msm_sort.hip: 10.9 ms of a 122 ms
+// step at 2^26) fits in there - if its kernels fit.  The two-level sort's do not (512 / 1024-thread blocks holding 16 - 24
+// entries per lane in registers), and shrinking them shrinks the runs they write: with 1024-way splits a 256-thread
+// block produces pieces of one or two entries, the memory system drowns in lone stores, and the accumulation above it
+// slows down by more than the sort costs alone (round 2 measured exactly that: profiles/r02_sort_under_accumulate.txt).
+// Hence three levels of at most 256 / 128 / 128 ways, so that a block of 256 lanes with 12 - 16 entries per lane still
+// writes pieces of 24 - 32 entries, every kernel at <= 96 VGPRs and 256 threads, wave priority raised (at equal priority
+// the accumulation's older waves starve the sort's):
+//
+//   bucket g (flat over the windows)  =  level-1 bin (g >> 14)  |  level-2 digit (7 bits)  |  level-3 digit (7 bits)
+//   k3_l1_count    scalars -> LDS histogram over the <= 2048 level-1 bins -> cnt1
+//   k3_l1_scatter  3072 scalars per block parked in LDS (lane-private, word-major: the block's register file stays
+//                  free), window by window: digits, LDS rank, bin-major stage, slot-major copy-out of
+//                  (index | sign : u32, low 14 bits of the bucket : u16) grouped by level-1 bin
+//   k3_l2_count / k3_l2_scatter   per slice of 4096 entries of a level-1 bin: 128-way split by the middle 7 bits;
+//                  out: (index | sign : u32, low 7 bits : u8) grouped by level-2 bin (= 128 consecutive buckets)
+//   k3_l3          one block per level-2 bin: bucket counts (-> count[], the scans of msm.hip turn them into off[] /
+//                  unit_off[]) and the bin's entries in bucket order, staged in LDS and written as one contiguous run
+//                  - the bin's position in entries[] is already final, no global bucket scan is needed before it
+// HBM traffic ~26 GB at 2^26 (the two-level sort: 18 GB) - it is hidden, what counts is that it is coalesced.
+// Same digits, same buckets as msm_sort.hip; the order of a bucket's entries differs (the group law does not care).
+// Used when another task of the handle is in flight (msm.hip run()); a task with nothing to hide under keeps the
+// two-level sort, which is faster when it has the chip to itself.  BLAZE_SORT_HIDE = 0 never / 2 always (tests).
+#include "msm_engine.hpp"
+#include "msm_digits.cuh"
+
+namespace blz {
+
+constexpr int S3_THREADS = 256;
+constexpr int S3_SH1 = 14;                      // level-1 bin = bucket >> 14
+constexpr int S3_SH2 = 7;                       // level-2 bin = bucket >> 7
+constexpr int S3_T = 12;                        // scalars per lane of the level-1 scatter
+constexpr int S3_PB = S3_THREADS * S3_T;        // 3072 points per block: 96 KiB of scalars + 24 KiB of stage
+constexpr uint32_t S3_SLICE2 = 4096;            // entries per level-2 work item (16 per lane)
+constexpr int S3_T2 = S3_SLICE2 / S3_THREADS;
+constexpr uint32_t S3_R3 = 8192;                // level 3 stages a bin of up to this many entries in LDS (mean at 2^26: 5.8 K)
+constexpr uint32_t S3_MAXNB1 = 2048;            // level-1 bins in all (LDS histogram of k3_l1_count)
+constexpr uint32_t S3_CNT_PTS = 16384;          // points per block of k3_l1_count
+
+struct S3Geom {
+    int W;
+    uint32_t NB1;
+    uint8_t width[MSM_MAX_W];
+    uint16_t bitoff[MSM_MAX_W];        // first scalar bit of window w
+    uint16_t binoff1[MSM_MAX_W + 1];   // first level-1 bin of window w
+};
+
+#define S3_PRIO() __builtin_amdgcn_s_setprio(3)
+
+__device__ __forceinline__ uint32_t s3_wave_incl_scan(uint32_t v) {
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t t = __shfl_up(v, o, 64);
+        if ((threadIdx.x & 63u) >= (uint32_t)o) v += t;
+    }
+    return v;
+}
+// exclusive scan of one value per thread over the block's 256 threads; returns the exclusive prefix, *total = sum
+__device__ __forceinline__ uint32_t s3_block_excl_scan(uint32_t v, uint32_t* wave_tot, uint32_t* total) {
+    const uint32_t incl = s3_wave_incl_scan(v);
+    if ((threadIdx.x & 63u) == 63u) wave_tot[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (uint32_t q = 0; q < (threadIdx.x >> 6); ++q) wbase += wave_tot[q];
+    *total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+    return wbase + incl - v;
+}
+
+// ---------------------------------------------------------------------------------------------- level 1
+__global__ __launch_bounds__(S3_THREADS, 4) void k3_l1_count(const uint32_t* __restrict__ scalars, uint32_t npts, S3Geom g,
+                                                            uint32_t* __restrict__ cnt1) {
+    S3_PRIO();
+    __shared__ uint32_t hist[S3_MAXNB1];
+    for (uint32_t i = threadIdx.x; i < g.NB1; i += S3_THREADS) hist[i] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * S3_CNT_PTS;
+    uint32_t end = base + S3_CNT_PTS;
+    if (end > npts) end = npts;
+    for (uint32_t p0 = base + threadIdx.x; p0 < end; p0 += 4 * S3_THREADS) {
+        ScalarWords<8> sw[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t p = p0 + u * S3_THREADS;
+            sw[u].load(scalars, p < end ? p : p0);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (p0 + u * S3_THREADS >= end) break;
+            uint32_t carry = 0;
+            for (int w = 0; w < g.W; ++w) {
+                const int cw = g.width[w];
+                const int d = sw[u].next(cw, (1u << cw) - 1u, 1u << (cw - 1), carry);
+                if (d != 0) {
+                    const uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1u;
+                    atomicAdd(&hist[g.binoff1[w] + (b >> S3_SH1)], 1u);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < g.NB1; i += S3_THREADS) {
+        const uint32_t v = hist[i];
+        if (v) atomicAdd(&cnt1[i], v);
+    }
+}
+
+// exclusive scan of n <= 2048 counters (one block): off[0..n], cur[i] = off[i]
+__global__ __launch_bounds__(S3_THREADS) void k3_scan_small(const uint32_t* __restrict__ cnt, uint32_t n, uint32_t* __restrict__ off,
+                                                           uint32_t* __restrict__ cur) {
+    S3_PRIO();
+    __shared__ uint32_t wave_tot[4];
+    uint32_t v[8], sum = 0;
+    const uint32_t b0 = threadIdx.x * 8u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        v[k] = b0 + k < n ? cnt[b0 + k] : 0u;
+        sum += v[k];
+    }
+    uint32_t total;
+    uint32_t run = s3_block_excl_scan(sum, wave_tot, &total);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (b0 + k < n) {
+            off[b0 + k] = run;
+            cur[b0 + k] = run;
+        }
+        run += v[k];
+    }
+    if (threadIdx.x == 0) off[n] = total;
+}
+
+__global__ __launch_bounds__(S3_THREADS, 4) void k3_l1_scatter(const uint32_t* __restrict__ scalars, uint32_t npts, S3Geom g,
+                                                              uint32_t* __restrict__ cur1, uint32_t* __restrict__ o_idx,
+                                                              uint16_t* __restrict__ o_rem) {
+    S3_PRIO();
+    extern __shared__ __attribute__((aligned(16))) uint32_t sh[];
+    uint32_t* sc = sh;                                          // [8][S3_PB]: word j of the lane's scalar u at j * PB + u * 256 + tid
+    uint2* stage = reinterpret_cast<uint2*>(sh + 8 * S3_PB);    // [S3_PB]
+    uint32_t* hist = sh + 10 * S3_PB;                           // [256]
+    uint32_t* lstart = hist + 256;
+    uint32_t* gbase = lstart + 256;
+    __shared__ uint32_t wave_tot[4];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t base = blockIdx.x * (uint32_t)S3_PB;
+    // the scalars are lane-private: LDS is this block's register spill area, nobody else reads a lane's words
+#pragma unroll
+    for (int u = 0; u < S3_T; ++u) {
+        const uint32_t p = base + u * S3_THREADS + tid;
+        uint4 a = make_uint4(0, 0, 0, 0), b = make_uint4(0, 0, 0, 0);
+        if (p < npts) {
+            const uint4* q = reinterpret_cast<const uint4*>(scalars) + 2 * (size_t)p;
+            a = q[0];
+            b = q[1];
+        }
+        const uint32_t i = u * S3_THREADS + tid;
+        sc[0 * S3_PB + i] = a.x; sc[1 * S3_PB + i] = a.y; sc[2 * S3_PB + i] = a.z; sc[3 * S3_PB + i] = a.w;
+        sc[4 * S3_PB + i] = b.x; sc[5 * S3_PB + i] = b.y; sc[6 * S3_PB + i] = b.z; sc[7 * S3_PB + i] = b.w;
+    }
+    uint32_t carry = 0;   // bit u: the carry of the lane's scalar u into the next window
+    for (int w = 0; w < g.W; ++w) {
+        const uint32_t cw = g.width[w], off = g.bitoff[w];
+        const uint32_t nb = (uint32_t)g.binoff1[w + 1] - (uint32_t)g.binoff1[w];   // <= 256
+        const uint32_t j = off >> 5, shb = off & 31u, mask = (1u << cw) - 1u, half = 1u << (cw - 1);
+        if (tid < nb) hist[tid] = 0;
+        __syncthreads();
+        uint32_t key[S3_T], rk[S3_T];   // key = low 14 bits | bin << 14 | sign << 31;  rk = rank in the bin, ~0 = no entry
+#pragma unroll
+        for (int u = 0; u < S3_T; ++u) {
+            const uint32_t i = u * S3_THREADS + tid;
+            const uint32_t lo = j < 8 ? sc[j * S3_PB + i] : 0u;
+            const uint32_t hi = j + 1 < 8 ? sc[(j + 1) * S3_PB + i] : 0u;
+            const uint32_t raw = (shb ? __builtin_amdgcn_alignbit(hi, lo, shb) : lo) & mask;
+            const uint32_t v = raw + ((carry >> u) & 1u);
+            int d;
+            if (v > half) { d = (int)v - (int)(half << 1); carry |= 1u << u; }
+            else { d = (int)v; carry &= ~(1u << u); }
+            rk[u] = ~0u;
+            key[u] = 0;
+            if (d != 0 && base + i < npts) {
+                const uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1u;
+                const uint32_t bin = b >> S3_SH1;
+                key[u] = (b & 0x3fffu) | (bin << 14) | (d < 0 ? 0x80000000u : 0u);
+                rk[u] = atomicAdd(&hist[bin], 1u);
+            }
+        }
+        __syncthreads();
+        {   // exclusive scan over the window's bins (one per thread) + one global reservation per non-empty bin
+            const uint32_t v = tid < nb ? hist[tid] : 0u;
+            uint32_t total;
+            const uint32_t excl = s3_block_excl_scan(v, wave_tot, &total);
+            if (tid < nb) {
+                lstart[tid] = excl;
+                gbase[tid] = v ? atomicAdd(&cur1[(uint32_t)g.binoff1[w] + tid], v) : 0u;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < S3_T; ++u) {
+                if (rk[u] != ~0u) {
+                    const uint32_t bin = (key[u] >> 14) & 0x1ffu;
+                    const uint32_t p = base + u * S3_THREADS + tid;
+                    stage[lstart[bin] + rk[u]] = make_uint2(p | (key[u] & 0x80000000u), (key[u] & 0x3fffu) | (bin << 16));
+                }
+            }
+            __syncthreads();
+            for (uint32_t slot = tid; slot < total; slot += S3_THREADS) {
+                const uint2 e = stage[slot];
+                const uint32_t bin = e.y >> 16;
+                const uint32_t dst = gbase[bin] + (slot - lstart[bin]);
+                o_idx[dst] = e.x;
+                o_rem[dst] = (uint16_t)e.y;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- work lists and scans
+// bin k (off[k] .. off[k+1]) cut into ceil(size / slice) work items (k, piece); one block, no host round trip
+__global__ __launch_bounds__(S3_THREADS) void k3_slice_map(const uint32_t* __restrict__ off, uint32_t nbins, uint32_t slice,
+                                                          uint2* __restrict__ map, uint32_t* __restrict__ nitems) {
+    S3_PRIO();
+    __shared__ uint32_t wave_tot[4];
+    __shared__ uint32_t carry_sh;
+    if (threadIdx.x == 0) carry_sh = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nbins; base += S3_THREADS) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t size = i < nbins ? off[i + 1] - off[i] : 0u;
+        const uint32_t v = (size + slice - 1) / slice;
+        uint32_t total;
+        const uint32_t excl = s3_block_excl_scan(v, wave_tot, &total);
+        const uint32_t first = carry_sh + excl;
+        for (uint32_t q = 0; q < v; ++q) map[first + q] = make_uint2(i, q);
+        __syncthreads();
+        if (threadIdx.x == 0) carry_sh += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *nitems = carry_sh;
+}
+
+// three-kernel exclusive scan of n counters (n <= 2048 * 256): block sums, their scan, final
+__global__ __launch_bounds__(S3_THREADS) void k3_scan_a(const uint32_t* __restrict__ cnt, uint32_t n, uint32_t* __restrict__ bsum) {
+    S3_PRIO();
+    __shared__ uint32_t wave_tot[4];
+    const uint32_t b0 = blockIdx.x * 2048u + threadIdx.x * 8u;
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sum += b0 + k < n ? cnt[b0 + k] : 0u;
+    uint32_t total;
+    (void)s3_block_excl_scan(sum, wave_tot, &total);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(S3_THREADS) void k3_scan_b(uint32_t* __restrict__ bsum, uint32_t nblocks) {   // nblocks <= 256
+    S3_PRIO();
+    __shared__ uint32_t wave_tot[4];
+    const uint32_t v = threadIdx.x < nblocks ? bsum[threadIdx.x] : 0u;
+    uint32_t total;
+    const uint32_t excl = s3_block_excl_scan(v, wave_tot, &total);
+    if (threadIdx.x < nblocks) bsum[threadIdx.x] = excl;
+    if (threadIdx.x == 0) bsum[256] = total;
+}
+__global__ __launch_bounds__(S3_THREADS) void k3_scan_c(const uint32_t* __restrict__ cnt, uint32_t n, const uint32_t* __restrict__ bsum,
+                                                       uint32_t* __restrict__ off, uint32_t* __restrict__ cur) {
+    S3_PRIO();
+    __shared__ uint32_t wave_tot[4];
+    const uint32_t b0 = blockIdx.x * 2048u + threadIdx.x * 8u;
+    uint32_t v[8], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        v[k] = b0 + k < n ? cnt[b0 + k] : 0u;
+        sum += v[k];
+    }
+    uint32_t total;
+    uint32_t run = bsum[blockIdx.x] + s3_block_excl_scan(sum, wave_tot, &total);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (b0 + k < n) {
+            off[b0 + k] = run;
+            cur[b0 + k] = run;
+        }
+        run += v[k];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) off[n] = bsum[256];
+}
+
+// ---------------------------------------------------------------------------------------------- level 2
+__device__ __forceinline__ bool s3_item(const uint32_t* off1, const uint2* map, const uint32_t* nitems, uint32_t id, uint32_t slice,
+                                        uint32_t& k, uint32_t& lo, uint32_t& hi) {
+    if (id >= *nitems) return false;
+    const uint2 m = map[id];
+    k = m.x;
+    const uint32_t a = off1[k], b = off1[k + 1];
+    lo = a + m.y * slice;
+    hi = lo + slice < b ? lo + slice : b;
+    return lo < hi;
+}
+
+__global__ __launch_bounds__(S3_THREADS, 4) void k3_l2_count(const uint16_t* __restrict__ rem, const uint32_t* __restrict__ off1,
+                                                            const uint2* __restrict__ map, const uint32_t* __restrict__ nitems,
+                                                            uint32_t* __restrict__ cnt2) {
+    S3_PRIO();
+    __shared__ uint32_t hist[128];
+    uint32_t k, lo, hi;
+    if (!s3_item(off1, map, nitems, blockIdx.x, S3_SLICE2, k, lo, hi)) return;
+    if (threadIdx.x < 128) hist[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t r[S3_T2];
+#pragma unroll
+    for (int t = 0; t < S3_T2; ++t) {
+        const uint32_t i = lo + t * S3_THREADS + threadIdx.x;
+        r[t] = i < hi ? rem[i] : 0xffffffffu;
+    }
+#pragma unroll
+    for (int t = 0; t < S3_T2; ++t)
+        if (r[t] != 0xffffffffu) atomicAdd(&hist[r[t] >> S3_SH2], 1u);
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const uint32_t v = hist[threadIdx.x];
+        if (v) atomicAdd(&cnt2[(k << 7) + threadIdx.x], v);
+    }
+}
+
+__global__ __launch_bounds__(S3_THREADS, 4) void k3_l2_scatter(const uint32_t* __restrict__ i_idx, const uint16_t* __restrict__ i_rem,
+                                                              const uint32_t* __restrict__ off1, const uint2* __restrict__ map,
+                                                              const uint32_t* __restrict__ nitems, uint32_t* __restrict__ cur2,
+                                                              uint32_t* __restrict__ o_idx, uint8_t* __restrict__ o_lo) {
+    S3_PRIO();
+    __shared__ uint2 stage[S3_SLICE2];
+    __shared__ uint32_t hist[128], lstart[128], gbase[128];
+    __shared__ uint32_t wave_tot[4];
+    uint32_t k, lo, hi;
+    if (!s3_item(off1, map, nitems, blockIdx.x, S3_SLICE2, k, lo, hi)) return;
+    const uint32_t tid = threadIdx.x;
+    if (tid < 128) hist[tid] = 0;
+    __syncthreads();
+    uint32_t ex[S3_T2], ky[S3_T2];   // ky = low 7 bits | level-2 digit << 8 | rank << 16; ~0 = no entry
+#pragma unroll
+    for (int t = 0; t < S3_T2; ++t) {
+        const uint32_t i = lo + t * S3_THREADS + tid;
+        ky[t] = 0xffffffffu;
+        ex[t] = 0;
+        if (i < hi) {
+            const uint32_t r = i_rem[i];
+            ex[t] = i_idx[i];
+            const uint32_t h2 = r >> S3_SH2;
+            const uint32_t rank = atomicAdd(&hist[h2], 1u);   // < 4096
+            ky[t] = (r & 127u) | (h2 << 8) | (rank << 16);
+        }
+    }
+    __syncthreads();
+    const uint32_t v = tid < 128 ? hist[tid] : 0u;
+    uint32_t total;
+    const uint32_t excl = s3_block_excl_scan(v, wave_tot, &total);
+    if (tid < 128) {
+        lstart[tid] = excl;
+        gbase[tid] = v ? atomicAdd(&cur2[(k << 7) + tid], v) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < S3_T2; ++t) {
+        if (ky[t] != 0xffffffffu) {
+            const uint32_t h2 = (ky[t] >> 8) & 127u;
+            stage[lstart[h2] + (ky[t] >> 16)] = make_uint2(ex[t], ky[t] & 0x7fffu);
+        }
+    }
+    __syncthreads();
+    for (uint32_t slot = tid; slot < total; slot += S3_THREADS) {
+        const uint2 e = stage[slot];
+        const uint32_t h2 = (e.y >> 8) & 127u;
+        const uint32_t dst = gbase[h2] + (slot - lstart[h2]);
+        o_idx[dst] = e.x;
+        o_lo[dst] = (uint8_t)(e.y & 127u);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- level 3
+// one block per level-2 bin (128 consecutive buckets): bucket counts, then the bin's entries in bucket order.  The bin's
+// run [off2[j], off2[j+1]) of entries[] is final already: buckets are laid out in order and a bin is a whole group of
+// them.  A bin of up to S3_R3 entries is staged in LDS and leaves as one contiguous copy; a larger one (hot buckets: the
+// reference harness's repeated tile) is written entry by entry - correct, slow, and not what this path is chosen for.
+__global__ __launch_bounds__(S3_THREADS, 4) void k3_l3(const uint32_t* __restrict__ i_idx, const uint8_t* __restrict__ i_lo,
+                                                      const uint32_t* __restrict__ off2, uint32_t* __restrict__ count,
+                                                      uint32_t* __restrict__ entries) {
+    S3_PRIO();
+    __shared__ uint32_t out[S3_R3];
+    __shared__ uint32_t hist[128], cursor[128];
+    __shared__ uint32_t wave_tot[4];
+    const uint32_t j = blockIdx.x, tid = threadIdx.x;
+    const uint32_t a = off2[j], b = off2[j + 1], s = b - a;
+    if (tid < 128) hist[tid] = 0;
+    __syncthreads();
+    for (uint32_t i = a + tid; i < b; i += S3_THREADS) atomicAdd(&hist[i_lo[i]], 1u);
+    __syncthreads();
+    const uint32_t v = tid < 128 ? hist[tid] : 0u;
+    uint32_t total;
+    const uint32_t excl = s3_block_excl_scan(v, wave_tot, &total);
+    if (tid < 128) {
+        count[((size_t)j << 7) + tid] = v;
+        cursor[tid] = excl;
+    }
+    __syncthreads();
+    if (s <= S3_R3) {
+        for (uint32_t i = a + tid; i < b; i += S3_THREADS) {
+            const uint32_t pos = atomicAdd(&cursor[i_lo[i]], 1u);
+            out[pos] = i_idx[i];
+        }
+        __syncthreads();
+        for (uint32_t t = tid; t < s; t += S3_THREADS) entries[a + t] = out[t];
+    } else {
+        for (uint32_t i = a + tid; i < b; i += S3_THREADS) {
+            const uint32_t pos = atomicAdd(&cursor[i_lo[i]], 1u);
+            entries[a + pos] = i_idx[i];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- host
+bool msm_sort3_ok(const MsmPlan& P, int sbits) {
+    if (sbits != 256 || P.W < 1) return false;
+    for (int w = 0; w < P.W; ++w)
+        if (P.width[w] < S3_SH1 + 1 || P.width[w] > 23) return false;   // every window a whole number of level-1 bins, <= 256 of them
+    if ((P.G >> S3_SH1) > S3_MAXNB1 || (P.G & ((1u << S3_SH1) - 1u))) return false;
+    if ((P.G >> S3_SH2) > 2048u * 256u) return false;
+    return true;
+}
+
+int msm_sort3(MsmEngine& E, const void* d_scalars, uint32_t npts) {
+    const MsmPlan& P = E.last_plan;
+    hipStream_t st = E.sort_st;
+    MsmEngine::SortBufs& B = E.sb();
+    S3Geom g;
+    g.W = P.W;
+    g.NB1 = (uint32_t)(P.G >> S3_SH1);
+    uint32_t bit = 0;
+    for (int w = 0; w < P.W; ++w) {
+        g.width[w] = P.width[w];
+        g.bitoff[w] = (uint16_t)bit;
+        g.binoff1[w] = (uint16_t)(P.boff[w] >> S3_SH1);
+        bit += P.width[w];
+    }
+    g.binoff1[P.W] = (uint16_t)(P.boff[P.W] >> S3_SH1);
+    const uint32_t NB1 = g.NB1, NB2 = (uint32_t)(P.G >> S3_SH2);
+    const uint64_t max_entries = (uint64_t)npts * P.W;
+    const uint32_t max_items = (uint32_t)(max_entries / S3_SLICE2) + NB1 + 1;
+    const uint32_t nsb = (NB2 + 2047u) / 2048u;
+    // tables: cnt1 | off1 (+1) | cur1 | cnt2 | off2 (+1) | cur2 | bsum (257) | nitems (1, padded) | map (uint2 per item)
+    const size_t tab_dw = (size_t)3 * (NB1 + 2) + (size_t)3 * (NB2 + 2) + 260 + 4 + 2 * ((size_t)max_items + 2);
+    BLZ_TRY(E.sort3_tabs.reserve(tab_dw * 4));
+    uint32_t* cnt1 = E.sort3_tabs.as<uint32_t>();
+    uint32_t* off1 = cnt1 + NB1 + 2;
+    uint32_t* cur1 = off1 + NB1 + 2;
+    uint32_t* cnt2 = cur1 + NB1 + 2;
+    uint32_t* off2 = cnt2 + NB2 + 2;
+    uint32_t* cur2 = off2 + NB2 + 2;
+    uint32_t* bsum = cur2 + NB2 + 2;
+    uint32_t* nitems = bsum + 260;
+    uint2* map = reinterpret_cast<uint2*>(nitems + 4);
+    BLZ_TRY(E.inter.reserve(max_entries * 6 + 64));
+    BLZ_TRY(E.inter2.reserve(max_entries * 5 + 64));
+    uint32_t* i1_idx = E.inter.as<uint32_t>();
+    uint16_t* i1_rem = reinterpret_cast<uint16_t*>(i1_idx + max_entries);
+    uint32_t* i2_idx = E.inter2.as<uint32_t>();
+    uint8_t* i2_lo = reinterpret_cast<uint8_t*>(i2_idx + max_entries);
+    const uint32_t* sc = (const uint32_t*)d_scalars;
+    const dim3 blk(S3_THREADS);
+
+    BLZ_HIP(hipMemsetAsync(cnt1, 0, (size_t)(NB1 + 2) * 4, st), BLZ_ERR_UNKNOWN);
+    BLZ_HIP(hipMemsetAsync(cnt2, 0, (size_t)(NB2 + 2) * 4, st), BLZ_ERR_UNKNOWN);
+    hipLaunchKernelGGL(k3_l1_count, dim3((npts + S3_CNT_PTS - 1) / S3_CNT_PTS), blk, 0, st, sc, npts, g, cnt1);
+    hipLaunchKernelGGL(k3_scan_small, dim3(1), blk, 0, st, cnt1, NB1, off1, cur1);
+    const size_t lds1 = (size_t)(10 * S3_PB + 3 * 256) * 4;
+    BLZ_TRY(ensure_dynamic_lds((const void*)k3_l1_scatter, (int)lds1));
+    hipLaunchKernelGGL(k3_l1_scatter, dim3((npts + S3_PB - 1) / S3_PB), blk, lds1, st, sc, npts, g, cur1, i1_idx, i1_rem);
+    hipLaunchKernelGGL(k3_slice_map, dim3(1), blk, 0, st, off1, NB1, S3_SLICE2, map, nitems);
+    hipLaunchKernelGGL(k3_l2_count, dim3(max_items), blk, 0, st, i1_rem, off1, map, nitems, cnt2);
+    hipLaunchKernelGGL(k3_scan_a, dim3(nsb), blk, 0, st, cnt2, NB2, bsum);
+    hipLaunchKernelGGL(k3_scan_b, dim3(1), blk, 0, st, bsum, nsb);
+    hipLaunchKernelGGL(k3_scan_c, dim3(nsb), blk, 0, st, cnt2, NB2, bsum, off2, cur2);
+    hipLaunchKernelGGL(k3_l2_scatter, dim3(max_items), blk, 0, st, i1_idx, i1_rem, off1, map, nitems, cur2, i2_idx, i2_lo);
+    hipLaunchKernelGGL(k3_l3, dim3(NB2), blk, 0, st, i2_idx, i2_lo, off2, B.count.as<uint32_t>(), B.entries.as<uint32_t>());
+    BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
+    return BLZ_OK;
+}
+
+}  // namespace blz
