@@ -41,14 +41,20 @@ constexpr uint32_t S3_MAXNB1 = 2048;            // level-1 bins in all (LDS hist
 constexpr uint32_t S3_CNT_PTS = 16384;          // points per block of k3_l1_count
 
 struct S3Geom {
-    int W;
+    int W, prio;
     uint32_t NB1;
     uint8_t width[MSM_MAX_W];
     uint16_t bitoff[MSM_MAX_W];        // first scalar bit of window w
     uint16_t binoff1[MSM_MAX_W + 1];   // first level-1 bin of window w
 };
 
-#define S3_PRIO() __builtin_amdgcn_s_setprio(3)
+// wave priority of the sort's kernels (s_setprio takes an immediate); BLAZE_SORT_PRIO = 0..3, default 3
+__device__ __forceinline__ void s3_setprio(int p) {
+    if (p >= 3) __builtin_amdgcn_s_setprio(3);
+    else if (p == 2) __builtin_amdgcn_s_setprio(2);
+    else if (p == 1) __builtin_amdgcn_s_setprio(1);
+}
+#define S3_PRIO() s3_setprio(prio)
 
 __device__ __forceinline__ uint32_t s3_wave_incl_scan(uint32_t v) {
     for (int o = 1; o < 64; o <<= 1) {
@@ -71,6 +77,7 @@ __device__ __forceinline__ uint32_t s3_block_excl_scan(uint32_t v, uint32_t* wav
 // ---------------------------------------------------------------------------------------------- level 1
 __global__ __launch_bounds__(S3_THREADS, 4) void k3_l1_count(const uint32_t* __restrict__ scalars, uint32_t npts, S3Geom g,
                                                             uint32_t* __restrict__ cnt1) {
+    const int prio = g.prio;
     S3_PRIO();
     __shared__ uint32_t hist[S3_MAXNB1];
     for (uint32_t i = threadIdx.x; i < g.NB1; i += S3_THREADS) hist[i] = 0;
@@ -108,7 +115,7 @@ __global__ __launch_bounds__(S3_THREADS, 4) void k3_l1_count(const uint32_t* __r
 
 // exclusive scan of n <= 2048 counters (one block): off[0..n], cur[i] = off[i]
 __global__ __launch_bounds__(S3_THREADS) void k3_scan_small(const uint32_t* __restrict__ cnt, uint32_t n, uint32_t* __restrict__ off,
-                                                           uint32_t* __restrict__ cur) {
+                                                           uint32_t* __restrict__ cur, int prio) {
     S3_PRIO();
     __shared__ uint32_t wave_tot[4];
     uint32_t v[8], sum = 0;
@@ -134,6 +141,7 @@ __global__ __launch_bounds__(S3_THREADS) void k3_scan_small(const uint32_t* __re
 __global__ __launch_bounds__(S3_THREADS, 4) void k3_l1_scatter(const uint32_t* __restrict__ scalars, uint32_t npts, S3Geom g,
                                                               uint32_t* __restrict__ cur1, uint32_t* __restrict__ o_idx,
                                                               uint16_t* __restrict__ o_rem) {
+    const int prio = g.prio;
     S3_PRIO();
     extern __shared__ __attribute__((aligned(16))) uint32_t sh[];
     uint32_t* sc = sh;                                          // [8][S3_PB]: word j of the lane's scalar u at j * PB + u * 256 + tid
@@ -219,7 +227,7 @@ __global__ __launch_bounds__(S3_THREADS, 4) void k3_l1_scatter(const uint32_t* _
 // ---------------------------------------------------------------------------------------------- work lists and scans
 // bin k (off[k] .. off[k+1]) cut into ceil(size / slice) work items (k, piece); one block, no host round trip
 __global__ __launch_bounds__(S3_THREADS) void k3_slice_map(const uint32_t* __restrict__ off, uint32_t nbins, uint32_t slice,
-                                                          uint2* __restrict__ map, uint32_t* __restrict__ nitems) {
+                                                          uint2* __restrict__ map, uint32_t* __restrict__ nitems, int prio) {
     S3_PRIO();
     __shared__ uint32_t wave_tot[4];
     __shared__ uint32_t carry_sh;
@@ -241,7 +249,7 @@ __global__ __launch_bounds__(S3_THREADS) void k3_slice_map(const uint32_t* __res
 }
 
 // three-kernel exclusive scan of n counters (n <= 2048 * 256): block sums, their scan, final
-__global__ __launch_bounds__(S3_THREADS) void k3_scan_a(const uint32_t* __restrict__ cnt, uint32_t n, uint32_t* __restrict__ bsum) {
+__global__ __launch_bounds__(S3_THREADS) void k3_scan_a(const uint32_t* __restrict__ cnt, uint32_t n, uint32_t* __restrict__ bsum, int prio) {
     S3_PRIO();
     __shared__ uint32_t wave_tot[4];
     const uint32_t b0 = blockIdx.x * 2048u + threadIdx.x * 8u;
@@ -252,7 +260,7 @@ __global__ __launch_bounds__(S3_THREADS) void k3_scan_a(const uint32_t* __restri
     (void)s3_block_excl_scan(sum, wave_tot, &total);
     if (threadIdx.x == 0) bsum[blockIdx.x] = total;
 }
-__global__ __launch_bounds__(S3_THREADS) void k3_scan_b(uint32_t* __restrict__ bsum, uint32_t nblocks) {   // nblocks <= 256
+__global__ __launch_bounds__(S3_THREADS) void k3_scan_b(uint32_t* __restrict__ bsum, uint32_t nblocks, int prio) {   // nblocks <= 256
     S3_PRIO();
     __shared__ uint32_t wave_tot[4];
     const uint32_t v = threadIdx.x < nblocks ? bsum[threadIdx.x] : 0u;
@@ -262,7 +270,7 @@ __global__ __launch_bounds__(S3_THREADS) void k3_scan_b(uint32_t* __restrict__ b
     if (threadIdx.x == 0) bsum[256] = total;
 }
 __global__ __launch_bounds__(S3_THREADS) void k3_scan_c(const uint32_t* __restrict__ cnt, uint32_t n, const uint32_t* __restrict__ bsum,
-                                                       uint32_t* __restrict__ off, uint32_t* __restrict__ cur) {
+                                                       uint32_t* __restrict__ off, uint32_t* __restrict__ cur, int prio) {
     S3_PRIO();
     __shared__ uint32_t wave_tot[4];
     const uint32_t b0 = blockIdx.x * 2048u + threadIdx.x * 8u;
@@ -299,7 +307,7 @@ __device__ __forceinline__ bool s3_item(const uint32_t* off1, const uint2* map, 
 
 __global__ __launch_bounds__(S3_THREADS, 4) void k3_l2_count(const uint16_t* __restrict__ rem, const uint32_t* __restrict__ off1,
                                                             const uint2* __restrict__ map, const uint32_t* __restrict__ nitems,
-                                                            uint32_t* __restrict__ cnt2) {
+                                                            uint32_t* __restrict__ cnt2, int prio) {
     S3_PRIO();
     __shared__ uint32_t hist[128];
     uint32_t k, lo, hi;
@@ -325,7 +333,7 @@ __global__ __launch_bounds__(S3_THREADS, 4) void k3_l2_count(const uint16_t* __r
 __global__ __launch_bounds__(S3_THREADS, 4) void k3_l2_scatter(const uint32_t* __restrict__ i_idx, const uint16_t* __restrict__ i_rem,
                                                               const uint32_t* __restrict__ off1, const uint2* __restrict__ map,
                                                               const uint32_t* __restrict__ nitems, uint32_t* __restrict__ cur2,
-                                                              uint32_t* __restrict__ o_idx, uint8_t* __restrict__ o_lo) {
+                                                              uint32_t* __restrict__ o_idx, uint8_t* __restrict__ o_lo, int prio) {
     S3_PRIO();
     __shared__ uint2 stage[S3_SLICE2];
     __shared__ uint32_t hist[128], lstart[128], gbase[128];
@@ -382,7 +390,7 @@ __global__ __launch_bounds__(S3_THREADS, 4) void k3_l2_scatter(const uint32_t* _
 // reference harness's repeated tile) is written entry by entry - correct, slow, and not what this path is chosen for.
 __global__ __launch_bounds__(S3_THREADS, 4) void k3_l3(const uint32_t* __restrict__ i_idx, const uint8_t* __restrict__ i_lo,
                                                       const uint32_t* __restrict__ off2, uint32_t* __restrict__ count,
-                                                      uint32_t* __restrict__ entries) {
+                                                      uint32_t* __restrict__ entries, int prio) {
     S3_PRIO();
     __shared__ uint32_t out[S3_R3];
     __shared__ uint32_t hist[128], cursor[128];
@@ -432,6 +440,7 @@ int msm_sort3(MsmEngine& E, const void* d_scalars, uint32_t npts) {
     MsmEngine::SortBufs& B = E.sb();
     S3Geom g;
     g.W = P.W;
+    g.prio = msm_env_int("BLAZE_SORT_PRIO", 3);
     g.NB1 = (uint32_t)(P.G >> S3_SH1);
     uint32_t bit = 0;
     for (int w = 0; w < P.W; ++w) {
@@ -469,17 +478,17 @@ int msm_sort3(MsmEngine& E, const void* d_scalars, uint32_t npts) {
     BLZ_HIP(hipMemsetAsync(cnt1, 0, (size_t)(NB1 + 2) * 4, st), BLZ_ERR_UNKNOWN);
     BLZ_HIP(hipMemsetAsync(cnt2, 0, (size_t)(NB2 + 2) * 4, st), BLZ_ERR_UNKNOWN);
     hipLaunchKernelGGL(k3_l1_count, dim3((npts + S3_CNT_PTS - 1) / S3_CNT_PTS), blk, 0, st, sc, npts, g, cnt1);
-    hipLaunchKernelGGL(k3_scan_small, dim3(1), blk, 0, st, cnt1, NB1, off1, cur1);
+    hipLaunchKernelGGL(k3_scan_small, dim3(1), blk, 0, st, cnt1, NB1, off1, cur1, g.prio);
     const size_t lds1 = (size_t)(10 * S3_PB + 3 * 256) * 4;
     BLZ_TRY(ensure_dynamic_lds((const void*)k3_l1_scatter, (int)lds1));
     hipLaunchKernelGGL(k3_l1_scatter, dim3((npts + S3_PB - 1) / S3_PB), blk, lds1, st, sc, npts, g, cur1, i1_idx, i1_rem);
-    hipLaunchKernelGGL(k3_slice_map, dim3(1), blk, 0, st, off1, NB1, S3_SLICE2, map, nitems);
-    hipLaunchKernelGGL(k3_l2_count, dim3(max_items), blk, 0, st, i1_rem, off1, map, nitems, cnt2);
-    hipLaunchKernelGGL(k3_scan_a, dim3(nsb), blk, 0, st, cnt2, NB2, bsum);
-    hipLaunchKernelGGL(k3_scan_b, dim3(1), blk, 0, st, bsum, nsb);
-    hipLaunchKernelGGL(k3_scan_c, dim3(nsb), blk, 0, st, cnt2, NB2, bsum, off2, cur2);
-    hipLaunchKernelGGL(k3_l2_scatter, dim3(max_items), blk, 0, st, i1_idx, i1_rem, off1, map, nitems, cur2, i2_idx, i2_lo);
-    hipLaunchKernelGGL(k3_l3, dim3(NB2), blk, 0, st, i2_idx, i2_lo, off2, B.count.as<uint32_t>(), B.entries.as<uint32_t>());
+    hipLaunchKernelGGL(k3_slice_map, dim3(1), blk, 0, st, off1, NB1, S3_SLICE2, map, nitems, g.prio);
+    hipLaunchKernelGGL(k3_l2_count, dim3(max_items), blk, 0, st, i1_rem, off1, map, nitems, cnt2, g.prio);
+    hipLaunchKernelGGL(k3_scan_a, dim3(nsb), blk, 0, st, cnt2, NB2, bsum, g.prio);
+    hipLaunchKernelGGL(k3_scan_b, dim3(1), blk, 0, st, bsum, nsb, g.prio);
+    hipLaunchKernelGGL(k3_scan_c, dim3(nsb), blk, 0, st, cnt2, NB2, bsum, off2, cur2, g.prio);
+    hipLaunchKernelGGL(k3_l2_scatter, dim3(max_items), blk, 0, st, i1_idx, i1_rem, off1, map, nitems, cur2, i2_idx, i2_lo, g.prio);
+    hipLaunchKernelGGL(k3_l3, dim3(NB2), blk, 0, st, i2_idx, i2_lo, off2, B.count.as<uint32_t>(), B.entries.as<uint32_t>(), g.prio);
     BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
     return BLZ_OK;
 }
