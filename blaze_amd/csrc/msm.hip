@@ -627,10 +627,6 @@ int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int 
                            B.off.as<uint32_t>(), B.unit_off.as<uint32_t>());
         if (!use_s3) BLZ_TRY(msm_sort_lds_scatter(E));
         BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
-        // the staged inputs (scalars, raw points) have been consumed once the LAST sort has run: a later task's host ->
-        // device copies may overwrite this staging set once the caller's event has passed (msm_capi.hip's copy stream
-        // waits for it)
-        if (inputs_event && (sl + 1 == nslices || (uint64_t)p0 + np >= npts)) BLZ_HIP(hipEventRecord(inputs_event, ss), BLZ_ERR_UNKNOWN);
         // No host round trip: the unit count stays on the device.  Buffers and grids are sized by the bound
         // (every bucket at most one short unit, plus entries / L full ones) and the kernels read the real count
         // from `stats`; the host copy below is for the log line, the sanity check of finish() and the hot-bucket guard.
@@ -641,6 +637,15 @@ int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int 
         if (hide) {
             BLZ_HIP(hipEventRecord(S.ev_s1, ss), BLZ_ERR_UNKNOWN);
             BLZ_HIP(hipStreamWaitEvent(st, S.ev_sorted, 0), BLZ_ERR_UNKNOWN);
+        }
+        // The staged inputs have been consumed once the LAST sort has read the scalars - and, in DMA mode, once the
+        // to-Montgomery pass, which msm_capi.hip enqueued on the MAIN stream ahead of this run(), has read the raw points
+        // (ev[0] sits behind it): only then may a later task's host -> device copies overwrite this staging set
+        // (msm_capi.hip's copy stream waits for the event).  On the sort stream the wait comes last, behind ev_sorted, so
+        // it delays nothing but the event.
+        if (inputs_event && (sl + 1 == nslices || (uint64_t)p0 + np >= npts)) {
+            if (hide) BLZ_HIP(hipStreamWaitEvent(ss, S.ev[0], 0), BLZ_ERR_UNKNOWN);
+            BLZ_HIP(hipEventRecord(inputs_event, ss), BLZ_ERR_UNKNOWN);
         }
         // ---- accumulation, on the main stream
         BLZ_TRY(ops->run_accumulate(E, pt_s, (uint32_t)max_units, nslices > 1 ? sl : -1));
