@@ -36,7 +36,8 @@ constexpr int S3_T = 12;                        // scalars per lane of the level
 constexpr int S3_PB = S3_THREADS * S3_T;        // 3072 points per block: 96 KiB of scalars + 24 KiB of stage
 constexpr uint32_t S3_SLICE2 = 4096;            // entries per level-2 work item (16 per lane)
 constexpr int S3_T2 = S3_SLICE2 / S3_THREADS;
-constexpr uint32_t S3_R3 = 8192;                // level 3 stages a bin of up to this many entries in LDS (mean at 2^26: 5.8 K)
+constexpr int S3_T3 = 28;                       // level 3: entries per lane held in registers
+constexpr uint32_t S3_R3 = S3_THREADS * S3_T3;  // ... so a level-2 bin of up to 7168 entries takes one pass (mean at 2^26: 5.8 K, sigma 76)
 constexpr uint32_t S3_MAXNB1 = 2048;            // level-1 bins in all (LDS histogram of k3_l1_count)
 constexpr uint32_t S3_CNT_PTS = 16384;          // points per block of k3_l1_count
 
@@ -386,8 +387,9 @@ __global__ __launch_bounds__(S3_THREADS, 4) void k3_l2_scatter(const uint32_t* _
 // ---------------------------------------------------------------------------------------------- level 3
 // one block per level-2 bin (128 consecutive buckets): bucket counts, then the bin's entries in bucket order.  The bin's
 // run [off2[j], off2[j+1]) of entries[] is final already: buckets are laid out in order and a bin is a whole group of
-// them.  A bin of up to S3_R3 entries is staged in LDS and leaves as one contiguous copy; a larger one (hot buckets: the
-// reference harness's repeated tile) is written entry by entry - correct, slow, and not what this path is chosen for.
+// them.  A bin of up to S3_R3 entries is read once (entries and ranks wait in registers while the counts are scanned),
+// placed in an LDS image of the run and leaves as one contiguous copy; a larger one (hot buckets: the reference
+// harness's repeated tile) is written entry by entry - correct, slow, and not what this path is chosen for.
 __global__ __launch_bounds__(S3_THREADS, 4) void k3_l3(const uint32_t* __restrict__ i_idx, const uint8_t* __restrict__ i_lo,
                                                       const uint32_t* __restrict__ off2, uint32_t* __restrict__ count,
                                                       uint32_t* __restrict__ entries, int prio) {
@@ -399,24 +401,48 @@ __global__ __launch_bounds__(S3_THREADS, 4) void k3_l3(const uint32_t* __restric
     const uint32_t a = off2[j], b = off2[j + 1], s = b - a;
     if (tid < 128) hist[tid] = 0;
     __syncthreads();
-    for (uint32_t i = a + tid; i < b; i += S3_THREADS) atomicAdd(&hist[i_lo[i]], 1u);
-    __syncthreads();
-    const uint32_t v = tid < 128 ? hist[tid] : 0u;
-    uint32_t total;
-    const uint32_t excl = s3_block_excl_scan(v, wave_tot, &total);
-    if (tid < 128) {
-        count[((size_t)j << 7) + tid] = v;
-        cursor[tid] = excl;
-    }
-    __syncthreads();
     if (s <= S3_R3) {
-        for (uint32_t i = a + tid; i < b; i += S3_THREADS) {
-            const uint32_t pos = atomicAdd(&cursor[i_lo[i]], 1u);
-            out[pos] = i_idx[i];
+        // one pass over the bin: every lane keeps its entries and their ranks in registers (all loads in flight at once)
+        uint32_t ex[S3_T3], ky[S3_T3];   // ky = bucket (7 bits) | rank in the bucket << 8; ~0 = no entry
+#pragma unroll
+        for (int t = 0; t < S3_T3; ++t) {
+            const uint32_t i = a + t * S3_THREADS + tid;
+            ky[t] = 0xffffffffu;
+            ex[t] = 0;
+            if (i < b) {
+                ky[t] = i_lo[i];
+                ex[t] = i_idx[i];
+            }
         }
+#pragma unroll
+        for (int t = 0; t < S3_T3; ++t)
+            if (ky[t] != 0xffffffffu) ky[t] |= atomicAdd(&hist[ky[t]], 1u) << 8;
+        __syncthreads();
+        const uint32_t v = tid < 128 ? hist[tid] : 0u;
+        uint32_t total;
+        const uint32_t excl = s3_block_excl_scan(v, wave_tot, &total);
+        if (tid < 128) {
+            count[((size_t)j << 7) + tid] = v;
+            cursor[tid] = excl;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < S3_T3; ++t)
+            if (ky[t] != 0xffffffffu) out[cursor[ky[t] & 127u] + (ky[t] >> 8)] = ex[t];
         __syncthreads();
         for (uint32_t t = tid; t < s; t += S3_THREADS) entries[a + t] = out[t];
     } else {
+        // a bin beyond the registers (hot buckets): count, then place entry by entry
+        for (uint32_t i = a + tid; i < b; i += S3_THREADS) atomicAdd(&hist[i_lo[i]], 1u);
+        __syncthreads();
+        const uint32_t v = tid < 128 ? hist[tid] : 0u;
+        uint32_t total;
+        const uint32_t excl = s3_block_excl_scan(v, wave_tot, &total);
+        if (tid < 128) {
+            count[((size_t)j << 7) + tid] = v;
+            cursor[tid] = excl;
+        }
+        __syncthreads();
         for (uint32_t i = a + tid; i < b; i += S3_THREADS) {
             const uint32_t pos = atomicAdd(&cursor[i_lo[i]], 1u);
             entries[a + pos] = i_idx[i];
