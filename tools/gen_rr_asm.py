@@ -58,6 +58,19 @@ def emit_qm(NL, K):
             f"        : [acc] \"+v\"(acc)\n        : {', '.join(ins)}\n        : \"vcc\");\n}}\n")
 
 
+def emit_as(NL, K):
+    """full column of a (VGPRs) times a wave-uniform constant s (SGPR operands): the q * (2^(B NL) - m) half of the
+    Shoup product (field_rr.cuh rr_mul_shoup)"""
+    ilo = 0 if K < NL else K - NL + 1
+    ihi = K if K < NL else NL - 1
+    idx = list(range(ilo, ihi + 1))
+    lines = [f'"v_mad_u64_u32 %[acc], vcc, %[a{i}], %[s{K - i}], %[acc]\\n\\t"' for i in idx]
+    ins = [f'[a{i}] "v"(a[{i}])' for i in idx] + [f'[s{K - i}] "s"(s[{K - i}])' for i in idx]
+    return (f"template <> BLZ_DEV void rr_as<{NL}, {K}>(uint64_t& acc, const uint32_t (&a)[{NL}], const uint32_t (&s)[{NL}]) {{\n"
+            f"    asm({chr(10).join('        ' + l for l in lines).lstrip()}\n"
+            f"        : [acc] \"+v\"(acc)\n        : {', '.join(ins)}\n        : \"vcc\");\n}}\n")
+
+
 def fused_ok(NL, K):
     """Can the caller's products and the reduction products of column K share one asm statement (30 operands)?"""
     n_ab = K + 1 if K < NL else 2 * NL - 1 - K
@@ -93,7 +106,9 @@ def main():
            "    const int n_ab = K < NL ? K + 1 : 2 * NL - 1 - K, n_qm = K < NL ? K : 2 * NL - 1 - K;",
            "    return n_qm > 0 && 2 * n_ab + 2 * n_qm + 1 <= 30;",
            "}",
-           "template <int NL, int K> BLZ_DEV void rr_abqm(uint64_t& acc, const uint32_t (&a)[NL], const uint32_t (&b)[NL], const uint32_t (&q)[NL], const uint32_t (&m)[NL]);\n"]
+           "template <int NL, int K> BLZ_DEV void rr_abqm(uint64_t& acc, const uint32_t (&a)[NL], const uint32_t (&b)[NL], const uint32_t (&q)[NL], const uint32_t (&m)[NL]);",
+           "// full column of a times a wave-uniform constant (the low half of the Shoup product)",
+           "template <int NL, int K> BLZ_DEV void rr_as(uint64_t& acc, const uint32_t (&a)[NL], const uint32_t (&s)[NL]);\n"]
     for NL in (9, 14):
         for K in range(2 * NL - 1):
             out.append(emit_ab(NL, K))
@@ -101,6 +116,8 @@ def main():
             out.append(emit_qm(NL, K))
             if fused_ok(NL, K):
                 out.append(emit_abqm(NL, K))
+            if NL == 9 and K < NL:
+                out.append(emit_as(NL, K))
     with open(dst, "w") as f:
         f.write("\n".join(out))
     print("wrote", os.path.normpath(dst))

@@ -1,0 +1,154 @@
+// Would a Shoup product be cheaper than the Montgomery product for the NTT's table twiddles (9 x 29-bit limbs)?
+//   Montgomery (shipped, rr_mul): 81 + 72 multiply-adds + per-column quotient bookkeeping (BLS12-381 Fr: r = 1 mod 2^29)
+//   Shoup (w canonical, wq = floor(w 2^261 / m) precomputed): high half of x wq from two guard columns up (53 multiply-adds)
+//   -> q; then (x w + q (2^261 - m)) mod 2^261 in 9 columns (90 multiply-adds): 143 in all, no quotient-digit chain; result < 3m
+// Dependent chains x = x * w on registers, 1 - 4 waves per SIMD, like tools/mul_variants.hip; the Shoup chain is checked against the
+// Montgomery chain (same residues) before it is timed.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I blaze_amd/csrc tools/shoup_probe.hip -o build/shoup_probe
+#include <hip/hip_runtime.h>
+#include "field_rr.cuh"
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+
+using namespace blz;
+using Q = Fr_BLS381_RR;
+constexpr int NL = Q::NL, B = Q::B;
+
+struct MBar { uint32_t v[NL]; };
+constexpr MBar make_mbar() {   // 2^(B NL) - m
+    MBar r{};
+    uint32_t borrow = 0;
+    for (int i = 0; i < NL; ++i) {
+        uint64_t d = (uint64_t)(i == 0 ? 0 : 0) - Q::MOD[i] - borrow;   // 0 - m_i - borrow (mod 2^B)
+        r.v[i] = (uint32_t)(d & Q::MASK);
+        borrow = (Q::MOD[i] + borrow) ? 1 : 0;
+    }
+    return r;
+}
+__device__ constexpr MBar kMBar = make_mbar();
+
+// r = x w mod m (< 3m), x normalised (< 2^261), w canonical, wq = floor(w 2^261 / m)
+template <int... Ks> struct seq {};
+__device__ __forceinline__ void mul_shoup(uint32_t (&r)[NL], const uint32_t (&x)[NL], const uint32_t (&w)[NL], const uint32_t (&wq)[NL]) {
+    uint32_t q[NL];
+    uint64_t acc = 0;
+    rr_ab<NL, NL - 2>(acc, x, wq); acc >>= B;
+    rr_ab<NL, NL - 1>(acc, x, wq); acc >>= B;
+    rr_ab<NL, NL + 0>(acc, x, wq); q[0] = (uint32_t)acc & Q::MASK; acc >>= B;
+    rr_ab<NL, NL + 1>(acc, x, wq); q[1] = (uint32_t)acc & Q::MASK; acc >>= B;
+    rr_ab<NL, NL + 2>(acc, x, wq); q[2] = (uint32_t)acc & Q::MASK; acc >>= B;
+    rr_ab<NL, NL + 3>(acc, x, wq); q[3] = (uint32_t)acc & Q::MASK; acc >>= B;
+    rr_ab<NL, NL + 4>(acc, x, wq); q[4] = (uint32_t)acc & Q::MASK; acc >>= B;
+    rr_ab<NL, NL + 5>(acc, x, wq); q[5] = (uint32_t)acc & Q::MASK; acc >>= B;
+    rr_ab<NL, NL + 6>(acc, x, wq); q[6] = (uint32_t)acc & Q::MASK; acc >>= B;
+    rr_ab<NL, NL + 7>(acc, x, wq); q[7] = (uint32_t)acc & Q::MASK; acc >>= B;
+    q[8] = (uint32_t)acc;
+    acc = 0;
+#define COL(K) rr_ab<NL, K>(acc, x, w); rr_as<NL, K>(acc, q, kMBar.v); r[K] = (uint32_t)acc & Q::MASK; acc >>= B;
+    COL(0) COL(1) COL(2) COL(3) COL(4) COL(5) COL(6) COL(7) COL(8)
+#undef COL
+}
+
+// floor(w 2^261 / m) by 261 shift-subtract steps (w canonical); 32-bit-free: works on the 29-bit limbs
+__device__ void shoup_quot(uint32_t (&q)[NL], const uint32_t (&w)[NL]) {
+    uint32_t t[NL];
+    for (int i = 0; i < NL; ++i) { t[i] = w[i]; q[i] = 0; }
+    for (int step = 0; step < B * NL; ++step) {
+        // t <<= 1 ; q <<= 1
+        uint32_t ct = 0, cq = 0;
+        for (int i = 0; i < NL; ++i) {
+            uint32_t nt = ((t[i] << 1) | ct), nq = ((q[i] << 1) | cq);
+            ct = nt >> B; cq = nq >> B;
+            t[i] = i == NL - 1 ? nt : (nt & Q::MASK);   // t < 2m < 2^257: the top limb never overflows its register
+            q[i] = nq & Q::MASK;
+        }
+        // if t >= m: t -= m, q |= 1
+        uint32_t d[NL], borrow = 0;
+        for (int i = 0; i < NL; ++i) {
+            uint32_t x = t[i] - Q::MOD[i] - borrow;
+            borrow = x >> 31;
+            d[i] = i == NL - 1 ? x : (x & Q::MASK);
+        }
+        if (!borrow) { for (int i = 0; i < NL; ++i) t[i] = d[i]; q[0] |= 1u; }
+    }
+}
+
+template <int MODE>   // 0 Montgomery chain, 1 Shoup chain, 2 check
+__global__ __launch_bounds__(64) void k_chain(uint32_t* out, int reps, uint32_t seed) {
+    Frr<Q, 1, 2> x, wm;
+    uint32_t w[NL], wq[NL], xs[NL];
+    // a canonical twiddle: the Montgomery one times something, brought to canonical plain form
+    for (int i = 0; i < NL; ++i) { w[i] = (Q::RR2[i] ^ (seed * (i + 1))) & Q::MASK; }
+    w[NL - 1] &= 0x3fffffu;   // < m
+    shoup_quot(wq, w);
+    // Montgomery form of the same w: w Rrr = mont_mul(w, RR2)
+    Frr<Q, 1, 1> wc, rr2;
+    for (int i = 0; i < NL; ++i) { wc.v[i] = w[i]; rr2.v[i] = Q::RR2[i]; }
+    rr_mul(wm, wc, rr2);
+    for (int i = 0; i < NL; ++i) { x.v[i] = (Q::ONE[i] + threadIdx.x * 977u + blockIdx.x) & Q::MASK; xs[i] = x.v[i]; }
+    x.v[NL - 1] &= 0x3fffffu; xs[NL - 1] = x.v[NL - 1];
+    if (MODE == 0) {
+        for (int r = 0; r < reps; ++r) rr_mul(x, x, wm);
+        uint32_t o = 0; for (int i = 0; i < NL; ++i) o ^= x.v[i];
+        if (o == 0x12345u) out[0] = o;
+    } else if (MODE == 1) {
+        for (int r = 0; r < reps; ++r) { uint32_t t[NL]; mul_shoup(t, xs, w, wq); for (int i = 0; i < NL; ++i) xs[i] = t[i]; }
+        uint32_t o = 0; for (int i = 0; i < NL; ++i) o ^= xs[i];
+        if (o == 0x12345u) out[0] = o;
+    } else {
+        // 64 steps of both chains; compare residues: canonicalise both (x < 2m, xs < 3m) and compare
+        uint32_t bad = 0;
+        for (int r = 0; r < 64; ++r) {
+            rr_mul(x, x, wm);
+            uint32_t t[NL]; mul_shoup(t, xs, w, wq); for (int i = 0; i < NL; ++i) xs[i] = t[i];
+            // canonical forms
+            uint32_t a[NL], b[NL];
+            for (int i = 0; i < NL; ++i) { a[i] = x.v[i]; b[i] = xs[i]; }
+            for (int pass = 0; pass < 3; ++pass) {
+                uint32_t d[NL], borrow = 0;
+                for (int i = 0; i < NL; ++i) { uint32_t v = a[i] - Q::MOD[i] - borrow; borrow = v >> 31; d[i] = i == NL - 1 ? v : (v & Q::MASK); }
+                if (!borrow) for (int i = 0; i < NL; ++i) a[i] = d[i];
+                borrow = 0;
+                for (int i = 0; i < NL; ++i) { uint32_t v = b[i] - Q::MOD[i] - borrow; borrow = v >> 31; d[i] = i == NL - 1 ? v : (v & Q::MASK); }
+                if (!borrow) for (int i = 0; i < NL; ++i) b[i] = d[i];
+            }
+            for (int i = 0; i < NL; ++i) bad |= a[i] ^ b[i];
+            // range of the Shoup result: < 3m  <=>  top limb small
+            if (xs[NL - 1] > 3u * (Q::MOD[NL - 1] + 1u)) bad |= 1u << 31;
+        }
+        if (bad) atomicAdd(&out[1], 1u);
+    }
+}
+
+int main() {
+    int cus = 0;
+    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
+    uint32_t* d;
+    hipMalloc(&d, 64);
+    hipMemset(d, 0, 64);
+    hipLaunchKernelGGL(k_chain<2>, dim3(256), dim3(64), 0, 0, d, 0, 12345u);
+    uint32_t h[2] = {0, 0};
+    hipMemcpy(h, d, 8, hipMemcpyDeviceToHost);
+    printf("check: %u of %d lanes disagree between the Shoup and the Montgomery chain (64 steps each)\n", h[1], 256 * 64);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    const int reps = 20000;
+    for (int mode = 0; mode < 2; ++mode)
+        for (int wps = 1; wps <= 4; ++wps) {
+            const int blocks = cus * 4 * wps;
+            float best = 1e9f;
+            for (int it = 0; it < 3; ++it) {
+                hipEventRecord(e0);
+                if (mode == 0) hipLaunchKernelGGL(k_chain<0>, dim3(blocks), dim3(64), 0, 0, d, reps, 7u);
+                else hipLaunchKernelGGL(k_chain<1>, dim3(blocks), dim3(64), 0, 0, d, reps, 7u);
+                hipEventRecord(e1);
+                hipDeviceSynchronize();
+                float ms; hipEventElapsedTime(&ms, e0, e1);
+                if (ms < best) best = ms;
+            }
+            printf("%s  %d waves/SIMD: %.3f ms -> %.3e lane-products/s\n", mode ? "Shoup      (143 mads)" : "Montgomery (153 mads)", wps, best,
+                   (double)blocks * 64 * reps / (best * 1e-3));
+        }
+    return 0;
+}
