@@ -111,8 +111,7 @@ BLZ_DEV void ptrr_madd(XYZZRR<Q>& acc, const AffineRR<Q>& q, bool neg) {
         return;
     }
     Frr<Q, 1, 2> U2, S2, PP, PPP, Qv, t, y3;
-    rr_mul(U2, q.x, acc.zz);
-    rr_mul(S2, y2, acc.zzz);
+    rr_mul_pair(U2, q.x, acc.zz, S2, y2, acc.zzz);
     const auto P0 = rr_sub<RR_JX<Q>>(U2, acc.x);       // U2 - X1 + 32m: (3, 34) | + 4m: (3, 6)
     const auto R0 = rr_sub<RR_JY<Q>>(S2, acc.y);       // S2 - Y1 + 8m: (3, 10) | + 4m: (3, 6)
     if (__builtin_expect(rr_maybe_equal(U2, acc.x), 0)) {
@@ -124,13 +123,11 @@ BLZ_DEV void ptrr_madd(XYZZRR<Q>& acc, const AffineRR<Q>& q, bool neg) {
     }
     const auto P = rr_tn(P0);                          // | (1, 6)
     const auto R = rr_tn(R0);                          // | (1, 6)
-    // ordered so that every input coordinate dies as early as possible (see ec.cuh's pt_madd)
-    rr_sqr(PP, P);
-    rr_mul(acc.zz, acc.zz, PP);                        // ZZ3
-    rr_mul(PPP, P, PP);
-    rr_mul(acc.zzz, acc.zzz, PPP);                     // ZZZ3
-    rr_mul(Qv, acc.x, PP);
-    rr_sqr(t, R);
+    // independent products go in pairs (field_rr.cuh rr_mul_pair: two column chains per wave), ordered so that every
+    // input coordinate dies as early as possible (see ec.cuh's pt_madd)
+    rr_sqr_pair(PP, P, t, R);
+    rr_mul_pair(acc.zz, acc.zz, PP, PPP, P, PP);       // ZZ3, PPP
+    rr_mul_pair(acc.zzz, acc.zzz, PPP, Qv, acc.x, PP); // ZZZ3, Q
     const auto X3 = rr_xfix(rr_sub_twice<2>(rr_sub<2>(t, PPP), Qv));  // R^2 - PPP - 2Q + 12m: (1, 14) | (1, 2)
     const auto D = rr_tn(rr_sub<RR_JX<Q>>(Qv, X3));    // Q - X3 + 32m: (3, 34) | + 4m: (1, 6)
     const auto nY = rr_neg<RR_JY<Q>>(acc.y);           // 8m - Y1: (2, 8) | 4m - Y1: (2, 4)

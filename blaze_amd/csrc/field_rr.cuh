@@ -192,6 +192,64 @@ BLZ_DEV void rr_mul2(Frr<Q, 1, 2>& r, const Frr<Q, Fa, Va>& a, const Frr<Q, Fb, 
     }, std::make_integer_sequence<int, 2 * Q::NL - 1>{});
 }
 
+// ---- two independent products, column by column in one instruction stream ------------------------------------------
+// A product is ONE dependent chain through its 64-bit column accumulator (every multiply-add waits for the one before, the
+// quotient digit for the column's sum); with two waves per SIMD the second wave covers most of that latency, not all.  Where
+// the group law has two products that do not depend on each other, their columns CAN alternate: two chains per wave
+// (-DBLZ_RR_PAIR).  Measured (round 3, 2^26 BLS12-381, same box): k_accumulate alone 104.0 -> 103.4 ms, but the second
+// chain's registers take the kernel from 198 to 211 VGPRs, and with 2 x 216 of a SIMD's 512 allocated the next task's
+// hidden digit sort no longer runs beside it (its level-2 scatter waits for the accumulation to end): 118.9 -> 122.7 ms
+// per step.  Off by default: the products of a pair run one after the other.
+template <class Q, class AB1, class AB2, int... Ks>
+BLZ_DEV void rr_columns_pair(Frr<Q, 1, 2>& r1, AB1&& ab1, Frr<Q, 1, 2>& r2, AB2&& ab2, std::integer_sequence<int, Ks...>) {
+    uint32_t q1[Q::NL], t1[Q::NL], q2[Q::NL], t2[Q::NL];
+    uint64_t acc1 = 0, acc2 = 0;
+    ((rr_column<Q, Ks>(acc1, q1, t1, ab1), rr_column<Q, Ks>(acc2, q2, t2, ab2)), ...);
+    t1[Q::NL - 1] = (uint32_t)acc1;
+    t2[Q::NL - 1] = (uint32_t)acc2;
+#pragma unroll
+    for (int i = 0; i < Q::NL; ++i) {
+        r1.v[i] = t1[i];
+        r2.v[i] = t2[i];
+    }
+}
+// r1 = a1 b1, r2 = a2 b2
+template <class Q, int Fa1, int Va1, int Fb1, int Vb1, int Fa2, int Va2, int Fb2, int Vb2>
+BLZ_DEV void rr_mul_pair(Frr<Q, 1, 2>& r1, const Frr<Q, Fa1, Va1>& a1, const Frr<Q, Fb1, Vb1>& b1, Frr<Q, 1, 2>& r2,
+                         const Frr<Q, Fa2, Va2>& a2, const Frr<Q, Fb2, Vb2>& b2) {
+#ifndef BLZ_RR_PAIR
+    rr_mul(r1, a1, b1);
+    rr_mul(r2, a2, b2);
+#else
+    static_assert(rr_cols_ok<Q>(Fa1 * Fb1) && rr_cols_ok<Q>(Fa2 * Fb2), "column sum would overflow 64 bits: normalise an operand");
+    static_assert(rr_vals_ok<Q>(Va1 * Vb1) && rr_vals_ok<Q>(Va2 * Vb2), "product would leave the lazy value range");
+    rr_columns_pair<Q>(r1, [&](auto k, uint64_t& c) { BLZ_RR_AB<Q::NL, decltype(k)::value>(c, a1.v, b1.v); },
+                       r2, [&](auto k, uint64_t& c) { BLZ_RR_AB<Q::NL, decltype(k)::value>(c, a2.v, b2.v); },
+                       std::make_integer_sequence<int, 2 * Q::NL - 1>{});
+#endif
+}
+// r1 = a1^2, r2 = a2^2
+template <class Q, int Fa1, int Va1, int Fa2, int Va2>
+BLZ_DEV void rr_sqr_pair(Frr<Q, 1, 2>& r1, const Frr<Q, Fa1, Va1>& a1, Frr<Q, 1, 2>& r2, const Frr<Q, Fa2, Va2>& a2) {
+#ifndef BLZ_RR_PAIR
+    rr_sqr(r1, a1);
+    rr_sqr(r2, a2);
+#else
+    static_assert(rr_cols_ok<Q>(Fa1 * Fa1) && 2 * Fa1 < (1 << (32 - Q::B)) && rr_cols_ok<Q>(Fa2 * Fa2) && 2 * Fa2 < (1 << (32 - Q::B)),
+                  "column sum would overflow 64 bits");
+    static_assert(rr_vals_ok<Q>(Va1 * Va1) && rr_vals_ok<Q>(Va2 * Va2), "product would leave the lazy value range");
+    uint32_t d1[Q::NL], d2[Q::NL];
+#pragma unroll
+    for (int i = 0; i < Q::NL; ++i) {
+        d1[i] = a1.v[i] << 1;
+        d2[i] = a2.v[i] << 1;
+    }
+    rr_columns_pair<Q>(r1, [&](auto k, uint64_t& c) { BLZ_RR_SQ<Q::NL, decltype(k)::value>(c, a1.v, d1); },
+                       r2, [&](auto k, uint64_t& c) { BLZ_RR_SQ<Q::NL, decltype(k)::value>(c, a2.v, d2); },
+                       std::make_integer_sequence<int, 2 * Q::NL - 1>{});
+#endif
+}
+
 // the same product in plain C++ (what hipcc schedules by itself: kept as the readable reference and for
 // tools/mul_variants.hip; it re-associates every column into "products first, carry-in last")
 template <class Q, int Fa, int Va, int Fb, int Vb>

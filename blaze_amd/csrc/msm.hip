@@ -176,19 +176,22 @@ __global__ __launch_bounds__(256) void k_scan_reduce(const uint32_t* __restrict_
 }
 
 // single block: exclusive scan of blocksums in place; totals -> stats[0] (units), stats[2] (entries)
-__global__ __launch_bounds__(1024) void k_scan_sums(uint64_t* __restrict__ blocksums, uint32_t nblocks,
-                                                    uint32_t* __restrict__ stats) {
+// (256 threads: the kernel belongs to the sort stage, which may have to fit beside another task's accumulation -
+// a 1024-thread block needs four waves per SIMD at once and 4 x its registers of the ~100 VGPRs the accumulation leaves)
+constexpr int SCAN_SUMS_THREADS = 256;
+__global__ __launch_bounds__(SCAN_SUMS_THREADS) void k_scan_sums(uint64_t* __restrict__ blocksums, uint32_t nblocks,
+                                                                 uint32_t* __restrict__ stats) {
     __builtin_amdgcn_s_setprio(3);   // sort-stage kernel: may run underneath another task's accumulation (msm_sort3.hip)
-    __shared__ uint64_t sh[1024];
+    __shared__ uint64_t sh[SCAN_SUMS_THREADS];
     __shared__ uint64_t carry_sh;
     if (threadIdx.x == 0) carry_sh = 0;
     __syncthreads();
-    for (uint32_t base = 0; base < nblocks; base += 1024) {
+    for (uint32_t base = 0; base < nblocks; base += SCAN_SUMS_THREADS) {
         uint32_t i = base + threadIdx.x;
         uint64_t v = i < nblocks ? blocksums[i] : 0;
         sh[threadIdx.x] = v;
         __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {
+        for (int o = 1; o < SCAN_SUMS_THREADS; o <<= 1) {
             uint64_t t = threadIdx.x >= (uint32_t)o ? sh[threadIdx.x - o] : 0;
             __syncthreads();
             sh[threadIdx.x] += t;
@@ -198,7 +201,7 @@ __global__ __launch_bounds__(1024) void k_scan_sums(uint64_t* __restrict__ block
         uint64_t carry = carry_sh;
         if (i < nblocks) blocksums[i] = carry + incl - v;
         __syncthreads();
-        if (threadIdx.x == 1023) carry_sh = carry + incl;
+        if (threadIdx.x == SCAN_SUMS_THREADS - 1) carry_sh = carry + incl;
         __syncthreads();
     }
     if (threadIdx.x == 0) {
@@ -622,7 +625,7 @@ int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int 
         }
         hipLaunchKernelGGL(k_scan_reduce, dim3(nscan), b256, 0, ss, B.count.as<uint32_t>(), G, P.L, blocksums.as<uint64_t>(),
                            B.stats.as<uint32_t>());
-        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, ss, blocksums.as<uint64_t>(), nscan, B.stats.as<uint32_t>());
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_SUMS_THREADS), 0, ss, blocksums.as<uint64_t>(), nscan, B.stats.as<uint32_t>());
         hipLaunchKernelGGL(k_scan_final, dim3(nscan), b256, 0, ss, B.count.as<uint32_t>(), G, P.L, blocksums.as<uint64_t>(),
                            B.off.as<uint32_t>(), B.unit_off.as<uint32_t>());
         if (!use_s3) BLZ_TRY(msm_sort_lds_scatter(E));
