@@ -192,6 +192,99 @@ BLZ_DEV void rr_mul2(Frr<Q, 1, 2>& r, const Frr<Q, Fa, Va>& a, const Frr<Q, Fb, 
     }, std::make_integer_sequence<int, 2 * Q::NL - 1>{});
 }
 
+// ---- Shoup product: x times a CONSTANT known in advance (the NTT's table twiddles) -----------------------------------
+// For a canonical w the table also holds wq = floor(w Rrr / m).  Then q = floor(x wq / Rrr) is floor(x w / m) or one
+// below it, and x w - q m is the product in [0, 2m).  Here: the high half of x wq is summed from two guard columns up
+// (NL^2 - 28 = 53 multiply-adds at NL = 9: the columns left out are worth < 2^-26 of q's unit, so q is that floor or one
+// below), then x w + q (Rrr - m), i.e. x w - q m modulo Rrr, in NL columns (90 multiply-adds): 143 against the Montgomery
+// product's 153, no quotient-digit chain between the columns (+14.6 % products per second at two waves per SIMD,
+// profiles/r03_shoup_probe.txt), the result the plain product x w - no Montgomery factor.  The truncation can leave the
+// result in [2m, 3m): a top-limb compare (T2M) and a rarely taken subtraction of m bring every result below 2m.
+// x: any limbs the column bound admits (F <= 6 at 9 x 29 bits), value < Rrr (guaranteed by the type: V m < Rrr).
+template <class Q>
+struct RRShoup {
+    uint32_t w[Q::NL];   // the twiddle, canonical
+    uint32_t wq[Q::NL];  // floor(w Rrr / m)
+};
+template <class Q, int K>
+BLZ_DEV void rr_shoup_hi(uint64_t& acc, uint32_t (&q)[Q::NL], const uint32_t (&x)[Q::NL], const uint32_t (&wq)[Q::NL]) {
+    rr_ab<Q::NL, K>(acc, x, wq);
+    if constexpr (K >= Q::NL) q[K - Q::NL] = (uint32_t)acc & Q::MASK;
+    acc >>= Q::B;
+}
+template <class Q, int K>
+BLZ_DEV void rr_shoup_lo(uint64_t& acc, uint32_t (&r)[Q::NL], const uint32_t (&x)[Q::NL], const uint32_t (&w)[Q::NL],
+                         const uint32_t (&q)[Q::NL]) {
+    rr_ab<Q::NL, K>(acc, x, w);
+    rr_as<Q::NL, K>(acc, q, Q::MBAR);
+    r[K] = (uint32_t)acc & Q::MASK;
+    acc >>= Q::B;
+}
+template <class Q, int... Hs, int... Ls>
+BLZ_DEV void rr_shoup_columns(uint32_t (&r)[Q::NL], const uint32_t (&x)[Q::NL], const RRShoup<Q>& t, std::integer_sequence<int, Hs...>,
+                              std::integer_sequence<int, Ls...>) {
+    uint32_t q[Q::NL];
+    uint64_t acc = 0;
+    (rr_shoup_hi<Q, Q::NL - 2 + Hs>(acc, q, x, t.wq), ...);   // columns NL - 2 .. 2 NL - 2
+    q[Q::NL - 1] = (uint32_t)acc;
+    acc = 0;
+    (rr_shoup_lo<Q, Ls>(acc, r, x, t.w, q), ...);             // columns 0 .. NL - 1
+}
+template <class Q, int F, int V>
+BLZ_DEV void rr_mul_shoup(Frr<Q, 1, 2>& r, const Frr<Q, F, V>& x, const RRShoup<Q>& t) {
+    static_assert(Q::NL == 9, "the constant-operand columns (rr_as) are generated for 9 limbs");
+    static_assert(rr_cols_ok<Q>(F), "column sum would overflow 64 bits: normalise x");
+    uint32_t o[Q::NL];
+    rr_shoup_columns<Q>(o, x.v, t, std::make_integer_sequence<int, Q::NL + 1>{}, std::make_integer_sequence<int, Q::NL>{});
+    if (__builtin_expect(o[Q::NL - 1] >= Q::T2M, 0)) {   // in [2m - eps, 3m): take m off (top limb < T2M means < 2m)
+        uint32_t borrow = 0;
+#pragma unroll
+        for (int i = 0; i < Q::NL - 1; ++i) {
+            const uint32_t d = o[i] - Q::MOD[i] - borrow;
+            borrow = d >> 31;
+            o[i] = d & Q::MASK;
+        }
+        o[Q::NL - 1] = o[Q::NL - 1] - Q::MOD[Q::NL - 1] - borrow;
+    }
+#pragma unroll
+    for (int i = 0; i < Q::NL; ++i) r.v[i] = o[i];
+}
+// wq = floor(w Rrr / m) for a canonical w, by B NL shift-and-subtract steps (table set-up only)
+template <class Q>
+BLZ_DEV void rr_shoup_quot(RRShoup<Q>& t, const Frr<Q, 1, 1>& w) {
+    constexpr int NL = Q::NL, B = Q::B;
+    uint32_t rem[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        t.w[i] = w.v[i];
+        rem[i] = w.v[i];
+        t.wq[i] = 0;
+    }
+    for (int step = 0; step < B * NL; ++step) {
+        uint32_t ct = 0, cq = 0;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const uint32_t nt = (rem[i] << 1) | ct, nq = (t.wq[i] << 1) | cq;
+            ct = nt >> B;
+            cq = nq >> B;
+            rem[i] = i == NL - 1 ? nt : (nt & Q::MASK);   // rem < 2m: the top limb stays inside its register
+            t.wq[i] = nq & Q::MASK;
+        }
+        uint32_t d[NL], borrow = 0;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const uint32_t x = rem[i] - Q::MOD[i] - borrow;
+            borrow = x >> 31;
+            d[i] = i == NL - 1 ? x : (x & Q::MASK);
+        }
+        if (!borrow) {
+#pragma unroll
+            for (int i = 0; i < NL; ++i) rem[i] = d[i];
+            t.wq[0] |= 1u;
+        }
+    }
+}
+
 // ---- two independent products, column by column in one instruction stream ------------------------------------------
 // A product is ONE dependent chain through its 64-bit column accumulator (every multiply-add waits for the one before, the
 // quotient digit for the column's sum); with two waves per SIMD the second wave covers most of that latency, not all.  Where

@@ -129,10 +129,10 @@ int ntt_setup(blz_ntt* h) {
     const char* envt = getenv("BLAZE_NTT_TABLE");
     const char* envr = getenv("BLAZE_NTT_RR");
     const bool want_ta = lc == 9 && !h->force_generic && !(envt && *envt == '0') && !(envr && *envr == '0');
-    BLZ_TRY(h->tables_rr.reserve(NTT_RR_TABLE_BYTES + (want_ta ? NTT_RR_BOUNDARY_ENTRIES * NTT_RR_ENTRY_DWORDS * 4 : 0)));
+    BLZ_TRY(h->tables_rr.reserve(NTT_RR_TABLE_BYTES + (want_ta ? NTT_RR_BOUNDARY_BYTES : 0)));
     {
         uint32_t* q = h->tables_rr.as<uint32_t>();
-        for (int i = 0; i < 3; ++i) { h->TR.wpass[i] = q; q += 512 * NTT_RR_ENTRY_DWORDS; }
+        for (int i = 0; i < 3; ++i) { h->TR.wpass[i] = q; q += 2 * 512 * NTT_RR_ENTRY_DWORDS; }   // Shoup entries
         h->TR.t0 = q; q += 512 * NTT_RR_ENTRY_DWORDS;
         h->TR.t1 = q; q += 512 * NTT_RR_ENTRY_DWORDS;
         h->TR.t2 = q; q += 512 * NTT_RR_ENTRY_DWORDS;

@@ -15,6 +15,8 @@ struct NttTables {  // all Montgomery form, device memory
 // reduced-radix twiddle tables of the 512-point kernel (ntt_rr.cuh): entries of 10 dwords (27-bit limbs), Montgomery
 // R_rr, < 2m
 struct NttTablesRR {
+    // wpass and tA hold SHOUP entries (canonical twiddle | floor(twiddle R_rr / m): 2 x 10 dwords, field_rr.cuh
+    // rr_mul_shoup); t0 / t1 / t2 / ts2 / fin stay Montgomery (R_rr): they feed the stepped boundary twiddles
     uint32_t* wpass[3];
     uint32_t* t0;
     uint32_t* t1;
@@ -27,7 +29,8 @@ struct NttTablesRR {
 };
 constexpr size_t NTT_RR_BOUNDARY_ENTRIES = (size_t)1 << 18;
 constexpr size_t NTT_RR_ENTRY_DWORDS = 10;
-constexpr size_t NTT_RR_TABLE_BYTES = (7 * 512 + 1) * NTT_RR_ENTRY_DWORDS * 4;
+constexpr size_t NTT_RR_TABLE_BYTES = (3 * 512 * 2 + 4 * 512 + 1) * NTT_RR_ENTRY_DWORDS * 4;   // 3 Shoup tables (2 entries' worth each), 4 Montgomery, fin
+constexpr size_t NTT_RR_BOUNDARY_BYTES = NTT_RR_BOUNDARY_ENTRIES * 2 * NTT_RR_ENTRY_DWORDS * 4;   // tA, Shoup entries
 
 struct NttGeom {
     int logA, logB, logC, logn;

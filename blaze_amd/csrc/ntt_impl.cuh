@@ -420,14 +420,14 @@ int ntt_setup_t(hipStream_t st, NttTables& T, NttTablesRR& TR, const NttGeom& g,
     // the same tables in the reduced radix for the 512-point kernel (ntt_rr.cuh)
     static_assert(rr_stride<typename Fr::RR>() == NTT_RR_ENTRY_DWORDS, "table entry size");
     for (int i = 0; i < 3; ++i)
-        hipLaunchKernelGGL(k_ntt_table_to_rr<Fr>, dim3(2), dim3(256), 0, st, T.wpass[i], TR.wpass[i], lrs[i] ? (1 << lrs[i]) : 1);
+        hipLaunchKernelGGL(k_ntt_table_to_shoup<Fr>, dim3(2), dim3(256), 0, st, T.wpass[i], TR.wpass[i], lrs[i] ? (1 << lrs[i]) : 1);
     hipLaunchKernelGGL(k_ntt_table_to_rr<Fr>, dim3(2), dim3(256), 0, st, T.t0, TR.t0, 512);
     hipLaunchKernelGGL(k_ntt_table_to_rr<Fr>, dim3(2), dim3(256), 0, st, T.t1, TR.t1, 512);
     hipLaunchKernelGGL(k_ntt_table_to_rr<Fr>, dim3(2), dim3(256), 0, st, T.t2, TR.t2, 512);
     if (TR.fin) hipLaunchKernelGGL(k_ntt_fin_rr<Fr>, dim3(1), dim3(64), 0, st, (const uint32_t*)T.ninv, TR.fin);
     hipLaunchKernelGGL(k_ntt_table_rr_pow<Fr>, dim3(2), dim3(256), 0, st, TR.ts2, 512u, l, (uint64_t)64 << g.logC, inverse);
     if (TR.tA)
-        hipLaunchKernelGGL(k_ntt_table_rr_pow<Fr>, dim3((unsigned)(NTT_RR_BOUNDARY_ENTRIES / 256)), dim3(256), 0, st, TR.tA,
+        hipLaunchKernelGGL((k_ntt_table_rr_pow<Fr, NTT_TA_SHOUP>), dim3((unsigned)(NTT_RR_BOUNDARY_ENTRIES / 256)), dim3(256), 0, st, TR.tA,
                            (uint32_t)NTT_RR_BOUNDARY_ENTRIES, l, (uint64_t)1 << g.logA, inverse);
     BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
     return BLZ_OK;

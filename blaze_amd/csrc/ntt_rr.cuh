@@ -14,7 +14,11 @@
 //   * every intermediate's limb and value bounds are part of its type, so the compiler proves that no 32-bit
 //     limb and no 64-bit column sum can overflow anywhere in the three DFT steps.
 // Data in HBM stay 32-byte words (canonical on the wire, < 2m between passes); tile elements in LDS and table
-// entries are rr_stride = 10 dwords apart (9 used), twiddle tables hold t R_rr mod m.
+// entries are rr_stride = 10 dwords apart (9 used).  Round 3: every product by a TABLE twiddle - the five inside an
+// 8-point DFT, the in-tile twiddles, the boundary table of pass 1 - is a Shoup product (field_rr.cuh rr_mul_shoup: the
+// table holds the canonical twiddle and its quotient floor(t R_rr / m), 2 x 10 dwords; 143 multiply-adds and no
+// quotient-digit chain against 153); the stepped boundary twiddles of pass 2 and the closing factor of the inverse
+// transform stay Montgomery products (their tables hold t R_rr mod m).
 #pragma once
 #include "field_rr.cuh"
 #include "ntt_engine.hpp"
@@ -89,6 +93,48 @@ BLZ_DEV void rr_mul_n(Frr<Q, 1, 2>& r, const Frr<Q, Fa, Va>& a, const Frr<Q, Fb,
     if constexpr (rr_cols_ok<Q>(Fa * Fb)) rr_mul(r, a, b);
     else rr_mul(r, rr_norm(a), b);
 }
+// ... and by a table twiddle in Shoup form (field_rr.cuh rr_mul_shoup): the plain product, no Montgomery factor
+template <class Q, int Fa, int Va>
+BLZ_DEV void rr_mul_n(Frr<Q, 1, 2>& r, const Frr<Q, Fa, Va>& a, const RRShoup<Q>& t) {
+    if constexpr (rr_cols_ok<Q>(Fa)) rr_mul_shoup(r, a, t);
+    else rr_mul_shoup(r, rr_norm(a), t);
+}
+// Shoup table entries: w | wq, rr_stride dwords each
+template <class Q>
+constexpr int rr_shoup_stride() { return 2 * rr_stride<Q>(); }
+template <class Q>
+BLZ_DEV void rr_load_shoup(RRShoup<Q>& t, const uint32_t* p) {
+    Frr<Q, 1, 1> a, b;
+    rr_load(a, p);
+    rr_load(b, p + rr_stride<Q>());
+#pragma unroll
+    for (int i = 0; i < Q::NL; ++i) {
+        t.w[i] = a.v[i];
+        t.wq[i] = b.v[i];
+    }
+}
+template <class Q>
+BLZ_DEV void rr_store_shoup(uint32_t* p, const RRShoup<Q>& t) {
+    Frr<Q, 1, 1> a, b;
+#pragma unroll
+    for (int i = 0; i < Q::NL; ++i) {
+        a.v[i] = t.w[i];
+        b.v[i] = t.wq[i];
+    }
+    rr_store(p, a);
+    rr_store(p + rr_stride<Q>(), b);
+}
+// x Rrr (Montgomery, < 2m) -> the plain canonical x with its Shoup quotient
+template <class Q>
+BLZ_DEV void rr_shoup_from_mont(RRShoup<Q>& t, const Frr<Q, 1, 2>& xm) {
+    Frr<Q, 1, 1> one;
+#pragma unroll
+    for (int i = 0; i < Q::NL; ++i) one.v[i] = i == 0 ? 1u : 0u;
+    Frr<Q, 1, 2> x;
+    rr_mul(x, xm, one);   // x Rrr * 1 / Rrr
+    rr_shoup_quot<Q>(t, rr_canon(x));
+}
+
 // a value < 2m (normalised) -> canonical
 template <class Q>
 BLZ_DEV Frr<Q, 1, 1> rr_canon(const Frr<Q, 1, 2>& a) {
@@ -184,6 +230,20 @@ __global__ void k_ntt_table_to_rr(const uint32_t* __restrict__ in, uint32_t* __r
     rr_from_mont32_words<Q>(r, w.v);
     rr_store(out + (size_t)j * rr_stride<Q>(), rr_canon(r));
 }
+// out[j] = in[j] as a Shoup table entry (canonical value | its quotient): the in-tile and DFT-internal twiddles
+template <class Fr>
+__global__ void k_ntt_table_to_shoup(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int count) {
+    using Q = typename Fr::RR;
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    Fp<Fr> w;
+    fp_load(w, in + (size_t)j * 8);
+    Frr<Q, 1, 2> r;
+    rr_from_mont32_words<Q>(r, w.v);
+    RRShoup<Q> t;
+    rr_shoup_from_mont<Q>(t, r);
+    rr_store_shoup<Q>(out + (size_t)j * rr_shoup_stride<Q>(), t);
+}
 // fin = n^-1 in Montgomery R_rr form (from the 32-bit ninv); forward transforms have no closing factor
 template <class Fr>
 __global__ void k_ntt_fin_rr(const uint32_t* __restrict__ ninv32, uint32_t* __restrict__ out) {
@@ -201,7 +261,7 @@ __global__ void k_ntt_fin_rr(const uint32_t* __restrict__ ninv32, uint32_t* __re
 }
 
 // out[j] = w^(j * mult) in the reduced radix, straight from the exponent (the boundary table tA)
-template <class Fr>
+template <class Fr, bool SHOUP = false>
 __global__ void k_ntt_table_rr_pow(uint32_t* __restrict__ out, uint32_t count, int logn, uint64_t mult, int inverse) {
     using Q = typename Fr::RR;
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -218,7 +278,13 @@ __global__ void k_ntt_table_rr_pow(uint32_t* __restrict__ out, uint32_t count, i
     }
     Frr<Q, 1, 2> r;
     rr_from_mont32_words<Q>(r, acc.v);
-    rr_store(out + (size_t)j * rr_stride<Q>(), rr_canon(r));
+    if constexpr (SHOUP) {
+        RRShoup<Q> t;
+        rr_shoup_from_mont<Q>(t, r);
+        rr_store_shoup<Q>(out + (size_t)j * rr_shoup_stride<Q>(), t);
+    } else {
+        rr_store(out + (size_t)j * rr_stride<Q>(), rr_canon(r));
+    }
 }
 
 // w^e for e < 2^27 from the three 512-entry tables
@@ -231,6 +297,14 @@ BLZ_DEV void tw_pow_rr(Frr<Q, 1, 2>& r, const NttTablesRR& T, uint32_t e) {
     if (e1) { rr_load(a, T.t1 + (size_t)e1 * ES); rr_mul(r, r, a); }
     if (e2) { rr_load(a, T.t2 + (size_t)e2 * ES); rr_mul(r, r, a); }
 }
+
+// the boundary table tA (2^18 entries, read once per element after pass 1) as Shoup entries (20 MiB) or Montgomery ones
+// (10 MiB, -DBLZ_NTT_TA_SHOUP=0).  Same-box: pass 1 5.48 ms with Shoup entries, 5.59 with Montgomery ones - and 5.49 before
+// any product of the pass was a Shoup product: pass 1 is bound by its access pattern (rows 8 MiB apart), not by its products.
+#ifndef BLZ_NTT_TA_SHOUP
+#define BLZ_NTT_TA_SHOUP 1
+#endif
+constexpr bool NTT_TA_SHOUP = BLZ_NTT_TA_SHOUP != 0;
 
 constexpr int NR_COLS_LOG = 2;
 constexpr int NR_COLS = 1 << NR_COLS_LOG;
@@ -277,13 +351,14 @@ __global__ __launch_bounds__(NR_THREADS, 2) void k_ntt512_rr(const uint32_t* __r
         in_rstride = 1;
         in_cstride = (uint64_t)A * B;
     }
-    const uint32_t* wp = T.wpass[PASS - 1];  // w512^j, j < 512
-    using WT = Frr<Q, 1, 1>;   // table entries are canonical
-    using W = Frr<Q, 1, 2>;    // stepped twiddles
+    const uint32_t* wp = T.wpass[PASS - 1];  // w512^j, j < 512, Shoup entries (canonical value | quotient)
+    constexpr uint32_t ES2 = rr_shoup_stride<Q>();
+    using WT = RRShoup<Q>;     // table twiddles: Shoup products (field_rr.cuh): 143 multiply-adds, no Montgomery factor
+    using W = Frr<Q, 1, 2>;    // stepped twiddles (Montgomery form) and data
     WT w1, w2, w3;
-    rr_load(w1, wp + 64 * ES);
-    rr_load(w2, wp + 128 * ES);
-    rr_load(w3, wp + 192 * ES);
+    rr_load_shoup<Q>(w1, wp + 64 * ES2);
+    rr_load_shoup<Q>(w2, wp + 128 * ES2);
+    rr_load_shoup<Q>(w3, wp + 192 * ES2);
 
     // ---- step 1: 8-point DFTs over n1 (rows 64 n1 + n2), straight from global memory.  The words on the wire are
     // any 256-bit value (canonical on the wire by contract; a stray one is still reduced correctly); between passes
@@ -305,7 +380,7 @@ __global__ __launch_bounds__(NR_THREADS, 2) void k_ntt512_rr(const uint32_t* __r
             t = rr_reduce2m(X);
         } else {
             WT w;
-            rr_load(w, wp + (size_t)(n2 * K) * ES);
+            rr_load_shoup<Q>(w, wp + (size_t)(n2 * K) * ES2);
             rr_mul_n(t, X, w);
         }
         rr_lds_store(lds, (64u * K + n2) * RS + col * ES, t);
@@ -324,7 +399,7 @@ __global__ __launch_bounds__(NR_THREADS, 2) void k_ntt512_rr(const uint32_t* __r
             t = rr_reduce2m(X);
         } else {
             WT w;
-            rr_load(w, wp + (size_t)(8u * n2p * K) * ES);
+            rr_load_shoup<Q>(w, wp + (size_t)(8u * n2p * K) * ES2);
             rr_mul_n(t, X, w);
         }
         rr_lds_store(lds, (64u * k1 + 8u * K + n2p) * RS + col * ES, t);
@@ -367,10 +442,22 @@ __global__ __launch_bounds__(NR_THREADS, 2) void k_ntt512_rr(const uint32_t* __r
     }
     BLZ_RR_FOR8(o3, {
         const uint32_t row = kb + 64u * K;
-        if (PASS == 1 && split) rr_load(w, T.tA + (size_t)(row * (uint32_t)fixed) * ES);   // w^(A i1 k2)
         W t;
-        if (PASS == 3 && !T.fin) t = rr_reduce2m(X);
-        else rr_mul_n(t, X, w);
+        if (PASS == 3 && !T.fin) {
+            t = rr_reduce2m(X);
+        } else if (PASS == 1 && split) {   // w^(A i1 k2), read from the boundary table
+            if constexpr (NTT_TA_SHOUP) {
+                WT wa;
+                rr_load_shoup<Q>(wa, T.tA + (size_t)(row * (uint32_t)fixed) * ES2);
+                rr_mul_n(t, X, wa);
+            } else {
+                Frr<Q, 1, 1> wa;
+                rr_load(wa, T.tA + (size_t)(row * (uint32_t)fixed) * ES);
+                rr_mul_n(t, X, wa);
+            }
+        } else {
+            rr_mul_n(t, X, w);
+        }
         Fp<Fr> y;
         rr_to_words<Q>(y.v, t);
         uint64_t oaddr;

@@ -77,6 +77,8 @@ def rr_struct(name, m, n32, B, NL):
     out.append(f"    static constexpr uint32_t RR2[{NL}] = {{{L(Rrr * Rrr % m)}}};  // Rrr^2 mod m")
     out.append(f"    static constexpr uint32_t TO32[{NL}] = {{{L((1 << (32 * n32)) % m)}}};  // 2^(32 N32) mod m, plain: x Rrr -> x R32")
     out.append(f"    static constexpr uint32_t FROM32[{NL}] = {{{L(Rrr * Rrr * pow(1 << (32 * n32), -1, m) % m)}}};  // Rrr^2 / R32: x R32 -> x Rrr")
+    out.append(f"    static constexpr uint32_t MBAR[{NL}] = {{{L(Rrr - m)}}};  // Rrr - m: the Shoup product's x w - q m as a sum (field_rr.cuh)")
+    out.append(f"    static constexpr uint32_t T2M = 0x{(2 * m) >> (B * (NL - 1)):08x}u;  // top limb of 2m: a value whose top limb is below it is < 2m")
     # K m in "borrow form" for carry-free subtraction a - b + K m: limb i gains 2^B, limb i + 1 loses 1,
     # so every limb but the top is >= 2^B - 1 >= any normalised limb of b, and the top limb is
     # (K m)_top - 1 >= b_top whenever b < (K / 2) m.
