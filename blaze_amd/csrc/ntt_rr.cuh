@@ -326,9 +326,15 @@ __global__ __launch_bounds__(NR_THREADS, 2) void k_ntt512_rr(const uint32_t* __r
         if (T.swz) {
             // tiles in flight together differ in the low 7 bits of i1 first (16 KiB apart) and only then in the column
             // group (128 B apart): a tile's 512 rows are 8 MiB apart, so neighbours in the column alone would put the
-            // whole chip on a 64 KiB window of every row - a few HBM channels - at any moment (pass 1: 6.9 -> 6.4 ms)
-            fixed = (tile & 127u) | ((tile >> 14) << 7);
-            col_base = ((tile >> 7) & 127u) << NR_COLS_LOG;
+            // whole chip on a 64 KiB window of every row - a few HBM channels - at any moment (pass 1: 6.9 -> 6.4 ms).
+            // swz = 1 + s: the lowest s bits of the tile number pick the column group instead, so that 2^s tiles dispatched
+            // back to back read ADJACENT 128-byte pieces of every row (one DRAM row activation serves them): pass 1 5.46 -> 5.19
+            // ms at s = 3 (15.34 -> 15.15 ms per transform, same box; s = 2: 15.20, s = 4: 15.45, s = 5: 15.8).
+            const uint32_t sb = T.swz - 1u;                       // 0 .. 5
+            const uint64_t lowcol = tile & ((1u << sb) - 1u);
+            const uint64_t t2 = tile >> sb;
+            fixed = (t2 & 127u) | ((tile >> 14) << 7);
+            col_base = (lowcol | (((t2 >> 7) & (127u >> sb)) << sb)) << NR_COLS_LOG;
         } else {
             fixed = tile / tiles_per;
             col_base = (tile % tiles_per) << NR_COLS_LOG;
