@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 T=${1:-r03_final}
 python3 bench.py > gpurun_out/${T}_bench_line.json 2> gpurun_out/${T}_bench.err
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$T -- python3 bench.py --no-cpu-baseline > gpurun_out/${T}_bench_line_under_rocprof.json 2> gpurun_out/prof_$T.err
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$T -- python3 bench.py --no-cpu-baseline --no-extras > gpurun_out/${T}_bench_line_under_rocprof.json 2> gpurun_out/prof_$T.err
 python3 tools/rocpd_summary.py gpurun_out/prof_$T/*/*_results.db > gpurun_out/${T}_bench_kernel_stats.txt
 python3 tools/rocpd_timeline.py gpurun_out/prof_$T/*/*_results.db > gpurun_out/${T}_step_timeline.txt
 BLAZE_SORT_HIDE=0 rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_fetch_$T -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras > gpurun_out/pmc_fetch_$T.log 2>&1
