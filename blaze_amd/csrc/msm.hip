@@ -584,6 +584,13 @@ int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int 
         const uint64_t mean = max_entries / (G ? G : 1) + 1;
         if ((uint64_t)S.stats_h[1] > 64 * mean + 4096 || (uint64_t)O.stats_h[1] > 64 * mean + 4096) s3 = false;
     }
+    if (s3 && hide_env == 1) {
+        // ... and the sort only hides if its waves fit BESIDE the accumulation's: two of those per SIMD (registers are
+        // allocated in eights out of 512) plus one of the sort's.  A build whose k_accumulate grew past that still works,
+        // it just sorts in the open (round 3 saw 211 VGPRs cost 4 ms per step before this check existed).
+        const int av = ops->accumulate_vgprs(), sv = msm_sort3_max_vgprs();
+        if (av > 0 && sv > 0 && 2 * ((av + 7) & ~7) + ((sv + 7) & ~7) > 512 - 32) s3 = false;   // (measured: fits at 2 x 200 + 72, does not at 2 x 216 + 72)
+    }
     const bool hide = s3 && O.busy;
     const bool use_s3 = s3 && (hide || hide_env == 2);
     S.sort_hidden = hide;

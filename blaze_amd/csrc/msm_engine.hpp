@@ -115,6 +115,7 @@ int msm_sort_lds(MsmEngine& E, const void* d_scalars, uint32_t npts, int sbits);
 // three-level, small-footprint digit sort built to run underneath another task's k_accumulate (msm_sort3.hip): fills
 // count[] and entries[] of the current slot's SortBufs on E.sort_st; msm_sort3_ok: does the plan qualify
 bool msm_sort3_ok(const MsmPlan& P, int sbits);
+int msm_sort3_max_vgprs();   // the largest register count among the three-level sort's kernels (0 if unknown)
 int msm_sort3(MsmEngine& E, const void* d_scalars, uint32_t npts);
 int msm_sort_lds_scatter(MsmEngine& E);
 int launch_fill_units(MsmEngine& E, uint32_t units);  // unit->bucket map + length-ordered unit list
@@ -131,6 +132,8 @@ struct MsmCurveOps {
     // phases 2 - 3 over bucket sums found at sums[unit_off[g]] (unit_off[g + 1] > unit_off[g], else the bucket is empty)
     int (*run_reduce)(MsmEngine&, const void* sums, const void* unit_off);
     int partial_dwords;   // dwords of one unit / bucket sum in `partial`
+    // VGPRs of k_accumulate as compiled (hipFuncGetAttributes): what the hidden sort has to fit beside
+    int (*accumulate_vgprs)();
     int (*combine)(MsmEngine&, const uint8_t* partials, size_t count, uint8_t* out, bool on_device);
 };
 const MsmCurveOps& msm_ops_bls377();

@@ -737,6 +737,16 @@ int combine_t(MsmEngine& E, const uint8_t* partials, size_t count, uint8_t* out,
 }
 
 template <class F>
+int accumulate_vgprs_t() {
+    hipFuncAttributes a;
+    if (hipFuncGetAttributes(&a, (const void*)k_accumulate<F>) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return a.numRegs;
+}
+
+template <class F>
 MsmCurveOps make_ops() {
     MsmCurveOps o;
     o.points_to_mont = &points_to_mont_t<F>;
@@ -745,6 +755,7 @@ MsmCurveOps make_ops() {
     o.merge_buckets = &merge_buckets_t<F>;
     o.run_reduce = &run_reduce_t<F>;
     o.partial_dwords = partial_dwords<F>();
+    o.accumulate_vgprs = &accumulate_vgprs_t<F>;
     o.combine = &combine_t<F>;
     return o;
 }

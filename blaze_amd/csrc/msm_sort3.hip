@@ -460,6 +460,23 @@ bool msm_sort3_ok(const MsmPlan& P, int sbits) {
     return true;
 }
 
+int msm_sort3_max_vgprs() {
+    static int cached = -1;
+    if (cached >= 0) return cached;
+    int mx = 0;
+    const void* ks[] = {(const void*)k3_l1_count, (const void*)k3_l1_scatter, (const void*)k3_l2_count, (const void*)k3_l2_scatter,
+                        (const void*)k3_l3};
+    for (const void* k : ks) {
+        hipFuncAttributes a;
+        if (hipFuncGetAttributes(&a, k) != hipSuccess) {
+            (void)hipGetLastError();
+            return cached = 0;
+        }
+        if (a.numRegs > mx) mx = a.numRegs;
+    }
+    return cached = mx;
+}
+
 int msm_sort3(MsmEngine& E, const void* d_scalars, uint32_t npts) {
     const MsmPlan& P = E.last_plan;
     hipStream_t st = E.sort_st;

@@ -137,7 +137,7 @@ int ntt_setup(blz_ntt* h) {
         h->TR.t1 = q; q += 512 * NTT_RR_ENTRY_DWORDS;
         h->TR.t2 = q; q += 512 * NTT_RR_ENTRY_DWORDS;
         h->TR.fin = h->inverse ? q : nullptr; q += NTT_RR_ENTRY_DWORDS;
-        h->TR.ts2 = q; q += 512 * NTT_RR_ENTRY_DWORDS;
+        h->TR.ts2 = q; q += 2 * 512 * NTT_RR_ENTRY_DWORDS;   // Shoup entries
         h->TR.tA = want_ta ? q : nullptr;
         // pass 1 tile order (ntt_rr.cuh); BLAZE_NTT_SWZ=0: the plain order (A/B runs)
         const char* envs = getenv("BLAZE_NTT_SWZ");

@@ -16,7 +16,7 @@ struct NttTables {  // all Montgomery form, device memory
 // R_rr, < 2m
 struct NttTablesRR {
     // wpass and tA hold SHOUP entries (canonical twiddle | floor(twiddle R_rr / m): 2 x 10 dwords, field_rr.cuh
-    // rr_mul_shoup); t0 / t1 / t2 / ts2 / fin stay Montgomery (R_rr): they feed the stepped boundary twiddles
+    // rr_mul_shoup), ts2 too (the step of pass 2's boundary twiddle: a constant); t0 / t1 / t2 / fin stay Montgomery (R_rr)
     uint32_t* wpass[3];
     uint32_t* t0;
     uint32_t* t1;
@@ -30,7 +30,7 @@ struct NttTablesRR {
 };
 constexpr size_t NTT_RR_BOUNDARY_ENTRIES = (size_t)1 << 18;
 constexpr size_t NTT_RR_ENTRY_DWORDS = 10;
-constexpr size_t NTT_RR_TABLE_BYTES = (3 * 512 * 2 + 4 * 512 + 1) * NTT_RR_ENTRY_DWORDS * 4;   // 3 Shoup tables (2 entries' worth each), 4 Montgomery, fin
+constexpr size_t NTT_RR_TABLE_BYTES = (4 * 512 * 2 + 3 * 512 + 1) * NTT_RR_ENTRY_DWORDS * 4;   // 4 Shoup tables (wpass x 3, ts2: 2 entries' worth each), 3 Montgomery, fin
 constexpr size_t NTT_RR_BOUNDARY_BYTES = NTT_RR_BOUNDARY_ENTRIES * 2 * NTT_RR_ENTRY_DWORDS * 4;   // tA, Shoup entries
 
 struct NttGeom {

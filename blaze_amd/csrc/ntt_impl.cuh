@@ -425,7 +425,7 @@ int ntt_setup_t(hipStream_t st, NttTables& T, NttTablesRR& TR, const NttGeom& g,
     hipLaunchKernelGGL(k_ntt_table_to_rr<Fr>, dim3(2), dim3(256), 0, st, T.t1, TR.t1, 512);
     hipLaunchKernelGGL(k_ntt_table_to_rr<Fr>, dim3(2), dim3(256), 0, st, T.t2, TR.t2, 512);
     if (TR.fin) hipLaunchKernelGGL(k_ntt_fin_rr<Fr>, dim3(1), dim3(64), 0, st, (const uint32_t*)T.ninv, TR.fin);
-    hipLaunchKernelGGL(k_ntt_table_rr_pow<Fr>, dim3(2), dim3(256), 0, st, TR.ts2, 512u, l, (uint64_t)64 << g.logC, inverse);
+    hipLaunchKernelGGL((k_ntt_table_rr_pow<Fr, true>), dim3(2), dim3(256), 0, st, TR.ts2, 512u, l, (uint64_t)64 << g.logC, inverse);   // Shoup entries
     if (TR.tA)
         hipLaunchKernelGGL((k_ntt_table_rr_pow<Fr, NTT_TA_SHOUP>), dim3((unsigned)(NTT_RR_BOUNDARY_ENTRIES / 256)), dim3(256), 0, st, TR.tA,
                            (uint32_t)NTT_RR_BOUNDARY_ENTRIES, l, (uint64_t)1 << g.logA, inverse);

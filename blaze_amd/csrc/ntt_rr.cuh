@@ -431,6 +431,7 @@ __global__ __launch_bounds__(NR_THREADS, 2) void k_ntt512_rr(const uint32_t* __r
     // geometric sequence along the lane's rows.
     const bool split = T.tA != nullptr;
     W w, step;
+    WT step_s;
     if (PASS == 1) {
         if (!split) {
             // x(i0, i1, k2 = row) *= w^(row (i0 + A i1)),  m = i0 + A i1 < 2^18
@@ -442,7 +443,7 @@ __global__ __launch_bounds__(NR_THREADS, 2) void k_ntt512_rr(const uint32_t* __r
         // x(i0, k1 = row, k2) *= w^(C i0 row)   [split: * w^(i0 k2) as well; k2 = fixed]
         const uint64_t i0 = col_base + col;
         tw_pow_rr<Q>(w, T, (uint32_t)((((uint64_t)kb << g.logC) + (split ? fixed : 0)) * i0));
-        rr_load(step, T.ts2 + (size_t)i0 * ES);   // w^(64 C i0)
+        rr_load_shoup<Q>(step_s, T.ts2 + (size_t)i0 * ES2);   // w^(64 C i0): a Shoup entry - w (Montgomery form) times a plain constant stays in Montgomery form
     } else if (T.fin) {
         rr_load(w, T.fin);   // inverse transform: n^-1; a forward transform closes with the product-free reduction
     }
@@ -471,7 +472,10 @@ __global__ __launch_bounds__(NR_THREADS, 2) void k_ntt512_rr(const uint32_t* __r
             fp_csub_const<Fr, Fr::MOD>(y);   // < 2m -> canonical: the wire format
             oaddr = (col_base + col) + (uint64_t)C * fixed + (uint64_t)C * B * row;
         } else {
-            if (K != 7 && !(PASS == 1 && split)) rr_mul(w, w, step);  // twiddle x twiddle
+            if (K != 7 && !(PASS == 1 && split)) {   // twiddle x twiddle
+                if (PASS == 2) rr_mul_shoup(w, w, step_s);
+                else rr_mul(w, w, step);
+            }
             oaddr = in_base + row * in_rstride + col;
         }
         fp_store(out + oaddr * 8, y);
