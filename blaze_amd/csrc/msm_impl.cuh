@@ -266,10 +266,12 @@ __global__ __launch_bounds__(128, 3) void k_combine_units(const uint32_t* __rest
                                                        const uint32_t* __restrict__ unit_order,
                                                        const uint32_t* __restrict__ nfull_ptr,
                                                        const uint32_t* __restrict__ stats, uint32_t L,
-                                                       uint32_t stride, uint32_t* __restrict__ partial) {
+                                                       uint32_t stride, uint32_t thr, uint32_t* __restrict__ partial) {
     // the host launches one pass per power of 16 up to the LARGEST possible bucket; the passes beyond this
-    // task's longest bucket (stats[1] entries) have nothing to fold
-    if (stride >= (stats[1] + L - 1) / L) return;
+    // task's longest bucket (stats[1] entries) have nothing to fold.  thr > 0: buckets of up to thr units are
+    // k_combine_buckets' (below); this tree only folds the hot ones - none at all in most tasks
+    const uint32_t max_units = (stats[1] + L - 1) / L;
+    if (stride >= max_units || max_units <= thr) return;
     // One DPP quad per 16 consecutive entries of the full-unit list (ec_quad.cuh): it scans them for
     // group leaders (at most two: a bucket's full units are contiguous in the list) and folds each
     // leader's group.  The chain of up to 15 additions is sequential and only hot buckets have any, so
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(128, 3) void k_combine_units(const uint32_t* __rest
         uint32_t u = unit_order[t0];
         uint32_t g = unit_bucket[u];
         uint32_t u0 = unit_off[g], u1 = unit_off[g + 1];
-        if (u1 - u0 > stride && (u - u0) % (16u * stride) == 0) leaders |= 1u << i;
+        if (u1 - u0 > stride && u1 - u0 > thr && (u - u0) % (16u * stride) == 0) leaders |= 1u << i;
     }
     while (leaders) {
         const uint32_t i = (uint32_t)__builtin_ctz(leaders);
@@ -304,6 +306,38 @@ __global__ __launch_bounds__(128, 3) void k_combine_units(const uint32_t* __rest
             quad_add(acc, t, ql);
         }
         if (ql == 0) store_partial32(partial, u, acc);
+    }
+}
+
+// The same fold for inputs where EVERY bucket has many units (the precompute shapes: 2^29 points in 2^17 buckets are
+// runs of 8192 = 32 units of 256): one lane per bucket adds its units up in sequence.  131 K lanes x 31 full additions
+// keep the chip busy for ~0.4 ms; the quad tree above, built for a handful of hot buckets, took 3.1 ms of config 3
+// scanning the 4 M entries of the full-unit list for group leaders.  Buckets of more than `thr` units stay the tree's
+// (a lane must not be handed a run of thousands of units: the reference harness's repeated tile).
+template <class F>
+__global__ __launch_bounds__(128, 3) void k_combine_buckets(const uint32_t* __restrict__ unit_off, uint64_t G, uint32_t thr,
+                                                          uint32_t* __restrict__ partial) {
+    const uint64_t g = (uint64_t)blockIdx.x * 128u + threadIdx.x;
+    if (g >= G) return;
+    const uint32_t u0 = unit_off[g], u1 = unit_off[g + 1];
+    if (u1 - u0 < 2 || u1 - u0 > thr) return;
+    if constexpr (USE_RR<F>) {
+        using Q = typename F::RR;
+        XYZZRR<Q> acc, t;
+        ptrr_load(acc, partial, u0);
+        for (uint32_t u = u0 + 1; u < u1; ++u) {
+            ptrr_load(t, partial, u);
+            ptrr_add<Q, 5>(acc, t);
+        }
+        ptrr_store(partial, u0, acc);
+    } else {
+        XYZZ<F> acc, t;
+        load_xyzz(acc, partial, u0);
+        for (uint32_t u = u0 + 1; u < u1; ++u) {
+            load_xyzz(t, partial, u);
+            pt_add_inl<F, 3>(acc, t);
+        }
+        store_xyzz(partial, u0, acc);
     }
 }
 
@@ -605,12 +639,18 @@ int run_accumulate_t(MsmEngine& E, const void* d_pts, uint32_t U, int slice) {
     const uint32_t maxunits = (P.npts + P.L - 1) / P.L;   // a bucket holds at most one entry per point
     uint64_t full_bound = (uint64_t)P.npts * P.W / P.L + 1;  // units of length L: at most entries / L
     if (full_bound > U) full_bound = U;
+    // where the plan itself says that buckets hold several units each (mean run > L / 2), the lane-per-bucket fold takes
+    // every bucket of up to 64 units and the tree only the hot ones beyond
+    const uint32_t thr = ((uint64_t)P.npts * P.W / (P.G ? P.G : 1) > P.L / 2) ? 64u : 0u;
     // (64-bit stride: with BLAZE_MSM_L < 8 and close to 2^31 points, maxunits exceeds 2^28 and a u32 stride would
     // wrap to 0 - an endless launch loop)
     for (uint64_t stride = 1; stride < maxunits; stride *= 16)
         hipLaunchKernelGGL(k_combine_units<F>, dim3((uint32_t)((full_bound / 16 + 1) * 4 / 128 + 1)), dim3(128), 0, st,
                            E.sb().unit_off.as<uint32_t>(), E.sb().unit_bucket.as<uint32_t>(), E.sb().unit_order.as<uint32_t>(),
-                           E.sb().lenhist.as<uint32_t>() + P.L, E.sb().stats.as<uint32_t>(), P.L, (uint32_t)stride, E.partial.as<uint32_t>());
+                           E.sb().lenhist.as<uint32_t>() + P.L, E.sb().stats.as<uint32_t>(), P.L, (uint32_t)stride, thr, E.partial.as<uint32_t>());
+    if (thr)
+        hipLaunchKernelGGL(k_combine_buckets<F>, dim3((uint32_t)((P.G + 127) / 128)), dim3(128), 0, st, E.sb().unit_off.as<uint32_t>(),
+                           (uint64_t)P.G, thr, E.partial.as<uint32_t>());
     BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
     return BLZ_OK;
 }
