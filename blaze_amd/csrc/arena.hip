@@ -34,6 +34,7 @@ void arena_free_extent(ArenaExtent& x) {
         else (void)hipFree(x.raw);
     }
     if (x.mont) (void)hipFree(x.mont);
+    if (x.table) (void)hipFree(x.table);
     if (x.shadow_ready) (void)hipEventDestroy(x.shadow_ready);
     x = ArenaExtent();
 }
@@ -111,6 +112,14 @@ int arena_write(int device_id, uint64_t pos, const void* src, size_t len, bool s
         e->mont_curve = -1;   // no shadow yet
     }
     mark_dirty(*e, pos - e->start, end - e->start);
+    if (e->table) {
+        // the window table is a function of the bytes: gone with any write (a task in flight may still gather from it)
+        BLZ_HIP(hipDeviceSynchronize(), BLZ_ERR_WRITE);
+        (void)hipFree(e->table);
+        e->table = nullptr;
+        e->table_bytes = 0;
+    }
+    e->table_refused = false;
     char* dst = (char*)e->raw + (pos - e->start);
     hipError_t he = hipMemcpyAsync(dst, src, len, src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st);
     if (he != hipSuccess)

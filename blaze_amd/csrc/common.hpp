@@ -129,6 +129,15 @@ struct ArenaExtent {
     uint64_t dirty_lo = 0, dirty_hi = 0;   // byte span (relative to start) whose points are stale in the shadow
     hipEvent_t shadow_ready = nullptr;     // recorded after the last conversion; consumers on other streams wait
     bool shadow_recorded = false;          // shadow_ready has been recorded at least once since the shadow was (re)built
+    // window table (msm_impl.cuh k_build_window_table; opt-in per handle): for the points [table_first, +table_npts) of the grid at `table_phase`
+    // the W multiples 2^(c j) P, j < W, in the shadow's point format, point-major.  Any write into the extent drops it.
+    void* table = nullptr;
+    size_t table_bytes = 0;
+    int table_format = -1, table_c = 0, table_W = 0;
+    uint32_t table_phase = 0;
+    uint64_t table_first = 0, table_npts = 0;
+    bool table_refused = false;            // a build failed (a base of even order, or no memory): do not retry until the next write
+    float table_build_ms = 0;              // (the build is synchronous: nothing to order other streams behind)
 };
 struct Arena {
     std::mutex mu;

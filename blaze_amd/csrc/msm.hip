@@ -120,6 +120,44 @@ MsmPlan make_plan(uint32_t npts, int sbits, int ebits, int force_c) {
     return best;
 }
 
+// Window-table plans (msm_engine.hpp MsmPlan::table, msm_impl.cuh k_build_window_table).  Costs fitted to the round-3 kernels on the table
+// shape: 0.130 ns per entry (one mixed addition; the sort is hidden), 0.34 ns per bucket slot (two full additions in the
+// level-0 reduce - 12.6 ms for the 2^25 buckets of c = 26 - scans, unit lists).  2^26 bases: c = 26, 10 windows (671 M
+// additions instead of the 805 M of the 12-window plan without a table: 106.6 ms per MSM against 116.2; c = 24, 11 windows:
+// 108.7); 2^24: c = 24 (30.0 against 33.2 ms); 2^23: c = 22 (17.2 against 18.3 ms).
+int table_window_bits(uint32_t npts) {
+    const int forced = msm_env_int("BLAZE_MSM_TABLE_C", 0);
+    int best = 0;
+    double best_cost = 1e300;
+    for (int c = 16; c <= 26; ++c) {
+        if (forced > 0 && c != forced) continue;
+        const int W = table_windows(c);
+        if (c > 16 && table_windows(c - 1) == W && forced <= 0) continue;   // same additions, twice the buckets: dominated
+        if ((uint64_t)npts * W >= (1ull << 30)) continue;
+        const double cost = (double)npts * W * 0.130 + (double)(1ull << (c - 1)) * 0.34;
+        if (cost < best_cost) { best_cost = cost; best = c; }
+    }
+    return best;
+}
+
+MsmPlan make_table_plan(uint32_t npts, int c) {
+    MsmPlan P;
+    if (c < 16 || c > 26) return P;
+    const int W = table_windows(c);
+    if ((uint64_t)npts * W >= (1ull << 30)) return P;
+    P.npts = npts; P.sbits = 256; P.c = c; P.W = W; P.table = true;
+    P.G = 1ull << (c - 1);
+    for (int w = 0; w < W; ++w) { P.width[w] = (uint8_t)c; P.boff[w] = 0; }
+    P.boff[W] = (uint32_t)P.G;
+    P.Bw = 1u << (c - 1 - 5);   // the one window is walked as 32 virtual windows (k_finish stitches them)
+    P.Wv = 32;
+    double chain = (double)npts * W * 5.5e-6;
+    uint32_t L = 16;
+    while (L < 256 && 2.0 * L <= chain) L <<= 1;
+    P.L = L;
+    return P;
+}
+
 // zero-fill (hipMemsetAsync's fill kernel took 0.7 ms for the 71 MB bucket-count array: ~100 GB/s)
 __global__ __launch_bounds__(256) void k_zero(uint4* __restrict__ p, size_t n16) {
     __builtin_amdgcn_s_setprio(3);   // sort-stage kernel: may run underneath another task's accumulation (msm_sort3.hip)
@@ -503,6 +541,12 @@ int MsmEngine::points_to_mont(const void* d_raw, void* d_mont, uint32_t npts) {
     return ops_for(curve, repr)->points_to_mont(*this, d_raw, d_mont, npts);
 }
 
+int MsmEngine::build_table(const void* d_raw, void* d_table, uint32_t npts, int c, int W, void* scratch, uint32_t* flag, hipStream_t st) {
+    BLZ_TRY(use_device(device));
+    return ops_for(curve, repr)->build_table(*this, d_raw, d_table, npts, c, W, scratch, flag, st);
+}
+size_t MsmEngine::table_scratch_bytes(int W) const { return ops_for(curve, repr)->table_scratch_bytes(W); }
+
 static const int kScalarFieldBits[3] = {253, 255, 254};  // bit length of r (BLS12-377 / 381 / BN254)
 
 MsmPlan MsmEngine::plan_for(uint32_t npts, int sbits) const {
@@ -510,7 +554,7 @@ MsmPlan MsmEngine::plan_for(uint32_t npts, int sbits) const {
     return make_plan(npts, sbits, ebits, msm_env_int("BLAZE_MSM_C", 0));
 }
 
-int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int sbits, int* slot_out) {
+int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int sbits, int* slot_out, int table_c) {
     BLZ_TRY(use_device(device));
     const MsmCurveOps* ops = ops_for(curve, repr);
     MsmEngine& E = *this;
@@ -534,8 +578,9 @@ int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int 
         return BLZ_OK;
     }
     const int ebits = sbits == 256 ? kScalarFieldBits[curve] : sbits;
-    MsmPlan P = make_plan(npts, sbits, ebits, msm_env_int("BLAZE_MSM_C", 0));
-    if (P.c == 0) return fail(BLZ_ERR_INVALID_PARAM, "no window plan for npts=%u sbits=%d", npts, sbits);
+    MsmPlan P = table_c > 0 ? make_table_plan(npts, table_c) : make_plan(npts, sbits, ebits, msm_env_int("BLAZE_MSM_C", 0));
+    if (P.c == 0) return fail(BLZ_ERR_INVALID_PARAM, "no window plan for npts=%u sbits=%d%s", npts, sbits, table_c > 0 ? " (window table)" : "");
+    if (P.table && (sbits != 256 || !msm_sort3t_ok(P))) return fail(BLZ_ERR_INVALID_PARAM, "window-table task outside the sort's range (c=%d)", P.c);
     P.L = (uint32_t)msm_env_int("BLAZE_MSM_L", (int)P.L);
     if (P.L < 1) P.L = 1;
     if (P.L > (uint32_t)MAX_L) P.L = MAX_L;
@@ -555,7 +600,7 @@ int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int 
     {
         const uint64_t table = (uint64_t)npts * mont_point_bytes(curve);
         const int forced = msm_env_int("BLAZE_MSM_SLICES", 0);
-        if (forced > 0) nslices = forced;
+        if (forced > 0 && !P.table) nslices = forced;
         (void)table;
         if (nslices > MSM_MAX_SLICES) nslices = MSM_MAX_SLICES;
         if ((uint64_t)nslices > npts) nslices = 1;
@@ -576,8 +621,9 @@ int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int 
     SortBufs& B = sb();
     const int hide_env = msm_env_int("BLAZE_SORT_HIDE", 1);
     const MsmSlot& O = slots[(slot + 1) % MSM_QUEUE_DEPTH];
-    bool s3 = hide_env != 0 && nslices == 1 && msm_sort3_ok(P, sbits);
-    if (s3 && hide_env == 1) {
+    bool s3 = P.table || (hide_env != 0 && nslices == 1 && msm_sort3_ok(P, sbits));   // (a table task has no other sort)
+    bool fits = true;
+    if (s3 && hide_env == 1 && !P.table) {
         // the three-level sort gives one block a whole level-2 bin: fine for the near-uniform digits of real scalars, a
         // cliff for inputs that pile entries into a few buckets (the reference harness repeats a 256-point tile).  The
         // handle's last tasks say which kind it is being fed: stats_h[1] is their largest bucket.
@@ -588,11 +634,12 @@ int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int 
         // ... and the sort only hides if its waves fit BESIDE the accumulation's: two of those per SIMD (registers are
         // allocated in eights out of 512) plus one of the sort's.  A build whose k_accumulate grew past that still works,
         // it just sorts in the open (round 3 saw 211 VGPRs cost 4 ms per step before this check existed).
-        const int av = ops->accumulate_vgprs(), sv = msm_sort3_max_vgprs();
-        if (av > 0 && sv > 0 && 2 * ((av + 7) & ~7) + ((sv + 7) & ~7) > 512 - 32) s3 = false;   // (measured: fits at 2 x 200 + 72, does not at 2 x 216 + 72)
+        const int av = ops->accumulate_vgprs(), sv = P.table ? msm_sort3t_max_vgprs() : msm_sort3_max_vgprs();
+        if (av > 0 && sv > 0 && 2 * ((av + 7) & ~7) + ((sv + 7) & ~7) > 512 - 32) fits = false;   // (measured: fits at 2 x 200 + 72, does not at 2 x 216 + 72)
+        if (!fits && !P.table) s3 = false;
     }
-    const bool hide = s3 && O.busy;
-    const bool use_s3 = s3 && (hide || hide_env == 2);
+    const bool hide = s3 && O.busy && hide_env != 0 && fits;
+    const bool use_s3 = s3 && (hide || hide_env == 2 || P.table);
     S.sort_hidden = hide;
     sort_st = hide ? sort_stream : st;
     hipStream_t ss = sort_st;
@@ -624,7 +671,7 @@ int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int 
         // ---- sort stage, on ss
         BLZ_HIP(hipMemsetAsync(B.stats.p, 0, 64, ss), BLZ_ERR_UNKNOWN);
         if (use_s3) {
-            BLZ_TRY(msm_sort3(E, sc_s, np));   // count[] and entries[] in one go
+            BLZ_TRY(P.table ? msm_sort3t(E, sc_s, np) : msm_sort3(E, sc_s, np));   // count[] and entries[] in one go
         } else {
             const size_t n16 = ((G + 1) * 4 + 15) / 16;   // the reserve above rounds the allocation up
             hipLaunchKernelGGL(k_zero, dim3(2048), dim3(256), 0, ss, (uint4*)B.count.p, n16);

@@ -51,6 +51,9 @@ struct blz_msm {
     ncclComm_t comm = nullptr;
     int comm_rank = 0, comm_size = 0;
     DevBuf comm_buf;   // [send: one partial | recv: comm_size partials]
+    // resident-base window table (blz_msm_set_window_table; BLAZE_MSM_TABLE sets the default of new handles)
+    bool window_table = false;
+    uint64_t table_info[4] = {0, 0, 0, 0};   // of the last HBM task: table bytes, window bits, windows, build time (us)
 };
 
 namespace {
@@ -125,6 +128,107 @@ int arena_points_mont(blz_msm* h, uint64_t pos, uint32_t npts, const void** out)
     return BLZ_OK;
 }
 
+// Window table of the `npts` bases at arena offset `pos` (msm_impl.cuh k_build_window_table, MsmPlan::table): built on first use - synchronously,
+// on this handle's main stream, about 2 s for 2^26 BLS bases - kept with the extent, dropped by any write into it.
+// *out stays null (and the task takes the plain path) when the table is not to be had: no memory for it, a base of even
+// order, a task over a sub-range whose best window width is not the table's.
+int arena_points_table(blz_msm* h, uint64_t pos, uint32_t npts, const void** out, int* c_out) {
+    *out = nullptr;
+    *c_out = 0;
+    const size_t ps = point_size(h), mp = mont_point_bytes(h->curve);
+    const size_t len = (size_t)npts * ps;
+    Arena& A = arena_for(h->device);
+    std::lock_guard<std::mutex> lk(A.mu);
+    ArenaExtent* e = arena_find(A, pos, len);
+    if (!e)
+        return fail(BLZ_ERR_INVALID_PARAM, "HBM bases: no loaded extent covers [%llu, +%zu) on device %d",
+                    (unsigned long long)pos, len, h->device);
+    if (npts == 0 || e->table_refused) return BLZ_OK;
+    const uint32_t phase = (uint32_t)((pos - e->start) % ps);
+    const uint64_t first = (pos - e->start - phase) / ps;
+    const int fmt = h->eng.format_id();
+    const int want_c = table_window_bits(npts);
+    if (want_c == 0) return BLZ_OK;
+    const bool covers = e->table && e->table_format == fmt && e->table_phase == phase && first >= e->table_first &&
+                        first + npts <= e->table_first + e->table_npts;
+    if (covers && e->table_c != want_c) return BLZ_OK;   // a sub-range that wants other windows: the plain path, not a rebuild
+    if (!covers) {
+        const int c = want_c, W = table_windows(c);
+        const size_t bytes = (size_t)npts * W * mp + 16;
+        if (e->table) {
+            BLZ_HIP(hipDeviceSynchronize(), BLZ_ERR_UNKNOWN);   // a task of another handle may still gather from the old one
+            (void)hipFree(e->table);
+            e->table = nullptr;
+            e->table_bytes = 0;
+        }
+        size_t free_b = 0, total_b = 0;
+        BLZ_HIP(hipMemGetInfo(&free_b, &total_b), BLZ_ERR_UNKNOWN);
+        const size_t scratch_b = h->eng.table_scratch_bytes(W) + 16;
+        // what a task of this shape still has to allocate next to the table: entries and sort intermediates (~32 B per
+        // entry), bucket tables and partial sums
+        const size_t workspace = (size_t)npts * W * 32 + ((size_t)1 << (c - 1)) * 256 + ((size_t)1 << 30);
+        if (free_b < bytes + scratch_b + workspace) {
+            BLZ_LOG(1, "window table: %zu bytes for %u bases (c = %d, %d windows) do not fit beside the workspace (%zu free): plain path",
+                    bytes, npts, c, W, free_b);
+            e->table_refused = true;
+            return BLZ_OK;
+        }
+        void* tab = nullptr;
+        if (hipMalloc(&tab, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            e->table_refused = true;
+            return BLZ_OK;
+        }
+        DevBuf scratch;
+        int rc = scratch.reserve(scratch_b);
+        hipEvent_t t0 = nullptr, t1 = nullptr;
+        float ms = 0;
+        uint32_t flag_h = 0;
+        if (rc == BLZ_OK) {
+            uint32_t* flag = reinterpret_cast<uint32_t*>((char*)scratch.p + scratch_b - 16);
+            hipStream_t st = h->eng.stream;
+            if (hipEventCreate(&t0) != hipSuccess || hipEventCreate(&t1) != hipSuccess) rc = fail(BLZ_ERR_UNKNOWN, "event creation failed");
+            if (rc == BLZ_OK && hipMemsetAsync(flag, 0, 16, st) != hipSuccess) rc = fail(BLZ_ERR_UNKNOWN, "memset failed");
+            if (rc == BLZ_OK) (void)hipEventRecord(t0, st);
+            if (rc == BLZ_OK) rc = h->eng.build_table((const char*)e->raw + phase + first * ps, tab, npts, c, W, scratch.p, flag, st);
+            if (rc == BLZ_OK) (void)hipEventRecord(t1, st);
+            if (rc == BLZ_OK) rc = sync_stream_bounded(st, "window table build");
+            if (rc == BLZ_OK && hipMemcpy(&flag_h, flag, 4, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(BLZ_ERR_READ, "window table: flag read failed");
+            if (rc == BLZ_OK) (void)hipEventElapsedTime(&ms, t0, t1);
+        }
+        if (t0) (void)hipEventDestroy(t0);
+        if (t1) (void)hipEventDestroy(t1);
+        if (rc != BLZ_OK) {
+            if (!wait_timed_out()) { scratch.release(); (void)hipFree(tab); }   // (wedged: the kernel may still write them - leak)
+            return rc;
+        }
+        scratch.release();
+        if (flag_h) {
+            BLZ_LOG(1, "window table: a base has a multiple at infinity (a point of even order): plain path for this extent");
+            (void)hipFree(tab);
+            e->table_refused = true;
+            return BLZ_OK;
+        }
+        e->table = tab;
+        e->table_bytes = bytes;
+        e->table_format = fmt;
+        e->table_phase = phase;
+        e->table_first = first;
+        e->table_npts = npts;
+        e->table_c = c;
+        e->table_W = W;
+        e->table_build_ms = ms;
+        BLZ_LOG(1, "window table: %u bases x %d windows of %d bits, %.1f MiB, built in %.1f ms", npts, W, c, bytes / 1048576.0, ms);
+    }
+    *out = (const char*)e->table + (first - e->table_first) * (size_t)e->table_W * mp;
+    *c_out = e->table_c;
+    h->table_info[0] = e->table_bytes;
+    h->table_info[1] = (uint64_t)e->table_c;
+    h->table_info[2] = (uint64_t)e->table_W;
+    h->table_info[3] = (uint64_t)(e->table_build_ms * 1000.0f);
+    return BLZ_OK;
+}
+
 int launch_if_ready(blz_msm* h) {
     if (!(h->armed && h->data_ready)) return BLZ_OK;
     if (!h->eng.can_accept())
@@ -134,9 +238,19 @@ int launch_if_ready(blz_msm* h) {
     int slot = 0;
     // bases in the arena: the shadow pointer is resolved now, not when the data was staged - a load by another
     // handle in between may have moved or re-converted the extent
-    if (h->staged_from_arena) BLZ_TRY(arena_points_mont(h, h->staged_arena_pos, npts, &h->d_points_mont));
+    int table_c = 0;
+    memset(h->table_info, 0, sizeof(h->table_info));
+    if (h->staged_from_arena) {
+        if (h->window_table && h->pf == 1) {
+            const void* tab = nullptr;
+            BLZ_WAIT(h, arena_points_table(h, h->staged_arena_pos, npts, &tab, &table_c));
+            if (tab) h->d_points_mont = tab;
+            else table_c = 0;
+        }
+        if (!table_c) BLZ_TRY(arena_points_mont(h, h->staged_arena_pos, npts, &h->d_points_mont));
+    }
     h->eng.inputs_event = h->staged_set >= 0 ? h->set_free[h->staged_set] : nullptr;
-    BLZ_TRY(h->eng.run(h->d_points_mont, h->d_scalars, npts, sbits, &slot));
+    BLZ_TRY(h->eng.run(h->d_points_mont, h->d_scalars, npts, sbits, &slot, table_c));
     if (h->staged_set >= 0) h->set_used[h->staged_set] = true;
     h->staged_set = -1;
     h->armed = false;
@@ -248,6 +362,7 @@ int blz_msm_new(int device_id, int mem_type, int is_precompute, int curve, blz_m
     h->mem_type = mem_type;
     h->pf = is_precompute ? BLZ_PRECOMPUTE_FACTOR : BLZ_PRECOMPUTE_FACTOR_BASE;
     h->curve = curve;
+    h->window_table = msm_env_int("BLAZE_MSM_TABLE", 0) != 0;
     int rc = h->eng.init(device_id, curve, (int)h->pf);
     if (rc == BLZ_OK && hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess)
         rc = fail(BLZ_ERR_UNKNOWN, "copy stream creation failed");
@@ -305,6 +420,18 @@ int blz_msm_loaded_binary_parameters(blz_msm* h, uint32_t out[2]) {
     const uint32_t width = P.c > 0 ? (uint32_t)(P.c - 1) : 0u;
     out[1] = put_msb_first(0, 28, 31) | put_msb_first((curve_code << 2) & 0xffu, 20, 27) | put_msb_first(adders, 16, 19) |
              put_msb_first(width & 0xffu, 8, 15) | put_msb_first(8u, 4, 7);
+    return BLZ_OK;
+}
+
+int blz_msm_set_window_table(blz_msm* h, int enable) {
+    if (!h) return fail(BLZ_ERR_INVALID_PARAM, "null handle");
+    h->window_table = enable != 0;
+    return BLZ_OK;
+}
+
+int blz_msm_window_table_info(blz_msm* h, uint64_t out[4]) {
+    if (!h || !out) return fail(BLZ_ERR_INVALID_PARAM, "null argument");
+    for (int i = 0; i < 4; ++i) out[i] = h->table_info[i];
     return BLZ_OK;
 }
 

@@ -22,8 +22,18 @@ struct MsmPlan {
     int Wv = 0;          // G / V
     uint64_t G = 0;      // bucket slots
     uint32_t L = 0;      // max run length handled by one accumulate unit
+    // Window-table tasks (msm_impl.cuh k_build_window_table): the points array holds, per base, its W multiples 2^(c j) P (point-major), so
+    // every window's digit d of base i is an addition of +-table[i W + j] into bucket |d| - 1 of ONE bucket set shared
+    // by all windows: boff[w] = 0 for every window, G = 2^(c-1), entries carry i W + j.  The reduce sees a single window.
+    bool table = false;
 };
 MsmPlan make_plan(uint32_t npts, int sbits, int ebits, int force_c);
+// window-table geometry for npts bases: the window width c (16..26) whose W = ceil(257 / c) windows make the cheapest task
+// (fewer windows = fewer additions, wider windows = more buckets to reduce); BLAZE_MSM_TABLE_C forces c.  0: none fits
+// (entries are indexed with 30 bits: npts W < 2^30)
+int table_window_bits(uint32_t npts);
+inline int table_windows(int c) { return (257 + c - 1) / c; }
+MsmPlan make_table_plan(uint32_t npts, int c);
 
 // Task queue (msm_hw_code.rs:19-25: the device has a task queue and a result queue): up to
 // MSM_QUEUE_DEPTH tasks may be in flight.  The throughput-bound part of a task (sort, bucket
@@ -97,8 +107,12 @@ struct MsmEngine {
     MsmPlan plan_for(uint32_t npts, int sbits) const;   // the plan run() will use (host-side only)
     // raw wire-format points (x||y canonical LE) -> Montgomery AoS at mont_point_bytes() stride (never in place)
     int points_to_mont(const void* d_raw, void* d_mont, uint32_t npts);
+    // window table of npts wire-format points (msm_impl.cuh k_build_window_table): see MsmCurveOps::build_table
+    int build_table(const void* d_raw, void* d_table, uint32_t npts, int c, int W, void* scratch, uint32_t* flag, hipStream_t st);
+    size_t table_scratch_bytes(int W) const;
     // enqueue the whole pipeline; *slot identifies the task for finish().  Fails when both slots are busy.
-    int run(const void* d_points_mont, const void* d_scalars, uint32_t npts, int sbits, int* slot);
+    // table_c > 0: d_points_mont is the window table of the npts bases (table_windows(table_c) entries per base)
+    int run(const void* d_points_mont, const void* d_scalars, uint32_t npts, int sbits, int* slot, int table_c = 0);
     // wait for task `slot`, copy the result out (result_size bytes), collect its phase timings
     int finish(int slot, uint8_t* out);
     // add `count` partial results (host bytes, or device bytes already ordered on aux_stream) on the device,
@@ -117,6 +131,10 @@ int msm_sort_lds(MsmEngine& E, const void* d_scalars, uint32_t npts, int sbits);
 bool msm_sort3_ok(const MsmPlan& P, int sbits);
 int msm_sort3_max_vgprs();   // the largest register count among the three-level sort's kernels (0 if unknown)
 int msm_sort3(MsmEngine& E, const void* d_scalars, uint32_t npts);
+// the same sort for window-table plans (shared bucket set, entries = point * W + window)
+bool msm_sort3t_ok(const MsmPlan& P);
+int msm_sort3t_max_vgprs();
+int msm_sort3t(MsmEngine& E, const void* d_scalars, uint32_t npts);
 int msm_sort_lds_scatter(MsmEngine& E);
 int launch_fill_units(MsmEngine& E, uint32_t units);  // unit->bucket map + length-ordered unit list
 
@@ -134,6 +152,11 @@ struct MsmCurveOps {
     int partial_dwords;   // dwords of one unit / bucket sum in `partial`
     // VGPRs of k_accumulate as compiled (hipFuncGetAttributes): what the hidden sort has to fit beside
     int (*accumulate_vgprs)();
+    // window table of npts wire-format points (msm_impl.cuh k_build_window_table): table[i W + j] = 2^(c j) P_i in the Montgomery point format,
+    // on `st`; scratch: table_scratch_bytes(W) bytes; *flag (device u32) is set when a multiple came out as infinity
+    int (*build_table)(MsmEngine&, const void* d_raw, void* d_table, uint32_t npts, int c, int W, void* scratch, uint32_t* flag,
+                       hipStream_t st);
+    size_t (*table_scratch_bytes)(int W);
     int (*combine)(MsmEngine&, const uint8_t* partials, size_t count, uint8_t* out, bool on_device);
 };
 const MsmCurveOps& msm_ops_bls377();

@@ -30,14 +30,9 @@ constexpr bool rr_point_packed() {
     else return false;
 }
 
+// one point (canonical x, y: 32-bit words) into slot `p` of a Montgomery point array
 template <class F>
-__global__ __launch_bounds__(256) void k_points_to_mont(const uint32_t* __restrict__ raw, uint32_t* __restrict__ mont,
-                                                        uint32_t npts) {
-    uint32_t p = blockIdx.x * 256u + threadIdx.x;
-    if (p >= npts) return;
-    Fp<F> x, y;
-    fp_load(x, raw + (size_t)p * 2 * F::N);
-    fp_load(y, raw + (size_t)p * 2 * F::N + F::N);
+BLZ_DEV void store_mont_point(uint32_t* __restrict__ mont, size_t p, Fp<F>& x, Fp<F>& y) {
     if constexpr (USE_RR<F>) {
         using Q = typename F::RR;
         Frr<Q, 1, 2> xr, yr;
@@ -47,20 +42,105 @@ __global__ __launch_bounds__(256) void k_points_to_mont(const uint32_t* __restri
             static_assert(2 * Q::N32 <= MONT_STRIDE<F>, "packed reduced-radix point does not fit its stride");
             rr_to_words<Q>(x.v, xr);
             rr_to_words<Q>(y.v, yr);
-            fp_store(mont + (size_t)p * MONT_STRIDE<F>, x);
-            fp_store(mont + (size_t)p * MONT_STRIDE<F> + F::N, y);
+            fp_store(mont + p * MONT_STRIDE<F>, x);
+            fp_store(mont + p * MONT_STRIDE<F> + F::N, y);
         } else {
             static_assert(2 * Q::NL <= MONT_STRIDE<F> && Q::NL % 2 == 0, "reduced-radix point does not fit its line");
-            rr_store(mont + (size_t)p * MONT_STRIDE<F>, xr);
-            rr_store(mont + (size_t)p * MONT_STRIDE<F> + Q::NL, yr);
+            rr_store(mont + p * MONT_STRIDE<F>, xr);
+            rr_store(mont + p * MONT_STRIDE<F> + Q::NL, yr);
         }
     } else {
         fp_to_mont(x, x);
         fp_to_mont(y, y);
-        fp_store(mont + (size_t)p * MONT_STRIDE<F>, x);
-        fp_store(mont + (size_t)p * MONT_STRIDE<F> + F::N, y);
+        fp_store(mont + p * MONT_STRIDE<F>, x);
+        fp_store(mont + p * MONT_STRIDE<F> + F::N, y);
     }
 }
+
+template <class F>
+__global__ __launch_bounds__(256) void k_points_to_mont(const uint32_t* __restrict__ raw, uint32_t* __restrict__ mont,
+                                                        uint32_t npts) {
+    uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= npts) return;
+    Fp<F> x, y;
+    fp_load(x, raw + (size_t)p * 2 * F::N);
+    fp_load(y, raw + (size_t)p * 2 * F::N + F::N);
+    store_mont_point<F>(mont, p, x, y);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Window table of resident bases (opt-in: blz_msm_set_window_table): table[i W + j] = 2^(c j) P_i, j < W, in the
+// Montgomery point format above.  With the window weights moved into the points, all W windows of a scalar add into
+// ONE bucket set, so the bucket count no longer multiplies with the window count and the windows can be as wide as
+// the entries-per-bucket ratio allows: 2^26 bases run 10 windows of 26 bits (671 M additions, 2^25 buckets) instead of
+// 12 windows of 21 - 23 bits (805 M additions, 12 x 2^21 buckets).  Costs W x the memory of the bases and, once per
+// load, this kernel: one lane per base walks the c (W - 1) doublings (32-bit XYZZ arithmetic, ec.cuh), parks the
+// W - 1 unnormalised multiples and the running products of their ZZZ in a lane-private scratch row, inverts the
+// last product once and normalises on the way back (Montgomery's trick inside the lane).
+// A base whose multiple comes out as infinity (only a point of even order can: none in the r-torsion) cannot be
+// tabulated: *flag is raised and the host falls back to the plain path.
+// ------------------------------------------------------------------------------------------------
+template <class F>
+constexpr size_t TABLE_SCRATCH_ROW = 5 * F::N;   // dwords per parked multiple: X, Y, ZZ, ZZZ, running product
+template <class F>
+__global__ __launch_bounds__(64, 3) void k_build_window_table(const uint32_t* __restrict__ raw, uint32_t* __restrict__ table,
+                                                              uint32_t npts, int c, int W, uint32_t* __restrict__ scratch,
+                                                              uint32_t* __restrict__ flag) {
+    const uint32_t lane = blockIdx.x * 64u + threadIdx.x, nlanes = gridDim.x * 64u;
+    uint32_t* row = scratch + (size_t)lane * (size_t)(W - 1) * TABLE_SCRATCH_ROW<F>;
+    for (uint32_t i = lane; i < npts; i += nlanes) {
+        Fp<F> x, y;
+        fp_load(x, raw + (size_t)i * 2 * F::N);
+        fp_load(y, raw + (size_t)i * 2 * F::N + F::N);
+        Affine<F> a;
+        fp_to_mont(a.x, x);
+        fp_to_mont(a.y, y);
+        store_mont_point<F>(table, (size_t)i * W, x, y);   // j = 0: the base itself (x, y are consumed)
+        XYZZ<F> p;
+        Fp<F> prod;
+        bool bad = false;
+        for (int j = 1; j < W; ++j) {
+            XYZZ<F> t;
+            if (j == 1) { pt_mdbl(p, a); }
+            else { pt_dbl(t, p); p = t; }
+            for (int d = 1; d < c; ++d) { pt_dbl(t, p); p = t; }
+            if (pt_is_inf(p)) { bad = true; break; }
+            if (j == 1) prod = p.zzz;
+            else fp_mul(prod, prod, p.zzz);
+            uint32_t* q = row + (size_t)(j - 1) * TABLE_SCRATCH_ROW<F>;
+            fp_store(q, p.x); fp_store(q + F::N, p.y); fp_store(q + 2 * F::N, p.zz); fp_store(q + 3 * F::N, p.zzz);
+            fp_store(q + 4 * F::N, prod);
+        }
+        if (bad) {
+            atomicOr(flag, 1u);
+            continue;
+        }
+        Fp<F> inv;
+        fp_inv(inv, prod);   // 1 / (ZZZ_1 ... ZZZ_(W-1))
+        for (int j = W - 1; j >= 1; --j) {
+            const uint32_t* q = row + (size_t)(j - 1) * TABLE_SCRATCH_ROW<F>;
+            Fp<F> X, Y, ZZ, ZZZ, w;
+            fp_load(X, q); fp_load(Y, q + F::N); fp_load(ZZ, q + 2 * F::N); fp_load(ZZZ, q + 3 * F::N);
+            if (j > 1) {
+                Fp<F> before;
+                fp_load(before, q - TABLE_SCRATCH_ROW<F> + 4 * F::N);   // ZZZ_1 ... ZZZ_(j-1)
+                fp_mul(w, inv, before);                                  // 1 / ZZZ_j
+                fp_mul(inv, inv, ZZZ);                                   // 1 / (ZZZ_1 ... ZZZ_(j-1))
+            } else {
+                w = inv;
+            }
+            Fp<F> zi;
+            fp_mul(zi, ZZ, w);     // 1 / z
+            fp_mul(Y, Y, w);
+            fp_sqr(zi, zi);
+            fp_mul(X, X, zi);
+            fp_from_mont(x, X);
+            fp_from_mont(y, Y);
+            store_mont_point<F>(table, (size_t)i * W + j, x, y);
+        }
+    }
+}
+
 template <class F>
 BLZ_DEV void load_affine_rr(AffineRR<typename F::RR>& a, const uint32_t* pts, uint32_t idx) {
     using Q = typename F::RR;
@@ -636,7 +716,8 @@ int run_accumulate_t(MsmEngine& E, const void* d_pts, uint32_t U, int slice) {
                        E.sb().unit_bucket.as<uint32_t>(), E.sb().unit_order.as<uint32_t>(), E.sb().stats.as<uint32_t>(), P.L,
                        E.partial.as<uint32_t>());
     BLZ_HIP(hipEventRecord(slice < 0 ? S.ev[6] : S.slice_ev[2 * slice + 1], st), BLZ_ERR_UNKNOWN);
-    const uint32_t maxunits = (P.npts + P.L - 1) / P.L;   // a bucket holds at most one entry per point
+    // a bucket holds at most one entry per point (window-table tasks: one per point and window)
+    const uint64_t maxunits = ((uint64_t)P.npts * (P.table ? P.W : 1) + P.L - 1) / P.L;
     uint64_t full_bound = (uint64_t)P.npts * P.W / P.L + 1;  // units of length L: at most entries / L
     if (full_bound > U) full_bound = U;
     // where the plan itself says that buckets hold several units each (mean run > L / 2), the lane-per-bucket fold takes
@@ -730,7 +811,13 @@ int run_reduce_t(MsmEngine& E, const void* sums, const void* unit_off_v) {
     fp.W = P.W;
     fp.logV = 0;
     while ((1u << fp.logV) < P.Bw) ++fp.logV;
-    {
+    if (P.table) {
+        // one bucket set for all the scalar's windows (their weights are in the table's points): a single window at bit 0
+        fp.W = 1;
+        fp.v0[0] = 0;
+        fp.m[0] = (uint8_t)(P.G >> fp.logV);
+        fp.off[0] = 0;
+    } else {
         int off = 0;
         for (int w = 0; w < P.W; ++w) {
             const uint32_t v0 = P.boff[w] >> fp.logV, m = (P.boff[w + 1] - P.boff[w]) >> fp.logV;
@@ -776,6 +863,24 @@ int combine_t(MsmEngine& E, const uint8_t* partials, size_t count, uint8_t* out,
     return rc;
 }
 
+constexpr uint32_t TABLE_BUILD_BLOCKS = 256 * 4 * 3;   // 64-lane blocks: three waves on every SIMD
+template <class F>
+size_t table_scratch_bytes_t(int W) {
+    return (size_t)TABLE_BUILD_BLOCKS * 64 * (size_t)(W > 1 ? W - 1 : 1) * TABLE_SCRATCH_ROW<F> * 4;
+}
+template <class F>
+int build_table_t(MsmEngine& E, const void* d_raw, void* d_table, uint32_t npts, int c, int W, void* scratch, uint32_t* flag,
+                  hipStream_t st) {
+    (void)E;
+    if (npts == 0) return BLZ_OK;
+    uint32_t blocks = (npts + 63) / 64;
+    if (blocks > TABLE_BUILD_BLOCKS) blocks = TABLE_BUILD_BLOCKS;
+    hipLaunchKernelGGL(k_build_window_table<F>, dim3(blocks), dim3(64), 0, st, (const uint32_t*)d_raw, (uint32_t*)d_table, npts, c, W,
+                       (uint32_t*)scratch, flag);
+    BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
+    return BLZ_OK;
+}
+
 template <class F>
 int accumulate_vgprs_t() {
     hipFuncAttributes a;
@@ -796,6 +901,8 @@ MsmCurveOps make_ops() {
     o.run_reduce = &run_reduce_t<F>;
     o.partial_dwords = partial_dwords<F>();
     o.accumulate_vgprs = &accumulate_vgprs_t<F>;
+    o.build_table = &build_table_t<F>;
+    o.table_scratch_bytes = &table_scratch_bytes_t<F>;
     o.combine = &combine_t<F>;
     return o;
 }

@@ -536,4 +536,414 @@ int msm_sort3(MsmEngine& E, const void* d_scalars, uint32_t npts) {
     return BLZ_OK;
 }
 
+// ================================================================================================ window-table tasks
+// The same three levels for plans whose windows share ONE bucket set (MsmPlan::table, msm_impl.cuh k_build_window_table): W windows of c bits,
+// G = 2^(c-1) buckets, an entry carries (base * W + window) | sign.  What changes against the kernels above:
+//   * every window scatters into the same <= 256 level-1 bins (bucket >> sh1, sh1 = c - 9), so the level-1 remainder is up
+//     to 17 bits wide: 16 travel in the u16 side array, the lowest one (xs = 1) in bit 30 of the index word (indices stay
+//     below 2^30: make_table_plan);
+//   * the split of the remainder between level 2 (b2 <= 8 bits) and the final level (b3 bits, one block per 2^b3 buckets) is
+//     chosen per task so that a final block holds about 6 K entries: wide windows have few entries per bucket (2^26 bases,
+//     c = 26: 20), and 128 buckets per block would leave the blocks with 2.5 K entries and 2^18 of them;
+//   * the final level keeps bins of up to S3_R3 entries in registers as above; a larger one (c = 26: 512 buckets, 10 K
+//     entries) is counted and placed in two passes over an LDS image of the run.
+struct S3TGeom {
+    int W, prio, c;
+    uint32_t sh1, b2, b3, xs, NB1;
+};
+constexpr uint32_t S3T_IMG = 12288;   // entries of the final level's LDS image (dynamic LDS: 48 KiB)
+
+__global__ __launch_bounds__(S3_THREADS, 4) void k3t_l1_count(const uint32_t* __restrict__ scalars, uint32_t npts, S3TGeom g,
+                                                             uint32_t* __restrict__ cnt1) {
+    const int prio = g.prio;
+    S3_PRIO();
+    __shared__ uint32_t hist[256];
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * S3_CNT_PTS;
+    uint32_t end = base + S3_CNT_PTS;
+    if (end > npts) end = npts;
+    const int cw = g.c;
+    for (uint32_t p0 = base + threadIdx.x; p0 < end; p0 += 4 * S3_THREADS) {
+        ScalarWords<8> sw[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t p = p0 + u * S3_THREADS;
+            sw[u].load(scalars, p < end ? p : p0);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (p0 + u * S3_THREADS >= end) break;
+            uint32_t carry = 0;
+            for (int w = 0; w < g.W; ++w) {
+                const int d = sw[u].next(cw, (1u << cw) - 1u, 1u << (cw - 1), carry);
+                if (d != 0) {
+                    const uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1u;
+                    atomicAdd(&hist[b >> g.sh1], 1u);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < g.NB1) {
+        const uint32_t v = hist[threadIdx.x];
+        if (v) atomicAdd(&cnt1[threadIdx.x], v);
+    }
+}
+
+__global__ __launch_bounds__(S3_THREADS, 4) void k3t_l1_scatter(const uint32_t* __restrict__ scalars, uint32_t npts, S3TGeom g,
+                                                               uint32_t* __restrict__ cur1, uint32_t* __restrict__ o_idx,
+                                                               uint16_t* __restrict__ o_rem) {
+    const int prio = g.prio;
+    S3_PRIO();
+    extern __shared__ __attribute__((aligned(16))) uint32_t sh[];
+    uint32_t* sc = sh;                                          // [8][S3_PB]: word j of the lane's scalar u at j * PB + u * 256 + tid
+    uint2* stage = reinterpret_cast<uint2*>(sh + 8 * S3_PB);    // [S3_PB]
+    uint32_t* hist = sh + 10 * S3_PB;                           // [256]
+    uint32_t* lstart = hist + 256;
+    uint32_t* gbase = lstart + 256;
+    __shared__ uint32_t wave_tot[4];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t base = blockIdx.x * (uint32_t)S3_PB;
+#pragma unroll
+    for (int u = 0; u < S3_T; ++u) {
+        const uint32_t p = base + u * S3_THREADS + tid;
+        uint4 a = make_uint4(0, 0, 0, 0), b = make_uint4(0, 0, 0, 0);
+        if (p < npts) {
+            const uint4* q = reinterpret_cast<const uint4*>(scalars) + 2 * (size_t)p;
+            a = q[0];
+            b = q[1];
+        }
+        const uint32_t i = u * S3_THREADS + tid;
+        sc[0 * S3_PB + i] = a.x; sc[1 * S3_PB + i] = a.y; sc[2 * S3_PB + i] = a.z; sc[3 * S3_PB + i] = a.w;
+        sc[4 * S3_PB + i] = b.x; sc[5 * S3_PB + i] = b.y; sc[6 * S3_PB + i] = b.z; sc[7 * S3_PB + i] = b.w;
+    }
+    const uint32_t cw = (uint32_t)g.c, mask = (1u << cw) - 1u, half = 1u << (cw - 1);
+    const uint32_t nb = g.NB1, sh1 = g.sh1, lowmask = (1u << sh1) - 1u, W = (uint32_t)g.W;
+    uint32_t carry = 0;   // bit u: the carry of the lane's scalar u into the next window
+    for (uint32_t w = 0; w < W; ++w) {
+        const uint32_t off = w * cw;
+        const uint32_t j = off >> 5, shb = off & 31u;
+        hist[tid] = 0;
+        __syncthreads();
+        uint32_t key[S3_T], rk[S3_T];   // key = low sh1 bits | bin << sh1 | sign << 31;  rk = rank in the bin, ~0 = no entry
+#pragma unroll
+        for (int u = 0; u < S3_T; ++u) {
+            const uint32_t i = u * S3_THREADS + tid;
+            const uint32_t lo = j < 8 ? sc[j * S3_PB + i] : 0u;
+            const uint32_t hi = j + 1 < 8 ? sc[(j + 1) * S3_PB + i] : 0u;
+            const uint32_t raw = (shb ? __builtin_amdgcn_alignbit(hi, lo, shb) : lo) & mask;
+            const uint32_t v = raw + ((carry >> u) & 1u);
+            int d;
+            if (v > half) { d = (int)v - (int)(half << 1); carry |= 1u << u; }
+            else { d = (int)v; carry &= ~(1u << u); }
+            rk[u] = ~0u;
+            key[u] = 0;
+            if (d != 0 && base + i < npts) {
+                const uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1u;
+                const uint32_t bin = b >> sh1;
+                key[u] = (b & lowmask) | (bin << sh1) | (d < 0 ? 0x80000000u : 0u);
+                rk[u] = atomicAdd(&hist[bin], 1u);
+            }
+        }
+        __syncthreads();
+        {
+            const uint32_t v = tid < nb ? hist[tid] : 0u;
+            uint32_t total;
+            const uint32_t excl = s3_block_excl_scan(v, wave_tot, &total);
+            if (tid < nb) {
+                lstart[tid] = excl;
+                gbase[tid] = v ? atomicAdd(&cur1[tid], v) : 0u;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < S3_T; ++u) {
+                if (rk[u] != ~0u) {
+                    const uint32_t bin = (key[u] >> sh1) & 0xffu;
+                    const uint32_t p = base + u * S3_THREADS + tid;
+                    const uint32_t rem = key[u] & lowmask;
+                    // index word: (base * W + window) | remainder bit 0 at bit 30 when the remainder has 17 bits | sign
+                    const uint32_t iw = (p * W + w) | (g.xs ? (rem & 1u) << 30 : 0u) | (key[u] & 0x80000000u);
+                    stage[lstart[bin] + rk[u]] = make_uint2(iw, (rem >> g.xs) | (bin << 16));
+                }
+            }
+            __syncthreads();
+            for (uint32_t slot = tid; slot < total; slot += S3_THREADS) {
+                const uint2 e = stage[slot];
+                const uint32_t bin = e.y >> 16;
+                const uint32_t dst = gbase[bin] + (slot - lstart[bin]);
+                o_idx[dst] = e.x;
+                o_rem[dst] = (uint16_t)e.y;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// level 2: the stored u16 is the remainder >> xs; its level-2 digit is the top b2 bits
+__global__ __launch_bounds__(S3_THREADS, 4) void k3t_l2_count(const uint16_t* __restrict__ rem, const uint32_t* __restrict__ off1,
+                                                             const uint2* __restrict__ map, const uint32_t* __restrict__ nitems,
+                                                             uint32_t* __restrict__ cnt2, S3TGeom g) {
+    const int prio = g.prio;
+    S3_PRIO();
+    __shared__ uint32_t hist[256];
+    uint32_t k, lo, hi;
+    if (!s3_item(off1, map, nitems, blockIdx.x, S3_SLICE2, k, lo, hi)) return;
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t sh = g.b3 - g.xs;
+    uint32_t r[S3_T2];
+#pragma unroll
+    for (int t = 0; t < S3_T2; ++t) {
+        const uint32_t i = lo + t * S3_THREADS + threadIdx.x;
+        r[t] = i < hi ? rem[i] : 0xffffffffu;
+    }
+#pragma unroll
+    for (int t = 0; t < S3_T2; ++t)
+        if (r[t] != 0xffffffffu) atomicAdd(&hist[r[t] >> sh], 1u);
+    __syncthreads();
+    if (threadIdx.x < (1u << g.b2)) {
+        const uint32_t v = hist[threadIdx.x];
+        if (v) atomicAdd(&cnt2[(k << g.b2) + threadIdx.x], v);
+    }
+}
+
+__global__ __launch_bounds__(S3_THREADS, 4) void k3t_l2_scatter(const uint32_t* __restrict__ i_idx, const uint16_t* __restrict__ i_rem,
+                                                               const uint32_t* __restrict__ off1, const uint2* __restrict__ map,
+                                                               const uint32_t* __restrict__ nitems, uint32_t* __restrict__ cur2,
+                                                               uint32_t* __restrict__ o_idx, uint16_t* __restrict__ o_lo, S3TGeom g) {
+    const int prio = g.prio;
+    S3_PRIO();
+    __shared__ uint2 stage[S3_SLICE2];
+    __shared__ uint32_t hist[256], lstart[256], gbase[256];
+    __shared__ uint32_t wave_tot[4];
+    uint32_t k, lo, hi;
+    if (!s3_item(off1, map, nitems, blockIdx.x, S3_SLICE2, k, lo, hi)) return;
+    const uint32_t tid = threadIdx.x;
+    hist[tid] = 0;
+    __syncthreads();
+    const uint32_t sh = g.b3 - g.xs, lomask = (1u << sh) - 1u, nb2 = 1u << g.b2;
+    uint32_t ex[S3_T2], ky[S3_T2];   // ky = final-level bucket (b3 <= 10 bits) | level-2 digit << 10 | rank << 18; ~0 = no entry
+#pragma unroll
+    for (int t = 0; t < S3_T2; ++t) {
+        const uint32_t i = lo + t * S3_THREADS + tid;
+        ky[t] = 0xffffffffu;
+        ex[t] = 0;
+        if (i < hi) {
+            const uint32_t r = i_rem[i];
+            const uint32_t iw = i_idx[i];
+            const uint32_t h2 = r >> sh;
+            const uint32_t low = g.xs ? ((r & lomask) << 1) | ((iw >> 30) & 1u) : (r & lomask);
+            ex[t] = iw & 0xbfffffffu;
+            const uint32_t rank = atomicAdd(&hist[h2], 1u);   // < 4096
+            ky[t] = low | (h2 << 10) | (rank << 18);
+        }
+    }
+    __syncthreads();
+    const uint32_t v = tid < nb2 ? hist[tid] : 0u;
+    uint32_t total;
+    const uint32_t excl = s3_block_excl_scan(v, wave_tot, &total);
+    if (tid < nb2) {
+        lstart[tid] = excl;
+        gbase[tid] = v ? atomicAdd(&cur2[(k << g.b2) + tid], v) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < S3_T2; ++t) {
+        if (ky[t] != 0xffffffffu) {
+            const uint32_t h2 = (ky[t] >> 10) & 0xffu;
+            stage[lstart[h2] + (ky[t] >> 18)] = make_uint2(ex[t], ky[t] & 0x3ffffu);
+        }
+    }
+    __syncthreads();
+    for (uint32_t slot = tid; slot < total; slot += S3_THREADS) {
+        const uint2 e = stage[slot];
+        const uint32_t h2 = (e.y >> 10) & 0xffu;
+        const uint32_t dst = gbase[h2] + (slot - lstart[h2]);
+        o_idx[dst] = e.x;
+        o_lo[dst] = (uint16_t)(e.y & 0x3ffu);
+    }
+}
+
+// final level: one block per level-2 bin = 2^b3 consecutive buckets (b3 <= 10).  Two builds, chosen by the task's mean bin:
+// REGS keeps a bin of up to S3_R3 entries in registers between the count and the placement (one pass over the bin, as
+// k3_l3 above; 70 VGPRs); the other one reads the bin twice - count, then place into the LDS image - and holds nothing
+// (bins of ~10 K entries: c = 26).  Both fall back to entry-by-entry placement for a bin beyond their capacity (hot buckets).
+template <bool REGS>
+__global__ __launch_bounds__(S3_THREADS, 4) void k3t_l3(const uint32_t* __restrict__ i_idx, const uint16_t* __restrict__ i_lo,
+                                                       const uint32_t* __restrict__ off2, uint32_t* __restrict__ count,
+                                                       uint32_t* __restrict__ entries, S3TGeom g, uint32_t img) {
+    const int prio = g.prio;
+    S3_PRIO();
+    extern __shared__ __attribute__((aligned(16))) uint32_t out[];   // [img]
+    __shared__ uint32_t hist[1024], cursor[1024];
+    __shared__ uint32_t wave_tot[4];
+    const uint32_t j = blockIdx.x, tid = threadIdx.x;
+    const uint32_t a = off2[j], b = off2[j + 1], s = b - a;
+    const uint32_t nb3 = 1u << g.b3;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) hist[q * S3_THREADS + tid] = 0;
+    __syncthreads();
+    // exclusive scan of the nb3 <= 1024 bucket counts (four consecutive counters per thread) -> count[], cursor[]
+    auto scan_counts = [&]() {
+        uint32_t v[4], sum = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t t = tid * 4u + q;
+            v[q] = t < nb3 ? hist[t] : 0u;
+            sum += v[q];
+        }
+        uint32_t total;
+        uint32_t run = s3_block_excl_scan(sum, wave_tot, &total);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t t = tid * 4u + q;
+            if (t < nb3) {
+                count[((size_t)j << g.b3) + t] = v[q];
+                cursor[t] = run;
+            }
+            run += v[q];
+        }
+    };
+    if (REGS && s <= S3_R3 && s <= img) {
+        uint32_t ex[S3_T3], ky[S3_T3];   // ky = bucket (10 bits) | rank in the bucket << 10; ~0 = no entry
+#pragma unroll
+        for (int t = 0; t < S3_T3; ++t) {
+            const uint32_t i = a + t * S3_THREADS + tid;
+            ky[t] = 0xffffffffu;
+            ex[t] = 0;
+            if (i < b) {
+                ky[t] = i_lo[i];
+                ex[t] = i_idx[i];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < S3_T3; ++t)
+            if (ky[t] != 0xffffffffu) ky[t] |= atomicAdd(&hist[ky[t]], 1u) << 10;
+        __syncthreads();
+        scan_counts();
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < S3_T3; ++t)
+            if (ky[t] != 0xffffffffu) out[cursor[ky[t] & 1023u] + (ky[t] >> 10)] = ex[t];
+        __syncthreads();
+        for (uint32_t t = tid; t < s; t += S3_THREADS) entries[a + t] = out[t];
+        return;
+    }
+    for (uint32_t i = a + tid; i < b; i += S3_THREADS) atomicAdd(&hist[i_lo[i]], 1u);
+    __syncthreads();
+    scan_counts();
+    __syncthreads();
+    if (s <= img) {
+        // second pass over the bin: place into the LDS image (the order inside a bucket is whatever the atomics make it)
+        for (uint32_t i = a + tid; i < b; i += S3_THREADS) out[atomicAdd(&cursor[i_lo[i]], 1u)] = i_idx[i];
+        __syncthreads();
+        for (uint32_t t = tid; t < s; t += S3_THREADS) entries[a + t] = out[t];
+    } else {
+        for (uint32_t i = a + tid; i < b; i += S3_THREADS) entries[a + atomicAdd(&cursor[i_lo[i]], 1u)] = i_idx[i];
+    }
+}
+
+static S3TGeom s3t_geometry(const MsmPlan& P, uint32_t npts) {
+    S3TGeom g;
+    g.W = P.W;
+    g.c = P.c;
+    g.prio = msm_env_int("BLAZE_SORT_PRIO", 3);
+    g.sh1 = (uint32_t)(P.c - 1 - 8);
+    g.NB1 = (uint32_t)(P.G >> g.sh1);   // 256
+    // final-level bins of about 6 K entries (uniform digits: entries per bucket = npts W / G)
+    const double per_bucket = (double)npts * P.W / (double)P.G;
+    int b3 = 4;
+    while (b3 < 10 && (double)(2u << b3) * per_bucket <= 6144.0) ++b3;
+    if ((uint32_t)b3 > g.sh1) b3 = (int)g.sh1;
+    int b2 = (int)g.sh1 - b3;
+    if (b2 > 8) { b2 = 8; b3 = (int)g.sh1 - 8; }
+    g.b2 = (uint32_t)b2;
+    g.b3 = (uint32_t)b3;
+    g.xs = g.sh1 > 16 ? g.sh1 - 16 : 0;
+    return g;
+}
+
+bool msm_sort3t_ok(const MsmPlan& P) {
+    if (!P.table || P.sbits != 256 || P.c < 16 || P.c > 26 || P.W * P.c < 257) return false;
+    if ((uint64_t)P.npts * P.W >= (1ull << 30)) return false;
+    const S3TGeom g = s3t_geometry(P, P.npts);
+    return g.NB1 <= 256 && g.b2 <= 8 && g.b3 >= 1 && g.b3 <= 10 && g.xs <= 1 && g.b3 > g.xs;
+}
+
+int msm_sort3t_max_vgprs() {
+    static int cached = -1;
+    if (cached >= 0) return cached;
+    int mx = 0;
+    const void* ks[] = {(const void*)k3t_l1_count, (const void*)k3t_l1_scatter, (const void*)k3t_l2_count, (const void*)k3t_l2_scatter,
+                        (const void*)k3t_l3<true>, (const void*)k3t_l3<false>};
+    for (const void* k : ks) {
+        hipFuncAttributes a;
+        if (hipFuncGetAttributes(&a, k) != hipSuccess) {
+            (void)hipGetLastError();
+            return cached = 0;
+        }
+        if (a.numRegs > mx) mx = a.numRegs;
+    }
+    return cached = mx;
+}
+
+int msm_sort3t(MsmEngine& E, const void* d_scalars, uint32_t npts) {
+    const MsmPlan& P = E.last_plan;
+    hipStream_t st = E.sort_st;
+    MsmEngine::SortBufs& B = E.sb();
+    const S3TGeom g = s3t_geometry(P, P.npts);
+    const uint32_t NB1 = g.NB1, NB2 = (uint32_t)(P.G >> g.b3);
+    const uint64_t max_entries = (uint64_t)npts * P.W;
+    const uint32_t max_items = (uint32_t)(max_entries / S3_SLICE2) + NB1 + 1;
+    const uint32_t nsb = (NB2 + 2047u) / 2048u;
+    if (nsb > 256) return fail(BLZ_ERR_UNKNOWN, "window-table sort: %u final-level bins exceed the scan's range", NB2);
+    const size_t tab_dw = (size_t)3 * (NB1 + 2) + (size_t)3 * (NB2 + 2) + 260 + 4 + 2 * ((size_t)max_items + 2);
+    BLZ_TRY(E.sort3_tabs.reserve(tab_dw * 4));
+    uint32_t* cnt1 = E.sort3_tabs.as<uint32_t>();
+    uint32_t* off1 = cnt1 + NB1 + 2;
+    uint32_t* cur1 = off1 + NB1 + 2;
+    uint32_t* cnt2 = cur1 + NB1 + 2;
+    uint32_t* off2 = cnt2 + NB2 + 2;
+    uint32_t* cur2 = off2 + NB2 + 2;
+    uint32_t* bsum = cur2 + NB2 + 2;
+    uint32_t* nitems = bsum + 260;
+    uint2* map = reinterpret_cast<uint2*>(nitems + 4);
+    BLZ_TRY(E.inter.reserve(max_entries * 6 + 64));
+    BLZ_TRY(E.inter2.reserve(max_entries * 6 + 64));
+    uint32_t* i1_idx = E.inter.as<uint32_t>();
+    uint16_t* i1_rem = reinterpret_cast<uint16_t*>(i1_idx + max_entries);
+    uint32_t* i2_idx = E.inter2.as<uint32_t>();
+    uint16_t* i2_lo = reinterpret_cast<uint16_t*>(i2_idx + max_entries);
+    const uint32_t* sc = (const uint32_t*)d_scalars;
+    const dim3 blk(S3_THREADS);
+    // LDS image of a final-level bin: the register path's 7168 entries unless the mean bin is larger than that
+    const double mean_bin = (double)max_entries / (double)(NB2 ? NB2 : 1);
+    const bool big_bins = mean_bin * 1.1 > (double)S3_R3;
+    const uint32_t img = big_bins ? S3T_IMG : S3_R3;
+
+    BLZ_HIP(hipMemsetAsync(cnt1, 0, (size_t)(NB1 + 2) * 4, st), BLZ_ERR_UNKNOWN);
+    BLZ_HIP(hipMemsetAsync(cnt2, 0, (size_t)(NB2 + 2) * 4, st), BLZ_ERR_UNKNOWN);
+    hipLaunchKernelGGL(k3t_l1_count, dim3((npts + S3_CNT_PTS - 1) / S3_CNT_PTS), blk, 0, st, sc, npts, g, cnt1);
+    hipLaunchKernelGGL(k3_scan_small, dim3(1), blk, 0, st, cnt1, NB1, off1, cur1, g.prio);
+    const size_t lds1 = (size_t)(10 * S3_PB + 3 * 256) * 4;
+    BLZ_TRY(ensure_dynamic_lds((const void*)k3t_l1_scatter, (int)lds1));
+    hipLaunchKernelGGL(k3t_l1_scatter, dim3((npts + S3_PB - 1) / S3_PB), blk, lds1, st, sc, npts, g, cur1, i1_idx, i1_rem);
+    hipLaunchKernelGGL(k3_slice_map, dim3(1), blk, 0, st, off1, NB1, S3_SLICE2, map, nitems, g.prio);
+    hipLaunchKernelGGL(k3t_l2_count, dim3(max_items), blk, 0, st, i1_rem, off1, map, nitems, cnt2, g);
+    hipLaunchKernelGGL(k3_scan_a, dim3(nsb), blk, 0, st, cnt2, NB2, bsum, g.prio);
+    hipLaunchKernelGGL(k3_scan_b, dim3(1), blk, 0, st, bsum, nsb, g.prio);
+    hipLaunchKernelGGL(k3_scan_c, dim3(nsb), blk, 0, st, cnt2, NB2, bsum, off2, cur2, g.prio);
+    hipLaunchKernelGGL(k3t_l2_scatter, dim3(max_items), blk, 0, st, i1_idx, i1_rem, off1, map, nitems, cur2, i2_idx, i2_lo, g);
+    if (big_bins) {
+        BLZ_TRY(ensure_dynamic_lds((const void*)k3t_l3<false>, (int)(img * 4)));
+        hipLaunchKernelGGL(k3t_l3<false>, dim3(NB2), blk, (size_t)img * 4, st, i2_idx, i2_lo, off2, B.count.as<uint32_t>(), B.entries.as<uint32_t>(), g, img);
+    } else {
+        BLZ_TRY(ensure_dynamic_lds((const void*)k3t_l3<true>, (int)(img * 4)));
+        hipLaunchKernelGGL(k3t_l3<true>, dim3(NB2), blk, (size_t)img * 4, st, i2_idx, i2_lo, off2, B.count.as<uint32_t>(), B.entries.as<uint32_t>(), g, img);
+    }
+    BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
+    return BLZ_OK;
+}
+
 }  // namespace blz

@@ -220,6 +220,17 @@ class MSMClient(DriverPrimitive[MSMInit, MSMParams, MSMInput, MSMResult]):
         check(lib().blz_comm_unique_id(C.cast(out, C.c_void_p)))
         return out.raw
 
+    def set_window_table(self, enable: bool) -> None:
+        """Opt in to the resident-base window table (include/blaze_hip.h blz_msm_set_window_table): pf = 1 handles whose
+        bases live in the arena; built on the first task over them, W x the memory of the bases, fewer bucket additions."""
+        check(lib().blz_msm_set_window_table(self._h, 1 if enable else 0))
+
+    def window_table_info(self) -> dict:
+        """Of the table the last HBM task used (all zero: it took the plain path)."""
+        out = (C.c_uint64 * 4)()
+        check(lib().blz_msm_window_table_info(self._h, out))
+        return {"bytes": int(out[0]), "window_bits": int(out[1]), "windows": int(out[2]), "build_ms": int(out[3]) / 1000.0}
+
     def comm_init(self, rank: int, nranks: int, comm_id: bytes) -> None:
         p, _n, _k = buf_ptr(comm_id)
         check(lib().blz_msm_comm_init(self._h, rank, nranks, p))

@@ -158,6 +158,22 @@ int blz_msm_precompute_bases_device(int device_id, int curve, const void* d_poin
  * (signed digits).  Diagnostic; no reference counterpart (the bitstream's plan is fixed). */
 int blz_msm_plan(int curve, uint32_t nof_elements, int is_precompute, uint32_t out[4], uint8_t* widths);
 
+/* Resident-base window table (opt-in; no reference counterpart - the closest is the caller-supplied x8 table of
+ * MSMInit.is_precompute, msm_api.rs:40-50, which costs 16 window passes per element where the plain path needs 12).
+ * With enable = 1, a pf = 1 handle whose bases live in the arena (hbm_point_addr) builds, on the first task over a
+ * range of bases, the table of their window multiples 2^(c j) P, j < W = ceil(257 / c) - synchronously, about 2 s for
+ * 2^26 BLS12-381 bases, W x the memory of the Montgomery copy (2^26: 10 x 8 GiB) - and keeps it with the arena
+ * extent until the next write into it.  Tasks over those bases then add every window's digit into ONE bucket set:
+ * 10 windows of 26 bits at 2^26 (671 M bucket additions, 2^25 buckets) instead of 12 windows of 21-23 bits (805 M).
+ * Results are bit-identical to the plain path's.  Falls back to the plain path (silently; BLAZE_LOG=1 says why) when
+ * the table does not fit the free memory, when a base has even order (a multiple at infinity cannot be tabulated;
+ * never the case in the r-torsion), or for a task over a sub-range that wants a different window width.
+ * The default of new handles is BLAZE_MSM_TABLE (0). */
+int blz_msm_set_window_table(blz_msm* h, int enable);
+/* out = {table bytes, window bits c, windows W, build time in microseconds} of the table the handle's last HBM task
+ * used; zeros when it took the plain path */
+int blz_msm_window_table_info(blz_msm* h, uint64_t out[4]);
+
 /* Multi-GPU: add G partial results (each result_size bytes, as returned by blz_msm_result on each
  * rank, in rank order) on this handle's device and emit the normalised sum, for hosts that move the
  * partials themselves (blz_msm_all_gather_combine below does the exchange too). */

@@ -171,6 +171,17 @@ impl MSMClient {
         check(unsafe { blz_msm_reset(self.h) })
     }
 
+    /// Opt in to the resident-base window table (`include/blaze_hip.h`): bases in the arena, `precompute_factor` 1.
+    pub fn set_window_table(&self, enable: bool) -> Result<()> {
+        check(unsafe { blz_msm_set_window_table(self.h, enable as i32) })
+    }
+    /// `[table bytes, window bits, windows, build time in microseconds]` of the table the last HBM task used.
+    pub fn window_table_info(&self) -> Result<[u64; 4]> {
+        let mut out = [0u64; 4];
+        check(unsafe { blz_msm_window_table_info(self.h, out.as_mut_ptr()) })?;
+        Ok(out)
+    }
+
     pub fn mem_type(&self) -> PointMemoryType {
         self.mem_type
     }

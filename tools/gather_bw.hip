@@ -69,6 +69,7 @@ __global__ __launch_bounds__(128) void k_gather(const uint4* __restrict__ pts, c
 int main(int argc, char** argv) {
     // optional argument: log2 of the table size in points (26 = the 8 GiB table of the 2^26 MSM); the entry count stays
     const int logp = argc > 1 ? atoi(argv[1]) : 26;
+    const int nmodes = argc > 2 ? atoi(argv[2]) : 2;   // 1: pattern A only (big tables: B's side buffer is 97 GB)
     const uint64_t npts = 1ull << logp, entries = 12ull << 26;
     printf("table: 2^%d points x 128 B = %.2f GiB\n", logp, (double)npts * 128 / (1ull << 30));
     const uint32_t len = 44;   // mean run length of the 2^26 plan (805 M entries over ~18 M buckets)
@@ -77,14 +78,14 @@ int main(int argc, char** argv) {
     uint32_t* idx;
     hipMalloc(&pts, npts * 128);
     hipMalloc(&idx, entries * 4);
-    hipMalloc(&side, nruns * (len / 2) * 11 * 16);
+    hipMalloc(&side, nmodes > 1 ? nruns * (len / 2) * 11 * 16 : 64);
     hipMalloc(&sink, 64);
     hipMemset(pts, 1, npts * 128);
     hipLaunchKernelGGL(k_fill_idx, dim3(4096), dim3(256), 0, 0, idx, entries, (uint32_t)(npts - 1));
     hipDeviceSynchronize();
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int mode = 0; mode < 2; ++mode) {
+    for (int mode = 0; mode < nmodes; ++mode) {
         float best = 1e9f;
         for (int rep = 0; rep < 3; ++rep) {
             hipEventRecord(e0);
