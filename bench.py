@@ -714,7 +714,8 @@ def main():
             "config": {"workload": f"2^{LOG_N} BLS12-381 G1 MSM, pf=1, scalars+points resident in HBM"
                                    + (" (points in the device arena, scalars-only set_data)" if hbm_mode else " (DMA-mode set_data with device pointers)"),
                        "elements": n, "elements_per_gpu": n_loc, "parallelism": f"shard{world}" if world > 1 else "single", "exchange": exchange, "tasks_in_flight": queue,
-                       "window_bits": int(api["window_bits"]), "windows": int(api["windows"])},
+                       "window_bits": int(api["window_bits"]), "windows": int(api["windows"]),
+                       "sort_hidden_under_previous_accumulation": bool(api.get("sort_hidden", 0))},
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_ref_semantics": cpu_ref, "result_check": check_rec,
             "ntt_2e27": ntt, "clock": clock, "exchange_native": native, "window_table": table_rec, "hbm_flow": hbm_flow, "config2_dma": cfg2,
             "phases_ms": {k: round(v, 3) for k, v in api.items() if k.endswith("_ms")},

@@ -79,14 +79,22 @@ BLZ_DEV bool ptrr_is_inf(const XYZZRR<Q>& p) { return rr_all_zero(p.zz); }
 template <class Q, int TAG = 0>
 __device__ __noinline__ XYZZRR<Q> ptrr_mdbl_val(Frr<Q, 1, 2> x, Frr<Q, 2, 4> y) {
     XYZZRR<Q> r;
+    // (the products are fenced from each other: this is the rare P + P branch, and left alone the scheduler overlaps
+    // the four independent ones - on BLS12-377 that made this callee, and with it k_accumulate, 212 VGPRs wide, 4 more
+    // than what lets the next task's sort fit beside the accumulation: msm.hip run())
     const auto U = rr_tn(rr_add(y, y));                // (4, 8) | (1, 8)
     Frr<Q, 1, 2> V, W, S, t, Msq, y3;
     rr_sqr(V, U);
+    __builtin_amdgcn_sched_barrier(0);
     rr_mul(W, U, V);
+    __builtin_amdgcn_sched_barrier(0);
     rr_mul(S, x, V);
+    __builtin_amdgcn_sched_barrier(0);
     rr_sqr(t, x);
+    __builtin_amdgcn_sched_barrier(0);
     const auto M = rr_tn(rr_add(rr_add(t, t), t));     // (3, 6) | (1, 6)
     rr_sqr(Msq, M);
+    __builtin_amdgcn_sched_barrier(0);
     const auto X3 = rr_xfix(rr_sub_twice<2>(Msq, S));  // M^2 - 2S + 8m: (1, 10) | (1, 2)
     const auto D = rr_tn(rr_sub<RR_JX<Q>>(S, X3));     // S - X3 + 32m: (3, 34) | + 4m: (1, 6)
     const auto nW = rr_neg<2>(W);                      // 4m - W: (2, 4)

@@ -632,10 +632,12 @@ int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int 
     }
     if (s3 && hide_env == 1) {
         // ... and the sort only hides if its waves fit BESIDE the accumulation's: two of those per SIMD (registers are
-        // allocated in eights out of 512) plus one of the sort's.  A build whose k_accumulate grew past that still works,
-        // it just sorts in the open (round 3 saw 211 VGPRs cost 4 ms per step before this check existed).
+        // allocated in eights) plus one of the sort's.  Measured: the sort runs beside 2 x 194..199 (-> 2 x 200) + 72 = 472
+        // registers, and waits for the accumulation to END behind 2 x 206 (-> 208) + 72 = 488 and 2 x 211 (-> 216) + 72 = 504 -
+        // the SIMD does not hand out all 512.  A build whose k_accumulate grew past that still works, it just sorts in
+        // the open (round 3 saw 211 VGPRs cost 4 ms per step before this check existed).
         const int av = ops->accumulate_vgprs(), sv = P.table ? msm_sort3t_max_vgprs() : msm_sort3_max_vgprs();
-        if (av > 0 && sv > 0 && 2 * ((av + 7) & ~7) + ((sv + 7) & ~7) > 512 - 32) fits = false;   // (measured: fits at 2 x 200 + 72, does not at 2 x 216 + 72)
+        if (av > 0 && sv > 0 && 2 * ((av + 7) & ~7) + ((sv + 7) & ~7) > 512 - 32) fits = false;
         if (!fits && !P.table) s3 = false;
     }
     const bool hide = s3 && O.busy && hide_env != 0 && fits;
@@ -743,6 +745,7 @@ int MsmEngine::finish(int slot, uint8_t* out) {
             last_ms[1] = t;
         }
     }
+    last_sort_hidden = S.sort_hidden && S.plan.c != 0;
     if (S.sort_hidden) (void)hipEventElapsedTime(&t, S.ev_s0, S.ev_s1);   // on sort_stream, underneath the previous task
     else (void)hipEventElapsedTime(&t, S.ev[0], S.ev[1]);
     last_ms[2] = t;

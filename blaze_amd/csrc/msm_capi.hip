@@ -52,7 +52,7 @@ struct blz_msm {
     int comm_rank = 0, comm_size = 0;
     DevBuf comm_buf;   // [send: one partial | recv: comm_size partials]
     // resident-base window table (blz_msm_set_window_table; BLAZE_MSM_TABLE sets the default of new handles)
-    bool window_table = false;
+    int window_table = 0;   // 0 off, 1 where it pays (the BLS curves), 2 always
     uint64_t table_info[4] = {0, 0, 0, 0};   // of the last HBM task: table bytes, window bits, windows, build time (us)
 };
 
@@ -241,7 +241,9 @@ int launch_if_ready(blz_msm* h) {
     int table_c = 0;
     memset(h->table_info, 0, sizeof(h->table_info));
     if (h->staged_from_arena) {
-        if (h->window_table && h->pf == 1) {
+        // (BN254 loses with a table - 64-byte points: its accumulation is already at the gather rate, 2^26 71.8 -> 74.6 ms -
+        // so "1" leaves it on the plain path)
+        if (h->pf == 1 && (h->window_table == 2 || (h->window_table == 1 && h->curve != BLZ_BN254))) {
             const void* tab = nullptr;
             BLZ_WAIT(h, arena_points_table(h, h->staged_arena_pos, npts, &tab, &table_c));
             if (tab) h->d_points_mont = tab;
@@ -362,7 +364,8 @@ int blz_msm_new(int device_id, int mem_type, int is_precompute, int curve, blz_m
     h->mem_type = mem_type;
     h->pf = is_precompute ? BLZ_PRECOMPUTE_FACTOR : BLZ_PRECOMPUTE_FACTOR_BASE;
     h->curve = curve;
-    h->window_table = msm_env_int("BLAZE_MSM_TABLE", 0) != 0;
+    h->window_table = msm_env_int("BLAZE_MSM_TABLE", 0);
+    if (h->window_table < 0 || h->window_table > 2) h->window_table = 0;
     int rc = h->eng.init(device_id, curve, (int)h->pf);
     if (rc == BLZ_OK && hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess)
         rc = fail(BLZ_ERR_UNKNOWN, "copy stream creation failed");
@@ -425,7 +428,8 @@ int blz_msm_loaded_binary_parameters(blz_msm* h, uint32_t out[2]) {
 
 int blz_msm_set_window_table(blz_msm* h, int enable) {
     if (!h) return fail(BLZ_ERR_INVALID_PARAM, "null handle");
-    h->window_table = enable != 0;
+    if (enable < 0 || enable > 2) return fail(BLZ_ERR_INVALID_PARAM, "window table mode %d (0 off, 1 where it pays, 2 always)", enable);
+    h->window_table = enable;
     return BLZ_OK;
 }
 
@@ -581,6 +585,12 @@ int blz_msm_reset(blz_msm* h) {
 int blz_msm_last_timings(blz_msm* h, float out[8]) {
     if (!h || !out) return fail(BLZ_ERR_INVALID_PARAM, "null argument");
     memcpy(out, h->eng.last_ms, sizeof(float) * 8);
+    return BLZ_OK;
+}
+
+int blz_msm_last_sort_hidden(blz_msm* h, int* out) {
+    if (!h || !out) return fail(BLZ_ERR_INVALID_PARAM, "null argument");
+    *out = h->eng.last_sort_hidden ? 1 : 0;
     return BLZ_OK;
 }
 

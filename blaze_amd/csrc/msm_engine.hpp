@@ -95,6 +95,7 @@ struct MsmEngine {
     uint8_t* combine_h = nullptr;  // pinned bytes of combine_partials
     MsmPlan last_plan;
     float last_ms[8] = {};
+    bool last_sort_hidden = false;   // of the last task collected by finish(): its sort stage ran on sort_stream
     uint32_t sort_slices = 1, sort_nc = 0;  // geometry of the last LDS sort (msm_sort.hip)
     int sort_cl = 0;
     void* sort_inter_fine = nullptr;  // u16 fine digits of the sort intermediate (second half of `inter`)

@@ -207,7 +207,11 @@ class MSMClient(DriverPrimitive[MSMInit, MSMParams, MSMInput, MSMResult]):
         check(lib().blz_msm_last_timings(self._h, t))
         keys = ["total_ms", "accumulate_kernel_ms", "sort_ms", "phase1_accumulate_ms", "phase2_reduce_ms", "phase3_final_ms",
                 "window_bits", "windows"]
-        return dict(zip(keys, [float(x) for x in t]))
+        api = dict(zip(keys, [float(x) for x in t]))
+        hid = C.c_int(0)
+        check(lib().blz_msm_last_sort_hidden(self._h, C.byref(hid)))
+        api["sort_hidden"] = int(hid.value)
+        return api
 
     def reset(self) -> None:
         check(lib().blz_msm_reset(self._h))
@@ -220,10 +224,11 @@ class MSMClient(DriverPrimitive[MSMInit, MSMParams, MSMInput, MSMResult]):
         check(lib().blz_comm_unique_id(C.cast(out, C.c_void_p)))
         return out.raw
 
-    def set_window_table(self, enable: bool) -> None:
+    def set_window_table(self, enable) -> None:
         """Opt in to the resident-base window table (include/blaze_hip.h blz_msm_set_window_table): pf = 1 handles whose
-        bases live in the arena; built on the first task over them, W x the memory of the bases, fewer bucket additions."""
-        check(lib().blz_msm_set_window_table(self._h, 1 if enable else 0))
+        bases live in the arena; built on the first task over them, W x the memory of the bases, fewer bucket additions.
+        False / 0 off, True / 1 where it pays (the BLS curves), 2 always."""
+        check(lib().blz_msm_set_window_table(self._h, int(enable)))
 
     def window_table_info(self) -> dict:
         """Of the table the last HBM task used (all zero: it took the plain path)."""

@@ -146,6 +146,9 @@ int blz_msm_reset(blz_msm* h);
  * [3] bucket accumulation (phase 1)  [4] bucket reduce (phase 2)  [5] window combine + affine (phase 3)
  * [6] window bits c  [7] number of windows */
 int blz_msm_last_timings(blz_msm* h, float out[8]);
+/* 1 when the digit sort of the last completed task ran underneath the accumulation of the task before it (two tasks in
+ * flight, the sort's kernels fit beside the accumulation's waves: DESIGN.md section 3), else 0.  Diagnostic. */
+int blz_msm_last_sort_hidden(blz_msm* h, int* out);
 
 /* precompute_base_* (tests/msm/mod.rs:360-380) on the device: for each of the n base points (x||y)
  * write PRECOMPUTE_FACTOR = 8 points P, 2^32 P, ..., 2^224 P contiguously to d_out (n*8 points).
@@ -160,7 +163,9 @@ int blz_msm_plan(int curve, uint32_t nof_elements, int is_precompute, uint32_t o
 
 /* Resident-base window table (opt-in; no reference counterpart - the closest is the caller-supplied x8 table of
  * MSMInit.is_precompute, msm_api.rs:40-50, which costs 16 window passes per element where the plain path needs 12).
- * With enable = 1, a pf = 1 handle whose bases live in the arena (hbm_point_addr) builds, on the first task over a
+ * enable: 0 off, 1 on where it was measured to pay (BLS12-377 / BLS12-381; BN254's 64-byte points are already
+ * gathered at the memory system's rate and lose 4 % with a table, so 1 leaves BN254 on the plain path), 2 always.
+ * With it, a pf = 1 handle whose bases live in the arena (hbm_point_addr) builds, on the first task over a
  * range of bases, the table of their window multiples 2^(c j) P, j < W = ceil(257 / c) - synchronously, about 2 s for
  * 2^26 BLS12-381 bases, W x the memory of the Montgomery copy (2^26: 10 x 8 GiB) - and keeps it with the arena
  * extent until the next write into it.  Tasks over those bases then add every window's digit into ONE bucket set:
@@ -168,7 +173,7 @@ int blz_msm_plan(int curve, uint32_t nof_elements, int is_precompute, uint32_t o
  * Results are bit-identical to the plain path's.  Falls back to the plain path (silently; BLAZE_LOG=1 says why) when
  * the table does not fit the free memory, when a base has even order (a multiple at infinity cannot be tabulated;
  * never the case in the r-torsion), or for a task over a sub-range that wants a different window width.
- * The default of new handles is BLAZE_MSM_TABLE (0). */
+ * The default of new handles is BLAZE_MSM_TABLE (0).  No other value of `enable` is accepted (InvalidPrimitiveParam). */
 int blz_msm_set_window_table(blz_msm* h, int enable);
 /* out = {table bytes, window bits c, windows W, build time in microseconds} of the table the handle's last HBM task
  * used; zeros when it took the plain path */

@@ -50,6 +50,7 @@ extern "C" {
     pub fn blz_msm_set_window_table(h: *mut BlzMsm, enable: c_int) -> c_int;
     pub fn blz_msm_window_table_info(h: *mut BlzMsm, out: *mut u64) -> c_int;
     pub fn blz_msm_last_timings(h: *mut BlzMsm, out: *mut f32) -> c_int;
+    pub fn blz_msm_last_sort_hidden(h: *mut BlzMsm, out: *mut c_int) -> c_int;
     // multi-GPU exchange (no reference counterpart: README.md:20-22 leaves it to a "management layer")
     pub fn blz_msm_combine_partials(h: *mut BlzMsm, partials: *const u8, count: usize, out: *mut u8, out_cap: usize) -> c_int;
     pub fn blz_comm_unique_id(out: *mut u8) -> c_int;

@@ -172,8 +172,9 @@ impl MSMClient {
     }
 
     /// Opt in to the resident-base window table (`include/blaze_hip.h`): bases in the arena, `precompute_factor` 1.
-    pub fn set_window_table(&self, enable: bool) -> Result<()> {
-        check(unsafe { blz_msm_set_window_table(self.h, enable as i32) })
+    /// `mode`: 0 off, 1 where it pays (the BLS curves), 2 always.
+    pub fn set_window_table(&self, mode: i32) -> Result<()> {
+        check(unsafe { blz_msm_set_window_table(self.h, mode) })
     }
     /// `[table bytes, window bits, windows, build time in microseconds]` of the table the last HBM task used.
     pub fn window_table_info(&self) -> Result<[u64; 4]> {

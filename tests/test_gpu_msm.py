@@ -843,17 +843,19 @@ def test_hidden_three_level_sort(gpu, orc, curve, logn, monkeypatch):
         b.free()
 
 
-def test_hidden_sort_fits_under_the_accumulation(gpu):
+@pytest.mark.parametrize("curve", ["BLS381", "BLS377"])
+def test_hidden_sort_fits_under_the_accumulation(gpu, curve):
     """The hidden sort only pays if its kernels really run BESIDE the accumulation's waves (registers, LDS and wave slots
     left over by 2 x 200 VGPRs per SIMD).  A build whose k_accumulate needs a few more registers still computes the right
     result but the sort then waits for the accumulation to end (seen in round 3 with 211 VGPRs: the step got 4 ms slower
     than not hiding at all).  Timing guard: in a steady stream of 2^24 tasks the hidden sort stage must end well inside
-    the accumulation it runs under."""
-    curve, n = "BLS381", 1 << 24
+    the accumulation it runs under - and it must have BEEN hidden (BLS12-377's k_accumulate once compiled to 212 VGPRs
+    and its tasks silently sorted in the open)."""
+    n = 1 << 24
     dp, ds = synth(curve, n, seed=21)
     cl = msm_client(curve, 1)
     params = MSMParams(n, None)
-    ratios = []
+    ratios, hidden = [], []
     for k in range(6):
         cl.initialize(params); cl.start_process(); cl.set_data(MSMInput(dp, ds, params))
         if k >= 1:
@@ -861,6 +863,8 @@ def test_hidden_sort_fits_under_the_accumulation(gpu):
             api = cl.get_api()
             if k >= 3:                      # steady state: this task's sort ran under the previous accumulation
                 ratios.append(api["sort_ms"] / api["accumulate_kernel_ms"])
+                hidden.append(api["sort_hidden"])
     cl.wait_result(); cl.result()
     cl.close(); dp.free(); ds.free()
+    assert hidden and all(hidden), hidden
     assert ratios and max(ratios) < 0.85, ratios

@@ -22,7 +22,7 @@ def _release():
 
 def _table_client(curve):
     cl = msm_client(curve, 1, PointMemoryType.HBM)
-    cl.set_window_table(True)
+    cl.set_window_table(2)     # always (mode 1 leaves BN254, which does not gain from a table, on the plain path)
     return cl
 
 
@@ -106,13 +106,30 @@ def test_table_follows_the_arena(gpu, orc):
     assert plain.window_table_info()["bytes"] == 0
     # a DMA-typed handle that opted in: tables for arena bases (msm_api.rs:41 lets it select them), none for host points
     dma = msm_client(curve, 1, PointMemoryType.DMA)
-    dma.set_window_table(True)
+    dma.set_window_table(1)
     assert run_msm(dma, None, sc, n, hbm=(0x4000, 0)) == orc.msm_pippenger(curve, newpts, sc, n, 1, threads=4)
     assert dma.window_table_info()["bytes"] > 0
     assert run_msm(dma, pts, sc, n) == exp
     assert dma.window_table_info()["bytes"] == 0
     for c in (cl, cl2, plain, dma):
         c.close()
+    _release()
+
+
+def test_mode_one_skips_bn254(gpu, orc):
+    """Mode 1 = "where it pays": the BLS curves get a table, BN254 (64-byte points, already gather-bound) does not."""
+    n = 512
+    for curve, expect in (("BLS381", True), ("BN254", False)):
+        _release()
+        pts, sc, exp = orc.input_generator(curve, n, 1, 71)
+        cl = msm_client(curve, 1, PointMemoryType.HBM)
+        cl.set_window_table(True)
+        cl.load_data_to_hbm(pts, 0, 0)
+        assert run_msm(cl, None, sc, n, hbm=(0, 0)) == exp
+        assert (cl.window_table_info()["bytes"] > 0) == expect, curve
+        with pytest.raises(blaze_amd.DriverClientError):
+            cl.set_window_table(3)
+        cl.close()
     _release()
 
 
