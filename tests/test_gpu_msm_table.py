@@ -152,10 +152,12 @@ def test_base_of_even_order_falls_back(gpu, orc):
     _release()
 
 
-@pytest.mark.parametrize("curve,logn,c", [("BLS381", 19, 0), ("BLS381", 20, 26), ("BLS377", 21, 24), ("BN254", 20, 20), ("BLS381", 22, 0)])
+@pytest.mark.parametrize("curve,logn,c", [("BLS381", 19, 0), ("BLS381", 20, 26), ("BLS377", 21, 24), ("BN254", 20, 20), ("BLS381", 22, 0),
+                                          ("BLS381", 17, 16), ("BN254", 18, 16)])
 def test_tasks_in_flight_and_geometries(gpu, orc, curve, logn, c, monkeypatch):
     """Synthetic bases P_i = (i + 1) G at sizes the sort's real geometry shows up (several level-1 blocks, level-2
-    slices, final bins in registers and - forced c = 26: a 17-bit level-1 remainder - in the two-pass LDS image), two
+    slices, a 17-bit level-1 remainder with forced c = 26; final bins in registers, in the two-pass LDS image - forced
+    c = 16 at 2^17: 8.7 K entries per bin, the shape of c = 26 at 2^26 - and beyond it - 2^18: 17 K per bin), two
     tasks in flight so that the second task's sort runs underneath the first one's accumulation; expected value by
     linearity, and equal to the plain path's bytes."""
     n = (1 << logn) - 4321
