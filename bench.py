@@ -223,12 +223,16 @@ def main():
     from blaze_amd._lib import check
     from blaze_amd.driver_client import DriverClient
     from blaze_amd.ingo_msm import Curve, MSMClient, MSMInit, MSMInput, MSMParams, PointMemoryType
-    from blaze_amd.multi_gpu import shard_range, sharded_msm
+    from blaze_amd.multi_gpu import shard_layout, sharded_msm
 
     L = blaze_amd.lib()
     n = 1 << LOG_N
-    lo, hi = shard_range(n, rank, world)
-    n_loc = hi - lo
+    # rank's shard: an element chunk x a range of the scalars' bits (blz_msm_shard_layout: the library picks the mix by the
+    # window planner's cost - 2 and 4 ranks split the bits of all 2^26 elements, 8 ranks take 64-bit ranges of half of the
+    # elements each; BLAZE_SHARD=elements forces the plain element split).  Partial results add up either way.
+    lay = shard_layout(Curve[CURVE], n, rank, world)
+    lo, n_loc = lay["first"], lay["count"]
+    ranged = (lay["bit_lo"], lay["bit_hi"]) != (0, 256)
     cid = int(Curve[CURVE])
 
     # ---- synthetic inputs, generated on the device: P_i = (i+1) G, scalars uniform-ish in [0, r)
@@ -251,6 +255,8 @@ def main():
         client = MSMClient(MSMInit(PointMemoryType.DMA, False, Curve[CURVE]), DriverClient(dev))
         params = MSMParams(n_loc, None)
         step_points = d_pts
+    if ranged:
+        client.set_scalar_range(lay["bit_lo"], lay["bit_hi"])
 
     # The device has a task queue and a result queue (src/ingo_msm/msm_hw_code.rs:19-25): QUEUE tasks
     # are kept in flight, so the few-lane tail of one MSM (upper bucket-reduce levels, Horner, inversion)
@@ -441,6 +447,8 @@ def main():
     # constant of the builder's boxes (3.1e13, profiles/r02_mul_variants.txt) is kept beside it for comparison.
     if CURVE in ("BLS381", "BLS377") and LOG_N >= 24:
         occupied = -(-(255 if CURVE == "BLS381" else 253) // int(api["window_bits"]))
+        if ranged:   # every window of a 64 / 128-bit range holds digits (the top one fewer: counted whole, an upper bound)
+            occupied = -(-(min(lay["bit_hi"], 255 if CURVE == "BLS381" else 253) - lay["bit_lo"]) // int(api["window_bits"]))
         mads = n_loc * occupied * 3542
         peak = calib["mad_lane_ops_per_s"] if calib else 3.1e13
         roofline["integer_issue"] = {"unit": "v_mad_u64_u32 lane-ops/s", "achieved": round(mads / (acc_avg_ms * 1e-3), 0),
@@ -455,7 +463,10 @@ def main():
     # handle tabulates the window multiples of the bases once (blz_msm_set_window_table) and then runs fewer, wider
     # windows into one bucket set.  Every rank runs it on its shard (the exchange included), timed like the headline.
     table_rec = None
-    if hbm_mode and not args.no_extras and os.environ.get("BLAZE_BENCH_TABLE", "1") == "1":
+    # (not with scalar-range shards: a range handle has no table, and every rank's whole-scalar sum over its element chunk
+    # would count the chunk once per range)
+    any_ranged = shard_layout(Curve[CURVE], n, 0, world)["bit_hi"] != 256
+    if hbm_mode and not args.no_extras and not any_ranged and os.environ.get("BLAZE_BENCH_TABLE", "1") == "1":
         wd.arm(900, "window-table leg")
         tcl = MSMClient(MSMInit(PointMemoryType.HBM, False, Curve[CURVE]), DriverClient(dev))
         tcl.set_window_table(True)
@@ -713,7 +724,8 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "u32 registers holding 28-bit limbs (381-bit Fq, Montgomery)", "data": "synthetic",
             "config": {"workload": f"2^{LOG_N} BLS12-381 G1 MSM, pf=1, scalars+points resident in HBM"
                                    + (" (points in the device arena, scalars-only set_data)" if hbm_mode else " (DMA-mode set_data with device pointers)"),
-                       "elements": n, "elements_per_gpu": n_loc, "parallelism": f"shard{world}" if world > 1 else "single", "exchange": exchange, "tasks_in_flight": queue,
+                       "elements": n, "elements_per_gpu": n_loc, "parallelism": f"shard{world}" if world > 1 else "single",
+                       "shard_rank0": lay, "exchange": exchange, "tasks_in_flight": queue,
                        "window_bits": int(api["window_bits"]), "windows": int(api["windows"]),
                        "sort_hidden_under_previous_accumulation": bool(api.get("sort_hidden", 0))},
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_ref_semantics": cpu_ref, "result_check": check_rec,

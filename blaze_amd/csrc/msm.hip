@@ -103,6 +103,7 @@ MsmPlan make_plan(uint32_t npts, int sbits, int ebits, int force_c) {
                     }
                     best.boff[W] = b;
                     best.Wv = (int)(G >> (cmin - 1));
+                    best.cost = cost;
                 }
             }
         }
@@ -163,6 +164,17 @@ __global__ __launch_bounds__(256) void k_zero(uint4* __restrict__ p, size_t n16)
     __builtin_amdgcn_s_setprio(3);   // sort-stage kernel: may run underneath another task's accumulation (msm_sort3.hip)
     const uint4 z = make_uint4(0, 0, 0, 0);
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) p[i] = z;
+}
+
+// scalar-range tasks: dst = words [w0, w0 + nw) of every 8-word scalar, zero-extended to 8 words
+__global__ __launch_bounds__(256) void k_extract_range(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, uint64_t n, uint32_t w0,
+                                                       uint32_t nw) {
+    __builtin_amdgcn_s_setprio(3);   // sort-stage kernel
+    const uint64_t total = n * 8;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (uint64_t)gridDim.x * 256) {
+        const uint32_t j = (uint32_t)(i & 7u);
+        dst[i] = j < nw ? src[(i & ~(uint64_t)7) + w0 + j] : 0u;
+    }
 }
 
 // p[i] = i: the "every bucket has exactly one sum, at its own index" unit_off of slice-major tasks
@@ -492,7 +504,7 @@ bool MsmEngine::destroy() {
     for (DevBuf* b : {&coarse, &inter, &inter2, &slice_map, &partial, &blocksums, &result, &sort3_tabs, &bucket_sums, &bucket_ident})
         b->release();
     for (auto& B : sbuf)
-        for (DevBuf* b : {&B.count, &B.off, &B.unit_off, &B.unit_bucket, &B.unit_order, &B.lenhist, &B.entries, &B.stats}) b->release();
+        for (DevBuf* b : {&B.count, &B.off, &B.unit_off, &B.unit_bucket, &B.unit_order, &B.lenhist, &B.entries, &B.stats, &B.range_scalars}) b->release();
     for (auto& S : slots) {
         for (DevBuf* b : {&S.lvlA[0], &S.lvlA[1], &S.lvlC[0], &S.lvlC[1]}) b->release();
         for (auto& e : S.ev)
@@ -554,7 +566,18 @@ MsmPlan MsmEngine::plan_for(uint32_t npts, int sbits) const {
     return make_plan(npts, sbits, ebits, msm_env_int("BLAZE_MSM_C", 0));
 }
 
-int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int sbits, int* slot_out, int table_c) {
+MsmPlan MsmEngine::plan_for_range(uint32_t npts, int bit_lo, int bit_hi) const {
+    const int vbits = bit_hi - bit_lo;
+    int ebits = kScalarFieldBits[curve] - bit_lo;   // real bits of canonical scalars inside the range
+    if (ebits > vbits) ebits = vbits;
+    if (ebits < 1) ebits = 1;
+    MsmPlan P = make_plan(npts, vbits, ebits, msm_env_int("BLAZE_MSM_C", 0));
+    P.base_bit = bit_lo;
+    return P;
+}
+
+int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int sbits, int* slot_out, int table_c, int bit_lo,
+                   int bit_hi) {
     BLZ_TRY(use_device(device));
     const MsmCurveOps* ops = ops_for(curve, repr);
     MsmEngine& E = *this;
@@ -578,7 +601,12 @@ int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int 
         return BLZ_OK;
     }
     const int ebits = sbits == 256 ? kScalarFieldBits[curve] : sbits;
-    MsmPlan P = table_c > 0 ? make_table_plan(npts, table_c) : make_plan(npts, sbits, ebits, msm_env_int("BLAZE_MSM_C", 0));
+    const bool ranged = bit_hi > bit_lo && !(bit_lo == 0 && bit_hi >= sbits);
+    if (ranged && (sbits != 256 || table_c > 0 || (bit_lo & 31) || (bit_hi & 31) || bit_hi > 256))
+        return fail(BLZ_ERR_INVALID_PARAM, "scalar range [%d, %d): 32-bit aligned ranges of 256-bit scalars, no window table", bit_lo, bit_hi);
+    MsmPlan P = table_c > 0 ? make_table_plan(npts, table_c)
+                : ranged    ? plan_for_range(npts, bit_lo, bit_hi)
+                            : make_plan(npts, sbits, ebits, msm_env_int("BLAZE_MSM_C", 0));
     if (P.c == 0) return fail(BLZ_ERR_INVALID_PARAM, "no window plan for npts=%u sbits=%d%s", npts, sbits, table_c > 0 ? " (window table)" : "");
     if (P.table && (sbits != 256 || !msm_sort3t_ok(P))) return fail(BLZ_ERR_INVALID_PARAM, "window-table task outside the sort's range (c=%d)", P.c);
     P.L = (uint32_t)msm_env_int("BLAZE_MSM_L", (int)P.L);
@@ -669,6 +697,14 @@ int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int 
         if (p0 >= npts) { S.slices = sl; break; }
         const uint32_t np = nslices > 1 ? (npts - p0 < pts_per_slice ? npts - p0 : pts_per_slice) : npts;
         const char* sc_s = (const char*)d_scalars + (size_t)p0 * (sbits / 8);
+        if (ranged) {
+            // the range of every scalar as a scalar of its own (zero-extended): everything downstream reads 32-byte scalars and
+            // walks the plan's windows from bit 0; k_finish puts the 2^bit_lo back (FinishPlan offsets)
+            BLZ_TRY(B.range_scalars.reserve((size_t)np * 32 + 16));
+            hipLaunchKernelGGL(k_extract_range, dim3(2048), dim3(256), 0, ss, (const uint32_t*)sc_s, B.range_scalars.as<uint32_t>(),
+                               (uint64_t)np, (uint32_t)(bit_lo >> 5), (uint32_t)((bit_hi - bit_lo) >> 5));
+            sc_s = (const char*)B.range_scalars.p;
+        }
         const char* pt_s = (const char*)d_pts + (size_t)p0 * mont_point_bytes(curve);
         // ---- sort stage, on ss
         BLZ_HIP(hipMemsetAsync(B.stats.p, 0, 64, ss), BLZ_ERR_UNKNOWN);

@@ -53,6 +53,8 @@ struct blz_msm {
     DevBuf comm_buf;   // [send: one partial | recv: comm_size partials]
     // resident-base window table (blz_msm_set_window_table; BLAZE_MSM_TABLE sets the default of new handles)
     int window_table = 0;   // 0 off, 1 where it pays (the BLS curves), 2 always
+    // scalar range of this handle's tasks (blz_msm_set_scalar_range): bits [range_lo, range_hi) of every scalar; 0, 0 = all
+    int range_lo = 0, range_hi = 0;
     uint64_t table_info[4] = {0, 0, 0, 0};   // of the last HBM task: table bytes, window bits, windows, build time (us)
 };
 
@@ -243,7 +245,7 @@ int launch_if_ready(blz_msm* h) {
     if (h->staged_from_arena) {
         // (BN254 loses with a table - 64-byte points: its accumulation is already at the gather rate, 2^26 71.8 -> 74.6 ms -
         // so "1" leaves it on the plain path)
-        if (h->pf == 1 && (h->window_table == 2 || (h->window_table == 1 && h->curve != BLZ_BN254))) {
+        if (h->pf == 1 && h->range_hi == 0 && (h->window_table == 2 || (h->window_table == 1 && h->curve != BLZ_BN254))) {
             const void* tab = nullptr;
             BLZ_WAIT(h, arena_points_table(h, h->staged_arena_pos, npts, &tab, &table_c));
             if (tab) h->d_points_mont = tab;
@@ -252,7 +254,7 @@ int launch_if_ready(blz_msm* h) {
         if (!table_c) BLZ_TRY(arena_points_mont(h, h->staged_arena_pos, npts, &h->d_points_mont));
     }
     h->eng.inputs_event = h->staged_set >= 0 ? h->set_free[h->staged_set] : nullptr;
-    BLZ_TRY(h->eng.run(h->d_points_mont, h->d_scalars, npts, sbits, &slot, table_c));
+    BLZ_TRY(h->eng.run(h->d_points_mont, h->d_scalars, npts, sbits, &slot, table_c, h->range_lo, h->range_hi));
     if (h->staged_set >= 0) h->set_used[h->staged_set] = true;
     h->staged_set = -1;
     h->armed = false;
@@ -430,6 +432,55 @@ int blz_msm_set_window_table(blz_msm* h, int enable) {
     if (!h) return fail(BLZ_ERR_INVALID_PARAM, "null handle");
     if (enable < 0 || enable > 2) return fail(BLZ_ERR_INVALID_PARAM, "window table mode %d (0 off, 1 where it pays, 2 always)", enable);
     h->window_table = enable;
+    return BLZ_OK;
+}
+
+int blz_msm_set_scalar_range(blz_msm* h, uint32_t bit_lo, uint32_t bit_hi) {
+    if (!h) return fail(BLZ_ERR_INVALID_PARAM, "null handle");
+    if ((bit_lo == 0 && bit_hi == 0) || (bit_lo == 0 && bit_hi == 256)) {
+        h->range_lo = h->range_hi = 0;
+        return BLZ_OK;
+    }
+    if (h->pf != 1) return fail(BLZ_ERR_INVALID_PARAM, "scalar ranges need precompute_factor 1 (a precompute handle's scalars are 32-bit chunks already)");
+    if (bit_lo >= bit_hi || bit_hi > 256 || (bit_lo & 31u) || (bit_hi & 31u))
+        return fail(BLZ_ERR_INVALID_PARAM, "scalar range [%u, %u): want 32-bit aligned 0 <= lo < hi <= 256", bit_lo, bit_hi);
+    h->range_lo = (int)bit_lo;
+    h->range_hi = (int)bit_hi;
+    return BLZ_OK;
+}
+
+int blz_msm_shard_layout(int curve, uint32_t nof_elements, int nranks, int rank, uint32_t out[4]) {
+    if (!out) return fail(BLZ_ERR_INVALID_PARAM, "null argument");
+    if (curve < 0 || curve > 2) return fail(BLZ_ERR_INVALID_PARAM, "unknown curve %d", curve);
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(BLZ_ERR_INVALID_PARAM, "rank %d of %d", rank, nranks);
+    static const int r_bits[3] = {253, 255, 254};
+    // candidates: R scalar ranges of 256 / R bits x nranks / R element chunks, R a power of two that divides nranks; the
+    // planner's estimate for the most expensive rank (range 0 holds the most real bits) picks.  BLAZE_SHARD = elements | bits
+    // forces R = 1 / the largest R
+    const char* mode = getenv("BLAZE_SHARD");
+    int bestR = 1;
+    double best = 1e300;
+    for (int R = 1; R <= 8; R *= 2) {
+        if (nranks % R) continue;
+        const int PC = nranks / R;
+        const uint32_t per = (uint32_t)(((uint64_t)nof_elements + PC - 1) / PC);
+        if (per == 0 && R > 1) continue;
+        const int vbits = 256 / R;
+        const MsmPlan P = make_plan(per ? per : 1, vbits, vbits < r_bits[curve] ? vbits : r_bits[curve], 0);
+        if (P.c == 0) continue;
+        double cost = P.cost;
+        if (mode && strcmp(mode, "elements") == 0) cost = R == 1 ? 0 : 1e299;
+        if (mode && strcmp(mode, "bits") == 0) cost = -(double)R;
+        if (cost < best) { best = cost; bestR = R; }
+    }
+    const int R = bestR, PC = nranks / R;
+    const int pc = rank / R, rg = rank % R;
+    const uint64_t base = nof_elements / PC, rem = nof_elements % PC;
+    const uint64_t first = (uint64_t)pc * base + ((uint64_t)pc < rem ? pc : rem);
+    out[0] = (uint32_t)first;
+    out[1] = (uint32_t)(base + ((uint64_t)pc < rem ? 1 : 0));
+    out[2] = (uint32_t)(rg * (256 / R));
+    out[3] = (uint32_t)((rg + 1) * (256 / R));
     return BLZ_OK;
 }
 

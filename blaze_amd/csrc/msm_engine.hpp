@@ -26,6 +26,8 @@ struct MsmPlan {
     // every window's digit d of base i is an addition of +-table[i W + j] into bucket |d| - 1 of ONE bucket set shared
     // by all windows: boff[w] = 0 for every window, G = 2^(c-1), entries carry i W + j.  The reduce sees a single window.
     bool table = false;
+    int base_bit = 0;    // scalar-range tasks (run() bit_lo): the windows start at this bit of the scalar; the result carries 2^base_bit
+    double cost = 0;     // the planner's estimate for this plan (ns; host-side comparisons only)
 };
 MsmPlan make_plan(uint32_t npts, int sbits, int ebits, int force_c);
 // window-table geometry for npts bases: the window width c (16..26) whose W = ceil(257 / c) windows make the cheapest task
@@ -82,6 +84,7 @@ struct MsmEngine {
     // k + 1 can run (on sort_stream, underneath task k's accumulation: msm_sort3.hip) while task k still reads its own.
     struct SortBufs {
         DevBuf count, off, unit_off, unit_bucket, unit_order, lenhist, entries, stats;
+        DevBuf range_scalars;   // scalar-range tasks: words [bit_lo / 32, bit_hi / 32) of every scalar, zero-extended to 32 bytes
     };
     SortBufs sbuf[MSM_QUEUE_DEPTH];
     SortBufs& sb() { return sbuf[cur]; }
@@ -113,7 +116,11 @@ struct MsmEngine {
     size_t table_scratch_bytes(int W) const;
     // enqueue the whole pipeline; *slot identifies the task for finish().  Fails when both slots are busy.
     // table_c > 0: d_points_mont is the window table of the npts bases (table_windows(table_c) entries per base)
-    int run(const void* d_points_mont, const void* d_scalars, uint32_t npts, int sbits, int* slot, int table_c = 0);
+    // bit_hi > bit_lo (multiples of 32, pf = 1, no table): only bits [bit_lo, bit_hi) of every scalar take part and the result
+    // is 2^bit_lo x their sum - one shard of a job split by scalar chunk (blz_msm_set_scalar_range)
+    int run(const void* d_points_mont, const void* d_scalars, uint32_t npts, int sbits, int* slot, int table_c = 0, int bit_lo = 0,
+            int bit_hi = 0);
+    MsmPlan plan_for_range(uint32_t npts, int bit_lo, int bit_hi) const;
     // wait for task `slot`, copy the result out (result_size bytes), collect its phase timings
     int finish(int slot, uint8_t* out);
     // add `count` partial results (host bytes, or device bytes already ordered on aux_stream) on the device,

@@ -596,6 +596,8 @@ __global__ __launch_bounds__(64, 3) void k_finish(const uint32_t* __restrict__ v
         pos = off;
         started = true;
     }
+    // scalar-range tasks: the lowest window starts at bit_lo of the scalar, the partial result carries that weight
+    for (int d = 0; d < pos; ++d) quad_dbl(acc, ql);
     if (threadIdx.x == 0) emit_result(out, acc);
 }
 
@@ -825,7 +827,7 @@ int run_reduce_t(MsmEngine& E, const void* sums, const void* unit_off_v) {
         fp.m[0] = (uint8_t)(P.G >> fp.logV);
         fp.off[0] = 0;
     } else {
-        int off = 0;
+        int off = P.base_bit;
         for (int w = 0; w < P.W; ++w) {
             const uint32_t v0 = P.boff[w] >> fp.logV, m = (P.boff[w + 1] - P.boff[w]) >> fp.logV;
             if (v0 > 0xffffu || m > 0xffu || off > 0xffff)

@@ -230,6 +230,12 @@ class MSMClient(DriverPrimitive[MSMInit, MSMParams, MSMInput, MSMResult]):
         False / 0 off, True / 1 where it pays (the BLS curves), 2 always."""
         check(lib().blz_msm_set_window_table(self._h, int(enable)))
 
+    def set_scalar_range(self, bit_lo: int, bit_hi: int) -> None:
+        """This client's tasks sum only bits [bit_lo, bit_hi) of every scalar and return 2^bit_lo x that sum: one shard of a
+        job split by scalar chunk (include/blaze_hip.h blz_msm_set_scalar_range; blaze_amd.multi_gpu.shard_layout).
+        (0, 256) = the whole scalar."""
+        check(lib().blz_msm_set_scalar_range(self._h, bit_lo, bit_hi))
+
     def window_table_info(self) -> dict:
         """Of the table the last HBM task used (all zero: it took the plain path)."""
         out = (C.c_uint64 * 4)()

@@ -1,8 +1,10 @@
-"""Multi-GPU MSM: shard by contiguous element chunk, one process per GPU, one tiny exchange.
+"""Multi-GPU MSM: shard by element chunk and / or scalar chunk, one process per GPU, one tiny exchange.
 
 MSM is a sum, so rank g of G takes elements [g n/G, (g+1) n/G) - its slice of the scalars and of
-the points.  Each rank runs the full single-GPU pipeline through its own
-MSMClient; the G partial results (144 / 96 bytes each) are exchanged with ONE all-gather (RCCL over
+the points (`shard_range`) - or, since round 3, a slice of the scalars' BITS of a larger
+element chunk (`shard_layout`: the library picks the mix by the window planner's cost; a rank's partial
+result then carries the weight 2^bit_lo of its range, and the partials still simply add up).  Each rank runs
+the full single-GPU pipeline through its own MSMClient; the G partial results (144 / 96 bytes each) are exchanged with ONE all-gather (RCCL over
 xGMI when the process group backend is "nccl"; gloo in the CPU tests) and every rank adds them in
 rank order on its device (`MSMClient.combine_partials`), so every rank returns identical, normalised
 bytes.  RCCL's reduce ops are arithmetic, not a group law, hence all-gather + local add instead of
@@ -18,6 +20,18 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     base, rem = divmod(n, world)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_layout(curve, n: int, rank: int, world: int) -> dict:
+    """The split the library picks for `world` equal devices (include/blaze_hip.h blz_msm_shard_layout): rank's element chunk
+    [first, first + count) and scalar range [bit_lo, bit_hi) - hand the latter to MSMClient.set_scalar_range."""
+    import ctypes as C
+
+    from ._lib import check, lib
+
+    out = (C.c_uint32 * 4)()
+    check(lib().blz_msm_shard_layout(int(curve), n, world, rank, out))
+    return {"first": int(out[0]), "count": int(out[1]), "bit_lo": int(out[2]), "bit_hi": int(out[3])}
 
 
 def all_gather_partials(partial: bytes, dist, device=None) -> bytes:

@@ -126,6 +126,7 @@ class MSMClient : public DriverPrimitive<MSMInit, MSMParams, MSMInput, MSMResult
         return id;
     }
     // resident-base window table (blaze_hip.h): opt-in, bases in the arena, precompute_factor 1
+    void set_scalar_range(uint32_t bit_lo, uint32_t bit_hi) { check(blz_msm_set_scalar_range(h_, bit_lo, bit_hi)); }   // one shard of a job split by scalar chunk
     void set_window_table(int mode) { check(blz_msm_set_window_table(h_, mode)); }   // 0 off, 1 where it pays, 2 always
     void comm_init(int rank, int nranks, const std::vector<uint8_t>& id) { check(blz_msm_comm_init(h_, rank, nranks, id.data())); }
     std::vector<uint8_t> all_gather_combine(const std::vector<uint8_t>& partial) {

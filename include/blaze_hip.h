@@ -179,6 +179,21 @@ int blz_msm_set_window_table(blz_msm* h, int enable);
  * used; zeros when it took the plain path */
 int blz_msm_window_table_info(blz_msm* h, uint64_t out[4]);
 
+/* Sharding by scalar chunk (multi-GPU; no reference counterpart - README.md:20-22 leaves the split to a "management
+ * layer").  A handle with a scalar range sums only bits [bit_lo, bit_hi) of every scalar it is given and returns
+ * 2^bit_lo x that sum: the partial results of the ranges of a partition of [0, 256) add up to the full MSM, like the partial
+ * results of element chunks do (blz_msm_combine_partials / blz_msm_all_gather_combine), and the two splits compose.
+ * Why: Pippenger's cost per rank is (elements x windows) additions + (windows x 2^(c-1)) bucket slots to reduce, and a rank
+ * that gets 1/8 of the ELEMENTS has to narrow its windows (2^23 elements: 15 windows of 19 bits - 126 M additions) where a
+ * rank that gets 1/4 of the elements' BITS for half of the elements keeps the big job's windows (2^25 elements x 3
+ * windows of 22 bits - 101 M).  32-bit aligned ranges, precompute_factor 1; (0, 0) or (0, 256) = the whole scalar. */
+int blz_msm_set_scalar_range(blz_msm* h, uint32_t bit_lo, uint32_t bit_hi);
+/* The split blz picks for `nranks` equal devices: out = {first element, element count, bit_lo, bit_hi} of `rank`.
+ * R ranges of 256 / R bits x nranks / R element chunks, R in {1, 2, 4, 8} dividing nranks, chosen by the window planner's
+ * cost estimate of a rank's task; rank = chunk * R + range.  BLAZE_SHARD=elements forces the element split (R = 1),
+ * BLAZE_SHARD=bits the largest R.  Host-side only (no device needed). */
+int blz_msm_shard_layout(int curve, uint32_t nof_elements, int nranks, int rank, uint32_t out[4]);
+
 /* Multi-GPU: add G partial results (each result_size bytes, as returned by blz_msm_result on each
  * rank, in rank order) on this handle's device and emit the normalised sum, for hosts that move the
  * partials themselves (blz_msm_all_gather_combine below does the exchange too). */

@@ -176,6 +176,16 @@ impl MSMClient {
     pub fn set_window_table(&self, mode: i32) -> Result<()> {
         check(unsafe { blz_msm_set_window_table(self.h, mode) })
     }
+    /// One shard of a job split by scalar chunk: only bits `[bit_lo, bit_hi)` of every scalar, result weighted `2^bit_lo`.
+    pub fn set_scalar_range(&self, bit_lo: u32, bit_hi: u32) -> Result<()> {
+        check(unsafe { blz_msm_set_scalar_range(self.h, bit_lo, bit_hi) })
+    }
+    /// `[first element, element count, bit_lo, bit_hi]` of `rank` in the split the library picks for `nranks` devices.
+    pub fn shard_layout(curve: Curve, nof_elements: u32, nranks: i32, rank: i32) -> Result<[u32; 4]> {
+        let mut out = [0u32; 4];
+        check(unsafe { blz_msm_shard_layout(curve.code(), nof_elements, nranks, rank, out.as_mut_ptr()) })?;
+        Ok(out)
+    }
     /// `[table bytes, window bits, windows, build time in microseconds]` of the table the last HBM task used.
     pub fn window_table_info(&self) -> Result<[u64; 4]> {
         let mut out = [0u64; 4];

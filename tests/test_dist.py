@@ -253,3 +253,45 @@ def test_shard_range_partitions_exactly():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_shard_layout_tiles_elements_and_bits():
+    """blz_msm_shard_layout (host-side): for every world size the ranks' (element chunk) x (scalar range) rectangles tile
+    [0, n) x [0, 256) exactly - no overlap, no hole - with 32-bit aligned ranges; BLAZE_SHARD=elements is the plain element
+    split of shard_range."""
+    import os
+
+    from blaze_amd.ingo_msm import Curve
+    from blaze_amd.multi_gpu import shard_layout, shard_range
+
+    for curve in (Curve.BLS381, Curve.BN254):
+        for n in (1, 7, 1000, (1 << 22) + 5, 1 << 26):
+            for world in range(1, 9):
+                lays = [shard_layout(curve, n, r, world) for r in range(world)]
+                cells = {}
+                for l in lays:
+                    assert l["bit_lo"] % 32 == 0 and l["bit_hi"] % 32 == 0 and 0 <= l["bit_lo"] < l["bit_hi"] <= 256
+                    if l["count"]:   # (more ranks than elements: the surplus chunks are empty)
+                        cells.setdefault((l["first"], l["count"]), []).append((l["bit_lo"], l["bit_hi"]))
+                chunks = sorted(cells)
+                pos = 0
+                for first, count in chunks:
+                    assert first == pos
+                    pos += count
+                    rs = sorted(cells[(first, count)])
+                    assert rs[0][0] == 0 and rs[-1][1] == 256 and all(a[1] == b[0] for a, b in zip(rs, rs[1:]))
+                assert pos == n
+    os.environ["BLAZE_SHARD"] = "elements"
+    try:
+        for world in (2, 8):
+            for r in range(world):
+                l = shard_layout(Curve.BLS381, 1 << 26, r, world)
+                lo, hi = shard_range(1 << 26, r, world)
+                assert (l["first"], l["first"] + l["count"], l["bit_lo"], l["bit_hi"]) == (lo, hi, 0, 256)
+    finally:
+        del os.environ["BLAZE_SHARD"]
+    # what the planner picks at the bench size (documented in DESIGN.md section 6): bits for 2 and 4 ranks, a mix for 8
+    picks = {w: shard_layout(Curve.BLS381, 1 << 26, 0, w) for w in (2, 4, 8)}
+    assert picks[2]["count"] == 1 << 26 and picks[2]["bit_hi"] == 128
+    assert picks[4]["count"] == 1 << 26 and picks[4]["bit_hi"] == 64
+    assert picks[8]["bit_hi"] < 256

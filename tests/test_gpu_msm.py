@@ -430,28 +430,37 @@ def test_cpp_host_mirror(gpu, orc, tmp_path):
     assert out.read_bytes() == exp
 
 
-def test_bench_sharded_path_two_ranks_one_gpu(gpu):
-    """bench.py's N > 1 path (shard by element chunk, one all-gather of the partials, rank-ordered
-    combine) driven by torch.distributed.run with two ranks sharing this box's single GPU over gloo:
-    the 2-rank result must equal the 1-rank result on the same synthetic job."""
+@pytest.mark.parametrize("shard", ["auto", "elements"])
+def test_bench_sharded_path_two_ranks_one_gpu(gpu, shard):
+    """bench.py's N > 1 path (rank's shard from blz_msm_shard_layout - at this size two ranks split the scalars' BITS of all
+    the elements; BLAZE_SHARD=elements: the plain element split - one all-gather of the partials, rank-ordered combine)
+    driven by torch.distributed.run with two ranks sharing this box's single GPU over gloo: the 2-rank result must equal the
+    1-rank result on the same synthetic job."""
     import json
     import subprocess
     import sys
 
     env = dict(os.environ, BLAZE_BENCH_LOGN="18", BLAZE_BENCH_EMIT_RESULT="1", BLAZE_BENCH_BACKEND="gloo",
                BLAZE_BENCH_ONE_GPU="1", MASTER_ADDR="127.0.0.1")
+    if shard == "elements":
+        env["BLAZE_SHARD"] = "elements"
     root = os.path.dirname(HERE)
     common = ["--steps", "1", "--warmup", "0", "--no-ntt", "--no-cpu-baseline"]
     one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + common, env=env,
                          capture_output=True, text=True, timeout=600)
     assert one.returncode == 0, one.stderr[-2000:]
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
-                          "--gpus", "2"] + common, env=env, capture_output=True, text=True, timeout=900)
+                          "--master-addr", "127.0.0.1", "--master-port", "29533" if shard == "auto" else "29534",
+                          os.path.join(root, "bench.py"), "--gpus", "2"] + common, env=env, capture_output=True, text=True, timeout=900)
     assert two.returncode == 0, two.stderr[-2000:]
     j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
     j2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
-    assert j2["n_gpus"] == 2 and j2["config"]["elements_per_gpu"] == (1 << 17) and j2["scaling"] == "strong"
+    assert j2["n_gpus"] == 2 and j2["scaling"] == "strong"
+    lay = j2["config"]["shard_rank0"]
+    if shard == "elements":
+        assert j2["config"]["elements_per_gpu"] == (1 << 17) and (lay["bit_lo"], lay["bit_hi"]) == (0, 256)
+    else:
+        assert lay["count"] * (lay["bit_hi"] - lay["bit_lo"]) * 2 == (1 << 18) * 256, lay
     assert j2["result_hex"] == j1["result_hex"] and len(j1["result_hex"]) == 288   # same job, same bytes
 
 
