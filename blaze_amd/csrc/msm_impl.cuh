@@ -767,12 +767,13 @@ int run_reduce_t(MsmEngine& E, const void* sums, const void* unit_off_v) {
     // ---- phase 2
     // level 0 is throughput-bound (2 adds per bucket): long segments; the upper levels have few
     // lanes and are latency-bound on their sequential chain: short segments, more levels
-    // (a small bucket space cannot fill the chip with long segments: 17 x 2^15 buckets give 272
-    // waves for 1024 SIMDs and the level costs 32 sequential steps; shorter segments put a wave on
-    // every SIMD and the extra segment sums are absorbed by the upper levels).  64 at the headline size: measured
-    // 12.2 / 10.3 / 9.1 / 8.6 ms of phase 2 for segments of 8 / 16 / 32 / 64 buckets (profiles/r03_seg_sweep.txt).
+    // (a small bucket space cannot fill the chip with long segments: the level wants >= 2^18 lanes - two full rounds of
+    // two waves per SIMD - before it wants long segments; the extra segment sums are absorbed by the upper levels, which
+    // run on the tail stream).  Same-box sweeps, profiles/r03_seg_sweep.txt: 17.8 M bucket slots (the 2^26 plan) 64 best; 12.6 M: 32 (61.9 against 62.9 ms per MSM);
+    // 5 - 7 M: 16 (17.2 against 17.8); 2.1 M (2^22): 8 (10.1 against 11.1).  Powers of two only: the upper levels weigh
+    // segment t by shifts.
     uint32_t seg0_auto = 64;
-    while (seg0_auto > 8 && G / seg0_auto < 65536) seg0_auto >>= 1;
+    while (seg0_auto > 8 && G / seg0_auto < 262144) seg0_auto >>= 1;
     const uint32_t SEG0 = (uint32_t)msm_env_int("BLAZE_MSM_SEG", (int)seg0_auto);
     const uint32_t SEGU = (uint32_t)msm_env_int("BLAZE_MSM_SEG_UPPER", 8);
     uint32_t M = P.Bw;
