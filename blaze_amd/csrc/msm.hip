@@ -544,7 +544,7 @@ int MsmEngine::sync_all() {
     BLZ_TRY(sync_stream_bounded(tail_stream, "reset: tail stream"));
     BLZ_TRY(sync_stream_bounded(aux_stream, "reset: exchange stream"));
     BLZ_TRY(sync_stream_bounded(sort_stream, "reset: sort stream"));
-    for (auto& S : slots) S.busy = false;
+    for (auto& S : slots) { S.busy = false; S.awaiting_points = false; S.pending_inputs_event = nullptr; }
     return BLZ_OK;
 }
 
@@ -589,6 +589,10 @@ int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int 
     cur = slot;
     MsmSlot& S = slots[slot];
     if (slot_out) *slot_out = slot;
+    const bool defer = defer_points && npts > 0;
+    defer_points = false;
+    S.awaiting_points = false;
+    S.pending_inputs_event = nullptr;
     BLZ_HIP(hipEventRecord(S.ev[0], st), BLZ_ERR_UNKNOWN);
     if (npts == 0) {
         BLZ_TRY(ops->emit_infinity(E));
@@ -628,7 +632,7 @@ int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int 
     {
         const uint64_t table = (uint64_t)npts * mont_point_bytes(curve);
         const int forced = msm_env_int("BLAZE_MSM_SLICES", 0);
-        if (forced > 0 && !P.table) nslices = forced;
+        if (forced > 0 && !P.table && !defer) nslices = forced;
         (void)table;
         if (nslices > MSM_MAX_SLICES) nslices = MSM_MAX_SLICES;
         if ((uint64_t)nslices > npts) nslices = 1;
@@ -677,8 +681,8 @@ int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int 
     if (hide) {
         // this slot's previous task must have let go of its sort outputs (its level-0 reduce read unit_off last)
         if (S.l0_recorded) BLZ_HIP(hipStreamWaitEvent(ss, S.ev_l0, 0), BLZ_ERR_UNKNOWN);
-        BLZ_HIP(hipEventRecord(S.ev_s0, ss), BLZ_ERR_UNKNOWN);
     }
+    BLZ_HIP(hipEventRecord(S.ev_s0, ss), BLZ_ERR_UNKNOWN);   // ev_s0 .. ev_s1: the sort stage, whichever stream it is on
     BLZ_TRY(B.count.reserve((G + 1) * 4 + 16));
     BLZ_TRY(B.off.reserve((G + 2) * 4));
     BLZ_TRY(B.unit_off.reserve((G + 2) * 4));
@@ -729,9 +733,16 @@ int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int 
         BLZ_TRY(launch_fill_units(E, (uint32_t)max_units));
         BLZ_HIP(hipEventRecord(S.ev_sorted, ss), BLZ_ERR_UNKNOWN);
         last_sort_done = S.ev_sorted;
-        if (hide) {
-            BLZ_HIP(hipEventRecord(S.ev_s1, ss), BLZ_ERR_UNKNOWN);
-            BLZ_HIP(hipStreamWaitEvent(st, S.ev_sorted, 0), BLZ_ERR_UNKNOWN);
+        BLZ_HIP(hipEventRecord(S.ev_s1, ss), BLZ_ERR_UNKNOWN);
+        if (hide) BLZ_HIP(hipStreamWaitEvent(st, S.ev_sorted, 0), BLZ_ERR_UNKNOWN);
+        if (defer) {
+            // the rest needs the points: run_points() - it also records inputs_event, on the main stream, where by then
+            // both readers of the staged inputs have passed (this sort: the main stream has waited for it or run it; the
+            // to-Montgomery pass: enqueued there by the caller in between)
+            S.pending_inputs_event = inputs_event;
+            S.awaiting_points = true;
+            S.busy = true;
+            return BLZ_OK;
         }
         // The staged inputs have been consumed once the LAST sort has read the scalars - and, in DMA mode, once the
         // to-Montgomery pass, which msm_capi.hip enqueued on the MAIN stream ahead of this run(), has read the raw points
@@ -757,9 +768,38 @@ int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int 
     return BLZ_OK;
 }
 
+int MsmEngine::run_points(int slot, const void* d_pts) {
+    BLZ_TRY(use_device(device));
+    if (slot < 0 || slot >= MSM_QUEUE_DEPTH || !slots[slot].busy || !slots[slot].awaiting_points)
+        return fail(BLZ_ERR_INVALID_PARAM, "slot %d is not waiting for its points", slot);
+    MsmSlot& S = slots[slot];
+    const MsmCurveOps* ops = ops_for(curve, repr);
+    cur = slot;
+    last_plan = S.plan;
+    BLZ_HIP(hipEventRecord(S.ev[0], stream), BLZ_ERR_UNKNOWN);   // the pipeline "starts" here: its sort ran during the copy
+    if (S.pending_inputs_event) BLZ_HIP(hipEventRecord(S.pending_inputs_event, stream), BLZ_ERR_UNKNOWN);
+    S.pending_inputs_event = nullptr;
+    BLZ_TRY(ops->run_accumulate(*this, d_pts, (uint32_t)S.max_units, -1));
+    BLZ_TRY(ops->run_reduce(*this, partial.p, sb().unit_off.p));
+    S.l0_recorded = true;
+    S.awaiting_points = false;
+    return BLZ_OK;
+}
+
+void MsmEngine::cancel(int slot) {
+    if (slot < 0 || slot >= MSM_QUEUE_DEPTH) return;
+    MsmSlot& S = slots[slot];
+    if (S.busy && S.awaiting_points) {
+        S.busy = false;
+        S.awaiting_points = false;
+        S.pending_inputs_event = nullptr;
+    }
+}
+
 int MsmEngine::finish(int slot, uint8_t* out) {
     BLZ_TRY(use_device(device));
     if (slot < 0 || slot >= MSM_QUEUE_DEPTH || !slots[slot].busy) return fail(BLZ_ERR_INVALID_PARAM, "no task in slot %d", slot);
+    if (slots[slot].awaiting_points) return fail(BLZ_ERR_INVALID_PARAM, "task in slot %d never received its points", slot);
     MsmSlot& S = slots[slot];
     // bounded: a wedged kernel must not hang the host for ever (common.hpp); on expiry the slot stays busy
     BLZ_TRY(sync_event_bounded(S.ev_done, "wait_result: MSM task"));
@@ -782,8 +822,8 @@ int MsmEngine::finish(int slot, uint8_t* out) {
         }
     }
     last_sort_hidden = S.sort_hidden && S.plan.c != 0;
-    if (S.sort_hidden) (void)hipEventElapsedTime(&t, S.ev_s0, S.ev_s1);   // on sort_stream, underneath the previous task
-    else (void)hipEventElapsedTime(&t, S.ev[0], S.ev[1]);
+    if (S.plan.c) (void)hipEventElapsedTime(&t, S.ev_s0, S.ev_s1);   // the sort stage: on the main stream, or on sort_stream underneath the previous task
+    else t = 0;
     last_ms[2] = t;
     (void)hipEventElapsedTime(&t, S.ev[1], S.ev[2]); last_ms[3] = t;
     (void)hipEventElapsedTime(&t, S.ev[2], S.ev[3]); last_ms[4] = t;

@@ -64,6 +64,8 @@ struct MsmSlot {
     int slices = 1;
     bool accum_timed = false;
     bool busy = false;             // enqueued, result not collected yet
+    bool awaiting_points = false;  // run() enqueued the sort stage only (defer_points); run_points() enqueues the rest
+    hipEvent_t pending_inputs_event = nullptr;  // ... and records the caller's inputs_event then
 };
 
 struct MsmEngine {
@@ -93,6 +95,12 @@ struct MsmEngine {
     hipEvent_t last_sort_done = nullptr; // sorts share their scratch (coarse, inter, inter2, ...): each waits for the one before
     DevBuf coarse, inter, inter2, slice_map, partial, blocksums, result, sort3_tabs;
     DevBuf bucket_sums, bucket_ident;   // slice-major tasks: running bucket sums across slices; identity unit_off for the reduce
+    // Set by the caller of run(), consumed by it: enqueue only the sort stage - everything that needs nothing but the
+    // scalars - and leave the task waiting for run_points().  msm_capi.hip uses it for host buffers (DMA mode): scalars are
+    // sent first, the sort runs while the points are still on the PCIe link, the accumulation is enqueued when they landed.
+    bool defer_points = false;
+    int run_points(int slot, const void* d_points_mont);
+    void cancel(int slot);   // give up a task that is awaiting its points (the copy failed)
     hipEvent_t inputs_event = nullptr;   // set by the caller of run(): recorded on `stream` once the task has read
                                          // its scalars / raw points (after the digit sort)
     uint8_t* combine_h = nullptr;  // pinned bytes of combine_partials
