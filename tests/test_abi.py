@@ -68,6 +68,14 @@ def test_invalid_arguments_are_rejected_before_touching_a_device():
     assert L.blz_ntt_new(0, 28, C.byref(h)) == 4           # > 2^27
     assert L.blz_msm_wait_result(None) == 4
     assert L.blz_msm_initialize(None, 1, 0, 0, 0) == 4
+    assert L.blz_msm_set_scalar_range(None, 0, 64) == 4
+    assert L.blz_msm_set_window_table(None, 1) == 4
+    out = (C.c_uint32 * 4)()
+    assert L.blz_msm_shard_layout(1, 1 << 20, 0, 0, out) == 4      # no ranks
+    assert L.blz_msm_shard_layout(1, 1 << 20, 4, 4, out) == 4      # rank out of range
+    assert L.blz_msm_shard_layout(9, 1 << 20, 4, 0, out) == 4      # unknown curve
+    assert L.blz_msm_shard_layout(1, 1 << 20, 4, 3, None) == 4
+    assert L.blz_msm_shard_layout(1, 1 << 20, 1, 0, out) == 0 and list(out) == [0, 1 << 20, 0, 256]
 
 
 def _build_cpp_example(tmp_path):
