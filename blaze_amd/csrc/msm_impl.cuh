@@ -428,6 +428,9 @@ __global__ __launch_bounds__(128, 3) void k_combine_buckets(const uint32_t* __re
     }
 }
 
+#ifndef BLZ_TAIL_PRIO
+#define BLZ_TAIL_PRIO 3
+#endif
 // ------------------------------------------------------------------------------------------------
 // phase 2: per window Sum_i (i + woff) * A_i by segments.  See DESIGN.md for the recurrence:
 //   F = Sum_t s_t + SEG * Sum_t t * r_t,  r_t = Sum_j A_(t SEG + j),  s_t = Sum_j (j + woff) A_(t SEG + j)
@@ -440,6 +443,11 @@ __global__ __launch_bounds__(64, FIRST ? 2 : 3) void k_reduce_level(const uint32
                                                      uint32_t* __restrict__ outC) {
     // level 0 (FIRST): one lane per segment, throughput-bound.  Upper levels: one DPP quad per
     // segment (ec_quad.cuh), because there the sequential chain, not the work, is the cost.
+    // The upper levels (and k_finish) are a few waves of sequential work on the tail stream, underneath the next task's
+    // accumulation: raised wave priority, or they crawl (k_finish 1.8 ms alone, 3.0 ms underneath) - and the host, which
+    // hands out the next-but-one task when this one's result arrives, enqueues that task's hidden sort too late for it
+    // to finish before the main stream wants its buckets (2^22: 0.8 ms of idle main stream per MSM).
+    if constexpr (!FIRST) __builtin_amdgcn_s_setprio(BLZ_TAIL_PRIO);
     const uint32_t gtid = blockIdx.x * 64u + threadIdx.x;
     const uint32_t tid = FIRST ? gtid : gtid >> 2;
     const uint32_t ql = gtid & 3u;
@@ -561,6 +569,7 @@ __global__ __launch_bounds__(64, 3) void k_finish(const uint32_t* __restrict__ v
                                                   FinishPlan fp, uint32_t* __restrict__ out) {
     // one wave; every DPP quad runs the same chain cooperatively (ec_quad.cuh), lane 0 emits
     if (blockIdx.x != 0) return;
+    __builtin_amdgcn_s_setprio(BLZ_TAIL_PRIO);   // (see k_reduce_level)
     const uint32_t ql = threadIdx.x & 3u;
     XYZZ<F> acc;
     pt_set_inf(acc);
