@@ -274,26 +274,35 @@ def main():
         client.start_process()
         client.set_data(MSMInput(step_points, d_sc, params))
 
-    def collect():
+    def collect_local():
         client.wait_result()
         part = client.result().result
-        api = client.get_api()  # HIP-event timers recorded on the streams the kernels run on
+        return part, client.get_api()  # HIP-event timers recorded on the streams the kernels run on
+
+    def exchange_partial(loc):
+        part, api = loc
         if multi:
             last_partial[0] = part
             part = sharded_msm(part, client.combine_partials, dist, gather_dev)
         return part, api
 
     def run_steps(k):
-        out, pending = [], 0
-        for _ in range(k):
-            submit()
-            pending += 1
-            if pending >= queue:
-                out.append(collect())
+        # a collected result frees a queue slot: the next task is handed to the device BEFORE the collected partial is
+        # exchanged (its digit sort has to be enqueued early enough to finish underneath the accumulation in flight)
+        out, pending, submitted = [], 0, 0
+        while submitted < k or pending:
+            if pending >= queue or submitted >= k:
+                loc = collect_local()
                 pending -= 1
-        while pending:
-            out.append(collect())
-            pending -= 1
+                if submitted < k:
+                    submit()
+                    submitted += 1
+                    pending += 1
+                out.append(exchange_partial(loc))
+            else:
+                submit()
+                submitted += 1
+                pending += 1
         return out
 
     def fence():
@@ -485,16 +494,24 @@ def main():
             return part, a
 
         def trun(k):
-            out, pending = [], 0
-            for _ in range(k):
-                tsubmit()
-                pending += 1
-                if pending >= queue:
-                    out.append(tcollect())
+            out, pending, submitted = [], 0, 0
+            while submitted < k or pending:
+                if pending >= queue or submitted >= k:
+                    tcl.wait_result()
+                    loc = (tcl.result().result, tcl.get_api())
                     pending -= 1
-            while pending:
-                out.append(tcollect())
-                pending -= 1
+                    if submitted < k:
+                        tsubmit()
+                        submitted += 1
+                        pending += 1
+                    part, a = loc
+                    if multi:
+                        part = sharded_msm(part, tcl.combine_partials, dist, gather_dev)
+                    out.append((part, a))
+                else:
+                    tsubmit()
+                    submitted += 1
+                    pending += 1
             return out
 
         t1 = time.perf_counter()
