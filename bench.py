@@ -472,13 +472,13 @@ def main():
     # handle tabulates the window multiples of the bases once (blz_msm_set_window_table) and then runs fewer, wider
     # windows into one bucket set.  Every rank runs it on its shard (the exchange included), timed like the headline.
     table_rec = None
-    # (not with scalar-range shards: a range handle has no table, and every rank's whole-scalar sum over its element chunk
-    # would count the chunk once per range)
-    any_ranged = shard_layout(Curve[CURVE], n, 0, world)["bit_hi"] != 256
-    if hbm_mode and not args.no_extras and not any_ranged and os.environ.get("BLAZE_BENCH_TABLE", "1") == "1":
+    # (a rank with a scalar range tabulates 2^(lo + c j) P: its few windows share one bucket set)
+    if hbm_mode and not args.no_extras and os.environ.get("BLAZE_BENCH_TABLE", "1") == "1":
         wd.arm(900, "window-table leg")
         tcl = MSMClient(MSMInit(PointMemoryType.HBM, False, Curve[CURVE]), DriverClient(dev))
         tcl.set_window_table(True)
+        if ranged:
+            tcl.set_scalar_range(lay["bit_lo"], lay["bit_hi"])
 
         def tsubmit():
             tcl.initialize(params)

@@ -134,6 +134,7 @@ struct ArenaExtent {
     void* table = nullptr;
     size_t table_bytes = 0;
     int table_format = -1, table_c = 0, table_W = 0;
+    int table_lo = 0, table_hi = 256;      // scalar range the table serves: entry j = 2^(table_lo + c j) P
     uint32_t table_phase = 0;
     uint64_t table_first = 0, table_npts = 0;
     bool table_refused = false;            // a build failed (a base of even order, or no memory): do not retry until the next write

@@ -126,14 +126,14 @@ MsmPlan make_plan(uint32_t npts, int sbits, int ebits, int force_c) {
 // level-0 reduce - 12.6 ms for the 2^25 buckets of c = 26 - scans, unit lists).  2^26 bases: c = 26, 10 windows (671 M
 // additions instead of the 805 M of the 12-window plan without a table: 106.6 ms per MSM against 116.2; c = 24, 11 windows:
 // 108.7); 2^24: c = 24 (30.0 against 33.2 ms); 2^23: c = 22 (17.2 against 18.3 ms).
-int table_window_bits(uint32_t npts) {
+int table_window_bits(uint32_t npts, int need_bits) {
     const int forced = msm_env_int("BLAZE_MSM_TABLE_C", 0);
     int best = 0;
     double best_cost = 1e300;
     for (int c = 16; c <= 26; ++c) {
         if (forced > 0 && c != forced) continue;
-        const int W = table_windows(c);
-        if (c > 16 && table_windows(c - 1) == W && forced <= 0) continue;   // same additions, twice the buckets: dominated
+        const int W = table_windows(c, need_bits);
+        if (c > 16 && table_windows(c - 1, need_bits) == W && forced <= 0) continue;   // same additions, twice the buckets: dominated
         if ((uint64_t)npts * W >= (1ull << 30)) continue;
         const double cost = (double)npts * W * 0.130 + (double)(1ull << (c - 1)) * 0.34;
         if (cost < best_cost) { best_cost = cost; best = c; }
@@ -141,12 +141,12 @@ int table_window_bits(uint32_t npts) {
     return best;
 }
 
-MsmPlan make_table_plan(uint32_t npts, int c) {
+MsmPlan make_table_plan(uint32_t npts, int c, int need_bits) {
     MsmPlan P;
-    if (c < 16 || c > 26) return P;
-    const int W = table_windows(c);
+    if (c < 16 || c > 26 || need_bits < 2 || need_bits > 257) return P;
+    const int W = table_windows(c, need_bits);
     if ((uint64_t)npts * W >= (1ull << 30)) return P;
-    P.npts = npts; P.sbits = 256; P.c = c; P.W = W; P.table = true;
+    P.npts = npts; P.sbits = need_bits - 1; P.c = c; P.W = W; P.table = true;
     P.G = 1ull << (c - 1);
     for (int w = 0; w < W; ++w) { P.width[w] = (uint8_t)c; P.boff[w] = 0; }
     P.boff[W] = (uint32_t)P.G;
@@ -553,9 +553,10 @@ int MsmEngine::points_to_mont(const void* d_raw, void* d_mont, uint32_t npts) {
     return ops_for(curve, repr)->points_to_mont(*this, d_raw, d_mont, npts);
 }
 
-int MsmEngine::build_table(const void* d_raw, void* d_table, uint32_t npts, int c, int W, void* scratch, uint32_t* flag, hipStream_t st) {
+int MsmEngine::build_table(const void* d_raw, void* d_table, uint32_t npts, int c, int W, int base_shift, void* scratch, uint32_t* flag,
+                           hipStream_t st) {
     BLZ_TRY(use_device(device));
-    return ops_for(curve, repr)->build_table(*this, d_raw, d_table, npts, c, W, scratch, flag, st);
+    return ops_for(curve, repr)->build_table(*this, d_raw, d_table, npts, c, W, base_shift, scratch, flag, st);
 }
 size_t MsmEngine::table_scratch_bytes(int W) const { return ops_for(curve, repr)->table_scratch_bytes(W); }
 
@@ -606,9 +607,10 @@ int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int 
     }
     const int ebits = sbits == 256 ? kScalarFieldBits[curve] : sbits;
     const bool ranged = bit_hi > bit_lo && !(bit_lo == 0 && bit_hi >= sbits);
-    if (ranged && (sbits != 256 || table_c > 0 || (bit_lo & 31) || (bit_hi & 31) || bit_hi > 256))
-        return fail(BLZ_ERR_INVALID_PARAM, "scalar range [%d, %d): 32-bit aligned ranges of 256-bit scalars, no window table", bit_lo, bit_hi);
-    MsmPlan P = table_c > 0 ? make_table_plan(npts, table_c)
+    if (ranged && (sbits != 256 || (bit_lo & 31) || (bit_hi & 31) || bit_hi > 256))
+        return fail(BLZ_ERR_INVALID_PARAM, "scalar range [%d, %d): 32-bit aligned ranges of 256-bit scalars", bit_lo, bit_hi);
+    // (a window table of a ranged handle holds 2^(lo + c j) P: the plan covers hi - lo bits + the carry, no closing doublings)
+    MsmPlan P = table_c > 0 ? make_table_plan(npts, table_c, ranged ? bit_hi - bit_lo + 1 : 257)
                 : ranged    ? plan_for_range(npts, bit_lo, bit_hi)
                             : make_plan(npts, sbits, ebits, msm_env_int("BLAZE_MSM_C", 0));
     if (P.c == 0) return fail(BLZ_ERR_INVALID_PARAM, "no window plan for npts=%u sbits=%d%s", npts, sbits, table_c > 0 ? " (window table)" : "");

@@ -149,13 +149,15 @@ int arena_points_table(blz_msm* h, uint64_t pos, uint32_t npts, const void** out
     const uint32_t phase = (uint32_t)((pos - e->start) % ps);
     const uint64_t first = (pos - e->start - phase) / ps;
     const int fmt = h->eng.format_id();
-    const int want_c = table_window_bits(npts);
+    const int lo = h->range_hi ? h->range_lo : 0, hi = h->range_hi ? h->range_hi : 256;
+    const int need = hi - lo < 256 ? hi - lo + 1 : 257;
+    const int want_c = table_window_bits(npts, need);
     if (want_c == 0) return BLZ_OK;
     const bool covers = e->table && e->table_format == fmt && e->table_phase == phase && first >= e->table_first &&
-                        first + npts <= e->table_first + e->table_npts;
+                        first + npts <= e->table_first + e->table_npts && e->table_lo == lo && e->table_hi == hi;
     if (covers && e->table_c != want_c) return BLZ_OK;   // a sub-range that wants other windows: the plain path, not a rebuild
     if (!covers) {
-        const int c = want_c, W = table_windows(c);
+        const int c = want_c, W = table_windows(c, need);
         const size_t bytes = (size_t)npts * W * mp + 16;
         if (e->table) {
             BLZ_HIP(hipDeviceSynchronize(), BLZ_ERR_UNKNOWN);   // a task of another handle may still gather from the old one
@@ -192,7 +194,7 @@ int arena_points_table(blz_msm* h, uint64_t pos, uint32_t npts, const void** out
             if (hipEventCreate(&t0) != hipSuccess || hipEventCreate(&t1) != hipSuccess) rc = fail(BLZ_ERR_UNKNOWN, "event creation failed");
             if (rc == BLZ_OK && hipMemsetAsync(flag, 0, 16, st) != hipSuccess) rc = fail(BLZ_ERR_UNKNOWN, "memset failed");
             if (rc == BLZ_OK) (void)hipEventRecord(t0, st);
-            if (rc == BLZ_OK) rc = h->eng.build_table((const char*)e->raw + phase + first * ps, tab, npts, c, W, scratch.p, flag, st);
+            if (rc == BLZ_OK) rc = h->eng.build_table((const char*)e->raw + phase + first * ps, tab, npts, c, W, lo, scratch.p, flag, st);
             if (rc == BLZ_OK) (void)hipEventRecord(t1, st);
             if (rc == BLZ_OK) rc = sync_stream_bounded(st, "window table build");
             if (rc == BLZ_OK && hipMemcpy(&flag_h, flag, 4, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(BLZ_ERR_READ, "window table: flag read failed");
@@ -219,6 +221,8 @@ int arena_points_table(blz_msm* h, uint64_t pos, uint32_t npts, const void** out
         e->table_npts = npts;
         e->table_c = c;
         e->table_W = W;
+        e->table_lo = lo;
+        e->table_hi = hi;
         e->table_build_ms = ms;
         BLZ_LOG(1, "window table: %u bases x %d windows of %d bits, %.1f MiB, built in %.1f ms", npts, W, c, bytes / 1048576.0, ms);
     }
@@ -245,7 +249,7 @@ int launch_if_ready(blz_msm* h) {
     if (h->staged_from_arena) {
         // (BN254 loses with a table - 64-byte points: its accumulation is already at the gather rate, 2^26 71.8 -> 74.6 ms -
         // so "1" leaves it on the plain path)
-        if (h->pf == 1 && h->range_hi == 0 && (h->window_table == 2 || (h->window_table == 1 && h->curve != BLZ_BN254))) {
+        if (h->pf == 1 && (h->window_table == 2 || (h->window_table == 1 && h->curve != BLZ_BN254))) {
             const void* tab = nullptr;
             BLZ_WAIT(h, arena_points_table(h, h->staged_arena_pos, npts, &tab, &table_c));
             if (tab) h->d_points_mont = tab;

@@ -33,9 +33,11 @@ MsmPlan make_plan(uint32_t npts, int sbits, int ebits, int force_c);
 // window-table geometry for npts bases: the window width c (16..26) whose W = ceil(257 / c) windows make the cheapest task
 // (fewer windows = fewer additions, wider windows = more buckets to reduce); BLAZE_MSM_TABLE_C forces c.  0: none fits
 // (entries are indexed with 30 bits: npts W < 2^30)
-int table_window_bits(uint32_t npts);
-inline int table_windows(int c) { return (257 + c - 1) / c; }
-MsmPlan make_table_plan(uint32_t npts, int c);
+// need_bits: the scalar bits the windows have to cover plus one for the last digit carry: 257, or hi - lo + 1 for a handle
+// with a scalar range [lo, hi) (its table holds 2^(lo + c j) P: the range's weight is in the points, too)
+int table_window_bits(uint32_t npts, int need_bits = 257);
+inline int table_windows(int c, int need_bits = 257) { return (need_bits + c - 1) / c; }
+MsmPlan make_table_plan(uint32_t npts, int c, int need_bits = 257);
 
 // Task queue (msm_hw_code.rs:19-25: the device has a task queue and a result queue): up to
 // MSM_QUEUE_DEPTH tasks may be in flight.  The throughput-bound part of a task (sort, bucket
@@ -120,7 +122,8 @@ struct MsmEngine {
     // raw wire-format points (x||y canonical LE) -> Montgomery AoS at mont_point_bytes() stride (never in place)
     int points_to_mont(const void* d_raw, void* d_mont, uint32_t npts);
     // window table of npts wire-format points (msm_impl.cuh k_build_window_table): see MsmCurveOps::build_table
-    int build_table(const void* d_raw, void* d_table, uint32_t npts, int c, int W, void* scratch, uint32_t* flag, hipStream_t st);
+    int build_table(const void* d_raw, void* d_table, uint32_t npts, int c, int W, int base_shift, void* scratch, uint32_t* flag,
+                    hipStream_t st);
     size_t table_scratch_bytes(int W) const;
     // enqueue the whole pipeline; *slot identifies the task for finish().  Fails when both slots are busy.
     // table_c > 0: d_points_mont is the window table of the npts bases (table_windows(table_c) entries per base)
@@ -168,10 +171,11 @@ struct MsmCurveOps {
     int partial_dwords;   // dwords of one unit / bucket sum in `partial`
     // VGPRs of k_accumulate as compiled (hipFuncGetAttributes): what the hidden sort has to fit beside
     int (*accumulate_vgprs)();
-    // window table of npts wire-format points (msm_impl.cuh k_build_window_table): table[i W + j] = 2^(c j) P_i in the Montgomery point format,
-    // on `st`; scratch: table_scratch_bytes(W) bytes; *flag (device u32) is set when a multiple came out as infinity
-    int (*build_table)(MsmEngine&, const void* d_raw, void* d_table, uint32_t npts, int c, int W, void* scratch, uint32_t* flag,
-                       hipStream_t st);
+    // window table of npts wire-format points (msm_impl.cuh k_build_window_table): table[i W + j] = 2^(base_shift + c j) P_i in the
+    // Montgomery point format, on `st`; scratch: table_scratch_bytes(W) bytes; *flag (device u32) is set when a multiple came
+    // out as infinity
+    int (*build_table)(MsmEngine&, const void* d_raw, void* d_table, uint32_t npts, int c, int W, int base_shift, void* scratch,
+                       uint32_t* flag, hipStream_t st);
     size_t (*table_scratch_bytes)(int W);
     int (*combine)(MsmEngine&, const uint8_t* partials, size_t count, uint8_t* out, bool on_device);
 };

@@ -84,10 +84,13 @@ template <class F>
 constexpr size_t TABLE_SCRATCH_ROW = 5 * F::N;   // dwords per parked multiple: X, Y, ZZ, ZZZ, running product
 template <class F>
 __global__ __launch_bounds__(64, 3) void k_build_window_table(const uint32_t* __restrict__ raw, uint32_t* __restrict__ table,
-                                                              uint32_t npts, int c, int W, uint32_t* __restrict__ scratch,
-                                                              uint32_t* __restrict__ flag) {
+                                                              uint32_t npts, int c, int W, int base_shift,
+                                                              uint32_t* __restrict__ scratch, uint32_t* __restrict__ flag) {
+    // entry j of a base is 2^(base_shift + c j) P.  base_shift = 0: entry 0 is the base as given; a handle with a scalar range
+    // [lo, hi) tabulates from base_shift = lo, so that entry 0 needs normalising like the others (one more scratch row)
     const uint32_t lane = blockIdx.x * 64u + threadIdx.x, nlanes = gridDim.x * 64u;
-    uint32_t* row = scratch + (size_t)lane * (size_t)(W - 1) * TABLE_SCRATCH_ROW<F>;
+    uint32_t* row = scratch + (size_t)lane * (size_t)W * TABLE_SCRATCH_ROW<F>;
+    const int j0 = base_shift > 0 ? 0 : 1;   // first entry that goes through the scratch rows
     for (uint32_t i = lane; i < npts; i += nlanes) {
         Fp<F> x, y;
         fp_load(x, raw + (size_t)i * 2 * F::N);
@@ -95,19 +98,19 @@ __global__ __launch_bounds__(64, 3) void k_build_window_table(const uint32_t* __
         Affine<F> a;
         fp_to_mont(a.x, x);
         fp_to_mont(a.y, y);
-        store_mont_point<F>(table, (size_t)i * W, x, y);   // j = 0: the base itself (x, y are consumed)
+        if (j0 == 1) store_mont_point<F>(table, (size_t)i * W, x, y);   // the base itself (x, y are consumed)
         XYZZ<F> p;
         Fp<F> prod;
         bool bad = false;
-        for (int j = 1; j < W; ++j) {
+        for (int j = j0; j < W; ++j) {
             XYZZ<F> t;
-            if (j == 1) { pt_mdbl(p, a); }
-            else { pt_dbl(t, p); p = t; }
-            for (int d = 1; d < c; ++d) { pt_dbl(t, p); p = t; }
+            int nd = j == 0 ? base_shift : c;   // doublings from the previous entry (or from the base)
+            if (j == j0) { pt_mdbl(p, a); --nd; }
+            for (int d = 0; d < nd; ++d) { pt_dbl(t, p); p = t; }
             if (pt_is_inf(p)) { bad = true; break; }
-            if (j == 1) prod = p.zzz;
+            if (j == j0) prod = p.zzz;
             else fp_mul(prod, prod, p.zzz);
-            uint32_t* q = row + (size_t)(j - 1) * TABLE_SCRATCH_ROW<F>;
+            uint32_t* q = row + (size_t)(j - j0) * TABLE_SCRATCH_ROW<F>;
             fp_store(q, p.x); fp_store(q + F::N, p.y); fp_store(q + 2 * F::N, p.zz); fp_store(q + 3 * F::N, p.zzz);
             fp_store(q + 4 * F::N, prod);
         }
@@ -115,17 +118,18 @@ __global__ __launch_bounds__(64, 3) void k_build_window_table(const uint32_t* __
             atomicOr(flag, 1u);
             continue;
         }
+        if (W - j0 < 1) continue;   // (a table of the bases alone)
         Fp<F> inv;
-        fp_inv(inv, prod);   // 1 / (ZZZ_1 ... ZZZ_(W-1))
-        for (int j = W - 1; j >= 1; --j) {
-            const uint32_t* q = row + (size_t)(j - 1) * TABLE_SCRATCH_ROW<F>;
+        fp_inv(inv, prod);   // 1 / (ZZZ of every parked entry)
+        for (int j = W - 1; j >= j0; --j) {
+            const uint32_t* q = row + (size_t)(j - j0) * TABLE_SCRATCH_ROW<F>;
             Fp<F> X, Y, ZZ, ZZZ, w;
             fp_load(X, q); fp_load(Y, q + F::N); fp_load(ZZ, q + 2 * F::N); fp_load(ZZZ, q + 3 * F::N);
-            if (j > 1) {
+            if (j > j0) {
                 Fp<F> before;
-                fp_load(before, q - TABLE_SCRATCH_ROW<F> + 4 * F::N);   // ZZZ_1 ... ZZZ_(j-1)
+                fp_load(before, q - TABLE_SCRATCH_ROW<F> + 4 * F::N);   // product of the ZZZ below this entry
                 fp_mul(w, inv, before);                                  // 1 / ZZZ_j
-                fp_mul(inv, inv, ZZZ);                                   // 1 / (ZZZ_1 ... ZZZ_(j-1))
+                fp_mul(inv, inv, ZZZ);
             } else {
                 w = inv;
             }
@@ -885,17 +889,17 @@ int combine_t(MsmEngine& E, const uint8_t* partials, size_t count, uint8_t* out,
 constexpr uint32_t TABLE_BUILD_BLOCKS = 256 * 4 * 3;   // 64-lane blocks: three waves on every SIMD
 template <class F>
 size_t table_scratch_bytes_t(int W) {
-    return (size_t)TABLE_BUILD_BLOCKS * 64 * (size_t)(W > 1 ? W - 1 : 1) * TABLE_SCRATCH_ROW<F> * 4;
+    return (size_t)TABLE_BUILD_BLOCKS * 64 * (size_t)(W > 1 ? W : 1) * TABLE_SCRATCH_ROW<F> * 4;
 }
 template <class F>
-int build_table_t(MsmEngine& E, const void* d_raw, void* d_table, uint32_t npts, int c, int W, void* scratch, uint32_t* flag,
-                  hipStream_t st) {
+int build_table_t(MsmEngine& E, const void* d_raw, void* d_table, uint32_t npts, int c, int W, int base_shift, void* scratch,
+                  uint32_t* flag, hipStream_t st) {
     (void)E;
     if (npts == 0) return BLZ_OK;
     uint32_t blocks = (npts + 63) / 64;
     if (blocks > TABLE_BUILD_BLOCKS) blocks = TABLE_BUILD_BLOCKS;
     hipLaunchKernelGGL(k_build_window_table<F>, dim3(blocks), dim3(64), 0, st, (const uint32_t*)d_raw, (uint32_t*)d_table, npts, c, W,
-                       (uint32_t*)scratch, flag);
+                       base_shift, (uint32_t*)scratch, flag);
     BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
     return BLZ_OK;
 }

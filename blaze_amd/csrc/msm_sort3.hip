@@ -865,7 +865,7 @@ static S3TGeom s3t_geometry(const MsmPlan& P, uint32_t npts) {
 }
 
 bool msm_sort3t_ok(const MsmPlan& P) {
-    if (!P.table || P.sbits != 256 || P.c < 16 || P.c > 26 || P.W * P.c < 257) return false;
+    if (!P.table || P.sbits < 1 || P.sbits > 256 || P.c < 16 || P.c > 26 || P.W * P.c < P.sbits + 1) return false;
     if ((uint64_t)P.npts * P.W >= (1ull << 30)) return false;
     const S3TGeom g = s3t_geometry(P, P.npts);
     return g.NB1 <= 256 && g.b2 <= 8 && g.b3 >= 1 && g.b3 <= 10 && g.xs <= 1 && g.b3 > g.xs;

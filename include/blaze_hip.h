@@ -173,6 +173,7 @@ int blz_msm_plan(int curve, uint32_t nof_elements, int is_precompute, uint32_t o
  * Results are bit-identical to the plain path's.  Falls back to the plain path (silently; BLAZE_LOG=1 says why) when
  * the table does not fit the free memory, when a base has even order (a multiple at infinity cannot be tabulated;
  * never the case in the r-torsion), or for a task over a sub-range that wants a different window width.
+ * A handle with a scalar range (blz_msm_set_scalar_range) tabulates 2^(bit_lo + c j) P for the windows of its range.
  * The default of new handles is BLAZE_MSM_TABLE (0).  No other value of `enable` is accepted (InvalidPrimitiveParam). */
 int blz_msm_set_window_table(blz_msm* h, int enable);
 /* out = {table bytes, window bits c, windows W, build time in microseconds} of the table the handle's last HBM task

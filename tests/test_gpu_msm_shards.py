@@ -102,3 +102,39 @@ def test_library_layouts_combine_to_the_full_result(gpu, orc, curve, logn):
             cl.wait_result(); parts.append(cl.result().result); pending -= 1
         assert cl.combine_partials(b"".join(parts), world) == exp, f"{curve} world={world} {lays}"
     cl.close(); dp.free(); ds.free()
+
+
+@pytest.mark.parametrize("curve,logn", [("BLS381", 20), ("BN254", 19)])
+def test_layouts_with_window_tables(gpu, orc, curve, logn):
+    """The same layouts on handles that opted in to the resident-base window table: a ranged handle's table holds
+    2^(lo + c j) P - the range's weight sits in the points, the task runs hi - lo bits' worth of windows into one bucket set
+    and closes without doublings.  Partials combined in rank order = the full MSM; every partial = the plain ranged partial."""
+    from blaze_amd.ingo_msm import PointMemoryType
+    n = (1 << logn) - 333
+    dp, ds = synth(curve, n, seed=41)
+    k = orc.index_weighted_sum(curve, ds.download(), n, 0, threads=8)
+    exp = orc.result_from_affine(curve, orc.generator_mul(curve, k))
+    ps = dp.nbytes // n
+    blaze_amd._lib.check(blaze_amd.lib().blz_arena_release(0))
+    tab = msm_client(curve, 1, PointMemoryType.HBM)
+    tab.set_window_table(2)
+    tab.load_data_to_hbm(dp, 0, 0)
+    plain = msm_client(curve, 1)
+    for world in (2, 4, 8):
+        parts = b""
+        for r in range(world):
+            l = shard_layout(Curve[curve], n, r, world)
+            vs = DeviceBuffer.__new__(DeviceBuffer); vs.device_id = 0; vs.ptr = ds.ptr + l["first"] * 32; vs.nbytes = l["count"] * 32
+            vp = DeviceBuffer.__new__(DeviceBuffer); vp.device_id = 0; vp.ptr = dp.ptr + l["first"] * ps; vp.nbytes = l["count"] * ps
+            tab.set_scalar_range(l["bit_lo"], l["bit_hi"])
+            got = run_msm(tab, None, vs, l["count"], hbm=(0, l["first"] * ps))
+            info = tab.window_table_info()
+            assert info["bytes"] > 0 and info["windows"] * info["window_bits"] >= l["bit_hi"] - l["bit_lo"] + 1, (l, info)
+            assert info["windows"] < 17 or l["bit_hi"] - l["bit_lo"] == 256, (l, info)    # fewer windows than a whole scalar needs
+            plain.set_scalar_range(l["bit_lo"], l["bit_hi"])
+            assert got == run_msm(plain, vp, vs, l["count"]), f"{curve} world={world} rank={r} {l}"
+            vs.ptr = None; vp.ptr = None
+            parts += got
+        assert tab.combine_partials(parts, world) == exp, f"{curve} world={world}"
+    tab.close(); plain.close(); dp.free(); ds.free()
+    blaze_amd._lib.check(blaze_amd.lib().blz_arena_release(0))

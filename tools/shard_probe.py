@@ -31,6 +31,8 @@ check(L.blz_synth_scalars_at(0, cid, ds.ptr, cnt, 0xB1A2E, lay["first"]))
 L.blz_arena_release(0)
 cl = MSMClient(MSMInit(PointMemoryType.HBM, False, Curve[curve]), DriverClient(0))
 cl.set_scalar_range(lay["bit_lo"], lay["bit_hi"])
+if os.environ.get("TABLE"):
+    cl.set_window_table(int(os.environ["TABLE"]))   # window table of the rank's bases and range
 cl.load_data_to_hbm(dp, 0, 0)
 params = MSMParams(cnt, (0, 0))
 
@@ -45,7 +47,7 @@ def collect():
     return r, cl.get_api()
 
 
-submit(); submit(); r0, _ = collect(); collect()
+submit(); tinfo = cl.window_table_info(); submit(); r0, _ = collect(); collect()
 t0 = time.perf_counter()
 pend, out = 0, []
 for _ in range(steps):
@@ -58,4 +60,5 @@ dt = (time.perf_counter() - t0) / steps * 1e3
 assert all(r == r0 for r, _ in out)
 a = out[-1][1]
 print(f"{curve} 2^{logn} rank {rank}/{world} {lay}: {dt:.3f} ms per MSM; windows {int(a['windows'])} x {int(a['window_bits'])} bits, "
-      f"accumulate {a['accumulate_kernel_ms']:.2f}, sort {a['sort_ms']:.2f} (hidden {a['sort_hidden']}), reduce {a['phase2_reduce_ms']:.2f}")
+      f"accumulate {a['accumulate_kernel_ms']:.2f}, sort {a['sort_ms']:.2f} (hidden {a['sort_hidden']}), reduce {a['phase2_reduce_ms']:.2f}"
+      + (f"; table {tinfo['bytes'] / 2**30:.1f} GiB built in {tinfo['build_ms']:.0f} ms" if tinfo["bytes"] else ""))

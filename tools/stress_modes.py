@@ -71,7 +71,7 @@ def collect(cl, key):
 
 for it in range(iters):
     c = rng.choice(curves)
-    kind = rng.choice(("plain", "table", "table", "range", "range", "rewrite"))
+    kind = rng.choice(("plain", "table", "table", "range", "range", "rewrite", "table+range"))
     n = rng.choice([1, 63, 4096, 100001, 1 << 18, (1 << 19) + 5, 1 << 20, NMAX])
     first = 0 if n == NMAX else rng.randrange(0, NMAX - n) & ~3
     dp, ds = dev[c]
@@ -86,8 +86,12 @@ for it in range(iters):
         cl.load_data_to_hbm(View(dp, at * ps[c], m * ps[c]), ARENA[c], at * ps[c])
         continue
     lo, hi = 0, 256
-    if kind == "table":
+    if kind in ("table", "table+range"):
         cl, key = table[c], ("t", c)
+        if kind == "table+range":
+            a, b = sorted(rng.sample(range(0, 9), 2))
+            lo, hi = 32 * a, 32 * b
+        cl.set_scalar_range(lo, hi)
         params = MSMParams(n, (ARENA[c], first * ps[c]))
         inp = MSMInput(None, View(ds, first * 32, n * 32), params)
     else:
