@@ -15,6 +15,14 @@ from oracle import pyref
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port() -> int:
+    """A TCP port nobody listens on right now (rendezvous of the torch.distributed.run children)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
 CURVES = ["BLS377", "BLS381", "BN254"]
 
 
@@ -450,7 +458,7 @@ def test_bench_sharded_path_two_ranks_one_gpu(gpu, shard):
                          capture_output=True, text=True, timeout=600)
     assert one.returncode == 0, one.stderr[-2000:]
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29533" if shard == "auto" else "29534",
+                          "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
                           os.path.join(root, "bench.py"), "--gpus", "2"] + common, env=env, capture_output=True, text=True, timeout=900)
     assert two.returncode == 0, two.stderr[-2000:]
     j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
@@ -479,7 +487,7 @@ def test_bench_native_exchange_next_to_torch_process_group(gpu):
     plain = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, env=env, capture_output=True, text=True, timeout=600)
     assert plain.returncode == 0, plain.stderr[-2000:]
     forced = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
-                             "--master-addr", "127.0.0.1", "--master-port", "29541", os.path.join(root, "bench.py")] + common,
+                             "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py")] + common,
                             env=dict(env, BLAZE_BENCH_FORCE_EXCHANGE="1"), capture_output=True, text=True, timeout=900)
     assert forced.returncode == 0, forced.stderr[-3000:]
     j0 = json.loads([l for l in plain.stdout.splitlines() if l.startswith("{")][-1])

@@ -59,6 +59,8 @@ while pend:
 dt = (time.perf_counter() - t0) / steps * 1e3
 assert all(r == r0 for r, _ in out)
 a = out[-1][1]
+gaps = [x[1]["total_ms"] - x[1]["phase1_accumulate_ms"] - x[1]["phase2_reduce_ms"] - x[1]["phase3_final_ms"] for x in out]
+print(f"main stream waited for the sort (ev0 -> accumulate start), median over the tasks: {sorted(gaps)[len(gaps) // 2]:.3f} ms")
 print(f"{curve} 2^{logn} rank {rank}/{world} {lay}: {dt:.3f} ms per MSM; windows {int(a['windows'])} x {int(a['window_bits'])} bits, "
       f"accumulate {a['accumulate_kernel_ms']:.2f}, sort {a['sort_ms']:.2f} (hidden {a['sort_hidden']}), reduce {a['phase2_reduce_ms']:.2f}"
       + (f"; table {tinfo['bytes'] / 2**30:.1f} GiB built in {tinfo['build_ms']:.0f} ms" if tinfo["bytes"] else ""))
