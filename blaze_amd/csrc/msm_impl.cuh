@@ -525,11 +525,43 @@ __global__ __launch_bounds__(64, BLZ_REDUCE_RR_WAVES) void k_reduce_level0_rr(co
         }
         ptrr_add<Q, 3>(s, run);  // weights i + 1 at the first level
     }
-    XYZZ<F> o;
-    ptrr_to_xyzz32<F>(o, run);
-    store_xyzz(outA, (size_t)w * T + t, o);
-    ptrr_to_xyzz32<F>(o, s);
-    store_xyzz(outC, (size_t)w * T + t, o);
+    ptrr_store(outA, (size_t)w * T + t, run);   // the upper levels and k_finish work in the reduced radix too (ec_quad.cuh)
+    ptrr_store(outC, (size_t)w * T + t, s);
+}
+
+// upper levels on the reduced-radix field: one DPP quad per segment, as k_reduce_level<F, false>, with the quad group law
+// of ec_quad.cuh's second half (the chain of a segment is sequential: the latency of a field product is the cost)
+template <class F>
+__global__ __launch_bounds__(64, 2) void k_reduce_level_rr(const uint32_t* __restrict__ inA, const uint32_t* __restrict__ inC, uint32_t M,
+                                                          uint32_t SEG, uint32_t T, int W, int shift, uint32_t* __restrict__ outA,
+                                                          uint32_t* __restrict__ outC) {
+    using Q = typename F::RR;
+    __builtin_amdgcn_s_setprio(BLZ_TAIL_PRIO);
+    const uint32_t gtid = blockIdx.x * 64u + threadIdx.x;
+    const uint32_t tid = gtid >> 2, ql = gtid & 3u;
+    if (tid >= T * (uint32_t)W) return;
+    const uint32_t w = tid / T, t = tid - w * T;
+    const uint32_t lo = t * SEG;
+    uint32_t hi = lo + SEG;
+    if (hi > M) hi = M;
+    XYZZRR<Q> run, s, cs;
+    ptrr_set_inf(run);
+    ptrr_set_inf(s);
+    ptrr_set_inf(cs);
+    for (uint32_t i = hi; i-- > lo;) {
+        const size_t idx = (size_t)w * M + i;
+        XYZZRR<Q> a, cc;
+        ptrr_load(a, inA, idx);
+        ptrr_load(cc, inC, idx);
+        quadrr_add(cs, cc, ql);
+        quadrr_add(run, a, ql);
+        if (i != lo) quadrr_add(s, run, ql);  // weights i at the upper levels
+    }
+    for (int d = 0; d < shift; ++d) quadrr_dbl(s, ql);
+    quadrr_add(cs, s, ql);
+    if (ql != 0) return;
+    ptrr_store(outA, (size_t)w * T + t, run);
+    ptrr_store(outC, (size_t)w * T + t, cs);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -568,50 +600,80 @@ struct FinishPlan {
 //   S_w = sum_j C_(v0+j) + V * sum_j j * A_(v0+j),
 // so the result is a Horner evaluation over the terms (off_w + log2 V, sum_j j A_j) and (off_w, sum_j C_j)
 // in descending bit offset (off_(w+1) >= off_w + log2 V + 1, so the order is strict).
+// (the body is written once over "a point type with quad operations": the reduced-radix accumulator for the curves that
+// have one, the 32-bit XYZZ otherwise)
 template <class F>
-__global__ __launch_bounds__(64, 3) void k_finish(const uint32_t* __restrict__ vsumA, const uint32_t* __restrict__ vsumC,
+struct FinishOps32 {
+    using Pt = XYZZ<F>;
+    static BLZ_DEV void inf(Pt& p) { pt_set_inf(p); }
+    static BLZ_DEV void load(Pt& p, const uint32_t* base, size_t idx) { load_xyzz(p, base, idx); }
+    static BLZ_DEV void add(Pt& a, const Pt& b, uint32_t ql) { quad_add(a, b, ql); }
+    static BLZ_DEV void dbl(Pt& a, uint32_t ql) { quad_dbl(a, ql); }
+    static BLZ_DEV void to32(XYZZ<F>& o, const Pt& p) { o = p; }
+};
+template <class F>
+struct FinishOpsRR {
+    using Q = typename F::RR;
+    using Pt = XYZZRR<Q>;
+    static BLZ_DEV void inf(Pt& p) { ptrr_set_inf(p); }
+    static BLZ_DEV void load(Pt& p, const uint32_t* base, size_t idx) { ptrr_load(p, base, idx); }
+    static BLZ_DEV void add(Pt& a, const Pt& b, uint32_t ql) { quadrr_add(a, b, ql); }
+    static BLZ_DEV void dbl(Pt& a, uint32_t ql) { quadrr_dbl(a, ql); }
+    static BLZ_DEV void to32(XYZZ<F>& o, const Pt& p) { ptrr_to_xyzz32<F>(o, p); }
+};
+template <class F>
+using FinishOps = std::conditional_t<USE_RR<F>, FinishOpsRR<F>, FinishOps32<F>>;
+
+template <class F>
+__global__ __launch_bounds__(64, USE_RR<F> ? 2 : 3) void k_finish(const uint32_t* __restrict__ vsumA, const uint32_t* __restrict__ vsumC,
                                                   FinishPlan fp, uint32_t* __restrict__ out) {
     // one wave; every DPP quad runs the same chain cooperatively (ec_quad.cuh), lane 0 emits
     if (blockIdx.x != 0) return;
     __builtin_amdgcn_s_setprio(BLZ_TAIL_PRIO);   // (see k_reduce_level)
+    using Ops = FinishOps<F>;
+    using Pt = typename Ops::Pt;
     const uint32_t ql = threadIdx.x & 3u;
-    XYZZ<F> acc;
-    pt_set_inf(acc);
+    Pt acc;
+    Ops::inf(acc);
     int pos = 0;
     bool started = false;
     for (int w = fp.W - 1; w >= 0; --w) {
         const int v0 = fp.v0[w], m = fp.m[w], off = fp.off[w];
         if (m > 1) {
-            XYZZ<F> t, u;
-            pt_set_inf(t);
-            pt_set_inf(u);
+            Pt t, u;
+            Ops::inf(t);
+            Ops::inf(u);
             for (int j = m - 1; j >= 1; --j) {
-                XYZZ<F> a;
-                load_xyzz(a, vsumA, (size_t)(v0 + j));
-                quad_add(t, a, ql);
-                quad_add(u, t, ql);
+                Pt a;
+                Ops::load(a, vsumA, (size_t)(v0 + j));
+                Ops::add(t, a, ql);
+                Ops::add(u, t, ql);
             }
             const int o2 = off + fp.logV;
-            if (started) for (int d = 0; d < pos - o2; ++d) quad_dbl(acc, ql);
-            quad_add(acc, u, ql);
+            if (started) for (int d = 0; d < pos - o2; ++d) Ops::dbl(acc, ql);
+            Ops::add(acc, u, ql);
             pos = o2;
             started = true;
         }
-        XYZZ<F> cs;
-        load_xyzz(cs, vsumC, (size_t)v0);
+        Pt cs;
+        Ops::load(cs, vsumC, (size_t)v0);
         for (int j = 1; j < m; ++j) {
-            XYZZ<F> a;
-            load_xyzz(a, vsumC, (size_t)(v0 + j));
-            quad_add(cs, a, ql);
+            Pt a;
+            Ops::load(a, vsumC, (size_t)(v0 + j));
+            Ops::add(cs, a, ql);
         }
-        if (started) for (int d = 0; d < pos - off; ++d) quad_dbl(acc, ql);
-        quad_add(acc, cs, ql);
+        if (started) for (int d = 0; d < pos - off; ++d) Ops::dbl(acc, ql);
+        Ops::add(acc, cs, ql);
         pos = off;
         started = true;
     }
     // scalar-range tasks: the lowest window starts at bit_lo of the scalar, the partial result carries that weight
-    for (int d = 0; d < pos; ++d) quad_dbl(acc, ql);
-    if (threadIdx.x == 0) emit_result(out, acc);
+    for (int d = 0; d < pos; ++d) Ops::dbl(acc, ql);
+    if (threadIdx.x == 0) {
+        XYZZ<F> o;
+        Ops::to32(o, acc);
+        emit_result(out, o);
+    }
 }
 
 template <class F>
@@ -800,8 +862,8 @@ int run_reduce_t(MsmEngine& E, const void* sums, const void* unit_off_v) {
         uint32_t T = (M + SEG - 1) / SEG;
         DevBuf& oA = S.lvlA[level & 1];
         DevBuf& oC = S.lvlC[level & 1];
-        BLZ_TRY(oA.reserve((size_t)T * P.Wv * 16 * F::N));
-        BLZ_TRY(oC.reserve((size_t)T * P.Wv * 16 * F::N));
+        BLZ_TRY(oA.reserve((size_t)T * P.Wv * 4 * partial_dwords<F>()));   // (reduced-radix accumulators where the curve has them)
+        BLZ_TRY(oC.reserve((size_t)T * P.Wv * 4 * partial_dwords<F>()));
         uint32_t nthreads = T * (uint32_t)P.Wv;
         if (level == 0) {
             if constexpr (USE_RR<F>)
@@ -816,8 +878,12 @@ int run_reduce_t(MsmEngine& E, const void* sums, const void* unit_off_v) {
             st = E.tail_stream;
             BLZ_HIP(hipStreamWaitEvent(st, S.ev_l0, 0), BLZ_ERR_UNKNOWN);
         } else {
-            hipLaunchKernelGGL((k_reduce_level<F, false>), dim3((nthreads * 4 + 63) / 64), dim3(64), 0, st, curA, curC,
-                               unit_off, M, SEG, T, P.Wv, shift, oA.as<uint32_t>(), oC.as<uint32_t>());
+            if constexpr (USE_RR<F>)
+                hipLaunchKernelGGL(k_reduce_level_rr<F>, dim3((nthreads * 4 + 63) / 64), dim3(64), 0, st, curA, curC, M, SEG, T, P.Wv,
+                                   shift, oA.as<uint32_t>(), oC.as<uint32_t>());
+            else
+                hipLaunchKernelGGL((k_reduce_level<F, false>), dim3((nthreads * 4 + 63) / 64), dim3(64), 0, st, curA, curC,
+                                   unit_off, M, SEG, T, P.Wv, shift, oA.as<uint32_t>(), oC.as<uint32_t>());
         }
         curA = oA.as<uint32_t>();
         curC = oC.as<uint32_t>();
