@@ -714,25 +714,31 @@ int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int 
         const char* pt_s = (const char*)d_pts + (size_t)p0 * mont_point_bytes(curve);
         // ---- sort stage, on ss
         BLZ_HIP(hipMemsetAsync(B.stats.p, 0, 64, ss), BLZ_ERR_UNKNOWN);
+        // a small task's whole sort stage - digits, bucket scan, entries, unit lists - is one block's work (msm_sort_tiny.hip)
+        const bool tiny = !use_s3 && nslices == 1 && msm_sort_tiny_ok(P, np, sbits);
         if (use_s3) {
             BLZ_TRY(P.table ? msm_sort3t(E, sc_s, np) : msm_sort3(E, sc_s, np));   // count[] and entries[] in one go
+        } else if (tiny) {
+            BLZ_TRY(msm_sort_tiny(E, sc_s, np, sbits, (uint32_t)max_units));
         } else {
             const size_t n16 = ((G + 1) * 4 + 15) / 16;   // the reserve above rounds the allocation up
             hipLaunchKernelGGL(k_zero, dim3(2048), dim3(256), 0, ss, (uint4*)B.count.p, n16);
             BLZ_TRY(msm_sort_lds(E, sc_s, np, sbits));
         }
-        hipLaunchKernelGGL(k_scan_reduce, dim3(nscan), b256, 0, ss, B.count.as<uint32_t>(), G, P.L, blocksums.as<uint64_t>(),
-                           B.stats.as<uint32_t>());
-        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_SUMS_THREADS), 0, ss, blocksums.as<uint64_t>(), nscan, B.stats.as<uint32_t>());
-        hipLaunchKernelGGL(k_scan_final, dim3(nscan), b256, 0, ss, B.count.as<uint32_t>(), G, P.L, blocksums.as<uint64_t>(),
-                           B.off.as<uint32_t>(), B.unit_off.as<uint32_t>());
-        if (!use_s3) BLZ_TRY(msm_sort_lds_scatter(E));
+        if (!tiny) {
+            hipLaunchKernelGGL(k_scan_reduce, dim3(nscan), b256, 0, ss, B.count.as<uint32_t>(), G, P.L, blocksums.as<uint64_t>(),
+                               B.stats.as<uint32_t>());
+            hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_SUMS_THREADS), 0, ss, blocksums.as<uint64_t>(), nscan, B.stats.as<uint32_t>());
+            hipLaunchKernelGGL(k_scan_final, dim3(nscan), b256, 0, ss, B.count.as<uint32_t>(), G, P.L, blocksums.as<uint64_t>(),
+                               B.off.as<uint32_t>(), B.unit_off.as<uint32_t>());
+            if (!use_s3) BLZ_TRY(msm_sort_lds_scatter(E));
+        }
         BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
         // No host round trip: the unit count stays on the device.  Buffers and grids are sized by the bound
         // (every bucket at most one short unit, plus entries / L full ones) and the kernels read the real count
         // from `stats`; the host copy below is for the log line, the sanity check of finish() and the hot-bucket guard.
         BLZ_HIP(hipMemcpyAsync(S.stats_h, B.stats.p, 16, hipMemcpyDeviceToHost, ss), BLZ_ERR_READ);
-        BLZ_TRY(launch_fill_units(E, (uint32_t)max_units));
+        if (!tiny) BLZ_TRY(launch_fill_units(E, (uint32_t)max_units));
         BLZ_HIP(hipEventRecord(S.ev_sorted, ss), BLZ_ERR_UNKNOWN);
         last_sort_done = S.ev_sorted;
         BLZ_HIP(hipEventRecord(S.ev_s1, ss), BLZ_ERR_UNKNOWN);

@@ -155,6 +155,9 @@ bool msm_sort3t_ok(const MsmPlan& P);
 int msm_sort3t_max_vgprs();
 int msm_sort3t(MsmEngine& E, const void* d_scalars, uint32_t npts);
 int msm_sort_lds_scatter(MsmEngine& E);
+// the whole sort stage of a small task (digits, bucket scan, entries, unit lists, stats) in one block (msm_sort_tiny.hip)
+bool msm_sort_tiny_ok(const MsmPlan& P, uint32_t npts, int sbits);
+int msm_sort_tiny(MsmEngine& E, const void* d_scalars, uint32_t npts, int sbits, uint32_t max_units);
 int launch_fill_units(MsmEngine& E, uint32_t units);  // unit->bucket map + length-ordered unit list
 
 // per-curve entry points (one translation unit per curve: msm_<curve>.hip)
