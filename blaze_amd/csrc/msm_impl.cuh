@@ -759,6 +759,37 @@ int emit_infinity_t(MsmEngine& E) {
     return BLZ_OK;
 }
 
+// The same fold for SMALL tasks, where a lane's chain of additions is the latency of the whole pipeline: the top window of a
+// 2^13-element plan holds 5 real bits, so its 32 buckets get 256 entries = 16 - 32 units each, and one lane folding 31 units at
+// ~14 us per addition kept everything waiting for 0.44 ms of a 3.6 ms MSM.  Here one wave takes a bucket: lane i loads unit i,
+// six rounds of pairwise additions (operands moved between lanes with ds_bpermute: 56 dwords per round, nothing against an
+// addition) leave the sum in lane 0 after log2(units) additions' worth of time.  One block per bucket - for small bucket
+// spaces only.
+template <class F>
+__global__ __launch_bounds__(64, 2) void k_combine_buckets_wave(const uint32_t* __restrict__ unit_off, uint32_t thr,
+                                                               uint32_t* __restrict__ partial) {
+    using Q = typename F::RR;
+    const uint64_t g = blockIdx.x;
+    const uint32_t u0 = unit_off[g], U = unit_off[g + 1] - u0;
+    if (U < 2 || U > thr) return;   // (uniform over the wave)
+    const uint32_t lane = threadIdx.x;
+    XYZZRR<Q> acc;
+    if (lane < U) ptrr_load(acc, partial, u0 + lane);
+    else ptrr_set_inf(acc);
+    for (uint32_t r = 1; r < U && r < 64; r <<= 1) {
+        XYZZRR<Q> o;
+#pragma unroll
+        for (int i = 0; i < Q::NL; ++i) {
+            o.x.v[i] = __shfl_down(acc.x.v[i], r, 64);
+            o.y.v[i] = __shfl_down(acc.y.v[i], r, 64);
+            o.zz.v[i] = __shfl_down(acc.zz.v[i], r, 64);
+            o.zzz.v[i] = __shfl_down(acc.zzz.v[i], r, 64);
+        }
+        if ((lane & (2u * r - 1u)) == 0 && lane + r < U) ptrr_add<Q, 6>(acc, o);
+    }
+    if (lane == 0) ptrr_store(partial, u0, acc);
+}
+
 // bucket_sums[g] += sum of bucket g in this slice (slice-major tasks, msm.hip run()).  After k_combine_units the sum of
 // a bucket's run sits in its first unit; an empty run leaves the bucket alone.
 template <class F>
@@ -813,9 +844,18 @@ int run_accumulate_t(MsmEngine& E, const void* d_pts, uint32_t U, int slice) {
         hipLaunchKernelGGL(k_combine_units<F>, dim3((uint32_t)((full_bound / 16 + 1) * 4 / 128 + 1)), dim3(128), 0, st,
                            E.sb().unit_off.as<uint32_t>(), E.sb().unit_bucket.as<uint32_t>(), E.sb().unit_order.as<uint32_t>(),
                            E.sb().lenhist.as<uint32_t>() + P.L, E.sb().stats.as<uint32_t>(), P.L, (uint32_t)stride, thr, E.partial.as<uint32_t>());
-    if (thr)
-        hipLaunchKernelGGL(k_combine_buckets<F>, dim3((uint32_t)((P.G + 127) / 128)), dim3(128), 0, st, E.sb().unit_off.as<uint32_t>(),
-                           (uint64_t)P.G, thr, E.partial.as<uint32_t>());
+    if (thr) {
+        bool wave = false;
+        if constexpr (USE_RR<F>) wave = P.G <= 32768;   // small bucket spaces: one wave per bucket (latency), else one lane (throughput)
+        if (wave) {
+            if constexpr (USE_RR<F>)
+                hipLaunchKernelGGL(k_combine_buckets_wave<F>, dim3((uint32_t)P.G), dim3(64), 0, st, E.sb().unit_off.as<uint32_t>(), thr,
+                                   E.partial.as<uint32_t>());
+        } else {
+            hipLaunchKernelGGL(k_combine_buckets<F>, dim3((uint32_t)((P.G + 127) / 128)), dim3(128), 0, st, E.sb().unit_off.as<uint32_t>(),
+                               (uint64_t)P.G, thr, E.partial.as<uint32_t>());
+        }
+    }
     BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
     return BLZ_OK;
 }
