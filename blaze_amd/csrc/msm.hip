@@ -104,6 +104,7 @@ MsmPlan make_plan(uint32_t npts, int sbits, int ebits, int force_c) {
                     best.boff[W] = b;
                     best.Wv = (int)(G >> (cmin - 1));
                     best.cost = cost;
+                    best.ebits = ebits;
                 }
             }
         }

@@ -26,6 +26,7 @@ struct MsmPlan {
     // every window's digit d of base i is an addition of +-table[i W + j] into bucket |d| - 1 of ONE bucket set shared
     // by all windows: boff[w] = 0 for every window, G = 2^(c-1), entries carry i W + j.  The reduce sees a single window.
     bool table = false;
+    int ebits = 0;       // significant bits the planner assumed for the scalars (bit length of r, or of the range / chunk)
     int base_bit = 0;    // scalar-range tasks (run() bit_lo): the windows start at this bit of the scalar; the result carries 2^base_bit
     double cost = 0;     // the planner's estimate for this plan (ns; host-side comparisons only)
 };

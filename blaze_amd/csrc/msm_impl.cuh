@@ -357,7 +357,7 @@ __global__ __launch_bounds__(128, 3) void k_combine_units(const uint32_t* __rest
                                                        const uint32_t* __restrict__ unit_order,
                                                        const uint32_t* __restrict__ nfull_ptr,
                                                        const uint32_t* __restrict__ stats, uint32_t L,
-                                                       uint32_t stride, uint32_t thr, uint32_t* __restrict__ partial) {
+                                                       uint32_t stride, uint32_t thr, uint32_t hot_start, uint32_t* __restrict__ partial) {
     // the host launches one pass per power of 16 up to the LARGEST possible bucket; the passes beyond this
     // task's longest bucket (stats[1] entries) have nothing to fold.  thr > 0: buckets of up to thr units are
     // k_combine_buckets' (below); this tree only folds the hot ones - none at all in most tasks
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(128, 3) void k_combine_units(const uint32_t* __rest
         uint32_t u = unit_order[t0];
         uint32_t g = unit_bucket[u];
         uint32_t u0 = unit_off[g], u1 = unit_off[g + 1];
-        if (u1 - u0 > stride && u1 - u0 > thr && (u - u0) % (16u * stride) == 0) leaders |= 1u << i;
+        if (g < hot_start && u1 - u0 > stride && u1 - u0 > thr && (u - u0) % (16u * stride) == 0) leaders |= 1u << i;   // (hot_start..: k_fold_hot's)
     }
     while (leaders) {
         const uint32_t i = (uint32_t)__builtin_ctz(leaders);
@@ -409,7 +409,7 @@ template <class F>
 __global__ __launch_bounds__(128, 3) void k_combine_buckets(const uint32_t* __restrict__ unit_off, uint64_t G, uint32_t thr,
                                                           uint32_t* __restrict__ partial) {
     const uint64_t g = (uint64_t)blockIdx.x * 128u + threadIdx.x;
-    if (g >= G) return;
+    if (g >= G) return;   // (the host passes G = hot_start when k_fold_hot takes the buckets above)
     const uint32_t u0 = unit_off[g], u1 = unit_off[g + 1];
     if (u1 - u0 < 2 || u1 - u0 > thr) return;
     if constexpr (USE_RR<F>) {
@@ -790,6 +790,60 @@ __global__ __launch_bounds__(64, 2) void k_combine_buckets_wave(const uint32_t* 
     if (lane == 0) ptrr_store(partial, u0, acc);
 }
 
+// ... and for the windows the PLAN knows to be hot - the top windows of a small or mid-sized task hold the last few bits of
+// the scalars: 2^18 elements in 20 windows of 13 bits leave 8 bits for the top one, 256 buckets of 1024 entries = 64 units
+// each; 2^16 in 22 x 12: 3 bits, 8 buckets of 512 units - eight waves take a bucket: every wave folds chunks of 64 units by
+// the shuffle tree, lane 0 adds the chunk sums up, the eight wave sums meet in LDS.  A lone 2^18 MSM spent 1.7 of its 5.8 ms
+// in the lane-per-bucket fold (63 additions in sequence) and the quad tree's passes; this takes 0.15.
+template <class F>
+__global__ __launch_bounds__(512, 1) void k_fold_hot(const uint32_t* __restrict__ unit_off, uint32_t hot_start, uint32_t* __restrict__ partial) {
+    using Q = typename F::RR;
+    constexpr int S = ptrr_dwords<Q>();
+    __shared__ uint32_t sh[8 * S];
+    const uint64_t g = (uint64_t)hot_start + blockIdx.x;
+    const uint32_t u0 = unit_off[g], U = unit_off[g + 1] - u0;
+    if (U < 2) return;   // (uniform over the block)
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    XYZZRR<Q> tot;
+    ptrr_set_inf(tot);
+    for (uint32_t base = wave * 64u; base < U; base += 8u * 64u) {
+        const uint32_t cnt = U - base < 64u ? U - base : 64u;
+        XYZZRR<Q> acc;
+        if (lane < cnt) ptrr_load(acc, partial, u0 + base + lane);
+        else ptrr_set_inf(acc);
+        for (uint32_t r = 1; r < cnt; r <<= 1) {
+            XYZZRR<Q> o;
+#pragma unroll
+            for (int i = 0; i < Q::NL; ++i) {
+                o.x.v[i] = __shfl_down(acc.x.v[i], r, 64);
+                o.y.v[i] = __shfl_down(acc.y.v[i], r, 64);
+                o.zz.v[i] = __shfl_down(acc.zz.v[i], r, 64);
+                o.zzz.v[i] = __shfl_down(acc.zzz.v[i], r, 64);
+            }
+            if ((lane & (2u * r - 1u)) == 0 && lane + r < cnt) ptrr_add<Q, 7>(acc, o);
+        }
+        if (lane == 0) ptrr_add<Q, 7>(tot, acc);
+    }
+    if (lane == 0) ptrr_store(sh, wave, tot);
+    __syncthreads();
+    if (wave != 0) return;
+    XYZZRR<Q> acc;
+    if (lane < 8) ptrr_load(acc, sh, lane);
+    else ptrr_set_inf(acc);
+    for (uint32_t r = 1; r < 8; r <<= 1) {
+        XYZZRR<Q> o;
+#pragma unroll
+        for (int i = 0; i < Q::NL; ++i) {
+            o.x.v[i] = __shfl_down(acc.x.v[i], r, 64);
+            o.y.v[i] = __shfl_down(acc.y.v[i], r, 64);
+            o.zz.v[i] = __shfl_down(acc.zz.v[i], r, 64);
+            o.zzz.v[i] = __shfl_down(acc.zzz.v[i], r, 64);
+        }
+        if ((lane & (2u * r - 1u)) == 0 && lane + r < 8) ptrr_add<Q, 7>(acc, o);
+    }
+    if (lane == 0) ptrr_store(partial, u0, acc);
+}
+
 // bucket_sums[g] += sum of bucket g in this slice (slice-major tasks, msm.hip run()).  After k_combine_units the sum of
 // a bucket's run sits in its first unit; an empty run leaves the bucket alone.
 template <class F>
@@ -838,22 +892,55 @@ int run_accumulate_t(MsmEngine& E, const void* d_pts, uint32_t U, int slice) {
     // where the plan itself says that buckets hold several units each (mean run > L / 2), the lane-per-bucket fold takes
     // every bucket of up to 64 units and the tree only the hot ones beyond
     const uint32_t thr = ((uint64_t)P.npts * P.W / (P.G ? P.G : 1) > P.L / 2) ? 64u : 0u;
+    // The windows the plan knows to be hot (the top ones, where the scalars' bits run out: a few buckets with long runs):
+    // a suffix [hot_start, G) of the bucket space goes to k_fold_hot - eight waves per bucket - and the two folds below
+    // leave it alone.  Only for a small suffix of a larger space: where EVERY window is like that (the precompute shapes) the
+    // lane-per-bucket fold below is the throughput-bound answer.
+    uint32_t hot_start = (uint32_t)P.G;
+    if constexpr (USE_RR<F>) {
+        if (!P.table && slice < 0 && P.ebits > 0 && msm_env_int("BLAZE_FOLD_HOT", 1) != 0) {
+            int lowest = -1, off = 0;
+            bool any = false;
+            int offs[MSM_MAX_W];
+            for (int w = 0; w < P.W; ++w) { offs[w] = off; off += P.width[w]; }
+            for (int w = P.W - 1; w >= 0; --w) {
+                const int cw = P.width[w];
+                int t = P.ebits - offs[w];
+                if (t > cw) t = cw;
+                const double slots = (double)(1ull << (cw - 1));
+                double active = t >= cw ? slots : t > 0 ? (double)(1ull << t) + 1.0 : t == 0 ? 1.0 : 0.0;
+                if (active > slots) active = slots;
+                const double entries = t >= 0 ? (double)P.npts : 0.0;
+                const bool hot = active > 0 && entries / active >= 12.0 * (double)P.L;   // a dozen units or more per bucket
+                if (!hot && entries > 0) break;       // a normal window: the suffix ends above it
+                lowest = w;
+                any = any || hot;
+            }
+            if (any && lowest > 0 && P.G - P.boff[lowest] <= 16384) hot_start = P.boff[lowest];
+        }
+    }
     // (64-bit stride: with BLAZE_MSM_L < 8 and close to 2^31 points, maxunits exceeds 2^28 and a u32 stride would
     // wrap to 0 - an endless launch loop)
     for (uint64_t stride = 1; stride < maxunits; stride *= 16)
         hipLaunchKernelGGL(k_combine_units<F>, dim3((uint32_t)((full_bound / 16 + 1) * 4 / 128 + 1)), dim3(128), 0, st,
                            E.sb().unit_off.as<uint32_t>(), E.sb().unit_bucket.as<uint32_t>(), E.sb().unit_order.as<uint32_t>(),
-                           E.sb().lenhist.as<uint32_t>() + P.L, E.sb().stats.as<uint32_t>(), P.L, (uint32_t)stride, thr, E.partial.as<uint32_t>());
-    if (thr) {
+                           E.sb().lenhist.as<uint32_t>() + P.L, E.sb().stats.as<uint32_t>(), P.L, (uint32_t)stride, thr, hot_start,
+                           E.partial.as<uint32_t>());
+    if constexpr (USE_RR<F>) {
+        if (hot_start < P.G)
+            hipLaunchKernelGGL(k_fold_hot<F>, dim3((uint32_t)(P.G - hot_start)), dim3(512), 0, st, E.sb().unit_off.as<uint32_t>(), hot_start,
+                               E.partial.as<uint32_t>());
+    }
+    if (thr && hot_start > 0) {
         bool wave = false;
-        if constexpr (USE_RR<F>) wave = P.G <= 32768;   // small bucket spaces: one wave per bucket (latency), else one lane (throughput)
+        if constexpr (USE_RR<F>) wave = hot_start <= 32768;   // small bucket spaces: one wave per bucket (latency), else one lane (throughput)
         if (wave) {
             if constexpr (USE_RR<F>)
-                hipLaunchKernelGGL(k_combine_buckets_wave<F>, dim3((uint32_t)P.G), dim3(64), 0, st, E.sb().unit_off.as<uint32_t>(), thr,
+                hipLaunchKernelGGL(k_combine_buckets_wave<F>, dim3(hot_start), dim3(64), 0, st, E.sb().unit_off.as<uint32_t>(), thr,
                                    E.partial.as<uint32_t>());
         } else {
-            hipLaunchKernelGGL(k_combine_buckets<F>, dim3((uint32_t)((P.G + 127) / 128)), dim3(128), 0, st, E.sb().unit_off.as<uint32_t>(),
-                               (uint64_t)P.G, thr, E.partial.as<uint32_t>());
+            hipLaunchKernelGGL(k_combine_buckets<F>, dim3((hot_start + 127) / 128), dim3(128), 0, st, E.sb().unit_off.as<uint32_t>(),
+                               (uint64_t)hot_start, thr, E.partial.as<uint32_t>());
         }
     }
     BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
