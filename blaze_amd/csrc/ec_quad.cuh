@@ -156,7 +156,7 @@ BLZ_DEV Frr<Q, 1, 2> rrq_diff(const Frr<Q, 1, 2>& t, const Frr<Q, 1, 2>& u) { re
 
 // p = 2p
 template <class Q>
-__device__ __noinline__ void quadrr_dbl(XYZZRR<Q>& p, uint32_t l) {
+BLZ_DEV void quadrr_dbl(XYZZRR<Q>& p, uint32_t l) {
     if (ptrr_is_inf(p)) return;
     Frr<Q, 1, 2> r, V, A, W, S, ZZ3, MM, t, WY, ZZZ3;
     const auto U = rr_tn(rr_add(p.y, p.y));
@@ -197,7 +197,7 @@ __device__ __noinline__ void quadrr_dbl(XYZZRR<Q>& p, uint32_t l) {
 
 // acc += q
 template <class Q>
-__device__ __noinline__ void quadrr_add(XYZZRR<Q>& acc, const XYZZRR<Q>& q, uint32_t l) {
+BLZ_DEV void quadrr_add(XYZZRR<Q>& acc, const XYZZRR<Q>& q, uint32_t l) {
     if (ptrr_is_inf(q)) return;
     if (ptrr_is_inf(acc)) { acc = q; return; }
     Frr<Q, 1, 2> r, U1, U2, S1, S2, PP, RRv, Z12, Z123, PPP, Qv, ZZ3, t, SP, ZZZ3;
