@@ -18,7 +18,7 @@ namespace blz {
 
 constexpr int TINY_THREADS = 1024;
 constexpr uint32_t TINY_MAX_G = 24576;        // 96 KiB of LDS for the histogram / cursor
-constexpr uint32_t TINY_MAX_PTS = 1u << 16;   // scalars (pf = 8: 32-bit chunks) one block walks twice
+constexpr uint32_t TINY_MAX_PTS = 20480;      // scalars (pf = 8: 32-bit chunks) one block walks twice: 0.25 ms at 2^13, 0.46 at 2^14, 0.87 at 2^15 - where the big path (0.6 ms flat) is the faster one again
 constexpr uint32_t TINY_MAX_L = 1024;
 
 struct TinyGeom {
