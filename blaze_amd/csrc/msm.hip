@@ -545,7 +545,7 @@ int MsmEngine::sync_all() {
     BLZ_TRY(sync_stream_bounded(tail_stream, "reset: tail stream"));
     BLZ_TRY(sync_stream_bounded(aux_stream, "reset: exchange stream"));
     BLZ_TRY(sync_stream_bounded(sort_stream, "reset: sort stream"));
-    for (auto& S : slots) { S.busy = false; S.awaiting_points = false; S.pending_inputs_event = nullptr; }
+    for (auto& S : slots) { S.busy = false; S.open = false; S.task_inputs_event = nullptr; }
     return BLZ_OK;
 }
 
@@ -578,34 +578,26 @@ MsmPlan MsmEngine::plan_for_range(uint32_t npts, int bit_lo, int bit_hi) const {
     return P;
 }
 
-int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int sbits, int* slot_out, int table_c, int bit_lo,
-                   int bit_hi) {
+// A task is enqueued in four steps - begin(), then per piece sort_slice() and accumulate_slice(), then end() - so that a
+// caller whose inputs arrive over time (msm_capi.hip: host buffers crossing the PCIe link piece by piece, the reference's
+// own flow: msm_api.rs:175-202 streams interleaved chunks of scalars and points into the card while it computes) can hand
+// each piece to the device when it has landed.  run() is the four steps back to back for inputs that are all there.
+//
+// A task of ONE piece is the classic pipeline: sort stage (hidden underneath the other slot's accumulation when there is
+// one), k_accumulate into per-unit sums, unit folds, bucket reduce over sums[unit_off[g]].  A task of SEVERAL pieces sorts
+// and accumulates piece by piece over the same bucket space: the bucket sums live in `bucket_sums`, indexed by bucket;
+// k_accumulate_cont resumes a bucket's sum where the previous piece left it (msm_impl.cuh), runs longer than L go through the
+// unit folds and k_merge_buckets, and the reduce reads bucket_sums through the identity map.
+int MsmEngine::begin(uint32_t npts, int sbits, int* slot_out, int table_c, int bit_lo, int bit_hi, int nslices, bool phased) {
     BLZ_TRY(use_device(device));
     const MsmCurveOps* ops = ops_for(curve, repr);
-    MsmEngine& E = *this;
     hipStream_t st = stream;
+    if (npts == 0) return fail(BLZ_ERR_INVALID_PARAM, "begin: empty task");
     // slots are handed out round-robin, so results complete in submission order
     int slot = (cur + 1) % MSM_QUEUE_DEPTH;
     if (slots[slot].busy) slot = (slot + 1) % MSM_QUEUE_DEPTH;
     if (slots[slot].busy) return fail(BLZ_ERR_INVALID_PARAM, "task queue full (%d tasks in flight)", MSM_QUEUE_DEPTH);
-    cur = slot;
     MsmSlot& S = slots[slot];
-    if (slot_out) *slot_out = slot;
-    const bool defer = defer_points && npts > 0;
-    defer_points = false;
-    S.awaiting_points = false;
-    S.pending_inputs_event = nullptr;
-    BLZ_HIP(hipEventRecord(S.ev[0], st), BLZ_ERR_UNKNOWN);
-    if (npts == 0) {
-        BLZ_TRY(ops->emit_infinity(E));
-        for (int i = 1; i <= 4; ++i) BLZ_HIP(hipEventRecord(S.ev[i], st), BLZ_ERR_UNKNOWN);
-        BLZ_HIP(hipMemcpyAsync(S.result_h, slot_result(slot), 3 * fq_bytes(curve), hipMemcpyDeviceToHost, st), BLZ_ERR_READ);
-        BLZ_HIP(hipEventRecord(S.ev_done, st), BLZ_ERR_UNKNOWN);
-        last_plan = S.plan = MsmPlan();
-        S.accum_timed = false;
-        S.busy = true;
-        return BLZ_OK;
-    }
     const int ebits = sbits == 256 ? kScalarFieldBits[curve] : sbits;
     const bool ranged = bit_hi > bit_lo && !(bit_lo == 0 && bit_hi >= sbits);
     if (ranged && (sbits != 256 || (bit_lo & 31) || (bit_hi & 31) || bit_hi > 256))
@@ -619,41 +611,24 @@ int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int 
     P.L = (uint32_t)msm_env_int("BLAZE_MSM_L", (int)P.L);
     if (P.L < 1) P.L = 1;
     if (P.L > (uint32_t)MAX_L) P.L = MAX_L;
-    last_plan = S.plan = P;
     const uint64_t G = P.G;
-    BLZ_LOG(2, "msm plan: npts=%u sbits=%d c=%d W=%d Bw=%u G=%llu L=%u", npts, sbits, P.c, P.W, P.Bw,
-            (unsigned long long)G, P.L);
-
-    // Slice-major accumulation (BLAZE_MSM_SLICES = n; off by default).  Built to test VERDICT r02's proposal for point
-    // tables beyond the reach of the address-translation caches: the table is cut into n slices, sort + accumulation run
-    // slice by slice (every gather of a launch inside one slice), a bucket's sums are added up across slices
-    // (k_merge_buckets) and the reduce sees one sum per bucket.  Measured on config 3 (2^26 BN254 elements x 8 bases =
-    // 32 GiB, profiles/r03_bn254_slices.txt): the accumulation kernels do get faster (85 -> 75 ms with 16 slices of
-    // 2 GiB on the reduced radix) but the per-slice sorts, the short units the slices need and their combine passes
-    // cost more than that; the best total (8 slices, L = 128: 98.5 ms) stays behind the plain 32-bit-limb path (95.3 ms).
-    int nslices = 1;
-    {
-        const uint64_t table = (uint64_t)npts * mont_point_bytes(curve);
-        const int forced = msm_env_int("BLAZE_MSM_SLICES", 0);
-        if (forced > 0 && !P.table && !defer) nslices = forced;
-        (void)table;
-        if (nslices > MSM_MAX_SLICES) nslices = MSM_MAX_SLICES;
-        if ((uint64_t)nslices > npts) nslices = 1;
-    }
-    S.slices = nslices;
-    const uint32_t pts_per_slice = (uint32_t)(((uint64_t)npts + nslices - 1) / nslices + 15) & ~15u;   // keeps scalar slices 16-byte aligned
-    const uint64_t max_entries = (uint64_t)(nslices > 1 ? pts_per_slice : npts) * P.W;
+    BLZ_LOG(2, "msm plan: npts=%u sbits=%d c=%d W=%d Bw=%u G=%llu L=%u pieces=%d", npts, sbits, P.c, P.W, P.Bw,
+            (unsigned long long)G, P.L, nslices);
+    if (nslices < 1 || P.table) nslices = 1;
+    if (nslices > MSM_MAX_SLICES) nslices = MSM_MAX_SLICES;
+    // pieces of whole 16-point groups (keeps every piece's scalars 16-byte aligned; pf = 8: whole elements)
+    uint32_t per = (uint32_t)((((uint64_t)npts + nslices - 1) / nslices + 15) & ~(uint64_t)15);
+    if (nslices > 1) nslices = (int)(((uint64_t)npts + per - 1) / per);
+    const uint64_t max_entries = (uint64_t)(nslices > 1 ? per : npts) * P.W;
     const uint64_t max_units = G + max_entries / P.L + 1;
     if (max_units >= (1ull << 32)) return fail(BLZ_ERR_INVALID_PARAM, "unit bound %llu exceeds 32 bits", (unsigned long long)max_units);
-    const uint32_t nscan = (uint32_t)((G + 1 + SCAN_TILE - 1) / SCAN_TILE);
 
-    // The sort stage (digit sort, bucket / unit scans, unit lists) of this task.  When the handle's other task is still
-    // in flight - its accumulation is running or about to - the stage goes to sort_stream with the small-footprint
+    // The sort stage (digit sort, bucket / unit scans, unit lists) of a one-piece task.  When the handle's other task is
+    // still in flight - its accumulation is running or about to - the stage goes to sort_stream with the small-footprint
     // three-level sort (msm_sort3.hip) and runs UNDERNEATH that accumulation; the accumulation of this task then starts
     // with its sort already done.  Its outputs are per slot (SortBufs); the scratch the sorts share is protected by
     // chaining every sort stage behind the one before (last_sort_done).  BLAZE_SORT_HIDE: 0 never, 1 when the other slot
     // is busy (default), 2 the three-level sort always (on the main stream when there is nothing to hide under: tests).
-    SortBufs& B = sb();
     const int hide_env = msm_env_int("BLAZE_SORT_HIDE", 1);
     const MsmSlot& O = slots[(slot + 1) % MSM_QUEUE_DEPTH];
     bool s3 = P.table || (hide_env != 0 && nslices == 1 && msm_sort3_ok(P, sbits));   // (a table task has no other sort)
@@ -676,139 +651,210 @@ int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int 
         if (!fits && !P.table) s3 = false;
     }
     const bool hide = s3 && O.busy && hide_env != 0 && fits;
-    const bool use_s3 = s3 && (hide || hide_env == 2 || P.table);
+
+    cur = slot;
+    if (slot_out) *slot_out = slot;
+    last_plan = S.plan = P;
+    S.npts = npts;
+    S.sbits = sbits;
+    S.ranged = ranged;
+    S.bit_lo = bit_lo;
+    S.bit_hi = bit_hi;
+    S.slices = nslices;
+    S.pts_per_slice = nslices > 1 ? per : npts;
+    S.max_units = max_units;
+    S.use_s3 = s3 && (hide || hide_env == 2 || P.table);
     S.sort_hidden = hide;
-    sort_st = hide ? sort_stream : st;
-    hipStream_t ss = sort_st;
-    if (last_sort_done) BLZ_HIP(hipStreamWaitEvent(ss, last_sort_done, 0), BLZ_ERR_UNKNOWN);
-    if (hide) {
-        // this slot's previous task must have let go of its sort outputs (its level-0 reduce read unit_off last)
-        if (S.l0_recorded) BLZ_HIP(hipStreamWaitEvent(ss, S.ev_l0, 0), BLZ_ERR_UNKNOWN);
-    }
-    BLZ_HIP(hipEventRecord(S.ev_s0, ss), BLZ_ERR_UNKNOWN);   // ev_s0 .. ev_s1: the sort stage, whichever stream it is on
-    BLZ_TRY(B.count.reserve((G + 1) * 4 + 16));
-    BLZ_TRY(B.off.reserve((G + 2) * 4));
-    BLZ_TRY(B.unit_off.reserve((G + 2) * 4));
-    BLZ_TRY(blocksums.reserve((size_t)nscan * 8));
-    BLZ_TRY(B.entries.reserve(max_entries * 4));
-    dim3 b256(256);
+    S.phased = phased;
+    S.task_inputs_event = inputs_event;
+    S.accum_timed = false;
+    BLZ_HIP(hipEventRecord(S.ev[0], st), BLZ_ERR_UNKNOWN);
+    BLZ_TRY(sbuf[slot].count.reserve((G + 1) * 4 + 16));
+    BLZ_TRY(sbuf[slot].off.reserve((G + 2) * 4));
+    BLZ_TRY(sbuf[slot].unit_off.reserve((G + 2) * 4));
+    BLZ_TRY(blocksums.reserve((size_t)((G + 1 + SCAN_TILE - 1) / SCAN_TILE) * 8));
+    BLZ_TRY(sbuf[slot].entries.reserve(max_entries * 4));
     if (nslices > 1) {
         const size_t sum_bytes = (size_t)ops->partial_dwords * 4;
         BLZ_TRY(bucket_sums.reserve((G + 1) * sum_bytes));
         BLZ_TRY(bucket_ident.reserve((G + 2) * 4));
         hipLaunchKernelGGL(k_zero, dim3(2048), dim3(256), 0, st, (uint4*)bucket_sums.p, ((G + 1) * sum_bytes + 15) / 16);   // all-zero = infinity
-    }
-    S.max_units = max_units;
-    for (int sl = 0; sl < nslices; ++sl) {
-        const uint32_t p0 = nslices > 1 ? (uint32_t)sl * pts_per_slice : 0u;
-        if (p0 >= npts) { S.slices = sl; break; }
-        const uint32_t np = nslices > 1 ? (npts - p0 < pts_per_slice ? npts - p0 : pts_per_slice) : npts;
-        const char* sc_s = (const char*)d_scalars + (size_t)p0 * (sbits / 8);
-        if (ranged) {
-            // the range of every scalar as a scalar of its own (zero-extended): everything downstream reads 32-byte scalars and
-            // walks the plan's windows from bit 0; k_finish puts the 2^bit_lo back (FinishPlan offsets)
-            BLZ_TRY(B.range_scalars.reserve((size_t)np * 32 + 16));
-            hipLaunchKernelGGL(k_extract_range, dim3(2048), dim3(256), 0, ss, (const uint32_t*)sc_s, B.range_scalars.as<uint32_t>(),
-                               (uint64_t)np, (uint32_t)(bit_lo >> 5), (uint32_t)((bit_hi - bit_lo) >> 5));
-            sc_s = (const char*)B.range_scalars.p;
-        }
-        const char* pt_s = (const char*)d_pts + (size_t)p0 * mont_point_bytes(curve);
-        // ---- sort stage, on ss
-        BLZ_HIP(hipMemsetAsync(B.stats.p, 0, 64, ss), BLZ_ERR_UNKNOWN);
-        // a small task's whole sort stage - digits, bucket scan, entries, unit lists - is one block's work (msm_sort_tiny.hip)
-        const bool tiny = !use_s3 && nslices == 1 && msm_sort_tiny_ok(P, np, sbits);
-        if (use_s3) {
-            BLZ_TRY(P.table ? msm_sort3t(E, sc_s, np) : msm_sort3(E, sc_s, np));   // count[] and entries[] in one go
-        } else if (tiny) {
-            BLZ_TRY(msm_sort_tiny(E, sc_s, np, sbits, (uint32_t)max_units));
-        } else {
-            const size_t n16 = ((G + 1) * 4 + 15) / 16;   // the reserve above rounds the allocation up
-            hipLaunchKernelGGL(k_zero, dim3(2048), dim3(256), 0, ss, (uint4*)B.count.p, n16);
-            BLZ_TRY(msm_sort_lds(E, sc_s, np, sbits));
-        }
-        if (!tiny) {
-            hipLaunchKernelGGL(k_scan_reduce, dim3(nscan), b256, 0, ss, B.count.as<uint32_t>(), G, P.L, blocksums.as<uint64_t>(),
-                               B.stats.as<uint32_t>());
-            hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_SUMS_THREADS), 0, ss, blocksums.as<uint64_t>(), nscan, B.stats.as<uint32_t>());
-            hipLaunchKernelGGL(k_scan_final, dim3(nscan), b256, 0, ss, B.count.as<uint32_t>(), G, P.L, blocksums.as<uint64_t>(),
-                               B.off.as<uint32_t>(), B.unit_off.as<uint32_t>());
-            if (!use_s3) BLZ_TRY(msm_sort_lds_scatter(E));
-        }
         BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
-        // No host round trip: the unit count stays on the device.  Buffers and grids are sized by the bound
-        // (every bucket at most one short unit, plus entries / L full ones) and the kernels read the real count
-        // from `stats`; the host copy below is for the log line, the sanity check of finish() and the hot-bucket guard.
-        BLZ_HIP(hipMemcpyAsync(S.stats_h, B.stats.p, 16, hipMemcpyDeviceToHost, ss), BLZ_ERR_READ);
-        if (!tiny) BLZ_TRY(launch_fill_units(E, (uint32_t)max_units));
-        BLZ_HIP(hipEventRecord(S.ev_sorted, ss), BLZ_ERR_UNKNOWN);
-        last_sort_done = S.ev_sorted;
-        BLZ_HIP(hipEventRecord(S.ev_s1, ss), BLZ_ERR_UNKNOWN);
-        if (hide) BLZ_HIP(hipStreamWaitEvent(st, S.ev_sorted, 0), BLZ_ERR_UNKNOWN);
-        if (defer) {
-            // the rest needs the points: run_points() - it also records inputs_event, on the main stream, where by then
-            // both readers of the staged inputs have passed (this sort: the main stream has waited for it or run it; the
-            // to-Montgomery pass: enqueued there by the caller in between)
-            S.pending_inputs_event = inputs_event;
-            S.awaiting_points = true;
-            S.busy = true;
-            return BLZ_OK;
-        }
-        // The staged inputs have been consumed once the LAST sort has read the scalars - and, in DMA mode, once the
-        // to-Montgomery pass, which msm_capi.hip enqueued on the MAIN stream ahead of this run(), has read the raw points
-        // (ev[0] sits behind it): only then may a later task's host -> device copies overwrite this staging set
-        // (msm_capi.hip's copy stream waits for the event).  On the sort stream the wait comes last, behind ev_sorted, so
-        // it delays nothing but the event.
-        if (inputs_event && (sl + 1 == nslices || (uint64_t)p0 + np >= npts)) {
-            if (hide) BLZ_HIP(hipStreamWaitEvent(ss, S.ev[0], 0), BLZ_ERR_UNKNOWN);
-            BLZ_HIP(hipEventRecord(inputs_event, ss), BLZ_ERR_UNKNOWN);
-        }
-        // ---- accumulation, on the main stream
-        BLZ_TRY(ops->run_accumulate(E, pt_s, (uint32_t)max_units, nslices > 1 ? sl : -1));
-        if (nslices > 1) BLZ_TRY(ops->merge_buckets(E));
     }
-    if (nslices > 1) {
-        hipLaunchKernelGGL(k_iota, dim3(1024), dim3(256), 0, st, bucket_ident.as<uint32_t>(), G + 2);
-        BLZ_TRY(ops->run_reduce(E, bucket_sums.p, bucket_ident.p));
-    } else {
-        BLZ_TRY(ops->run_reduce(E, partial.p, B.unit_off.p));
-    }
-    S.l0_recorded = true;
+    S.open = true;
     S.busy = true;
     return BLZ_OK;
 }
 
-int MsmEngine::run_points(int slot, const void* d_pts) {
+// the sort stage of piece `sl`: np points whose scalars start at d_scalars (np x sbits / 8 bytes)
+int MsmEngine::sort_slice(int slot, int sl, const void* d_scalars, uint32_t np) {
     BLZ_TRY(use_device(device));
-    if (slot < 0 || slot >= MSM_QUEUE_DEPTH || !slots[slot].busy || !slots[slot].awaiting_points)
-        return fail(BLZ_ERR_INVALID_PARAM, "slot %d is not waiting for its points", slot);
+    if (slot < 0 || slot >= MSM_QUEUE_DEPTH || !slots[slot].open) return fail(BLZ_ERR_INVALID_PARAM, "slot %d has no task being enqueued", slot);
+    MsmSlot& S = slots[slot];
+    if (sl < 0 || sl >= S.slices || np == 0 || np > S.pts_per_slice) return fail(BLZ_ERR_INVALID_PARAM, "piece %d of %d with %u points", sl, S.slices, np);
+    MsmEngine& E = *this;
+    cur = slot;
+    last_plan = S.plan;
+    const MsmPlan& P = S.plan;
+    const uint64_t G = P.G;
+    const uint32_t nscan = (uint32_t)((G + 1 + SCAN_TILE - 1) / SCAN_TILE);
+    hipStream_t st = stream;
+    SortBufs& B = sb();
+    const bool hide = S.sort_hidden;
+    sort_st = hide ? sort_stream : st;
+    hipStream_t ss = sort_st;
+    if (last_sort_done) BLZ_HIP(hipStreamWaitEvent(ss, last_sort_done, 0), BLZ_ERR_UNKNOWN);
+    // this slot's previous task must have let go of its sort outputs (its level-0 reduce read unit_off last)
+    if (hide && S.l0_recorded) BLZ_HIP(hipStreamWaitEvent(ss, S.ev_l0, 0), BLZ_ERR_UNKNOWN);
+    BLZ_HIP(hipEventRecord(S.ev_s0, ss), BLZ_ERR_UNKNOWN);   // ev_s0 .. ev_s1: the sort stage, whichever stream it is on
+    dim3 b256(256);
+    const char* sc_s = (const char*)d_scalars;
+    if (S.ranged) {
+        // the range of every scalar as a scalar of its own (zero-extended): everything downstream reads 32-byte scalars and
+        // walks the plan's windows from bit 0; k_finish puts the 2^bit_lo back (FinishPlan offsets)
+        BLZ_TRY(B.range_scalars.reserve((size_t)np * 32 + 16));
+        hipLaunchKernelGGL(k_extract_range, dim3(2048), dim3(256), 0, ss, (const uint32_t*)sc_s, B.range_scalars.as<uint32_t>(),
+                           (uint64_t)np, (uint32_t)(S.bit_lo >> 5), (uint32_t)((S.bit_hi - S.bit_lo) >> 5));
+        sc_s = (const char*)B.range_scalars.p;
+    }
+    BLZ_HIP(hipMemsetAsync(B.stats.p, 0, 64, ss), BLZ_ERR_UNKNOWN);
+    // a small task's whole sort stage - digits, bucket scan, entries, unit lists - is one block's work (msm_sort_tiny.hip)
+    const bool tiny = !S.use_s3 && S.slices == 1 && msm_sort_tiny_ok(P, np, S.sbits);
+    if (S.use_s3) {
+        BLZ_TRY(P.table ? msm_sort3t(E, sc_s, np) : msm_sort3(E, sc_s, np));   // count[] and entries[] in one go
+    } else if (tiny) {
+        BLZ_TRY(msm_sort_tiny(E, sc_s, np, S.sbits, (uint32_t)S.max_units));
+    } else {
+        const size_t n16 = ((G + 1) * 4 + 15) / 16;   // the reserve of begin() rounds the allocation up
+        hipLaunchKernelGGL(k_zero, dim3(2048), dim3(256), 0, ss, (uint4*)B.count.p, n16);
+        BLZ_TRY(msm_sort_lds(E, sc_s, np, S.sbits));
+    }
+    if (!tiny) {
+        hipLaunchKernelGGL(k_scan_reduce, dim3(nscan), b256, 0, ss, B.count.as<uint32_t>(), G, P.L, blocksums.as<uint64_t>(),
+                           B.stats.as<uint32_t>());
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_SUMS_THREADS), 0, ss, blocksums.as<uint64_t>(), nscan, B.stats.as<uint32_t>());
+        hipLaunchKernelGGL(k_scan_final, dim3(nscan), b256, 0, ss, B.count.as<uint32_t>(), G, P.L, blocksums.as<uint64_t>(),
+                           B.off.as<uint32_t>(), B.unit_off.as<uint32_t>());
+        if (!S.use_s3) BLZ_TRY(msm_sort_lds_scatter(E));
+    }
+    BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
+    // No host round trip: the unit count stays on the device.  Buffers and grids are sized by the bound
+    // (every bucket at most one short unit, plus entries / L full ones) and the kernels read the real count
+    // from `stats`; the host copy below is for the log line, the sanity check of finish() and the hot-bucket guard.
+    BLZ_HIP(hipMemcpyAsync(S.stats_h, B.stats.p, 16, hipMemcpyDeviceToHost, ss), BLZ_ERR_READ);
+    if (!tiny) BLZ_TRY(launch_fill_units(E, (uint32_t)S.max_units));
+    BLZ_HIP(hipEventRecord(S.ev_sorted, ss), BLZ_ERR_UNKNOWN);
+    last_sort_done = S.ev_sorted;
+    BLZ_HIP(hipEventRecord(S.ev_s1, ss), BLZ_ERR_UNKNOWN);
+    // run() (inputs all there before the task began): the staged inputs have been consumed once the LAST sort has read
+    // the scalars - and, in DMA mode, once the to-Montgomery pass, which msm_capi.hip enqueued on the MAIN stream ahead of
+    // run(), has read the raw points (ev[0] sits behind it): only then may a later task's host -> device copies overwrite
+    // this staging set (msm_capi.hip's copy stream waits for the event).  On the sort stream the wait comes last, behind
+    // ev_sorted, so it delays nothing but the event.  (Phased tasks: end() records it.)
+    if (!S.phased && S.task_inputs_event && sl + 1 == S.slices) {
+        if (hide) BLZ_HIP(hipStreamWaitEvent(ss, S.ev[0], 0), BLZ_ERR_UNKNOWN);
+        BLZ_HIP(hipEventRecord(S.task_inputs_event, ss), BLZ_ERR_UNKNOWN);
+        S.task_inputs_event = nullptr;
+    }
+    return BLZ_OK;
+}
+
+// the accumulation of piece `sl` (its sort stage has been enqueued): d_pts = Montgomery points of the piece's first point
+int MsmEngine::accumulate_slice(int slot, int sl, const void* d_pts) {
+    BLZ_TRY(use_device(device));
+    if (slot < 0 || slot >= MSM_QUEUE_DEPTH || !slots[slot].open) return fail(BLZ_ERR_INVALID_PARAM, "slot %d has no task being enqueued", slot);
     MsmSlot& S = slots[slot];
     const MsmCurveOps* ops = ops_for(curve, repr);
     cur = slot;
     last_plan = S.plan;
-    BLZ_HIP(hipEventRecord(S.ev[0], stream), BLZ_ERR_UNKNOWN);   // the pipeline "starts" here: its sort ran during the copy
-    if (S.pending_inputs_event) BLZ_HIP(hipEventRecord(S.pending_inputs_event, stream), BLZ_ERR_UNKNOWN);
-    S.pending_inputs_event = nullptr;
-    BLZ_TRY(ops->run_accumulate(*this, d_pts, (uint32_t)S.max_units, -1));
-    BLZ_TRY(ops->run_reduce(*this, partial.p, sb().unit_off.p));
-    S.l0_recorded = true;
-    S.awaiting_points = false;
+    sort_st = S.sort_hidden ? sort_stream : stream;
+    if (S.sort_hidden) BLZ_HIP(hipStreamWaitEvent(stream, S.ev_sorted, 0), BLZ_ERR_UNKNOWN);
+    BLZ_TRY(ops->run_accumulate(*this, d_pts, (uint32_t)S.max_units, S.slices > 1 ? sl : -1));
+    if (S.slices > 1) BLZ_TRY(ops->merge_buckets(*this));
     return BLZ_OK;
 }
 
-void MsmEngine::cancel(int slot) {
+// every piece is enqueued: bucket reduce + tail
+int MsmEngine::end(int slot) {
+    BLZ_TRY(use_device(device));
+    if (slot < 0 || slot >= MSM_QUEUE_DEPTH || !slots[slot].open) return fail(BLZ_ERR_INVALID_PARAM, "slot %d has no task being enqueued", slot);
+    MsmSlot& S = slots[slot];
+    const MsmCurveOps* ops = ops_for(curve, repr);
+    cur = slot;
+    last_plan = S.plan;
+    if (S.task_inputs_event) {
+        // phased task: every reader of the staged inputs - the pieces' sorts and the caller's to-Montgomery passes - is on
+        // the main stream or has been waited for by it
+        BLZ_HIP(hipEventRecord(S.task_inputs_event, stream), BLZ_ERR_UNKNOWN);
+        S.task_inputs_event = nullptr;
+    }
+    if (S.slices > 1) {
+        hipLaunchKernelGGL(k_iota, dim3(1024), dim3(256), 0, stream, bucket_ident.as<uint32_t>(), S.plan.G + 2);
+        BLZ_TRY(ops->run_reduce(*this, bucket_sums.p, bucket_ident.p));
+    } else {
+        BLZ_TRY(ops->run_reduce(*this, partial.p, sb().unit_off.p));
+    }
+    S.l0_recorded = true;
+    S.open = false;
+    return BLZ_OK;
+}
+
+// give up a task whose inputs never arrived in full (a copy failed): what was enqueued runs to completion and is ignored
+void MsmEngine::abandon(int slot) {
     if (slot < 0 || slot >= MSM_QUEUE_DEPTH) return;
     MsmSlot& S = slots[slot];
-    if (S.busy && S.awaiting_points) {
+    if (S.busy && S.open) {
         S.busy = false;
-        S.awaiting_points = false;
-        S.pending_inputs_event = nullptr;
+        S.open = false;
+        S.task_inputs_event = nullptr;
     }
+}
+
+int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int sbits, int* slot_out, int table_c, int bit_lo,
+                   int bit_hi) {
+    BLZ_TRY(use_device(device));
+    if (npts == 0) {
+        const MsmCurveOps* ops = ops_for(curve, repr);
+        hipStream_t st = stream;
+        int slot = (cur + 1) % MSM_QUEUE_DEPTH;
+        if (slots[slot].busy) slot = (slot + 1) % MSM_QUEUE_DEPTH;
+        if (slots[slot].busy) return fail(BLZ_ERR_INVALID_PARAM, "task queue full (%d tasks in flight)", MSM_QUEUE_DEPTH);
+        cur = slot;
+        MsmSlot& S = slots[slot];
+        if (slot_out) *slot_out = slot;
+        BLZ_HIP(hipEventRecord(S.ev[0], st), BLZ_ERR_UNKNOWN);
+        BLZ_TRY(ops->emit_infinity(*this));
+        for (int i = 1; i <= 4; ++i) BLZ_HIP(hipEventRecord(S.ev[i], st), BLZ_ERR_UNKNOWN);
+        BLZ_HIP(hipMemcpyAsync(S.result_h, slot_result(slot), 3 * fq_bytes(curve), hipMemcpyDeviceToHost, st), BLZ_ERR_READ);
+        BLZ_HIP(hipEventRecord(S.ev_done, st), BLZ_ERR_UNKNOWN);
+        last_plan = S.plan = MsmPlan();
+        S.accum_timed = false;
+        S.open = false;
+        S.busy = true;
+        return BLZ_OK;
+    }
+    // resident inputs: one piece (BLAZE_MSM_PIECES = n forces n: tests of the piecewise path at sizes the oracle checks)
+    int pieces = msm_env_int("BLAZE_MSM_PIECES", 1);
+    int slot = -1;
+    BLZ_TRY(begin(npts, sbits, &slot, table_c, bit_lo, bit_hi, pieces, false));
+    if (slot_out) *slot_out = slot;
+    MsmSlot& S = slots[slot];
+    int rc = BLZ_OK;
+    for (int sl = 0; sl < S.slices && rc == BLZ_OK; ++sl) {
+        const uint32_t p0 = (uint32_t)sl * S.pts_per_slice;
+        const uint32_t np = npts - p0 < S.pts_per_slice ? npts - p0 : S.pts_per_slice;
+        rc = sort_slice(slot, sl, (const char*)d_scalars + (size_t)p0 * (sbits / 8), np);
+        if (rc == BLZ_OK) rc = accumulate_slice(slot, sl, (const char*)d_pts + (size_t)p0 * mont_point_bytes(curve));
+    }
+    if (rc == BLZ_OK) rc = end(slot);
+    if (rc != BLZ_OK) abandon(slot);
+    return rc;
 }
 
 int MsmEngine::finish(int slot, uint8_t* out) {
     BLZ_TRY(use_device(device));
     if (slot < 0 || slot >= MSM_QUEUE_DEPTH || !slots[slot].busy) return fail(BLZ_ERR_INVALID_PARAM, "no task in slot %d", slot);
-    if (slots[slot].awaiting_points) return fail(BLZ_ERR_INVALID_PARAM, "task in slot %d never received its points", slot);
+    if (slots[slot].open) return fail(BLZ_ERR_INVALID_PARAM, "task in slot %d never received all of its data", slot);
     MsmSlot& S = slots[slot];
     // bounded: a wedged kernel must not hang the host for ever (common.hpp); on expiry the slot stays busy
     BLZ_TRY(sync_event_bounded(S.ev_done, "wait_result: MSM task"));

@@ -327,11 +327,72 @@ int stage_common(blz_msm* h, bool have_points, const void* points, size_t points
     } else {
         h->staged_from_arena = false;
     }
-    // The scalars first: the digit sort needs nothing else.  With host buffers (DMA mode) and a task already armed, the
-    // sort stage is enqueued as soon as the scalars have landed and runs while the POINTS are still crossing the link
-    // (MsmEngine::defer_points); the points then arrive in four pieces, each converted to Montgomery form while the next
-    // one is on the link, and the accumulation is enqueued behind the last conversion.  Config 2 (2^22 elements,
-    // 512 MB of host buffers): the 1.0 ms sort and three quarters of the 0.35 ms conversion leave the critical path.
+    // Host buffers with a task already armed (DMA mode, the reference's primary flow: tests/integration_msm.rs:149-207):
+    // the task is enqueued PIECE BY PIECE while its data crosses the link, the way the reference streams interleaved chunks
+    // of scalars and points into the card's FIFOs while the card computes (msm_api.rs:175-202).  Per piece: its scalars,
+    // then its sort stage goes to the device; its points, then their to-Montgomery pass and the piece's accumulation
+    // (MsmEngine::begin / sort_slice / accumulate_slice / end: the pieces share one bucket space and the bucket sums are
+    // carried from piece to piece).  Link and multiplier work at the same time; what is left on the critical path behind the
+    // last byte is the last piece's accumulation, the bucket reduce and the tail.
+    const int sbits = h->pf == 1 ? 256 : 32;
+    if (!on_device && !has_hbm && h->armed && npts > 0 && msm_env_int("BLAZE_DMA_OVERLAP", 1) != 0) {
+        const size_t mp = mont_point_bytes(h->curve), ps = point_size(h), sb = (size_t)sbits / 8;
+        BLZ_TRY(h->scalars_buf[set].reserve(scalars_len));
+        BLZ_TRY(h->points_raw[set].reserve(want_pts));
+        BLZ_TRY(h->points_mont.reserve((size_t)npts * mp));
+        // pieces of >= 2^19 points (64 MiB of host bytes: 1.2 ms of link), at most 16.  Measured (profiles/r04_dma_pieces.txt):
+        // 2^22 elements 22.6 ms in one piece, 16.2 / 15.35 / 17.1 in 4 / 8 / 16; 2^26 270.8, 191.8 / 178.3 / 171.5
+        int pieces = msm_env_int("BLAZE_DMA_PIECES", 0);
+        if (pieces <= 0) {
+            pieces = (int)(npts >> 19);
+            if (pieces > 16) pieces = 16;
+        }
+        if (pieces < 1) pieces = 1;
+        int slot = -1;
+        h->eng.inputs_event = h->set_free[set];
+        memset(h->table_info, 0, sizeof(h->table_info));
+        BLZ_TRY(h->eng.begin(npts, sbits, &slot, 0, h->range_lo, h->range_hi, pieces, true));
+        const uint32_t per = h->eng.slots[slot].pts_per_slice;
+        pieces = h->eng.slots[slot].slices;
+        int rc = BLZ_OK;
+        auto copy_in = [&](void* dst, const void* src, size_t len, const char* what) -> int {
+            if (hipMemcpyAsync(dst, src, len, hipMemcpyHostToDevice, cst) != hipSuccess) return fail(BLZ_ERR_WRITE, "%s failed", what);
+            // the caller may drop its buffers as soon as we return (set_data is synchronous: utils.rs:71), and the piece's
+            // device work is enqueued when its bytes are there.  The first copy waits for the staging set's previous user
+            // (set_free, two tasks back): bounded like every wait
+            wait_clear();
+            const int r = sync_stream_bounded(cst, what);
+            if (r != BLZ_OK && wait_timed_out()) h->wedged = true;
+            return r;
+        };
+        for (int k = 0; k < pieces && rc == BLZ_OK; ++k) {
+            const uint32_t p0 = (uint32_t)k * per;
+            const uint32_t np = npts - p0 < per ? npts - p0 : per;
+            char* d_sc = (char*)h->scalars_buf[set].p + (size_t)p0 * sb;
+            rc = copy_in(d_sc, (const char*)scalars + (size_t)p0 * sb, (size_t)np * sb, "set_data: host -> device copy of the scalars");
+            if (rc == BLZ_OK) rc = h->eng.sort_slice(slot, k, d_sc, np);
+            char* d_raw = (char*)h->points_raw[set].p + (size_t)p0 * ps;
+            char* d_mont = (char*)h->points_mont.p + (size_t)p0 * mp;
+            if (rc == BLZ_OK) rc = copy_in(d_raw, (const char*)points + (size_t)p0 * ps, (size_t)np * ps, "set_data: host -> device copy of the points");
+            if (rc == BLZ_OK) rc = h->eng.points_to_mont(d_raw, d_mont, np);
+            if (rc == BLZ_OK) rc = h->eng.accumulate_slice(slot, k, d_mont);
+        }
+        if (rc == BLZ_OK) rc = h->eng.end(slot);
+        if (rc != BLZ_OK) {
+            h->eng.abandon(slot);
+            return rc;
+        }
+        h->d_scalars = h->scalars_buf[set].p;
+        h->d_points_mont = h->points_mont.p;
+        h->staged_n = n;
+        h->set_used[set] = true;
+        h->staged_set = -1;
+        h->armed = false;
+        h->data_ready = false;
+        h->in_flight.push_back({slot, h->task_label});
+        return BLZ_OK;
+    }
+    // Everything else is staged whole: the scalars first ...
     if (on_device) {
         if (((uintptr_t)scalars) % 16) return fail(BLZ_ERR_INVALID_PARAM, "device scalars must be 16-byte aligned");
         h->d_scalars = scalars;
@@ -345,7 +406,8 @@ int stage_common(blz_msm* h, bool have_points, const void* points, size_t points
     }
     h->staged_n = n;
     if (!has_hbm) {
-        const size_t mp = mont_point_bytes(h->curve), ps = point_size(h);
+        // ... then the points, converted to Montgomery form on the main stream
+        const size_t mp = mont_point_bytes(h->curve);
         const size_t want_mont = (size_t)npts * mp;
         BLZ_TRY(h->points_mont.reserve(want_mont ? want_mont : 16));
         if (on_device) {
@@ -353,46 +415,9 @@ int stage_common(blz_msm* h, bool have_points, const void* points, size_t points
             BLZ_TRY(h->eng.points_to_mont(points, h->points_mont.p, npts));
         } else {
             BLZ_TRY(h->points_raw[set].reserve(want_pts ? want_pts : 16));
-            int slot = -1;
-            const bool defer = h->armed && npts > 0 && msm_env_int("BLAZE_DMA_OVERLAP", 1) != 0;
-            if (defer) {
-                h->eng.inputs_event = h->set_free[set];
-                h->eng.defer_points = true;
-                memset(h->table_info, 0, sizeof(h->table_info));
-                const int rrc = h->eng.run(nullptr, h->d_scalars, npts, h->pf == 1 ? 256 : 32, &slot, 0, h->range_lo, h->range_hi);
-                h->eng.defer_points = false;
-                if (rrc != BLZ_OK) return rrc;
-            }
-            // pieces of whole points; small inputs go in one
-            const uint32_t pieces = defer && npts >= (1u << 16) ? 4u : 1u;
-            const uint32_t per = (npts + pieces - 1) / pieces;
-            int rc = BLZ_OK;
-            for (uint32_t p0 = 0; p0 < npts && rc == BLZ_OK; p0 += per) {
-                const uint32_t cnt = npts - p0 < per ? npts - p0 : per;
-                if (hipMemcpyAsync((char*)h->points_raw[set].p + (size_t)p0 * ps, (const char*)points + (size_t)p0 * ps, (size_t)cnt * ps,
-                                   hipMemcpyHostToDevice, cst) != hipSuccess)
-                    rc = fail(BLZ_ERR_WRITE, "set_data: host -> device copy of the points failed");
-                wait_clear();
-                if (rc == BLZ_OK) rc = sync_stream_bounded(cst, "set_data: host -> device copy of the points");
-                if (rc != BLZ_OK && wait_timed_out()) h->wedged = true;
-                if (rc == BLZ_OK)
-                    rc = h->eng.points_to_mont((const char*)h->points_raw[set].p + (size_t)p0 * ps, (char*)h->points_mont.p + (size_t)p0 * mp, cnt);
-            }
-            h->d_points_mont = h->points_mont.p;
-            if (defer) {
-                if (rc == BLZ_OK) rc = h->eng.run_points(slot, h->d_points_mont);
-                if (rc != BLZ_OK) {
-                    h->eng.cancel(slot);
-                    return rc;
-                }
-                h->set_used[set] = true;
-                h->staged_set = -1;
-                h->armed = false;
-                h->data_ready = false;
-                h->in_flight.push_back({slot, h->task_label});
-                return BLZ_OK;
-            }
-            if (rc != BLZ_OK) return rc;
+            if (want_pts) BLZ_HIP(hipMemcpyAsync(h->points_raw[set].p, points, want_pts, hipMemcpyHostToDevice, cst), BLZ_ERR_WRITE);
+            BLZ_WAIT(h, sync_stream_bounded(cst, "set_data: host -> device copy of the points"));
+            BLZ_TRY(h->eng.points_to_mont(h->points_raw[set].p, h->points_mont.p, npts));
         }
         h->d_points_mont = h->points_mont.p;
     }

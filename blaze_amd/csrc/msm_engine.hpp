@@ -62,13 +62,18 @@ struct MsmSlot {
     uint32_t* stats_h = nullptr;   // pinned: [0] total units, [1] max bucket count, [2] total entries (read in finish())
     uint64_t max_units = 0;        // the bound the launches of this task were sized by
     MsmPlan plan;
-    // slice-major tasks (msm.hip run()): one event pair per slice around its k_accumulate launch; finish() sums them
+    // piecewise tasks (msm.hip begin()): one event pair per piece around its k_accumulate_cont launch; finish() sums them
     hipEvent_t slice_ev[2 * 64] = {};
     int slices = 1;
     bool accum_timed = false;
     bool busy = false;             // enqueued, result not collected yet
-    bool awaiting_points = false;  // run() enqueued the sort stage only (defer_points); run_points() enqueues the rest
-    hipEvent_t pending_inputs_event = nullptr;  // ... and records the caller's inputs_event then
+    // state of a task between begin() and end() (msm.hip)
+    bool open = false;             // begun, not every piece enqueued yet
+    bool phased = false;           // the caller enqueues the pieces as their data lands (inputs_event is recorded by end())
+    bool use_s3 = false, ranged = false;
+    uint32_t npts = 0, pts_per_slice = 0;
+    int sbits = 0, bit_lo = 0, bit_hi = 0;
+    hipEvent_t task_inputs_event = nullptr;   // the caller's inputs_event, until it has been recorded
 };
 
 struct MsmEngine {
@@ -97,15 +102,18 @@ struct MsmEngine {
     hipStream_t sort_st = nullptr;       // the stream the CURRENT task's sort stage is being enqueued on (stream or sort_stream)
     hipEvent_t last_sort_done = nullptr; // sorts share their scratch (coarse, inter, inter2, ...): each waits for the one before
     DevBuf coarse, inter, inter2, slice_map, partial, blocksums, result, sort3_tabs;
-    DevBuf bucket_sums, bucket_ident;   // slice-major tasks: running bucket sums across slices; identity unit_off for the reduce
-    // Set by the caller of run(), consumed by it: enqueue only the sort stage - everything that needs nothing but the
-    // scalars - and leave the task waiting for run_points().  msm_capi.hip uses it for host buffers (DMA mode): scalars are
-    // sent first, the sort runs while the points are still on the PCIe link, the accumulation is enqueued when they landed.
-    bool defer_points = false;
-    int run_points(int slot, const void* d_points_mont);
-    void cancel(int slot);   // give up a task that is awaiting its points (the copy failed)
-    hipEvent_t inputs_event = nullptr;   // set by the caller of run(): recorded on `stream` once the task has read
-                                         // its scalars / raw points (after the digit sort)
+    DevBuf bucket_sums, bucket_ident;   // piecewise tasks: the bucket sums carried across pieces; identity unit_off for the reduce
+    // A task in four steps (msm.hip): begin() plans it and takes a slot; per piece sort_slice() (needs the piece's scalars)
+    // and accumulate_slice() (needs its points); end() enqueues the bucket reduce and the tail.  msm_capi.hip uses the steps
+    // for host buffers (DMA mode): a piece is handed to the device as soon as it has crossed the PCIe link.  `pieces` > 1:
+    // the pieces share one bucket space, the sums are carried from piece to piece (k_accumulate_cont).
+    int begin(uint32_t npts, int sbits, int* slot, int table_c, int bit_lo, int bit_hi, int pieces, bool phased);
+    int sort_slice(int slot, int piece, const void* d_scalars, uint32_t np);
+    int accumulate_slice(int slot, int piece, const void* d_points_mont);
+    int end(int slot);
+    void abandon(int slot);   // give up a task between begin() and end() (a copy failed)
+    hipEvent_t inputs_event = nullptr;   // set by the caller of run() / begin(): recorded once the task has read
+                                         // its scalars / raw points
     uint8_t* combine_h = nullptr;  // pinned bytes of combine_partials
     MsmPlan last_plan;
     float last_ms[8] = {};
@@ -166,9 +174,9 @@ struct MsmCurveOps {
     int (*points_to_mont)(MsmEngine&, const void* d_raw, void* d_mont, uint32_t npts);
     int (*emit_infinity)(MsmEngine&);
     // phase 1 after a digit sort: unit lists, k_accumulate, k_combine_units (at most max_units units; the real count is on
-    // the device).  slice >= 0: part of a slice-major task - only the accumulate kernel is bracketed, by the slice's events.
+    // the device).  slice >= 0: piece of a piecewise task - k_accumulate_cont, bracketed by the piece's events.
     int (*run_accumulate)(MsmEngine&, const void* d_pts, uint32_t max_units, int slice);
-    // slice-major tasks: bucket_sums[g] += the slice's sum of bucket g (the leader unit of its run)
+    // piecewise tasks: bucket_sums[g] += the piece's sum of bucket g where its run needed several units
     int (*merge_buckets)(MsmEngine&);
     // phases 2 - 3 over bucket sums found at sums[unit_off[g]] (unit_off[g + 1] > unit_off[g], else the bucket is empty)
     int (*run_reduce)(MsmEngine&, const void* sums, const void* unit_off);

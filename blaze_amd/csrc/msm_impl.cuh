@@ -259,28 +259,48 @@ BLZ_DEV void store_xyzz(uint32_t* base, size_t idx, const XYZZ<F>& a) {
 #else
 #define BLZ_PT_IDX(e) ((e) & 0x7fffffffu)
 #endif
-template <class F>
-__global__ __launch_bounds__(128, USE_RR<F> ? BLZ_ACC_RR_WAVES : 3) __attribute__((amdgpu_num_vgpr(BLZ_ACC_VGPR_CAP))) void k_accumulate(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ entries,
-                                                    const uint32_t* __restrict__ off, const uint32_t* __restrict__ unit_off,
-                                                    const uint32_t* __restrict__ unit_bucket,
-                                                    const uint32_t* __restrict__ unit_order,
-                                                    const uint32_t* __restrict__ stats, uint32_t L,
-                                                    uint32_t* __restrict__ partial) {
+// CONT (piecewise tasks, msm.hip begin() / accumulate_slice()): the task's elements arrive in pieces, every piece is sorted
+// and accumulated on its own and the bucket sums live in `sums`, indexed by BUCKET, across the pieces.  A unit that is its
+// bucket's only unit of this piece - every unit, bar the runs longer than L - takes the bucket's sum so far as its
+// starting value and puts the new sum back (`first`: the task's first piece - nothing to load, the run's first addition is
+// the cheap affine + affine one); the units of a bucket that needed several go through `partial` and the unit folds as
+// ever, and k_merge_buckets adds their total to sums[g].  Against merging every piece's sums bucket by bucket this saves a
+// full addition per occupied bucket and piece and costs the first addition of a run its affine + affine shortcut.
+template <class F, bool CONT>
+BLZ_DEV void accumulate_body(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ entries,
+                             const uint32_t* __restrict__ off, const uint32_t* __restrict__ unit_off,
+                             const uint32_t* __restrict__ unit_bucket, const uint32_t* __restrict__ unit_order,
+                             const uint32_t* __restrict__ stats, uint32_t L, uint32_t* __restrict__ partial,
+                             uint32_t* __restrict__ sums, bool first) {
     // the grid covers the host's upper bound of the unit count; the real count is on the device (stats[0])
     uint32_t t = blockIdx.x * 128u + threadIdx.x;
     if (t >= stats[0]) return;
     const uint32_t u = unit_order[t];  // units of equal run length sit in the same wave
     uint32_t g = unit_bucket[u];
-    uint32_t k = u - unit_off[g];
+    const uint32_t u0 = unit_off[g];
+    uint32_t k = u - u0;
     uint32_t start = off[g] + k * L;
     uint32_t end = off[g + 1];
     if (end - start > L) end = start + L;
+    uint32_t* dst = partial;
+    size_t didx = u;
+    bool resume = false;
+    if constexpr (CONT) {
+        if (unit_off[g + 1] - u0 == 1) {
+            dst = sums;
+            didx = g;
+            resume = !first;
+        }
+    }
     if constexpr (USE_RR<F>) {
         // reduced-radix arithmetic (ec_rr.cuh): 2 waves per SIMD reach 95 % of the multiplier's rate
         // (profiles/r02_mul_variants.txt), which leaves 256 VGPRs: room for the next point's prefetch
         using Q = typename F::RR;
         XYZZRR<Q> acc;
         ptrr_set_inf(acc);
+        if constexpr (CONT) {
+            if (resume) ptrr_load(acc, sums, g);
+        }
         uint32_t e = entries[start];
 #if BLZ_ACC_RR_WAVES == 2
         // Two loads run ahead of the arithmetic: the POINT of entry j + 1 (28 / 16 VGPRs) and the INDEX of entry j + 2.
@@ -292,7 +312,7 @@ __global__ __launch_bounds__(128, USE_RR<F> ? BLZ_ACC_RR_WAVES : 3) __attribute_
         load_affine_rr<F>(nxt, pts, BLZ_PT_IDX(e));
         uint32_t j = start;
 #ifndef BLZ_ACC_NO_AADD
-        if (end - start >= 2) {
+        if ((!CONT || first) && end - start >= 2) {
             // the run's first two points are both affine: a cheaper addition than the mixed one (ptrr_aadd);
             // units are ordered by length, so the lanes of a wave take this branch together
             const AffineRR<Q> p0 = nxt;
@@ -328,10 +348,13 @@ __global__ __launch_bounds__(128, USE_RR<F> ? BLZ_ACC_RR_WAVES : 3) __attribute_
             ptrr_madd<Q, 1>(acc, cur, neg);
         }
 #endif
-        ptrr_store(partial, u, acc);
+        ptrr_store(dst, didx, acc);
     } else {
         XYZZ<F> acc;
         pt_set_inf(acc);
+        if constexpr (CONT) {
+            if (resume) load_xyzz(acc, sums, g);
+        }
         // only the next entry INDEX is prefetched: holding the next point as well costs 24 VGPRs, which at
         // 3 waves per SIMD (168 VGPRs) turned into scratch spills (100 GB of HBM writes per 2^26 MSM in
         // the WRITE_SIZE counter); the other two waves of the SIMD cover the gather latency instead
@@ -344,8 +367,28 @@ __global__ __launch_bounds__(128, USE_RR<F> ? BLZ_ACC_RR_WAVES : 3) __attribute_
             if (ecur & 0x80000000u) fp_neg(cur.y, cur.y);
             pt_madd(acc, cur);
         }
-        store_xyzz(partial, u, acc);
+        store_xyzz(dst, didx, acc);
     }
+}
+
+template <class F>
+__global__ __launch_bounds__(128, USE_RR<F> ? BLZ_ACC_RR_WAVES : 3) __attribute__((amdgpu_num_vgpr(BLZ_ACC_VGPR_CAP))) void k_accumulate(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ entries,
+                                                    const uint32_t* __restrict__ off, const uint32_t* __restrict__ unit_off,
+                                                    const uint32_t* __restrict__ unit_bucket,
+                                                    const uint32_t* __restrict__ unit_order,
+                                                    const uint32_t* __restrict__ stats, uint32_t L,
+                                                    uint32_t* __restrict__ partial) {
+    accumulate_body<F, false>(pts, entries, off, unit_off, unit_bucket, unit_order, stats, L, partial, nullptr, false);
+}
+// the piecewise twin (no register cap: no sort is ever hidden underneath it)
+template <class F>
+__global__ __launch_bounds__(128, USE_RR<F> ? BLZ_ACC_RR_WAVES : 3) void k_accumulate_cont(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ entries,
+                                                    const uint32_t* __restrict__ off, const uint32_t* __restrict__ unit_off,
+                                                    const uint32_t* __restrict__ unit_bucket,
+                                                    const uint32_t* __restrict__ unit_order,
+                                                    const uint32_t* __restrict__ stats, uint32_t L,
+                                                    uint32_t* __restrict__ partial, uint32_t* __restrict__ sums, uint32_t first) {
+    accumulate_body<F, true>(pts, entries, off, unit_off, unit_bucket, unit_order, stats, L, partial, sums, first != 0);
 }
 
 // buckets that needed several units: fold partial[u0 + k*stride] for k in the same 16-group.
@@ -844,15 +887,16 @@ __global__ __launch_bounds__(512, 1) void k_fold_hot(const uint32_t* __restrict_
     if (lane == 0) ptrr_store(partial, u0, acc);
 }
 
-// bucket_sums[g] += sum of bucket g in this slice (slice-major tasks, msm.hip run()).  After k_combine_units the sum of
-// a bucket's run sits in its first unit; an empty run leaves the bucket alone.
+// bucket_sums[g] += sum of bucket g in this piece, for the buckets whose run needed SEVERAL units (piecewise tasks, msm.hip:
+// the single-unit buckets were summed in place by k_accumulate_cont).  After the unit folds the sum of such a run sits in its
+// first unit.
 template <class F>
 __global__ __launch_bounds__(128, 2) void k_merge_buckets(const uint32_t* __restrict__ partial, const uint32_t* __restrict__ unit_off,
                                                          uint64_t G, uint32_t* __restrict__ sums) {
     const uint64_t g = (uint64_t)blockIdx.x * 128u + threadIdx.x;
     if (g >= G) return;
     const uint32_t u0 = unit_off[g], u1 = unit_off[g + 1];
-    if (u1 <= u0) return;
+    if (u1 - u0 < 2 || u1 < u0) return;
     if constexpr (USE_RR<F>) {
         using Q = typename F::RR;
         XYZZRR<Q> a, b;
@@ -880,10 +924,16 @@ int run_accumulate_t(MsmEngine& E, const void* d_pts, uint32_t U, int slice) {
     S.accum_timed = true;
     // ev5..ev6 (or the slice's pair) bracket the dominant kernel alone
     BLZ_HIP(hipEventRecord(slice < 0 ? S.ev[5] : S.slice_ev[2 * slice], st), BLZ_ERR_UNKNOWN);
-    hipLaunchKernelGGL(k_accumulate<F>, dim3((U + 127) / 128), dim3(128), 0, st, (const uint32_t*)d_pts,
-                       E.sb().entries.as<uint32_t>(), E.sb().off.as<uint32_t>(), E.sb().unit_off.as<uint32_t>(),
-                       E.sb().unit_bucket.as<uint32_t>(), E.sb().unit_order.as<uint32_t>(), E.sb().stats.as<uint32_t>(), P.L,
-                       E.partial.as<uint32_t>());
+    if (slice < 0)
+        hipLaunchKernelGGL(k_accumulate<F>, dim3((U + 127) / 128), dim3(128), 0, st, (const uint32_t*)d_pts,
+                           E.sb().entries.as<uint32_t>(), E.sb().off.as<uint32_t>(), E.sb().unit_off.as<uint32_t>(),
+                           E.sb().unit_bucket.as<uint32_t>(), E.sb().unit_order.as<uint32_t>(), E.sb().stats.as<uint32_t>(), P.L,
+                           E.partial.as<uint32_t>());
+    else   // piecewise task: single-unit buckets carry their sums in bucket_sums from piece to piece
+        hipLaunchKernelGGL(k_accumulate_cont<F>, dim3((U + 127) / 128), dim3(128), 0, st, (const uint32_t*)d_pts,
+                           E.sb().entries.as<uint32_t>(), E.sb().off.as<uint32_t>(), E.sb().unit_off.as<uint32_t>(),
+                           E.sb().unit_bucket.as<uint32_t>(), E.sb().unit_order.as<uint32_t>(), E.sb().stats.as<uint32_t>(), P.L,
+                           E.partial.as<uint32_t>(), E.bucket_sums.as<uint32_t>(), slice == 0 ? 1u : 0u);
     BLZ_HIP(hipEventRecord(slice < 0 ? S.ev[6] : S.slice_ev[2 * slice + 1], st), BLZ_ERR_UNKNOWN);
     // a bucket holds at most one entry per point (window-table tasks: one per point and window)
     const uint64_t maxunits = ((uint64_t)P.npts * (P.table ? P.W : 1) + P.L - 1) / P.L;

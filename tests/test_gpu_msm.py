@@ -5,6 +5,7 @@ import ctypes as C
 import json
 import os
 
+import numpy as np
 import pytest
 
 import blaze_amd
@@ -801,28 +802,65 @@ def test_wait_result_is_bounded(gpu, orc, monkeypatch):
 
 
 @pytest.mark.parametrize("curve,pf", [("BN254", 8), ("BN254", 1), ("BLS381", 8), ("BLS377", 1)])
-def test_slice_major_accumulation(gpu, orc, curve, pf, monkeypatch):
-    """Big point tables are accumulated slice by slice (every gather of a launch inside <= 2 GiB of the table; the
-    buckets' sums are merged across slices, msm.hip run()): automatic only for the 32 GiB table of config 3, forced
-    here at sizes the oracle checks byte for byte - ragged slice counts, slices that end up empty, hot buckets
-    (the reference harness's repeated tile), two tasks in flight."""
+def test_piecewise_accumulation(gpu, orc, curve, pf, monkeypatch):
+    """A task whose data arrives over time is sorted and accumulated piece by piece over one bucket space, the bucket sums
+    carried from piece to piece (msm.hip begin / sort_slice / accumulate_slice / end, k_accumulate_cont).  Forced here on
+    device-resident inputs (BLAZE_MSM_PIECES) at sizes the oracle checks byte for byte: ragged piece counts, hot buckets
+    whose runs need several units per piece (the reference harness's repeated tile: P + P across pieces), two tasks in
+    flight sharing the bucket-sum buffer."""
     n = 5000
     pts, sc, exp = orc.input_generator(curve, n, pf, 4100 + pf)
-    for slices in ("3", "7", "64"):
-        monkeypatch.setenv("BLAZE_MSM_SLICES", slices)
+    sc2 = bytes(sc[32:]) + bytes(sc[:32])
+    exp2 = orc.msm_pippenger(curve, pts, sc2, n, pf, threads=4)
+    bufs = []
+    for data in (pts, sc, sc2):
+        b_ = DeviceBuffer(0, len(data))
+        b_.upload(data)
+        bufs.append(b_)
+    dp, ds, ds2 = bufs
+    p = MSMParams(n, None)
+    for pieces in ("3", "7", "64", "1"):
+        monkeypatch.setenv("BLAZE_MSM_PIECES", pieces)
         cl = msm_client(curve, pf)
-        assert run_msm(cl, pts, sc, n) == exp, f"{curve} pf={pf} slices={slices}"
+        assert run_msm(cl, dp, ds, n) == exp, f"{curve} pf={pf} pieces={pieces}"
         # two in flight, the second with other scalars
-        sc2 = bytes(sc[32:]) + bytes(sc[:32])
-        exp2 = orc.msm_pippenger(curve, pts, sc2, n, pf, threads=4)
-        p = MSMParams(n, None)
-        cl.initialize(p); cl.start_process(); cl.set_data(MSMInput(pts, sc, p))
-        cl.initialize(p); cl.start_process(); cl.set_data(MSMInput(pts, sc2, p))
+        cl.initialize(p); cl.start_process(); cl.set_data(MSMInput(dp, ds, p))
+        cl.initialize(p); cl.start_process(); cl.set_data(MSMInput(dp, ds2, p))
         cl.wait_result(); assert cl.result().result == exp
         cl.wait_result(); assert cl.result().result == exp2
         assert cl.get_api()["accumulate_kernel_ms"] > 0
         cl.close()
-    monkeypatch.setenv("BLAZE_MSM_SLICES", "1")
+    for b_ in bufs:
+        b_.free()
+
+
+@pytest.mark.parametrize("curve,pf,n", [("BLS381", 1, 70001), ("BLS377", 8, 9000), ("BN254", 1, 33333), ("BN254", 8, 4100)])
+def test_dma_pieces_host_buffers(gpu, orc, curve, pf, n, monkeypatch):
+    """DMA mode with host buffers and a task already armed: the task is enqueued piece by piece while its bytes cross the
+    link (msm_capi.hip stage_common; the reference streams interleaved chunks of scalars and points while the card computes,
+    msm_api.rs:175-202).  Forced to 1 / 4 / 5 / 16 pieces at oracle-checkable sizes (ragged last piece, pieces of whole
+    16-point groups), uniform scalars; then two tasks in flight, and the same handle with the overlap switched off."""
+    pts, sc, _ = orc.input_generator(curve, n, pf, 777 + pf)
+    rng = np.random.default_rng(n)
+    sc = bytearray(rng.integers(0, 256, size=32 * n, dtype=np.uint8).tobytes())
+    for i in range(n):
+        sc[32 * i + 31] &= 0x0F                 # < 2^252: canonical in all three scalar fields
+    sc = bytes(sc)
+    exp = orc.msm_pippenger(curve, pts, sc, n, pf, threads=8)
+    sc2 = bytes(sc[64:]) + bytes(sc[:64])
+    exp2 = orc.msm_pippenger(curve, pts, sc2, n, pf, threads=8)
+    p = MSMParams(n, None)
+    for pieces in ("1", "4", "5", "16"):
+        monkeypatch.setenv("BLAZE_DMA_PIECES", pieces)
+        cl = msm_client(curve, pf)
+        assert run_msm(cl, pts, sc, n) == exp, f"{curve} pf={pf} pieces={pieces}"
+        cl.initialize(p); cl.start_process(); cl.set_data(MSMInput(pts, sc, p))
+        cl.initialize(p); cl.start_process(); cl.set_data(MSMInput(pts, sc2, p))
+        cl.wait_result(); assert cl.result().result == exp
+        cl.wait_result(); assert cl.result().result == exp2
+        assert run_msm(cl, pts, sc2, n) == exp2
+        cl.close()
+    monkeypatch.setenv("BLAZE_DMA_OVERLAP", "0")
     cl = msm_client(curve, pf)
     assert run_msm(cl, pts, sc, n) == exp
     cl.close()
