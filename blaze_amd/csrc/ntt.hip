@@ -142,7 +142,7 @@ int ntt_setup(blz_ntt* h) {
         // pass 1 tile order (ntt_rr.cuh); BLAZE_NTT_SWZ=0: the plain order (A/B runs)
         const char* envs = getenv("BLAZE_NTT_SWZ");
         h->TR.swz = (la == 9 && lb == 9) ? (envs && *envs ? (uint32_t)atoi(envs) : 4u) : 0u;   // BLAZE_NTT_SWZ: 0 plain, 1 + s (s <= 5); default s = 3
-        if (h->TR.swz > 6u) h->TR.swz = 6u;
+        if ((h->TR.swz & 15u) > 6u) h->TR.swz = 6u;
     }
     BLZ_TRY(h->ops->setup(h->stream, h->T, h->TR, h->geom, h->inverse));
     // both transform buffers exist from the start, zero-filled, like the card's two HBM buffers: the reference's

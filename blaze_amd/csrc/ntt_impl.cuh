@@ -441,11 +441,18 @@ int ntt_pass_t(hipStream_t st, const void* in, void* out, const NttGeom& g, cons
     // BLAZE_NTT_RR=0: the 32-bit-limb 512-point kernel (kept for A/B measurements)
     static const bool use_rr = []() { const char* e = getenv("BLAZE_NTT_RR"); return !(e && *e == '0'); }();
     if (lr == 9 && cols_avail >= NR_COLS_LOG && !force_generic && use_rr) {
-        BLZ_TRY(ensure_dynamic_lds((const void*)k_ntt512_rr<Fr, PASS>, 160 * 1024));
-        const size_t ldsr = (size_t)512 * NR_COLS * rr_stride<typename Fr::RR>() * 4;
+        static const bool half = []() { const char* e = getenv("BLAZE_NTT_HALF"); return !(e && *e == '0'); }();
+        const size_t ldsr = (size_t)(half ? 256 : 512) * NR_COLS * rr_stride<typename Fr::RR>() * 4;
         const uint64_t tilesr = (1ull << g.logn) >> (9 + NR_COLS_LOG);
-        hipLaunchKernelGGL((k_ntt512_rr<Fr, PASS>), dim3((unsigned)tilesr), dim3(NR_THREADS), ldsr, st, (const uint32_t*)in,
-                           (uint32_t*)out, g, TR);
+        if (half) {
+            BLZ_TRY(ensure_dynamic_lds((const void*)k_ntt512_rr<Fr, PASS, true>, 160 * 1024));
+            hipLaunchKernelGGL((k_ntt512_rr<Fr, PASS, true>), dim3((unsigned)tilesr), dim3(NR_THREADS), ldsr, st, (const uint32_t*)in,
+                               (uint32_t*)out, g, TR);
+        } else {
+            BLZ_TRY(ensure_dynamic_lds((const void*)k_ntt512_rr<Fr, PASS, false>, 160 * 1024));
+            hipLaunchKernelGGL((k_ntt512_rr<Fr, PASS, false>), dim3((unsigned)tilesr), dim3(NR_THREADS), ldsr, st, (const uint32_t*)in,
+                               (uint32_t*)out, g, TR);
+        }
         BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
         return BLZ_OK;
     }

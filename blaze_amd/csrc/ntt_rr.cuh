@@ -310,8 +310,14 @@ constexpr int NR_COLS_LOG = 2;
 constexpr int NR_COLS = 1 << NR_COLS_LOG;
 constexpr int NR_THREADS = 64 * NR_COLS;
 
-template <class Fr, int PASS>
-__global__ __launch_bounds__(NR_THREADS, 2) void k_ntt512_rr(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, NttGeom g,
+// HALF: the tile goes through the LDS in two halves, so that a block needs 40 KiB instead of 80 and THREE blocks share a CU
+// (the registers allow three waves per SIMD; with a whole tile in the LDS two blocks are all that fit, and the waves then
+// wait ~30 % of their time at the barriers and the tile loads with nobody to take the multiplier).  Both exchanges move
+// outputs K = 0..3 first and K = 4..7 second: the consumers of an output K of the first exchange are the lanes with
+// k1 = K - waves 0 and 1 for the first half, waves 2 and 3 for the second - and of the second exchange the lanes with
+// k1' = K of the same wave.  Costs: three more block barriers and four outputs kept in registers across a half.
+template <class Fr, int PASS, bool HALF>
+__global__ __launch_bounds__(NR_THREADS, HALF ? 3 : 2) void k_ntt512_rr(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, NttGeom g,
                                                             NttTablesRR T) {
     using Q = typename Fr::RR;
     constexpr uint32_t ES = rr_stride<Q>();  // element stride in LDS and in the tables (dwords)
@@ -330,11 +336,12 @@ __global__ __launch_bounds__(NR_THREADS, 2) void k_ntt512_rr(const uint32_t* __r
             // swz = 1 + s: the lowest s bits of the tile number pick the column group instead, so that 2^s tiles dispatched
             // back to back read ADJACENT 128-byte pieces of every row (one DRAM row activation serves them): pass 1 5.46 -> 5.19
             // ms at s = 3 (15.34 -> 15.15 ms per transform, same box; s = 2: 15.20, s = 4: 15.45, s = 5: 15.8).
-            const uint32_t sb = T.swz - 1u;                       // 0 .. 5
+            const uint32_t sb = (T.swz & 15u) - 1u;               // 0 .. 5
+            const uint32_t ib = (T.swz >> 4) ? (T.swz >> 4) : 7u; // bits of i1 walked before the next column groups
             const uint64_t lowcol = tile & ((1u << sb) - 1u);
             const uint64_t t2 = tile >> sb;
-            fixed = (t2 & 127u) | ((tile >> 14) << 7);
-            col_base = (lowcol | (((t2 >> 7) & (127u >> sb)) << sb)) << NR_COLS_LOG;
+            fixed = (t2 & ((1u << ib) - 1u)) | ((tile >> (ib + 7u)) << ib);
+            col_base = (lowcol | (((t2 >> ib) & (127u >> sb)) << sb)) << NR_COLS_LOG;
         } else {
             fixed = tile / tiles_per;
             col_base = (tile % tiles_per) << NR_COLS_LOG;
@@ -380,48 +387,117 @@ __global__ __launch_bounds__(NR_THREADS, 2) void k_ntt512_rr(const uint32_t* __r
         rr_from_words<Q>(a1[j], x.v);
     }
     auto o1 = dft8_rr<Q>(a1, w1, w2, w3);
-    BLZ_RR_FOR8(o1, {   // * w512^(n2 k1); the un-twiddled output (k1 = 0) is brought below 2m without a product
-        W t;
-        if constexpr (K == 0) {
-            t = rr_reduce2m(X);
-        } else {
-            WT w;
-            rr_load_shoup<Q>(w, wp + (size_t)(n2 * K) * ES2);
-            rr_mul_n(t, X, w);
-        }
-        rr_lds_store(lds, (64u * K + n2) * RS + col * ES, t);
-    })
-    __syncthreads();
-    // ---- step 2a: lane (k1, n2', col): 8-point DFTs over n1' (rows 64 k1 + 8 n1' + n2')
     const uint32_t k1 = n2 >> 3, n2p = n2 & 7u;
     W a2[8];
+    if constexpr (!HALF) {
+        BLZ_RR_FOR8(o1, {   // * w512^(n2 k1); the un-twiddled output (k1 = 0) is brought below 2m without a product
+            W t;
+            if constexpr (K == 0) {
+                t = rr_reduce2m(X);
+            } else {
+                WT w;
+                rr_load_shoup<Q>(w, wp + (size_t)(n2 * K) * ES2);
+                rr_mul_n(t, X, w);
+            }
+            rr_lds_store(lds, (64u * K + n2) * RS + col * ES, t);
+        })
+        __syncthreads();
+        // ---- step 2a: lane (k1, n2', col): 8-point DFTs over n1' (rows 64 k1 + 8 n1' + n2')
 #pragma unroll
-    for (int j = 0; j < 8; ++j) rr_lds_load(a2[j], lds, (64u * k1 + 8u * BR[j] + n2p) * RS + col * ES);
-    auto o2 = dft8_rr<Q>(a2, w1, w2, w3);
-    // no barrier: the lane overwrites exactly the 8 elements it has just read (rows 64 k1 + 8 j + n2', its column)
-    BLZ_RR_FOR8(o2, {   // * w64^(n2' k1') = w512^(8 n2' k1')
-        W t;
-        if constexpr (K == 0) {
-            t = rr_reduce2m(X);
-        } else {
-            WT w;
-            rr_load_shoup<Q>(w, wp + (size_t)(8u * n2p * K) * ES2);
-            rr_mul_n(t, X, w);
+        for (int j = 0; j < 8; ++j) rr_lds_load(a2[j], lds, (64u * k1 + 8u * BR[j] + n2p) * RS + col * ES);
+    } else {
+        // first half: outputs K = 0..3 at rows 64 K + n2, read by the lanes with k1 < 4 (waves 0, 1); second half:
+        // K = 4..7 at rows 64 (K - 4) + n2, read by waves 2, 3
+        W keep[4];
+        BLZ_RR_FOR8(o1, {
+            W t;
+            if constexpr (K == 0) {
+                t = rr_reduce2m(X);
+            } else {
+                WT w;
+                rr_load_shoup<Q>(w, wp + (size_t)(n2 * K) * ES2);
+                rr_mul_n(t, X, w);
+            }
+            if constexpr (K < 4) rr_lds_store(lds, (64u * K + n2) * RS + col * ES, t);
+            else keep[K - 4] = t;
+        })
+        __syncthreads();
+        if (k1 < 4) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rr_lds_load(a2[j], lds, (64u * k1 + 8u * BR[j] + n2p) * RS + col * ES);
         }
-        rr_lds_store(lds, (64u * k1 + 8u * K + n2p) * RS + col * ES, t);
-    })
-    // the second exchange stays inside the 32 lanes that share k1 (n2 = 8 k1 + 0..7, four columns): one wave, whose LDS
-    // operations complete in order - a wave-level fence instead of a block barrier
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __syncthreads();
+#pragma unroll
+        for (int K = 4; K < 8; ++K) rr_lds_store(lds, (64u * (K - 4) + n2) * RS + col * ES, keep[K - 4]);
+        __syncthreads();
+        if (k1 >= 4) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rr_lds_load(a2[j], lds, (64u * (k1 - 4u) + 8u * BR[j] + n2p) * RS + col * ES);
+        }
+        __syncthreads();   // the second exchange reuses the rows
+    }
+    auto o2 = dft8_rr<Q>(a2, w1, w2, w3);
+    const uint32_t k1p = n2 & 7u;
+    W a3[8];
+    if constexpr (!HALF) {
+        // no barrier: the lane overwrites exactly the 8 elements it has just read (rows 64 k1 + 8 j + n2', its column)
+        BLZ_RR_FOR8(o2, {   // * w64^(n2' k1') = w512^(8 n2' k1')
+            W t;
+            if constexpr (K == 0) {
+                t = rr_reduce2m(X);
+            } else {
+                WT w;
+                rr_load_shoup<Q>(w, wp + (size_t)(8u * n2p * K) * ES2);
+                rr_mul_n(t, X, w);
+            }
+            rr_lds_store(lds, (64u * k1 + 8u * K + n2p) * RS + col * ES, t);
+        })
+        // the second exchange stays inside the 32 lanes that share k1 (n2 = 8 k1 + 0..7, four columns): one wave, whose LDS
+        // operations complete in order - a wave-level fence instead of a block barrier
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rr_lds_load(a3[j], lds, (64u * k1 + 8u * k1p + BR[j]) * RS + col * ES);
+    } else {
+        // a wave's 64 rows of the half tile: (k1 & 1) 32 + 8 (K mod 4) + n2'; readers k1' < 4 first, then k1' >= 4
+        const uint32_t wrow = (threadIdx.x >> 6) * 64u + (k1 & 1u) * 32u;
+        W keep[4];
+        BLZ_RR_FOR8(o2, {
+            W t;
+            if constexpr (K == 0) {
+                t = rr_reduce2m(X);
+            } else {
+                WT w;
+                rr_load_shoup<Q>(w, wp + (size_t)(8u * n2p * K) * ES2);
+                rr_mul_n(t, X, w);
+            }
+            if constexpr (K < 4) rr_lds_store(lds, (wrow + 8u * K + n2p) * RS + col * ES, t);
+            else keep[K - 4] = t;
+        })
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (k1p < 4) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rr_lds_load(a3[j], lds, (wrow + 8u * k1p + BR[j]) * RS + col * ES);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int K = 4; K < 8; ++K) rr_lds_store(lds, (wrow + 8u * (K - 4) + n2p) * RS + col * ES, keep[K - 4]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (k1p >= 4) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rr_lds_load(a3[j], lds, (wrow + 8u * (k1p - 4u) + BR[j]) * RS + col * ES);
+        }
+    }
     // ---- step 2b: lane (k1, k1', col): 8-point DFTs over n2' (rows 64 k1 + 8 k1' + n2'); outputs k = k1 + 8 k1' + 64 k2'
     // leave with the inter-pass twiddle (passes 1, 2) or the closing factor (pass 3), which also brings them back
     // below 2m for the 32-byte word
-    const uint32_t k1p = n2 & 7u;
-    W a3[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) rr_lds_load(a3[j], lds, (64u * k1 + 8u * k1p + BR[j]) * RS + col * ES);
     auto o3 = dft8_rr<Q>(a3, w1, w2, w3);
     const uint32_t kb = k1 + 8u * k1p;  // output row of x_(k2') is kb + 64 k2'
     // Boundary factors.  Between passes 1 and 2 every element owes w^(k2 (i0 + A i1)), between 2 and 3 w^(C i0 k1).
