@@ -215,8 +215,12 @@ BLZ_DEV void rr_shoup_hi(uint64_t& acc, uint32_t (&q)[Q::NL], const uint32_t (&x
 template <class Q, int K>
 BLZ_DEV void rr_shoup_lo(uint64_t& acc, uint32_t (&r)[Q::NL], const uint32_t (&x)[Q::NL], const uint32_t (&w)[Q::NL],
                          const uint32_t (&q)[Q::NL]) {
-    rr_ab<Q::NL, K>(acc, x, w);
-    rr_as<Q::NL, K>(acc, q, Q::MBAR);
+    if constexpr (rr_lo2_ok(K)) {
+        rr_abqs<Q::NL, K>(acc, x, w, q, Q::MBAR);
+    } else {
+        rr_ab<Q::NL, K>(acc, x, w);
+        rr_as<Q::NL, K>(acc, q, Q::MBAR);
+    }
     r[K] = (uint32_t)acc & Q::MASK;
     acc >>= Q::B;
 }
@@ -229,6 +233,73 @@ BLZ_DEV void rr_shoup_columns(uint32_t (&r)[Q::NL], const uint32_t (&x)[Q::NL], 
     q[Q::NL - 1] = (uint32_t)acc;
     acc = 0;
     (rr_shoup_lo<Q, Ls>(acc, r, x, t.w, q), ...);             // columns 0 .. NL - 1
+}
+// The same entry held in SGPRs: a twiddle every lane of the wave shares (the w8 powers inside an 8-point DFT).  Its
+// multiply-adds take the constant as their scalar operand (rr_as); as a VGPR operand each use cost a v_mov from the SGPR the
+// compiler keeps the uniform value in: 18 per product, 15 products per lane and pass.
+template <class Q>
+struct RRShoupU {
+    uint32_t w[Q::NL];
+    uint32_t wq[Q::NL];
+};
+template <class Q>
+BLZ_DEV void rr_shoup_uniform(RRShoupU<Q>& u, const RRShoup<Q>& t) {
+#pragma unroll
+    for (int i = 0; i < Q::NL; ++i) {
+        u.w[i] = __builtin_amdgcn_readfirstlane(t.w[i]);
+        u.wq[i] = __builtin_amdgcn_readfirstlane(t.wq[i]);
+    }
+}
+template <class Q, int K>
+BLZ_DEV void rr_shoup_hi_u(uint64_t& acc, uint32_t (&q)[Q::NL], const uint32_t (&x)[Q::NL], const uint32_t (&wq)[Q::NL]) {
+    rr_as<Q::NL, K>(acc, x, wq);
+    if constexpr (K >= Q::NL) q[K - Q::NL] = (uint32_t)acc & Q::MASK;
+    acc >>= Q::B;
+}
+template <class Q, int K>
+BLZ_DEV void rr_shoup_lo_u(uint64_t& acc, uint32_t (&r)[Q::NL], const uint32_t (&x)[Q::NL], const uint32_t (&w)[Q::NL],
+                           const uint32_t (&q)[Q::NL]) {
+    if constexpr (rr_lo2_ok(K)) {
+        rr_asqs<Q::NL, K>(acc, x, w, q, Q::MBAR);
+    } else {
+        rr_as<Q::NL, K>(acc, x, w);
+        rr_as<Q::NL, K>(acc, q, Q::MBAR);
+    }
+    r[K] = (uint32_t)acc & Q::MASK;
+    acc >>= Q::B;
+}
+template <class Q, int... Hs, int... Ls>
+BLZ_DEV void rr_shoup_columns_u(uint32_t (&r)[Q::NL], const uint32_t (&x)[Q::NL], const RRShoupU<Q>& t, std::integer_sequence<int, Hs...>,
+                                std::integer_sequence<int, Ls...>) {
+    uint32_t q[Q::NL];
+    uint64_t acc = 0;
+    (rr_shoup_hi_u<Q, Q::NL - 2 + Hs>(acc, q, x, t.wq), ...);
+    q[Q::NL - 1] = (uint32_t)acc;
+    acc = 0;
+    (rr_shoup_lo_u<Q, Ls>(acc, r, x, t.w, q), ...);
+}
+template <class Q>
+BLZ_DEV void rr_shoup_fix(Frr<Q, 1, 2>& r, uint32_t (&o)[Q::NL]) {
+    if (__builtin_expect(o[Q::NL - 1] >= Q::T2M, 0)) {   // in [2m - eps, 3m): take m off (top limb < T2M means < 2m)
+        uint32_t borrow = 0;
+#pragma unroll
+        for (int i = 0; i < Q::NL - 1; ++i) {
+            const uint32_t d = o[i] - Q::MOD[i] - borrow;
+            borrow = d >> 31;
+            o[i] = d & Q::MASK;
+        }
+        o[Q::NL - 1] = o[Q::NL - 1] - Q::MOD[Q::NL - 1] - borrow;
+    }
+#pragma unroll
+    for (int i = 0; i < Q::NL; ++i) r.v[i] = o[i];
+}
+template <class Q, int F, int V>
+BLZ_DEV void rr_mul_shoup(Frr<Q, 1, 2>& r, const Frr<Q, F, V>& x, const RRShoupU<Q>& t) {
+    static_assert(Q::NL == 9, "the constant-operand columns (rr_as) are generated for 9 limbs");
+    static_assert(rr_cols_ok<Q>(F), "column sum would overflow 64 bits: normalise x");
+    uint32_t o[Q::NL];
+    rr_shoup_columns_u<Q>(o, x.v, t, std::make_integer_sequence<int, Q::NL + 1>{}, std::make_integer_sequence<int, Q::NL>{});
+    rr_shoup_fix<Q>(r, o);
 }
 template <class Q, int F, int V>
 BLZ_DEV void rr_mul_shoup(Frr<Q, 1, 2>& r, const Frr<Q, F, V>& x, const RRShoup<Q>& t) {

@@ -99,6 +99,11 @@ BLZ_DEV void rr_mul_n(Frr<Q, 1, 2>& r, const Frr<Q, Fa, Va>& a, const RRShoup<Q>
     if constexpr (rr_cols_ok<Q>(Fa)) rr_mul_shoup(r, a, t);
     else rr_mul_shoup(r, rr_norm(a), t);
 }
+template <class Q, int Fa, int Va>
+BLZ_DEV void rr_mul_n(Frr<Q, 1, 2>& r, const Frr<Q, Fa, Va>& a, const RRShoupU<Q>& t) {
+    if constexpr (rr_cols_ok<Q>(Fa)) rr_mul_shoup(r, a, t);
+    else rr_mul_shoup(r, rr_norm(a), t);
+}
 // Shoup table entries: w | wq, rr_stride dwords each
 template <class Q>
 constexpr int rr_shoup_stride() { return 2 * rr_stride<Q>(); }
@@ -368,10 +373,16 @@ __global__ __launch_bounds__(NR_THREADS, HALF ? 3 : 2) void k_ntt512_rr(const ui
     constexpr uint32_t ES2 = rr_shoup_stride<Q>();
     using WT = RRShoup<Q>;     // table twiddles: Shoup products (field_rr.cuh): 143 multiply-adds, no Montgomery factor
     using W = Frr<Q, 1, 2>;    // stepped twiddles (Montgomery form) and data
-    WT w1, w2, w3;
-    rr_load_shoup<Q>(w1, wp + 64 * ES2);
-    rr_load_shoup<Q>(w2, wp + 128 * ES2);
-    rr_load_shoup<Q>(w3, wp + 192 * ES2);
+    RRShoupU<Q> w1, w2, w3;   // the w8 powers inside the 8-point DFTs: the same for every lane, kept in SGPRs
+    {
+        WT t;
+        rr_load_shoup<Q>(t, wp + 64 * ES2);
+        rr_shoup_uniform<Q>(w1, t);
+        rr_load_shoup<Q>(t, wp + 128 * ES2);
+        rr_shoup_uniform<Q>(w2, t);
+        rr_load_shoup<Q>(t, wp + 192 * ES2);
+        rr_shoup_uniform<Q>(w3, t);
+    }
 
     // ---- step 1: 8-point DFTs over n1 (rows 64 n1 + n2), straight from global memory.  The words on the wire are
     // any 256-bit value (canonical on the wire by contract; a stray one is still reduced correctly); between passes

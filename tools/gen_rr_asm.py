@@ -71,6 +71,21 @@ def emit_as(NL, K):
             f"        : [acc] \"+v\"(acc)\n        : {', '.join(ins)}\n        : \"vcc\");\n}}\n")
 
 
+def emit_lo2(NL, K, uniform):
+    """Shoup product, low half, column K < NL in ONE statement: a (VGPRs) times b (VGPRs; `uniform`: SGPRs) plus q (VGPRs)
+    times the constant s (SGPRs).  4 (K + 1) + 1 operands: K <= 6."""
+    idx = list(range(0, K + 1))
+    lines = [f'"v_mad_u64_u32 %[acc], vcc, %[a{i}], %[b{K - i}], %[acc]\\n\\t"' for i in idx]
+    lines += [f'"v_mad_u64_u32 %[acc], vcc, %[q{i}], %[s{K - i}], %[acc]\\n\\t"' for i in idx]
+    bc = "s" if uniform else "v"
+    ins = ([f'[a{i}] "v"(a[{i}])' for i in idx] + [f'[b{K - i}] "{bc}"(b[{K - i}])' for i in idx] +
+           [f'[q{i}] "v"(q[{i}])' for i in idx] + [f'[s{K - i}] "s"(s[{K - i}])' for i in idx])
+    name = "rr_asqs" if uniform else "rr_abqs"
+    return (f"template <> BLZ_DEV void {name}<{NL}, {K}>(uint64_t& acc, const uint32_t (&a)[{NL}], const uint32_t (&b)[{NL}], const uint32_t (&q)[{NL}], const uint32_t (&s)[{NL}]) {{\n"
+            f"    asm({chr(10).join('        ' + l for l in lines).lstrip()}\n"
+            f"        : [acc] \"+v\"(acc)\n        : {', '.join(ins)}\n        : \"vcc\");\n}}\n")
+
+
 def fused_ok(NL, K):
     """Can the caller's products and the reduction products of column K share one asm statement (30 operands)?"""
     n_ab = K + 1 if K < NL else 2 * NL - 1 - K
@@ -108,7 +123,11 @@ def main():
            "}",
            "template <int NL, int K> BLZ_DEV void rr_abqm(uint64_t& acc, const uint32_t (&a)[NL], const uint32_t (&b)[NL], const uint32_t (&q)[NL], const uint32_t (&m)[NL]);",
            "// full column of a times a wave-uniform constant (the low half of the Shoup product)",
-           "template <int NL, int K> BLZ_DEV void rr_as(uint64_t& acc, const uint32_t (&a)[NL], const uint32_t (&s)[NL]);\n"]
+           "template <int NL, int K> BLZ_DEV void rr_as(uint64_t& acc, const uint32_t (&a)[NL], const uint32_t (&s)[NL]);",
+           "// a low column of the Shoup product in one statement (K <= 6: 30 operands): a b + q s, b in VGPRs / in SGPRs",
+           "constexpr bool rr_lo2_ok(int K) { return 4 * (K + 1) + 1 <= 30; }",
+           "template <int NL, int K> BLZ_DEV void rr_abqs(uint64_t& acc, const uint32_t (&a)[NL], const uint32_t (&b)[NL], const uint32_t (&q)[NL], const uint32_t (&s)[NL]);",
+           "template <int NL, int K> BLZ_DEV void rr_asqs(uint64_t& acc, const uint32_t (&a)[NL], const uint32_t (&b)[NL], const uint32_t (&q)[NL], const uint32_t (&s)[NL]);\n"]
     for NL in (9, 14):
         for K in range(2 * NL - 1):
             out.append(emit_ab(NL, K))
@@ -116,7 +135,10 @@ def main():
             out.append(emit_qm(NL, K))
             if fused_ok(NL, K):
                 out.append(emit_abqm(NL, K))
-            if NL == 9 and K < NL:
+            if NL == 9 and K < NL and 4 * (K + 1) + 1 <= 30:
+                out.append(emit_lo2(NL, K, False))
+                out.append(emit_lo2(NL, K, True))
+            if NL == 9:   # K < NL: the q * (R - m) half of the Shoup product; every K: products by a wave-uniform twiddle
                 out.append(emit_as(NL, K))
     with open(dst, "w") as f:
         f.write("\n".join(out))
