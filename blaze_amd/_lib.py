@@ -72,6 +72,8 @@ _SIGS = {
     "blz_msm_set_window_table": (C.c_int, [C.c_void_p, C.c_int]),
     "blz_msm_set_scalar_range": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
     "blz_msm_shard_layout": (C.c_int, [C.c_int, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_uint32)]),
+    "blz_msm_shard_layout_ex": (C.c_int, [C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "blz_msm_shard_layout_candidate": (C.c_int, [C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_uint32, C.c_int, C.POINTER(C.c_uint32)]),
     "blz_msm_window_table_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "blz_msm_plan": (C.c_int, [C.c_int, C.c_uint32, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)]),
     "blz_ntt_new": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p)]),

@@ -34,6 +34,30 @@ def shard_layout(curve, n: int, rank: int, world: int) -> dict:
     return {"first": int(out[0]), "count": int(out[1]), "bit_lo": int(out[2]), "bit_hi": int(out[3])}
 
 
+SHARD_SCALARS_FROM_HOST = 1   # include/blaze_hip.h BLZ_SHARD_*: the scalars cross the rank's PCIe link with every task
+SHARD_BASES_FROM_HOST = 2     # ... and the bases too (DMA flow)
+
+
+def _layout_dict(out) -> dict:
+    return {"first": int(out[0]), "count": int(out[1]), "bit_lo": int(out[2]), "bit_hi": int(out[3]), "ranges": int(out[4]),
+            "est_compute_ms": out[5] / 1e3, "est_link_ms": out[6] / 1e3, "device_mib": int(out[7])}
+
+
+def shard_layout_ex(curve, n: int, rank: int, world: int, flags: int = 0, ranges: int | None = None) -> dict:
+    """blz_msm_shard_layout_ex: the split with the flow's transfers priced in (flags: SHARD_*); `ranges` asks for the
+    estimates of one candidate (R scalar ranges) instead of the library's pick."""
+    import ctypes as C
+
+    from ._lib import check, lib
+
+    out = (C.c_uint32 * 8)()
+    if ranges is None:
+        check(lib().blz_msm_shard_layout_ex(int(curve), n, world, rank, flags, out))
+    else:
+        check(lib().blz_msm_shard_layout_candidate(int(curve), n, world, rank, flags, ranges, out))
+    return _layout_dict(out)
+
+
 def all_gather_partials(partial: bytes, dist, device=None) -> bytes:
     """One all-gather of the fixed-size partial results, returned concatenated in rank order."""
     import torch

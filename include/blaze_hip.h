@@ -194,6 +194,21 @@ int blz_msm_set_scalar_range(blz_msm* h, uint32_t bit_lo, uint32_t bit_hi);
  * cost estimate of a rank's task; rank = chunk * R + range.  BLAZE_SHARD=elements forces the element split (R = 1),
  * BLAZE_SHARD=bits the largest R.  Host-side only (no device needed). */
 int blz_msm_shard_layout(int curve, uint32_t nof_elements, int nranks, int rank, uint32_t out[4]);
+/* The same choice with the flow's transfers priced in.  A split into R scalar ranges makes the R ranks of a range group need
+ * the SAME element chunk: R x the scalar bytes per rank on its PCIe link when the scalars come from host memory with every
+ * task (the reference's HBM flow, tests/integration_msm_hbm.rs:57-100), R x the bases per rank in device memory - and on
+ * the link too when the bases travel with every task (DMA flow).  With t = bytes over the rank's link / 56 GB/s (measured)
+ * and c = the window planner's compute estimate, cost(R) = max(c + 0.15 t, 1.1 t) per task (a stream of tasks overlaps the
+ * two, not for free: profiles/r04_shard_layouts.txt), and a layout whose per-rank bases and scalars exceed half of the
+ * device memory is not considered.  R > 1 is taken only when it beats the element split by more than
+ * 2 % (the simpler layout wins ties).  flags: BLZ_SHARD_SCALARS_FROM_HOST, BLZ_SHARD_BASES_FROM_HOST; 0 = everything
+ * resident (what blz_msm_shard_layout prices).  out = {first element, element count, bit_lo, bit_hi, R, estimated compute us,
+ * estimated link us, device MiB per rank (bases raw + Montgomery copy + scalars)}.  Host-side only. */
+#define BLZ_SHARD_SCALARS_FROM_HOST 1u
+#define BLZ_SHARD_BASES_FROM_HOST 2u
+int blz_msm_shard_layout_ex(int curve, uint32_t nof_elements, int nranks, int rank, uint32_t flags, uint32_t out[8]);
+/* the estimates of one candidate (R ranges) for tools and tests: out as above; InvalidPrimitiveParam if R does not divide nranks */
+int blz_msm_shard_layout_candidate(int curve, uint32_t nof_elements, int nranks, int rank, uint32_t flags, int R, uint32_t out[8]);
 
 /* Multi-GPU: add G partial results (each result_size bytes, as returned by blz_msm_result on each
  * rank, in rank order) on this handle's device and emit the normalised sum, for hosts that move the

@@ -50,6 +50,8 @@ extern "C" {
     pub fn blz_msm_set_window_table(h: *mut BlzMsm, enable: c_int) -> c_int;
     pub fn blz_msm_set_scalar_range(h: *mut BlzMsm, bit_lo: u32, bit_hi: u32) -> c_int;
     pub fn blz_msm_shard_layout(curve: c_int, nof_elements: u32, nranks: c_int, rank: c_int, out: *mut u32) -> c_int;
+    pub fn blz_msm_shard_layout_ex(curve: c_int, nof_elements: u32, nranks: c_int, rank: c_int, flags: u32, out: *mut u32) -> c_int;
+    pub fn blz_msm_shard_layout_candidate(curve: c_int, nof_elements: u32, nranks: c_int, rank: c_int, flags: u32, r: c_int, out: *mut u32) -> c_int;
     pub fn blz_msm_window_table_info(h: *mut BlzMsm, out: *mut u64) -> c_int;
     pub fn blz_msm_last_timings(h: *mut BlzMsm, out: *mut f32) -> c_int;
     pub fn blz_msm_last_sort_hidden(h: *mut BlzMsm, out: *mut c_int) -> c_int;

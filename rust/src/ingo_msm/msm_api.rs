@@ -186,6 +186,13 @@ impl MSMClient {
         check(unsafe { blz_msm_shard_layout(curve.code(), nof_elements, nranks, rank, out.as_mut_ptr()) })?;
         Ok(out)
     }
+    /// The same choice with the flow's transfers priced in (`flags`: 1 = scalars from host memory with every task, 2 = bases
+    /// too): `[first, count, bit_lo, bit_hi, ranges, compute us, link us, device MiB per rank]`.
+    pub fn shard_layout_ex(curve: Curve, nof_elements: u32, nranks: i32, rank: i32, flags: u32) -> Result<[u32; 8]> {
+        let mut out = [0u32; 8];
+        check(unsafe { blz_msm_shard_layout_ex(curve.code(), nof_elements, nranks, rank, flags, out.as_mut_ptr()) })?;
+        Ok(out)
+    }
     /// `[table bytes, window bits, windows, build time in microseconds]` of the table the last HBM task used.
     pub fn window_table_info(&self) -> Result<[u64; 4]> {
         let mut out = [0u64; 4];

@@ -295,3 +295,30 @@ def test_shard_layout_tiles_elements_and_bits():
     assert picks[2]["count"] == 1 << 26 and picks[2]["bit_hi"] == 128
     assert picks[4]["count"] == 1 << 26 and picks[4]["bit_hi"] == 64
     assert picks[8]["bit_hi"] < 256
+    # blz_msm_shard_layout_ex prices the flow's transfers: R scalar ranges make a rank receive R x the
+    # scalar bytes and hold R x the bases.  Everything resident: the picks above.  Scalars from host memory with every task
+    # (the reference's HBM flow): four ranks may not take all 2^26 scalars each (2 GiB = 38 ms over the link against a ~32 ms
+    # task), and even a hidden upload costs ~15 % of its duration: the element split; bases travelling too (DMA flow): same.
+    from blaze_amd.multi_gpu import SHARD_BASES_FROM_HOST, SHARD_SCALARS_FROM_HOST, shard_layout_ex
+    for w in (2, 4, 8):
+        res = shard_layout_ex(Curve.BLS381, 1 << 26, 0, w, 0)
+        assert (res["first"], res["count"], res["bit_lo"], res["bit_hi"]) == tuple(picks[w][k] for k in ("first", "count", "bit_lo", "bit_hi"))
+        assert res["est_link_ms"] == 0 and res["device_mib"] == res["count"] * (96 + 128 + 32) // (1 << 20)
+        host = shard_layout_ex(Curve.BLS381, 1 << 26, 0, w, SHARD_SCALARS_FROM_HOST)
+        assert host["ranges"] == 1            # measured (profiles/r04_shard_layouts.txt): the element split wins at 2, 4 and 8 ranks
+        assert abs(host["est_link_ms"] - host["count"] * 32 / 56.3e6) < 0.01
+        dma = shard_layout_ex(Curve.BLS381, 1 << 26, 0, w, SHARD_SCALARS_FROM_HOST | SHARD_BASES_FROM_HOST)
+        assert dma["ranges"] == 1 and dma["count"] == (1 << 26) // w
+        # candidates: same rectangles, R x the bytes
+        for R in (1, 2, 4, 8):
+            if w % R == 0:
+                c = shard_layout_ex(Curve.BLS381, 1 << 26, 0, w, SHARD_SCALARS_FROM_HOST, R)
+                assert c["ranges"] == R and c["count"] == (1 << 26) * R // w and c["bit_hi"] == 256 // R
+    # every rank of a transfer-aware layout still tiles the job
+    for flags in (SHARD_SCALARS_FROM_HOST, SHARD_SCALARS_FROM_HOST | SHARD_BASES_FROM_HOST):
+        for w in (2, 3, 4, 6, 8):
+            area = 0
+            for r in range(w):
+                l = shard_layout_ex(Curve.BLS377, (1 << 24) + 3, r, w, flags)
+                area += l["count"] * (l["bit_hi"] - l["bit_lo"])
+            assert area == ((1 << 24) + 3) * 256
