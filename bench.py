@@ -196,9 +196,12 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if "MASTER_PORT" not in os.environ:
+            if world > 1:   # every rank picking its own port would rendezvous nowhere, until the watchdog fires
+                raise SystemExit("bench: WORLD_SIZE > 1 without MASTER_PORT - start the ranks with torch.distributed.run "
+                                 "(or `python bench.py --gpus N`, which does)")
             import socket
 
-            with socket.socket() as so:
+            with socket.socket() as so:   # the one-rank BLAZE_BENCH_FORCE_EXCHANGE path
                 so.bind(("127.0.0.1", 0))
                 os.environ["MASTER_PORT"] = str(so.getsockname()[1])
         # "nccl" is RCCL on ROCm (xGMI between the GPUs of the node).  BLAZE_BENCH_BACKEND=gloo with
@@ -223,14 +226,15 @@ def main():
     from blaze_amd._lib import check
     from blaze_amd.driver_client import DriverClient
     from blaze_amd.ingo_msm import Curve, MSMClient, MSMInit, MSMInput, MSMParams, PointMemoryType
-    from blaze_amd.multi_gpu import shard_layout, sharded_msm
+    from blaze_amd.multi_gpu import SHARD_SCALARS_FROM_HOST, shard_layout_ex, sharded_msm
 
     L = blaze_amd.lib()
     n = 1 << LOG_N
     # rank's shard: an element chunk x a range of the scalars' bits (blz_msm_shard_layout: the library picks the mix by the
     # window planner's cost - 2 and 4 ranks split the bits of all 2^26 elements, 8 ranks take 64-bit ranges of half of the
     # elements each; BLAZE_SHARD=elements forces the plain element split).  Partial results add up either way.
-    lay = shard_layout(Curve[CURVE], n, rank, world)
+    # (blz_msm_shard_layout_ex prices the flow: the timed loop's scalars are resident, so nothing crosses a rank's link)
+    lay = shard_layout_ex(Curve[CURVE], n, rank, world, 0)
     lo, n_loc = lay["first"], lay["count"]
     ranged = (lay["bit_lo"], lay["bit_hi"]) != (0, 256)
     cid = int(Curve[CURVE])
@@ -477,7 +481,7 @@ def main():
     # after it, reached by every rank whatever happened to it (N > 1: the ranks' tasks are timed without the 144-byte exchange)
     if hbm_mode and not args.no_extras and os.environ.get("BLAZE_BENCH_TABLE", "1") == "1":
         wd.arm(900, "window-table leg")
-        terr, tdt, tinfo, first_ms, tkernel = None, -1.0, {}, 0.0, 0.0
+        terr, tdt, tinfo, first_ms, tkernel, n_before, until_ms, paced_ms = None, -1.0, {"bytes": 0, "window_bits": 0, "windows": 0, "build_ms": 0.0}, 0.0, 0.0, 0, 0.0, 0.0
         k_t = args.steps
         tcl = None
         try:
@@ -507,11 +511,27 @@ def main():
                         pending += 1
                 return out
 
+            # The build is paced by the tasks (msm_capi.hip arena_points_table): every task over the bases first enqueues two
+            # ~9 ms chunks of it and takes the plain path until the table is complete.  first_task_ms is the first task's
+            # latency (plain path + its two chunks); a few more tasks show the surcharge in a stream; then the host says it
+            # would rather have the table now (prepare_window_table with a wait: all the remaining chunks at once) and the
+            # steady state is timed.
             t1 = time.perf_counter()
-            tsubmit()                       # the first task over these bases builds the table (synchronous)
-            tinfo = tcl.window_table_info()
+            tsubmit()
             first = tcollect()
             first_ms = (time.perf_counter() - t1) * 1e3
+            t_sw = time.perf_counter()
+            paced = trun(4)
+            paced_ms = (time.perf_counter() - t_sw) / 4 * 1e3
+            n_before = 5
+            if any(r_ != first[0] for r_, _ in paced):
+                raise RuntimeError("results differ while the table is being built")
+            t_sw = time.perf_counter()
+            tcl.prepare_window_table(n_loc, (0, 0), -1)
+            until_ms = (time.perf_counter() - t_sw) * 1e3
+            tsubmit()
+            tinfo = tcl.window_table_info()
+            tcollect()
             trun(max(2, args.warmup))
             torch.cuda.synchronize(tdev)
             t1 = time.perf_counter()
@@ -543,59 +563,150 @@ def main():
                 table_rec = {"ms_per_step": round(tdt / k_t * 1e3, 3), "msm_per_s": round(k_t / tdt, 4), "steps": k_t,
                              "used": tinfo["bytes"] > 0, "table_bytes_per_gpu": tinfo["bytes"], "window_bits": tinfo["window_bits"],
                              "windows": tinfo["windows"], "build_ms": round(tinfo["build_ms"], 1),
-                             "first_task_ms_incl_build": round(first_ms, 1), "kernel_ms": round(tkernel, 3),
+                             "first_task_ms": round(first_ms, 1), "ms_per_task_while_building": round(paced_ms, 1),
+                             "tasks_on_the_plain_path": n_before, "prepare_wait_ms": round(until_ms, 1), "kernel_ms": round(tkernel, 3),
                              "result_check": "this rank's result bytes equal its result in the headline loop (which the oracle checked"
                                              + (" after the exchange)" if multi else ")"),
-                             "what": "opt-in blz_msm_set_window_table: the bases' window multiples 2^(c j) P tabulated once per load "
-                                     "(build_ms, outside the timed steps like the load itself), every window's digit added into one bucket "
-                                     "set; same steps / queue as the headline" + (", the slowest rank's time, without the 144-byte exchange" if multi else "")}
+                             "what": "opt-in blz_msm_set_window_table: the bases' window multiples 2^(c j) P tabulated once per load - paced by "
+                                     "the tasks (two ~9 ms chunks ahead of each task, which takes the plain path meanwhile: first_task_ms, "
+                                     "ms_per_task_while_building), the rest at once when the host asks for it (prepare_wait_ms) - then every "
+                                     "window's digit added into one bucket set; same steps / queue as the headline" + (", the slowest rank's time, without the 144-byte exchange" if multi else "")}
+        wd.disarm()
+
+    def stream(cl, prm, pts_in, sc_in, k, on_set=None, on_done=None):
+        """k tasks through `cl`, `queue` in flight (the headline's submission pattern); returns (seconds, results, apis)."""
+        outs, apis, pending = [], [], 0
+        t_0 = time.perf_counter()
+        for _ in range(k):
+            cl.initialize(prm)
+            cl.start_process()
+            t_s = time.perf_counter()
+            cl.set_data(MSMInput(pts_in, sc_in, prm))
+            if on_set is not None:
+                on_set((time.perf_counter() - t_s) * 1e3)
+            pending += 1
+            if pending >= queue:
+                cl.wait_result()
+                outs.append(cl.result().result)
+                apis.append(cl.get_api())
+                if on_done is not None:
+                    on_done(time.perf_counter())
+                pending -= 1
+        while pending:
+            cl.wait_result()
+            outs.append(cl.result().result)
+            apis.append(cl.get_api())
+            if on_done is not None:
+                on_done(time.perf_counter())
+            pending -= 1
+        torch.cuda.synchronize(tdev)
+        return time.perf_counter() - t_0, outs, apis
+
+    def all_ranks(dt_local, err_local):
+        """(max over ranks of a leg's time, error of any rank): every rank calls it once per leg, whatever happened to it"""
+        if not multi:
+            return dt_local, err_local
+        fdev2 = gather_dev if gather_dev is not None else "cpu"
+        t = torch.tensor([dt_local if err_local is None else -1.0, 0.0 if err_local is None else 1.0], dtype=torch.float64, device=fdev2)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if float(t[1].item()) > 0:
+            return -1.0, err_local or "the leg failed on another rank"
+        return float(t[0].item()), None
+
+    # ---- N > 1: the PLAIN ELEMENT SPLIT beside the headline's layout, and the reference's HBM flow per rank (extra keys).
+    # The headline shards by blz_msm_shard_layout_ex's pick for resident scalars (scalar ranges of larger element chunks at
+    # 2 / 4 / 8 ranks); `alt_layout_elements` times the same job cut into plain element chunks, so a scaling run records both
+    # (ADVICE r03: the ranged layout had never met N > 1 hardware).  `hbm_flow` is the layout_ex pick for scalars that come from
+    # host memory with every task - the element split - timed with pageable host scalars.  Each rank's tasks are timed
+    # without the 144-byte exchange (the slowest rank's time is reported); ONE exchange per leg checks the result.
+    alt_rec = None
+    hbm_flow = cfg2 = None
+    el_client, el_params, el_sc, el_pts = client, params, d_sc, None
+    if multi and not args.no_extras and hbm_mode:
+        wd.arm(900, "element-split / hbm_flow legs")
+        err, dt_alt, api_alt, part_alt = None, -1.0, None, None
+        # the element split, asked for by name (R = 1); blz_msm_shard_layout_ex's own pick for host scalars is recorded beside it
+        # (it IS the element split at 2^26 on 2 / 4 / 8 ranks: tests/test_dist.py, profiles/r04_shard_layouts.txt)
+        lay_e = shard_layout_ex(Curve[CURVE], n, rank, world, SHARD_SCALARS_FROM_HOST, 1)
+        pick_host = shard_layout_ex(Curve[CURVE], n, rank, world, SHARD_SCALARS_FROM_HOST)["ranges"]
+        try:
+            if (lay_e["first"], lay_e["count"], lay_e["bit_lo"], lay_e["bit_hi"]) != (lay["first"], lay["count"], lay["bit_lo"], lay["bit_hi"]):
+                el_pts = DeviceBuffer(dev, max(lay_e["count"], 1) * 96)
+                el_sc = DeviceBuffer(dev, max(lay_e["count"], 1) * 32)
+                check(L.blz_synth_points(dev, cid, el_pts.ptr, lay_e["count"], 1, lay_e["first"]))
+                check(L.blz_synth_scalars_at(dev, cid, el_sc.ptr, lay_e["count"], 0xB1A2E, lay_e["first"]))
+                el_client = MSMClient(MSMInit(PointMemoryType.HBM, False, Curve[CURVE]), DriverClient(dev))
+                el_base = 1 << 40   # its own extent of the device arena, far from the headline's bases at 0
+                el_client.load_data_to_hbm(el_pts, el_base, 0)
+                el_params = MSMParams(lay_e["count"], (el_base, 0))
+                if (lay_e["bit_lo"], lay_e["bit_hi"]) != (0, 256):
+                    el_client.set_scalar_range(lay_e["bit_lo"], lay_e["bit_hi"])
+                stream(el_client, el_params, None, el_sc, max(2, args.warmup))
+                dt_alt, outs_alt, apis_alt = stream(el_client, el_params, None, el_sc, args.steps)
+                part_alt, api_alt = outs_alt[-1], apis_alt[-1]
+                if any(o != part_alt for o in outs_alt):
+                    err = "a rank's results differ from task to task"
+        except Exception as e:   # noqa: BLE001 - an extra key, never fatal
+            err = f"{type(e).__name__}: {e}"
+        ran_alt = el_client is not client
+        dt_alt, err = all_ranks(dt_alt if ran_alt else 0.0, err)
+        if err is None and ran_alt:
+            full = sharded_msm(part_alt, client.combine_partials, dist, gather_dev)
+            if full != res:
+                err = "the element split's combined result differs from the headline's"
+        if rank == 0:
+            if err is not None:
+                alt_rec = {"error": err}
+            elif ran_alt:
+                alt_rec = {"ms_per_step": round(dt_alt / args.steps * 1e3, 3), "msm_per_s": round(args.steps / dt_alt, 4), "steps": args.steps,
+                           "shard_rank0": lay_e, "kernel_ms": round(api_alt["accumulate_kernel_ms"], 3),
+                           "what": "the same job cut into plain element chunks (BLAZE_SHARD=elements would make it the headline): the slowest "
+                                   "rank's time per task, two in flight, without the 144-byte exchange",
+                           "result_check": "one exchange of the ranks' partials: bytes equal the headline result (which the oracle checked)"}
+            else:
+                alt_rec = {"same_as_headline": True}
+        # the reference's HBM flow on every rank: bases resident, the rank's scalars from pageable host memory with every task
+        err, dt_h, part_h, set_ms, done_at = None, -1.0, None, [], []
+        k_hf = max(4, min(args.steps, 8))
+        try:
+            sc_host = el_sc.download()
+            stream(el_client, el_params, None, sc_host, 2)
+            dt_h, outs_h, _ = stream(el_client, el_params, None, sc_host, k_hf, on_set=set_ms.append, on_done=done_at.append)
+            part_h = outs_h[-1]
+            if any(o != part_h for o in outs_h):
+                err = "a rank's results differ from task to task"
+            del sc_host
+        except Exception as e:   # noqa: BLE001
+            err = f"{type(e).__name__}: {e}"
+        gaps = [(b_ - a_) * 1e3 for a_, b_ in zip(done_at, done_at[1:])]
+        steady = statistics.median(gaps) if gaps else -1.0
+        dt_h, err = all_ranks(steady, err)
+        if err is None:
+            full = sharded_msm(part_h, client.combine_partials, dist, gather_dev)
+            if full != res:
+                err = "the combined result differs from the headline's"
+        if rank == 0:
+            hbm_flow = {"error": err} if err is not None else {
+                "ms_per_msm_steady": round(dt_h, 3), "msm_per_s_steady": round(1e3 / dt_h, 4), "set_data_ms_median": round(statistics.median(set_ms), 3),
+                "msms": k_hf, "tasks_in_flight": queue, "shard_rank0": lay_e, "layout_ex_pick_for_host_scalars_ranges": pick_host,
+                "what": f"2^{LOG_N} BLS12-381 on {world} ranks: each rank's bases in its device arena, its scalars from pageable host memory "
+                        "every task (tests/integration_msm_hbm.rs:57-100), element split; the "
+                        "slowest rank's steady-state interval between results; PCIe-inclusive, never the headline value",
+                "result_check": {"ok": True, "method": "one exchange of the ranks' partials: bytes equal the headline result"}}
         wd.disarm()
 
     # ---- the reference's own flows, timed as the reference runs them (extra keys, never the headline value)
-    hbm_flow = cfg2 = None
     if rank == 0 and world == 1 and not multi and not args.no_extras and hbm_mode:
         # (1) tests/integration_msm_hbm.rs:57-100: bases resident in the card's memory (loaded once), the SCALARS
         # come from a host Vec<u8> with every task; two tasks in flight like the headline.  The 2 GiB host -> device
         # copy of task k+1 runs under the accumulation of task k (copy stream + two staging sets).
         sc_host = d_sc.download()
         k_hf = max(4, min(args.steps, 8))
-
         set_ms, done_at = [], []
-
-        def submit_host():
-            client.initialize(params)
-            client.start_process()
-            t_s = time.perf_counter()
-            client.set_data(MSMInput(None, sc_host, params))
-            set_ms.append((time.perf_counter() - t_s) * 1e3)
-
-        def collect_host(out):
-            client.wait_result()
-            out.append(client.result().result)
-            done_at.append(time.perf_counter())
-
-        def run_host(k):
-            out, pending = [], 0
-            for _ in range(k):
-                submit_host()
-                pending += 1
-                if pending >= queue:
-                    collect_host(out)
-                    pending -= 1
-            while pending:
-                collect_host(out)
-                pending -= 1
-            return out
-
         wd.arm(600, "hbm_flow leg")
-        run_host(2)
-        torch.cuda.synchronize(tdev)
-        set_ms.clear()
-        done_at.clear()
-        t1 = time.perf_counter()
-        outs = run_host(k_hf)
-        torch.cuda.synchronize(tdev)
-        t_hf = (time.perf_counter() - t1) / k_hf * 1e3
+        stream(client, params, None, sc_host, 2)
+        t_hf, outs, _ = stream(client, params, None, sc_host, k_hf, on_set=set_ms.append, on_done=done_at.append)
+        t_hf = t_hf / k_hf * 1e3
         wd.disarm()
         # steady state: the interval between consecutive results (the first MSM of the leg pays its 2 GiB copy with the
         # GPU idle - pipeline fill - which a stream of tasks pays once)
@@ -647,13 +758,106 @@ def main():
                 "result_check": chk2}
         del p2, s2
 
+    # ---- the other two BASELINE configs on this GPU (extra keys): config 3 - 2^26 BN254, precompute
+    # factor 8, the 2^29 bases (32 GiB) resident in the device arena, scalars-only set_data - and one rank's task of config 4 -
+    # rank 0 of 8 of a 2^26 BLS12-377 job as blz_msm_shard_layout cuts it.  Each checked against the oracle by linearity.
+    cfg3 = cfg4 = None
+    if rank == 0 and world == 1 and not multi and not args.no_extras and hbm_mode and LOG_N == 26:
+        def weighted_expect(curve_name, sc_bytes, count, first):
+            import oracle
+
+            kk = oracle.index_weighted_sum(curve_name, sc_bytes, count, first, threads=min(64, host_threads()))
+            return oracle.result_from_affine(curve_name, oracle.generator_mul(curve_name, kk))
+
+        wd.arm(600, "config 3 leg")
+        try:
+            client.close()        # the BLS12-381 handle's workspace and the arena's 14 GiB: not needed any more
+            L.blz_arena_release(dev)
+            n3, c3 = 1 << 26, int(Curve["BN254"])
+            p3 = DeviceBuffer(dev, n3 * 8 * 64)
+            s3 = DeviceBuffer(dev, n3 * 32)
+            check(L.blz_synth_points(dev, c3, p3.ptr, n3, 8, 0))          # 2^(32 j) (i + 1) G, j < 8: the reference's precompute
+            check(L.blz_synth_scalars_at(dev, c3, s3.ptr, n3, 0xC0F3, 0))
+            cl3 = MSMClient(MSMInit(PointMemoryType.HBM, True, Curve["BN254"]), DriverClient(dev))
+            cl3.load_data_to_hbm(p3, 0, 0)
+            p3.free()
+            prm3 = MSMParams(n3, (0, 0))
+            stream(cl3, prm3, None, s3, 2)
+            dt3, outs3, apis3 = stream(cl3, prm3, None, s3, 4)
+            k3 = statistics.mean(a_["accumulate_kernel_ms"] for a_ in apis3)
+            bytes3 = n3 * (32 + 8 * 64)
+            chk3 = None
+            if not args.no_check:
+                if outs3[-1] != weighted_expect("BN254", s3.download(), n3, 0) or any(o != outs3[-1] for o in outs3):
+                    raise SystemExit("bench: the config 3 result is WRONG")
+                chk3 = {"ok": True, "method": "result == (sum_i s_i (i+1) mod r) G over all 2^26 scalars (the bases are 2^(32 j) (i+1) G), CPU oracle"}
+            cfg3 = {"ms_per_msm": round(dt3 / 4 * 1e3, 3), "msms": 4, "tasks_in_flight": queue, "kernel_ms": round(k3, 3),
+                    "window_bits": int(apis3[-1]["window_bits"]), "windows": int(apis3[-1]["windows"]),
+                    "roofline": {"bound": "hbm", "kernel": "k_accumulate", "algorithmic_bytes_per_launch": bytes3,
+                                 "achieved": round(bytes3 / (k3 * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": round(bytes3 / (k3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)},
+                    "what": "config 3: 2^26 BN254 elements, precompute factor 8: 2^29 bases (32 GiB) resident in the device arena, scalars-only "
+                            "set_data (device-resident scalars), tests/integration_msm_hbm.rs flow", "result_check": chk3}
+            cl3.close()
+            s3.free()
+            L.blz_arena_release(dev)
+        except SystemExit:
+            raise
+        except Exception as e:   # noqa: BLE001 - an extra key, never fatal
+            cfg3 = {"error": f"{type(e).__name__}: {e}"}
+        wd.arm(600, "config 4 leg")
+        try:
+            c4 = Curve["BLS377"]
+            lay4 = shard_layout_ex(c4, 1 << 26, 0, 8, 0)
+            n4 = lay4["count"]
+            p4 = DeviceBuffer(dev, n4 * 96)
+            s4 = DeviceBuffer(dev, n4 * 32)
+            check(L.blz_synth_points(dev, int(c4), p4.ptr, n4, 1, lay4["first"]))
+            check(L.blz_synth_scalars_at(dev, int(c4), s4.ptr, n4, 0x377, lay4["first"]))
+            cl4 = MSMClient(MSMInit(PointMemoryType.HBM, False, c4), DriverClient(dev))
+            cl4.load_data_to_hbm(p4, 0, 0)
+            p4.free()
+            if (lay4["bit_lo"], lay4["bit_hi"]) != (0, 256):
+                cl4.set_scalar_range(lay4["bit_lo"], lay4["bit_hi"])
+            prm4 = MSMParams(n4, (0, 0))
+            stream(cl4, prm4, None, s4, 3)
+            dt4, outs4, apis4 = stream(cl4, prm4, None, s4, 10)
+            chk4 = None
+            if not args.no_check:
+                import numpy as np
+
+                sc4 = np.frombuffer(s4.download(), dtype=np.uint8).reshape(n4, 32).copy()
+                sc4[:, : lay4["bit_lo"] // 8] = 0          # the rank sums bits [bit_lo, bit_hi) of every scalar, result weighted 2^bit_lo:
+                sc4[:, lay4["bit_hi"] // 8:] = 0           # the same bytes as the scalars with every other bit cleared
+                if outs4[-1] != weighted_expect("BLS377", sc4.tobytes(), n4, lay4["first"]) or any(o != outs4[-1] for o in outs4):
+                    raise SystemExit("bench: the config 4 rank-task result is WRONG")
+                chk4 = {"ok": True, "method": "partial == (sum_i (s_i masked to the rank's bit range) (i+1) mod r) G over the rank's elements, CPU oracle"}
+                del sc4
+            cfg4 = {"ms_per_task": round(dt4 / 10 * 1e3, 3), "tasks": 10, "tasks_in_flight": queue, "shard_rank0_of_8": lay4,
+                    "kernel_ms": round(statistics.mean(a_["accumulate_kernel_ms"] for a_ in apis4), 3),
+                    "window_bits": int(apis4[-1]["window_bits"]), "windows": int(apis4[-1]["windows"]),
+                    "what": "config 4, one rank's share: rank 0 of 8 of a 2^26 BLS12-377 job as blz_msm_shard_layout_ex cuts it (resident "
+                            "scalars), bases in the device arena, a stream of the rank's tasks; 8 x this GPU-time is the job's compute, the "
+                            "RCCL exchange of the 144-byte partials is not in it", "result_check": chk4}
+            cl4.close()
+            s4.free()
+            L.blz_arena_release(dev)
+        except SystemExit:
+            raise
+        except Exception as e:   # noqa: BLE001
+            cfg4 = {"error": f"{type(e).__name__}: {e}"}
+        wd.disarm()
+
     # ---- NTT 2^27 latency (replica per rank; rank 0 reports), timed like benches/ntt_bench.rs:34-39
     # minus the 100 ms sleep of reset(): initialize + start_process + wait_result on a resident buffer
     ntt = None
     if not args.no_ntt:
         from blaze_amd.ingo_ntt import NTT, NTTClient, NTTInput, NttInit
 
-        client.close()
+        try:
+            client.close()
+        except Exception:   # noqa: BLE001 - already closed by the config 3 leg
+            pass
         nn = 1 << NTT_LOG
         d_in = DeviceBuffer(dev, 32 * nn)
         check(L.blz_synth_field_elements(dev, d_in.ptr, nn, 5))
@@ -676,6 +880,19 @@ def main():
                "roofline": {"bound": "hbm", "achieved": round(nb / (k * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": round(nb / (k * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
                             "algorithmic_bytes": nb, "traffic": None}}
+        # The resource the passes saturate, beside the prescribed HBM figure: 32-bit integer multiply issue.  Per lane (8 elements)
+        # and pass the 512-point kernel does 37 / 46 / 29 field products: Shoup products by table twiddles at
+        # 143 v_mad_u64_u32, Montgomery products (pass 2's stepped boundary twiddle: 8 applications + 2 to start the chain) at 153,
+        # and a 9-multiply-add quotient reduction for each un-twiddled output: 5309 + 6696 + 4237 = 16 242 per lane
+        # (tests/test_isa_counts.py counts them in the code object), n / 8 lanes per pass.
+        if NTT_LOG == 27:
+            ntt_mads = (37 * 143 + 2 * 9) + (36 * 143 + 10 * 153 + 2 * 9) + (29 * 143 + 10 * 9)
+            mads_t = ntt_mads * (nn // 8)
+            peak_i = calib["mad_lane_ops_per_s"] if calib else 3.1e13
+            ntt["roofline"]["integer_issue"] = {"unit": "v_mad_u64_u32 lane-ops/s", "achieved": round(mads_t / (k * 1e-3), 0), "peak": round(peak_i, 0),
+                                                "frac": round(mads_t / (k * 1e-3) / peak_i, 4), "multiply_adds_per_transform": mads_t,
+                                                "multiply_adds_per_lane": ntt_mads,
+                                                "peak_source": "calibration kernel on this device, this run" if calib else "constant measured on another box"}
         try:   # PMC record of the three passes, quoted only while it matches the kernels being timed (see above)
             rec = json.load(open(tf)).get(f"ntt_2e{NTT_LOG}_BLS381")
             if rec and abs(k - rec.get("kernel_ms_at_measurement", k)) <= 0.10 * k:
@@ -751,7 +968,8 @@ def main():
                        "window_bits": int(api["window_bits"]), "windows": int(api["windows"]),
                        "sort_hidden_under_previous_accumulation": bool(api.get("sort_hidden", 0))},
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_ref_semantics": cpu_ref, "result_check": check_rec,
-            "ntt_2e27": ntt, "clock": clock, "exchange_native": native, "window_table": table_rec, "hbm_flow": hbm_flow, "config2_dma": cfg2,
+            "ntt_2e27": ntt, "clock": clock, "exchange_native": native, "window_table": table_rec, "alt_layout_elements": alt_rec, "hbm_flow": hbm_flow, "config2_dma": cfg2,
+            "config3_bn254_pf8": cfg3, "config4_rank_task": cfg4,
             "phases_ms": {k: round(v, 3) for k, v in api.items() if k.endswith("_ms")},
         }
         if os.environ.get("BLAZE_BENCH_EMIT_RESULT") == "1":

@@ -70,6 +70,7 @@ _SIGS = {
     "blz_msm_combine_partials": (C.c_int, [C.c_void_p, _u8p, C.c_size_t, _u8p, C.c_size_t]),
     "blz_msm_last_sort_hidden": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "blz_msm_set_window_table": (C.c_int, [C.c_void_p, C.c_int]),
+    "blz_msm_prepare_window_table": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_int)]),
     "blz_msm_set_scalar_range": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
     "blz_msm_shard_layout": (C.c_int, [C.c_int, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_uint32)]),
     "blz_msm_shard_layout_ex": (C.c_int, [C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_uint32, C.POINTER(C.c_uint32)]),

@@ -28,13 +28,24 @@ ArenaExtent* arena_find(Arena& a, uint64_t pos, size_t len) {
     return nullptr;
 }
 
+// the table and a build in flight (the caller has drained the device)
+void arena_drop_table(ArenaExtent& x) {
+    for (auto& t : x.tables)
+        if (t.p) (void)hipFree(t.p);
+    x.tables.clear();
+    if (x.build.tab) (void)hipFree(x.build.tab);
+    if (x.build.done) (void)hipEventDestroy(x.build.done);
+    if (x.build.t0) (void)hipEventDestroy(x.build.t0);
+    x.build = ArenaExtent::TableBuild();
+}
+
 void arena_free_extent(ArenaExtent& x) {
     if (x.raw) {
         if (x.imported) (void)hipIpcCloseMemHandle(x.raw);
         else (void)hipFree(x.raw);
     }
     if (x.mont) (void)hipFree(x.mont);
-    if (x.table) (void)hipFree(x.table);
+    arena_drop_table(x);
     if (x.shadow_ready) (void)hipEventDestroy(x.shadow_ready);
     x = ArenaExtent();
 }
@@ -95,13 +106,16 @@ int arena_write(int device_id, uint64_t pos, const void* src, size_t len, bool s
             return fail(BLZ_ERR_WRITE, "arena: hipMalloc(%zu) at offset %llu failed: %s", n.cap, (unsigned long long)nstart,
                         hipGetErrorString(he));
         if (!hit.empty()) {
-            // tasks in flight may still read the old extents or their shadows: drain before they go
-            BLZ_HIP(hipDeviceSynchronize(), BLZ_ERR_WRITE);
+            // tasks in flight may still read the old extents or their shadows: drain (bounded) before they go
+            if (sync_device_bounded("load_data_to_hbm: drain before the extents merge") != BLZ_OK) {
+                (void)hipFree(n.raw);
+                return BLZ_ERR_WRITE;
+            }
             for (size_t i : hit) {
                 const ArenaExtent& x = A.ext[i];
                 BLZ_HIP(hipMemcpyAsync((char*)n.raw + (x.start - nstart), x.raw, x.len, hipMemcpyDeviceToDevice, st), BLZ_ERR_WRITE);
             }
-            BLZ_HIP(hipStreamSynchronize(st), BLZ_ERR_WRITE);
+            if (sync_stream_bounded(st, "load_data_to_hbm: carrying the old extents over") != BLZ_OK) return BLZ_ERR_WRITE;   // (the new allocation is leaked: the copy may still run)
             for (size_t k = hit.size(); k-- > 0;) {
                 arena_free_extent(A.ext[hit[k]]);
                 A.ext.erase(A.ext.begin() + hit[k]);
@@ -112,12 +126,11 @@ int arena_write(int device_id, uint64_t pos, const void* src, size_t len, bool s
         e->mont_curve = -1;   // no shadow yet
     }
     mark_dirty(*e, pos - e->start, end - e->start);
-    if (e->table) {
-        // the window table is a function of the bytes: gone with any write (a task in flight may still gather from it)
-        BLZ_HIP(hipDeviceSynchronize(), BLZ_ERR_WRITE);
-        (void)hipFree(e->table);
-        e->table = nullptr;
-        e->table_bytes = 0;
+    if (!e->tables.empty() || e->build.tab) {
+        // the window table is a function of the bytes: gone with any write (a task in flight may still gather from it, a
+        // build in flight still writes it)
+        if (sync_device_bounded("load_data_to_hbm: drain before the window table goes") != BLZ_OK) return BLZ_ERR_WRITE;
+        arena_drop_table(*e);
     }
     e->table_refused = false;
     char* dst = (char*)e->raw + (pos - e->start);
@@ -146,9 +159,14 @@ int blz_arena_release(int device_id) {
     BLZ_TRY(use_device(device_id));
     Arena& A = arena_for(device_id);
     std::lock_guard<std::mutex> lk(A.mu);
-    (void)hipDeviceSynchronize();
+    BLZ_TRY(sync_device_bounded("arena release"));   // (on expiry nothing is freed: wedged work may still read the extents)
     for (auto& x : A.ext) arena_free_extent(x);
     A.ext.clear();
+    if (A.build_scratch) (void)hipFree(A.build_scratch);
+    A.build_scratch = nullptr;
+    A.build_scratch_bytes = 0;
+    if (A.build_flags) (void)hipFree(A.build_flags);
+    A.build_flags = nullptr;
     return BLZ_OK;
 }
 

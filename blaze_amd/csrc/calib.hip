@@ -54,7 +54,7 @@ extern "C" int blz_calib_mad_rate(int device_id, uint32_t target_ms, double out[
         (void)hipEventRecord(e0, 0);
         hipLaunchKernelGGL(k_calib_mad, grid, block, 0, 0, d, reps, 7u + pass);
         (void)hipEventRecord(e1, 0);
-        if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || ms <= 0.f) {
+        if (sync_event_bounded(e1, "calibration kernel") != BLZ_OK || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || ms <= 0.f) {
             rc = fail(BLZ_ERR_UNKNOWN, "calibration kernel failed");
             break;
         }

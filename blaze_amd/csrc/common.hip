@@ -1,6 +1,9 @@
 // Error convention, device selection and the per-device arena of libblaze_hip.
 #include "common.hpp"
 
+#include <condition_variable>
+#include <memory>
+
 #include <chrono>
 #include <cstdlib>
 #include <thread>
@@ -83,6 +86,74 @@ int sync_event_bounded(hipEvent_t ev, const char* what) {
 }
 int sync_stream_bounded(hipStream_t st, const char* what) {
     return bounded_wait([st] { return hipStreamQuery(st); }, what);
+}
+
+// The whole device against the same deadline.  HIP has no query for "every stream of the device is idle", so the drain
+// (hipDeviceSynchronize) runs on a helper thread and the caller waits for it against the deadline; on expiry the helper - parked
+// inside the runtime until the wedged work ends, if ever - is abandoned (it owns its state through the shared_ptr).
+namespace {
+struct DrainJob {
+    std::mutex mu;
+    std::condition_variable cv;
+    bool done = false;
+    hipError_t err = hipSuccess;
+};
+}  // namespace
+int sync_device_bounded(const char* what) {
+    g_wait_timed_out = false;
+    // nothing pending anywhere is the common case for callers that drain before freeing: the null stream's query covers the
+    // blocking streams only, so it cannot replace the drain, but an idle device makes the drain itself return at once
+    int dev = 0;
+    BLZ_HIP(hipGetDevice(&dev), BLZ_ERR_UNKNOWN);
+    auto job = std::make_shared<DrainJob>();
+    std::thread([job, dev] {
+        hipError_t e = hipSetDevice(dev);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        std::lock_guard<std::mutex> lk(job->mu);
+        job->err = e;
+        job->done = true;
+        job->cv.notify_all();
+    }).detach();
+    std::unique_lock<std::mutex> lk(job->mu);
+    const int limit_ms = wait_timeout_ms();
+    if (!job->cv.wait_for(lk, std::chrono::milliseconds(limit_ms), [&] { return job->done; })) {
+        g_wait_timed_out = true;
+        return fail(BLZ_ERR_UNKNOWN, "%s timed out after %d ms (BLAZE_WAIT_TIMEOUT_MS): device work in flight did not complete; the "
+                    "buffers it may still touch are leaked, not freed", what, limit_ms);
+    }
+    if (job->err != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(BLZ_ERR_UNKNOWN, "%s failed: %s", what, hipGetErrorString(job->err));
+    }
+    return BLZ_OK;
+}
+
+int DevBuf::reserve(size_t bytes) {
+    if (bytes <= cap) return BLZ_OK;
+    if (p) {
+        // hipFree waits for the whole device: bounded here instead (a wedged kernel may still use the old buffer: leak it)
+        const int rc = sync_device_bounded("growing a device buffer");
+        if (rc != BLZ_OK) {
+            p = nullptr;
+            cap = 0;
+            return rc;
+        }
+        (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    size_t want = bytes + bytes / 8;  // slack so slightly larger tasks do not reallocate
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+        e = hipMalloc(&p, bytes);
+        want = bytes;
+    }
+    if (e != hipSuccess) {
+        p = nullptr;
+        return fail(BLZ_ERR_UNKNOWN, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    }
+    cap = want;
+    return BLZ_OK;
 }
 
 __global__ void k_stall(uint32_t* flag, uint64_t max_ticks) {

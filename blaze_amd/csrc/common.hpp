@@ -66,6 +66,7 @@ int use_device(int device_id);
 int wait_timeout_ms();
 int sync_event_bounded(hipEvent_t ev, const char* what);
 int sync_stream_bounded(hipStream_t st, const char* what);
+int sync_device_bounded(const char* what);   // every stream of the current device (before buffers other handles' tasks may read are freed)
 bool wait_timed_out();   // the last sync_*_bounded of this thread ended on its deadline
 void wait_clear();       // forget it (before a call that may fail without ever reaching a wait)
 
@@ -82,22 +83,7 @@ int ensure_dynamic_lds(const void* kernel, int bytes);
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
-    int reserve(size_t bytes) {
-        if (bytes <= cap) return BLZ_OK;
-        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-        size_t want = bytes + bytes / 8;  // slack so slightly larger tasks do not reallocate
-        hipError_t e = hipMalloc(&p, want);
-        if (e != hipSuccess) {
-            e = hipMalloc(&p, bytes);
-            want = bytes;
-        }
-        if (e != hipSuccess) {
-            p = nullptr;
-            return fail(BLZ_ERR_UNKNOWN, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
-        }
-        cap = want;
-        return BLZ_OK;
-    }
+    int reserve(size_t bytes);   // growth frees the old allocation behind a BOUNDED drain of the device (common.hip)
     void release() {
         if (p) (void)hipFree(p);
         p = nullptr;
@@ -129,20 +115,46 @@ struct ArenaExtent {
     uint64_t dirty_lo = 0, dirty_hi = 0;   // byte span (relative to start) whose points are stale in the shadow
     hipEvent_t shadow_ready = nullptr;     // recorded after the last conversion; consumers on other streams wait
     bool shadow_recorded = false;          // shadow_ready has been recorded at least once since the shadow was (re)built
-    // window table (msm_impl.cuh k_build_window_table; opt-in per handle): for the points [table_first, +table_npts) of the grid at `table_phase`
-    // the W multiples 2^(c j) P, j < W, in the shadow's point format, point-major.  Any write into the extent drops it.
-    void* table = nullptr;
-    size_t table_bytes = 0;
-    int table_format = -1, table_c = 0, table_W = 0;
-    int table_lo = 0, table_hi = 256;      // scalar range the table serves: entry j = 2^(table_lo + c j) P
-    uint32_t table_phase = 0;
-    uint64_t table_first = 0, table_npts = 0;
+    // window tables (msm_impl.cuh k_build_window_table; opt-in per handle): for the points [first, +npts) of the grid at `phase`
+    // the W multiples 2^(lo + c j) P, j < W, in the shadow's point format, point-major.  One per (bases, scalar range) that
+    // a handle asked for - the ranks of a job sharded by scalar chunk each tabulate their own range - at most
+    // MAX_TABLES per extent.  Any write into the extent drops them all.
+    struct WindowTable {
+        void* p = nullptr;
+        size_t bytes = 0;
+        int format = -1, c = 0, W = 0;
+        int lo = 0, hi = 256;              // scalar range the table serves: entry j = 2^(lo + c j) P
+        uint32_t phase = 0;
+        uint64_t first = 0, npts = 0;
+        float build_ms = 0;
+    };
+    static constexpr size_t MAX_TABLES = 32;
+    std::vector<WindowTable> tables;
     bool table_refused = false;            // a build failed (a base of even order, or no memory): do not retry until the next write
-    float table_build_ms = 0;              // (the build is synchronous: nothing to order other streams behind)
+    // A table being built (msm_capi.hip arena_points_table): in chunks, paced by the tasks over these bases (each enqueues a
+    // few chunks on its own stream ahead of itself and takes the plain path); the task that finds `done` complete behind the
+    // last chunk adopts the table.
+    struct TableBuild {
+        void* tab = nullptr;
+        uint32_t* flag = nullptr;          // a slot of the arena's build_flags: set by the build when a multiple came out as infinity
+        size_t bytes = 0;
+        hipEvent_t done = nullptr, t0 = nullptr;
+        int format = -1, c = 0, W = 0, lo = 0, hi = 256;
+        uint32_t phase = 0;
+        uint64_t first = 0, npts = 0;
+        uint64_t next_chunk = 0;           // chunks [0, next_chunk) have been enqueued
+        bool recorded = false;             // `done` has been recorded behind the last enqueued chunk
+    } build;
 };
 struct Arena {
     std::mutex mu;
     std::vector<ArenaExtent> ext;
+    void* build_scratch = nullptr;         // the builds' lane-private rows (chunks are chained through the build's event)
+    size_t build_scratch_bytes = 0;
+    hipEvent_t scratch_event = nullptr;    // recorded behind the last chunk that used the rows
+    bool scratch_recorded = false;
+    uint32_t* build_flags = nullptr;       // 256 flag slots, one per build in turn
+    uint32_t build_flag_next = 0;
 };
 Arena& arena_for(int device_id);
 // find extent containing [pos, pos+len); nullptr if none
@@ -150,5 +162,6 @@ ArenaExtent* arena_find(Arena& a, uint64_t pos, size_t len);
 // write bytes (host or device source) at pos; extends / merges extents as needed; blocking
 int arena_write(int device_id, uint64_t pos, const void* src, size_t len, bool src_is_device, hipStream_t st);
 void arena_free_extent(ArenaExtent& x);
+void arena_drop_table(ArenaExtent& x);   // the table and a build in flight; the caller has drained the device
 
 }  // namespace blz

@@ -97,7 +97,7 @@ int arena_points_mont(blz_msm* h, uint64_t pos, uint32_t npts, const void** out)
     if (e->mont_curve != h->eng.format_id() || e->mont_phase != phase || e->mont_bytes < cap_pts * mp) {
         // another curve / grid (or the first use): a fresh shadow, everything stale
         if (e->mont) {
-            BLZ_HIP(hipDeviceSynchronize(), BLZ_ERR_UNKNOWN);   // a task of another handle may still read the old one
+            BLZ_TRY(sync_device_bounded("replacing a Montgomery shadow"));   // a task of another handle may still read the old one
             (void)hipFree(e->mont);
             e->mont = nullptr;
         }
@@ -130,11 +130,24 @@ int arena_points_mont(blz_msm* h, uint64_t pos, uint32_t npts, const void** out)
     return BLZ_OK;
 }
 
-// Window table of the `npts` bases at arena offset `pos` (msm_impl.cuh k_build_window_table, MsmPlan::table): built on first use - synchronously,
-// on this handle's main stream, about 2 s for 2^26 BLS bases - kept with the extent, dropped by any write into it.
-// *out stays null (and the task takes the plain path) when the table is not to be had: no memory for it, a base of even
-// order, a task over a sub-range whose best window width is not the table's.
-int arena_points_table(blz_msm* h, uint64_t pos, uint32_t npts, const void** out, int* c_out) {
+// Window table of the `npts` bases at arena offset `pos` (msm_impl.cuh k_build_window_table, MsmPlan::table), kept with the
+// extent, dropped by any write into it.  *out stays null - and the task takes the plain path - while the table is not to be
+// had: it is still being built, there is no memory for it, a base has even order, or the task is over a sub-range whose
+// best window width is not the table's.
+//
+// The build is never one blocking lump inside a task (round 3 built synchronously inside the first task's launch: 3.1 s for
+// 2^26 bases in a call a host expects to take milliseconds), and it does not run BESIDE the tasks either - measured
+// (profiles/r04_window_table_async.txt): on a lowest-priority stream its long-lived waves hold their registers and halve the
+// tasks' speed for as long as it takes; confined to a quarter of the CUs it is worse (the accumulation's blocks on the shared CUs
+// issue behind the build's older waves and become the kernel's tail).  So the build is PACED by the tasks: it is cut into chunks
+// of TABLE_BUILD_CHUNK bases (~9 ms of the chip), every task launched over the bases first enqueues `chunk_budget` of them on
+// its own main stream - a fixed, small surcharge per task while the table is being built - and keeps taking the plain path;
+// the first task launched after the last chunk has completed adopts the table.  blz_msm_prepare_window_table enqueues ALL the
+// remaining chunks at once for a host that would rather pay the build now.  Results are bit-identical either way
+// (tests/test_gpu_msm_table.py).
+constexpr uint32_t TABLE_BUILD_CHUNK = 3u << 16;   // bases per launch = the build kernel's lanes (msm_impl.cuh TABLE_BUILD_BLOCKS x 64)
+constexpr int TABLE_CHUNKS_PER_TASK = 2;           // ~18 ms on top of a 2^26 task's 117: 171 tasks until a 2^26 table is there
+int arena_points_table(blz_msm* h, uint64_t pos, uint32_t npts, const void** out, int* c_out, int chunk_budget) {
     *out = nullptr;
     *c_out = 0;
     const size_t ps = point_size(h), mp = mont_point_bytes(h->curve);
@@ -153,18 +166,93 @@ int arena_points_table(blz_msm* h, uint64_t pos, uint32_t npts, const void** out
     const int need = hi - lo < 256 ? hi - lo + 1 : 257;
     const int want_c = table_window_bits(npts, need);
     if (want_c == 0) return BLZ_OK;
-    const bool covers = e->table && e->table_format == fmt && e->table_phase == phase && first >= e->table_first &&
-                        first + npts <= e->table_first + e->table_npts && e->table_lo == lo && e->table_hi == hi;
-    if (covers && e->table_c != want_c) return BLZ_OK;   // a sub-range that wants other windows: the plain path, not a rebuild
-    if (!covers) {
+    ArenaExtent::TableBuild& B = e->build;
+    // the chunks this launch owes the build in flight (chained through B.done: the chunks share the scratch rows)
+    auto enqueue_chunks = [&](int budget) -> int {
+        hipStream_t st = h->eng.stream;
+        const uint64_t nchunks = (B.npts + TABLE_BUILD_CHUNK - 1) / TABLE_BUILD_CHUNK;
+        if (B.next_chunk >= nchunks || budget == 0) return BLZ_OK;
+        // (the scratch rows are the arena's: chunks of every build on the device run one after the other)
+        if (!A.scratch_event) BLZ_HIP(hipEventCreateWithFlags(&A.scratch_event, hipEventDisableTiming), BLZ_ERR_UNKNOWN);
+        if (A.scratch_recorded) BLZ_HIP(hipStreamWaitEvent(st, A.scratch_event, 0), BLZ_ERR_UNKNOWN);
+        for (; B.next_chunk < nchunks && budget != 0; ++B.next_chunk, --budget) {
+            const uint64_t p0 = B.next_chunk * TABLE_BUILD_CHUNK;
+            const uint32_t cnt = (uint32_t)(B.npts - p0 < TABLE_BUILD_CHUNK ? B.npts - p0 : TABLE_BUILD_CHUNK);
+            if (B.next_chunk == 0) BLZ_HIP(hipEventRecord(B.t0, st), BLZ_ERR_UNKNOWN);
+            BLZ_TRY(h->eng.build_table((const char*)e->raw + B.phase + (B.first + p0) * ps, (char*)B.tab + p0 * (size_t)B.W * mp, cnt, B.c, B.W, B.lo,
+                                       A.build_scratch, B.flag, st));
+        }
+        BLZ_HIP(hipEventRecord(B.done, st), BLZ_ERR_UNKNOWN);
+        B.recorded = true;
+        BLZ_HIP(hipEventRecord(A.scratch_event, st), BLZ_ERR_UNKNOWN);
+        A.scratch_recorded = true;
+        return BLZ_OK;
+    };
+    hipError_t bq = hipErrorNotReady;
+    if (B.tab) {
+        const uint64_t nchunks = (B.npts + TABLE_BUILD_CHUNK - 1) / TABLE_BUILD_CHUNK;
+        if (B.next_chunk >= nchunks && B.recorded) {
+            bq = hipEventQuery(B.done);
+            if (bq != hipSuccess && bq != hipErrorNotReady) { (void)hipGetLastError(); return fail(BLZ_ERR_UNKNOWN, "window table build failed: %s", hipGetErrorString(bq)); }
+        }
+    }
+    if (B.tab && bq == hipSuccess) {
+        // a build has completed: adopt its table
+        uint32_t flag_h = 0;
+        float ms = 0;
+        BLZ_HIP(hipMemcpy(&flag_h, B.flag, 4, hipMemcpyDeviceToHost), BLZ_ERR_READ);   // (the build is complete: nothing to wait for)
+        (void)hipEventElapsedTime(&ms, B.t0, B.done);   // first chunk .. last chunk, the tasks in between included
+        if (flag_h) {
+            BLZ_LOG(1, "window table: a base has a multiple at infinity (a point of even order): plain path for this extent");
+            BLZ_TRY(sync_device_bounded("dropping a refused window table"));   // (hipFree waits for the device: bounded first)
+            (void)hipFree(B.tab);
+            (void)hipEventDestroy(B.done);
+            (void)hipEventDestroy(B.t0);
+            B = ArenaExtent::TableBuild();
+            e->table_refused = true;
+            return BLZ_OK;
+        }
+        ArenaExtent::WindowTable t;
+        t.p = B.tab;
+        t.bytes = B.bytes;
+        t.format = B.format;
+        t.phase = B.phase;
+        t.first = B.first;
+        t.npts = B.npts;
+        t.c = B.c;
+        t.W = B.W;
+        t.lo = B.lo;
+        t.hi = B.hi;
+        t.build_ms = ms;
+        e->tables.push_back(t);
+        B.tab = nullptr;
+        (void)hipEventDestroy(B.done);
+        (void)hipEventDestroy(B.t0);
+        B = ArenaExtent::TableBuild();
+        BLZ_LOG(1, "window table: %llu bases x %d windows of %d bits, %.1f MiB, complete %.1f ms after its first chunk", (unsigned long long)t.npts,
+                t.W, t.c, t.bytes / 1048576.0, ms);
+    }
+    // one table per (bases, scalar range) that was asked for: the handles of a curve share it, a sub-range of its bases is
+    // served from it, a handle with another scalar range gets its own (two handles evicting each other's table on every
+    // launch would rebuild for ever: ADVICE r03)
+    const ArenaExtent::WindowTable* T = nullptr;
+    for (const auto& t : e->tables)
+        if (t.format == fmt && t.phase == phase && first >= t.first && first + npts <= t.first + t.npts && t.lo == lo && t.hi == hi) T = &t;
+    if (T && T->c != want_c) return BLZ_OK;   // a sub-range that wants other windows: the plain path, not a rebuild
+    if (!T) {
+        if (B.tab) {
+            // a build in flight: this launch pays its share if the build is for this handle's bases and range (one build at a
+            // time: another's turn comes when this one is through)
+            if (B.format == fmt && B.phase == phase && first >= B.first && first + npts <= B.first + B.npts && B.lo == lo && B.hi == hi)
+                BLZ_TRY(enqueue_chunks(chunk_budget));
+            return BLZ_OK;
+        }
+        if (e->tables.size() >= ArenaExtent::MAX_TABLES) {
+            BLZ_LOG(1, "window table: the extent already holds %zu tables: plain path for this handle", e->tables.size());
+            return BLZ_OK;
+        }
         const int c = want_c, W = table_windows(c, need);
         const size_t bytes = (size_t)npts * W * mp + 16;
-        if (e->table) {
-            BLZ_HIP(hipDeviceSynchronize(), BLZ_ERR_UNKNOWN);   // a task of another handle may still gather from the old one
-            (void)hipFree(e->table);
-            e->table = nullptr;
-            e->table_bytes = 0;
-        }
         size_t free_b = 0, total_b = 0;
         BLZ_HIP(hipMemGetInfo(&free_b, &total_b), BLZ_ERR_UNKNOWN);
         const size_t scratch_b = h->eng.table_scratch_bytes(W) + 16;
@@ -177,62 +265,84 @@ int arena_points_table(blz_msm* h, uint64_t pos, uint32_t npts, const void** out
             e->table_refused = true;
             return BLZ_OK;
         }
+        // the build's scratch rows belong to the arena and are kept (freeing them would wait for every task in flight)
+        if (A.build_scratch_bytes < scratch_b) {
+            if (A.build_scratch) {
+                BLZ_TRY(sync_device_bounded("growing the window-table scratch"));
+                (void)hipFree(A.build_scratch);
+                A.build_scratch = nullptr;
+                A.build_scratch_bytes = 0;
+            }
+            if (hipMalloc(&A.build_scratch, scratch_b) != hipSuccess) {
+                (void)hipGetLastError();
+                A.build_scratch = nullptr;
+                e->table_refused = true;
+                return BLZ_OK;
+            }
+            A.build_scratch_bytes = scratch_b;
+        }
         void* tab = nullptr;
-        if (hipMalloc(&tab, bytes) != hipSuccess) {
+        const auto t_alloc = std::chrono::steady_clock::now();
+        const hipError_t he_tab = hipMalloc(&tab, bytes);
+        BLZ_LOG(1, "window table: hipMalloc(%zu) took %.1f ms", bytes,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_alloc).count());
+        if (he_tab != hipSuccess) {
             (void)hipGetLastError();
             e->table_refused = true;
             return BLZ_OK;
         }
-        DevBuf scratch;
-        int rc = scratch.reserve(scratch_b);
-        hipEvent_t t0 = nullptr, t1 = nullptr;
-        float ms = 0;
-        uint32_t flag_h = 0;
-        if (rc == BLZ_OK) {
-            uint32_t* flag = reinterpret_cast<uint32_t*>((char*)scratch.p + scratch_b - 16);
-            hipStream_t st = h->eng.stream;
-            if (hipEventCreate(&t0) != hipSuccess || hipEventCreate(&t1) != hipSuccess) rc = fail(BLZ_ERR_UNKNOWN, "event creation failed");
-            if (rc == BLZ_OK && hipMemsetAsync(flag, 0, 16, st) != hipSuccess) rc = fail(BLZ_ERR_UNKNOWN, "memset failed");
-            if (rc == BLZ_OK) (void)hipEventRecord(t0, st);
-            if (rc == BLZ_OK) rc = h->eng.build_table((const char*)e->raw + phase + first * ps, tab, npts, c, W, lo, scratch.p, flag, st);
-            if (rc == BLZ_OK) (void)hipEventRecord(t1, st);
-            if (rc == BLZ_OK) rc = sync_stream_bounded(st, "window table build");
-            if (rc == BLZ_OK && hipMemcpy(&flag_h, flag, 4, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(BLZ_ERR_READ, "window table: flag read failed");
-            if (rc == BLZ_OK) (void)hipEventElapsedTime(&ms, t0, t1);
-        }
-        if (t0) (void)hipEventDestroy(t0);
-        if (t1) (void)hipEventDestroy(t1);
-        if (rc != BLZ_OK) {
-            if (!wait_timed_out()) { scratch.release(); (void)hipFree(tab); }   // (wedged: the kernel may still write them - leak)
-            return rc;
-        }
-        scratch.release();
-        if (flag_h) {
-            BLZ_LOG(1, "window table: a base has a multiple at infinity (a point of even order): plain path for this extent");
+        hipEvent_t done = nullptr, t0 = nullptr;
+        int rc = BLZ_OK;
+        if (hipEventCreate(&t0) != hipSuccess || hipEventCreate(&done) != hipSuccess) rc = fail(BLZ_ERR_UNKNOWN, "event creation failed");
+        // the build's "a multiple came out as infinity" flag: its own slot (builds share the scratch rows in stream order, but a
+        // flag is read by the host when its build is ADOPTED, possibly after a later build has started)
+        if (!A.build_flags && hipMalloc((void**)&A.build_flags, 256 * sizeof(uint32_t)) != hipSuccess) {
+            (void)hipGetLastError();
+            A.build_flags = nullptr;
             (void)hipFree(tab);
             e->table_refused = true;
             return BLZ_OK;
         }
-        e->table = tab;
-        e->table_bytes = bytes;
-        e->table_format = fmt;
-        e->table_phase = phase;
-        e->table_first = first;
-        e->table_npts = npts;
-        e->table_c = c;
-        e->table_W = W;
-        e->table_lo = lo;
-        e->table_hi = hi;
-        e->table_build_ms = ms;
-        BLZ_LOG(1, "window table: %u bases x %d windows of %d bits, %.1f MiB, built in %.1f ms", npts, W, c, bytes / 1048576.0, ms);
+        uint32_t* flag = A.build_flags + (A.build_flag_next++ & 255u);
+        if (rc == BLZ_OK && hipMemsetAsync(flag, 0, 4, h->eng.stream) != hipSuccess) rc = fail(BLZ_ERR_UNKNOWN, "memset failed");
+        if (rc != BLZ_OK) {
+            if (t0) (void)hipEventDestroy(t0);
+            if (done) (void)hipEventDestroy(done);
+            (void)hipFree(tab);
+            return rc;
+        }
+        B.tab = tab;
+        B.flag = flag;
+        B.bytes = bytes;
+        B.done = done;
+        B.t0 = t0;
+        B.format = fmt;
+        B.c = c;
+        B.W = W;
+        B.lo = lo;
+        B.hi = hi;
+        B.phase = phase;
+        B.first = first;
+        B.npts = npts;
+        B.next_chunk = 0;
+        B.recorded = false;
+        BLZ_LOG(1, "window table: build of %u bases x %d windows of %d bits started (%.1f MiB, %u chunks); tasks take the plain path until it is there",
+                npts, W, c, bytes / 1048576.0, (unsigned)((npts + TABLE_BUILD_CHUNK - 1) / TABLE_BUILD_CHUNK));
+        return enqueue_chunks(chunk_budget);   // (the raw bases are in place: every arena write ends with a host-side wait)
     }
-    *out = (const char*)e->table + (first - e->table_first) * (size_t)e->table_W * mp;
-    *c_out = e->table_c;
-    h->table_info[0] = e->table_bytes;
-    h->table_info[1] = (uint64_t)e->table_c;
-    h->table_info[2] = (uint64_t)e->table_W;
-    h->table_info[3] = (uint64_t)(e->table_build_ms * 1000.0f);
+    *out = (const char*)T->p + (first - T->first) * (size_t)T->W * mp;
+    *c_out = T->c;
+    h->table_info[0] = T->bytes;
+    h->table_info[1] = (uint64_t)T->c;
+    h->table_info[2] = (uint64_t)T->W;
+    h->table_info[3] = (uint64_t)(T->build_ms * 1000.0f);
     return BLZ_OK;
+}
+
+// (BN254 loses with a table - 64-byte points: its accumulation is already at the gather rate, 2^26 71.8 -> 74.6 ms - so mode 1,
+// "where it pays", leaves it on the plain path)
+bool wants_table(const blz_msm* h) {
+    return h->pf == 1 && (h->window_table == 2 || (h->window_table == 1 && h->curve != BLZ_BN254));
 }
 
 int launch_if_ready(blz_msm* h) {
@@ -247,11 +357,9 @@ int launch_if_ready(blz_msm* h) {
     int table_c = 0;
     memset(h->table_info, 0, sizeof(h->table_info));
     if (h->staged_from_arena) {
-        // (BN254 loses with a table - 64-byte points: its accumulation is already at the gather rate, 2^26 71.8 -> 74.6 ms -
-        // so "1" leaves it on the plain path)
-        if (h->pf == 1 && (h->window_table == 2 || (h->window_table == 1 && h->curve != BLZ_BN254))) {
+        if (wants_table(h)) {
             const void* tab = nullptr;
-            BLZ_WAIT(h, arena_points_table(h, h->staged_arena_pos, npts, &tab, &table_c));
+            BLZ_TRY(arena_points_table(h, h->staged_arena_pos, npts, &tab, &table_c, TABLE_CHUNKS_PER_TASK));
             if (tab) h->d_points_mont = tab;
             else table_c = 0;
         }
@@ -508,6 +616,36 @@ int blz_msm_set_window_table(blz_msm* h, int enable) {
     if (enable < 0 || enable > 2) return fail(BLZ_ERR_INVALID_PARAM, "window table mode %d (0 off, 1 where it pays, 2 always)", enable);
     h->window_table = enable;
     return BLZ_OK;
+}
+
+int blz_msm_prepare_window_table(blz_msm* h, uint32_t nof_elements, uint64_t hbm_addr, uint64_t hbm_off, int wait_ms, int* ready) {
+    if (!h) return fail(BLZ_ERR_INVALID_PARAM, "null handle");
+    BLZ_LIVE(h);
+    if (ready) *ready = 0;
+    BLZ_TRY(use_device(h->device));
+    if (!wants_table(h) || nof_elements == 0) return BLZ_OK;
+    const auto t0 = std::chrono::steady_clock::now();
+    const int limit = wait_ms < 0 ? wait_timeout_ms() : wait_ms;
+    for (;;) {
+        const void* tab = nullptr;
+        int c = 0;
+        // starts the build / enqueues what is left of it (a waiting host has nothing better to do: all of it), or adopts a finished one
+        BLZ_TRY(arena_points_table(h, hbm_addr + hbm_off, nof_elements, &tab, &c, wait_ms != 0 ? -1 : TABLE_CHUNKS_PER_TASK));
+        if (tab) {
+            if (ready) *ready = 1;
+            return BLZ_OK;
+        }
+        bool building = false;
+        {
+            Arena& A = arena_for(h->device);
+            std::lock_guard<std::mutex> lk(A.mu);
+            ArenaExtent* e = arena_find(A, hbm_addr + hbm_off, (size_t)nof_elements * point_size(h));
+            building = e && e->build.tab != nullptr;
+        }
+        if (!building) return BLZ_OK;   // refused (no memory, a base of even order), or another handle's table stays
+        if (std::chrono::steady_clock::now() - t0 >= std::chrono::milliseconds(limit)) return BLZ_OK;
+        std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
 }
 
 int blz_msm_set_scalar_range(blz_msm* h, uint32_t bit_lo, uint32_t bit_hi) {

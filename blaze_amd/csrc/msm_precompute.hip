@@ -45,7 +45,7 @@ int precompute_t(const void* d_in, void* d_out, uint64_t n) {
     hipLaunchKernelGGL(k_precompute_bases<F>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, (const uint32_t*)d_in,
                        (uint32_t*)d_out, n);
     BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
-    BLZ_HIP(hipDeviceSynchronize(), BLZ_ERR_UNKNOWN);
+    BLZ_TRY(sync_stream_bounded(0, "precompute expansion"));
     return BLZ_OK;
 }
 

@@ -153,7 +153,7 @@ int ntt_setup(blz_ntt* h) {
         BLZ_HIP(hipMemsetAsync(h->buf[b].p, 0, ntt_bytes(h), h->stream), BLZ_ERR_UNKNOWN);
     }
     BLZ_TRY(h->scratch.reserve(ntt_bytes(h)));
-    BLZ_HIP(hipStreamSynchronize(h->stream), BLZ_ERR_UNKNOWN);
+    BLZ_TRY(sync_stream_bounded(h->stream, "NTT set-up: tables and zero-filled buffers"));
     return BLZ_OK;
 }
 
@@ -335,7 +335,7 @@ int blz_ntt_banks_preprocess_device(blz_ntt* h, const void* d_in, void* d_banks)
     hipLaunchKernelGGL(k_ntt_banks_pre, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->copy_stream, (const uint4*)d_in,
                        (uint4*)d_banks, n);
     BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
-    BLZ_HIP(hipStreamSynchronize(h->copy_stream), BLZ_ERR_UNKNOWN);
+    BLZ_TRY(sync_stream_bounded(h->copy_stream, "banks preprocess"));
     return BLZ_OK;
 }
 int blz_ntt_banks_postprocess_device(blz_ntt* h, const void* d_banks, void* d_out) {
@@ -346,7 +346,7 @@ int blz_ntt_banks_postprocess_device(blz_ntt* h, const void* d_banks, void* d_ou
     hipLaunchKernelGGL(k_ntt_banks_post, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->copy_stream, (const uint4*)d_banks,
                        (uint4*)d_out, n, G, Bg);
     BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
-    BLZ_HIP(hipStreamSynchronize(h->copy_stream), BLZ_ERR_UNKNOWN);
+    BLZ_TRY(sync_stream_bounded(h->copy_stream, "banks postprocess"));
     return BLZ_OK;
 }
 

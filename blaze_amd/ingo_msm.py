@@ -226,9 +226,16 @@ class MSMClient(DriverPrimitive[MSMInit, MSMParams, MSMInput, MSMResult]):
 
     def set_window_table(self, enable) -> None:
         """Opt in to the resident-base window table (include/blaze_hip.h blz_msm_set_window_table): pf = 1 handles whose
-        bases live in the arena; built on the first task over them, W x the memory of the bases, fewer bucket additions.
+        bases live in the arena; built beside the tasks (prepare_window_table), W x the memory of the bases, fewer bucket additions.
         False / 0 off, True / 1 where it pays (the BLS curves), 2 always."""
         check(lib().blz_msm_set_window_table(self._h, int(enable)))
+
+    def prepare_window_table(self, nof_elements: int, hbm_addr=(0, 0), wait_ms: int = -1) -> bool:
+        """Enqueue the table's build for the bases at hbm_addr - it runs beside the tasks, which take the plain path until it
+        is there - and wait up to wait_ms for it (0: not at all; < 0: the library's wait deadline).  True: the table is in place."""
+        ready = C.c_int(0)
+        check(lib().blz_msm_prepare_window_table(self._h, nof_elements, hbm_addr[0], hbm_addr[1], wait_ms, C.byref(ready)))
+        return bool(ready.value)
 
     def set_scalar_range(self, bit_lo: int, bit_hi: int) -> None:
         """This client's tasks sum only bits [bit_lo, bit_hi) of every scalar and return 2^bit_lo x that sum: one shard of a

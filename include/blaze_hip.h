@@ -176,6 +176,14 @@ int blz_msm_plan(int curve, uint32_t nof_elements, int is_precompute, uint32_t o
  * A handle with a scalar range (blz_msm_set_scalar_range) tabulates 2^(bit_lo + c j) P for the windows of its range.
  * The default of new handles is BLAZE_MSM_TABLE (0).  No other value of `enable` is accepted (InvalidPrimitiveParam). */
 int blz_msm_set_window_table(blz_msm* h, int enable);
+/* The table is built BESIDE the tasks, never inside one: the first task over bases that have none enqueues the build (chunks
+ * of bases on a lowest-priority stream of the device) and takes the plain path, like every task until the build has
+ * completed; the next task adopts the table.  Results are bit-identical either way.  A host that wants the table in place
+ * before its first task - or wants the build to overlap something else - calls this after load_data_to_hbm: it enqueues the
+ * build for the nof_elements bases at hbm_addr + hbm_off and waits up to wait_ms (0: not at all; < 0: BLAZE_WAIT_TIMEOUT_MS)
+ * for it; *ready = 1 when the table is in place, 0 otherwise (still building, not opted in, no memory, a base of even
+ * order, another handle's table serves the extent). */
+int blz_msm_prepare_window_table(blz_msm* h, uint32_t nof_elements, uint64_t hbm_addr, uint64_t hbm_off, int wait_ms, int* ready);
 /* out = {table bytes, window bits c, windows W, build time in microseconds} of the table the handle's last HBM task
  * used; zeros when it took the plain path */
 int blz_msm_window_table_info(blz_msm* h, uint64_t out[4]);

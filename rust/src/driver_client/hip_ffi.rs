@@ -48,6 +48,7 @@ extern "C" {
     pub fn blz_msm_is_engine_ready(h: *mut BlzMsm, out: *mut u32) -> c_int;
     pub fn blz_msm_reset(h: *mut BlzMsm) -> c_int;
     pub fn blz_msm_set_window_table(h: *mut BlzMsm, enable: c_int) -> c_int;
+    pub fn blz_msm_prepare_window_table(h: *mut BlzMsm, nof_elements: u32, hbm_addr: u64, hbm_off: u64, wait_ms: c_int, ready: *mut c_int) -> c_int;
     pub fn blz_msm_set_scalar_range(h: *mut BlzMsm, bit_lo: u32, bit_hi: u32) -> c_int;
     pub fn blz_msm_shard_layout(curve: c_int, nof_elements: u32, nranks: c_int, rank: c_int, out: *mut u32) -> c_int;
     pub fn blz_msm_shard_layout_ex(curve: c_int, nof_elements: u32, nranks: c_int, rank: c_int, flags: u32, out: *mut u32) -> c_int;

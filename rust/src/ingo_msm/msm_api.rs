@@ -176,6 +176,13 @@ impl MSMClient {
     pub fn set_window_table(&self, mode: i32) -> Result<()> {
         check(unsafe { blz_msm_set_window_table(self.h, mode) })
     }
+    /// Enqueue the table's build for the bases at `hbm_addr` (it runs beside the tasks, which take the plain path until it is
+    /// there) and wait up to `wait_ms` for it (0: not at all, negative: the library's wait deadline); `true`: the table is in place.
+    pub fn prepare_window_table(&self, nof_elements: u32, hbm_addr: (u64, u64), wait_ms: i32) -> Result<bool> {
+        let mut ready: std::os::raw::c_int = 0;
+        check(unsafe { blz_msm_prepare_window_table(self.h, nof_elements, hbm_addr.0, hbm_addr.1, wait_ms, &mut ready) })?;
+        Ok(ready != 0)
+    }
     /// One shard of a job split by scalar chunk: only bits `[bit_lo, bit_hi)` of every scalar, result weighted `2^bit_lo`.
     pub fn set_scalar_range(&self, bit_lo: u32, bit_hi: u32) -> Result<()> {
         check(unsafe { blz_msm_set_scalar_range(self.h, bit_lo, bit_hi) })

@@ -439,7 +439,7 @@ def test_cpp_host_mirror(gpu, orc, tmp_path):
     assert out.read_bytes() == exp
 
 
-@pytest.mark.parametrize("shard", ["auto", "elements"])
+@pytest.mark.parametrize("shard", ["auto", "bits", "elements"])
 def test_bench_sharded_path_two_ranks_one_gpu(gpu, shard):
     """bench.py's N > 1 path (rank's shard from blz_msm_shard_layout - at this size two ranks split the scalars' BITS of all
     the elements; BLAZE_SHARD=elements: the plain element split - one all-gather of the partials, rank-ordered combine)
@@ -451,8 +451,8 @@ def test_bench_sharded_path_two_ranks_one_gpu(gpu, shard):
 
     env = dict(os.environ, BLAZE_BENCH_LOGN="18", BLAZE_BENCH_EMIT_RESULT="1", BLAZE_BENCH_BACKEND="gloo",
                BLAZE_BENCH_ONE_GPU="1", MASTER_ADDR="127.0.0.1")
-    if shard == "elements":
-        env["BLAZE_SHARD"] = "elements"
+    if shard != "auto":
+        env["BLAZE_SHARD"] = shard       # "bits": two ranks split the scalars' bits of all the elements, whatever the planner thinks
     root = os.path.dirname(HERE)
     common = ["--steps", "1", "--warmup", "0", "--no-ntt", "--no-cpu-baseline"]
     one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + common, env=env,
@@ -468,9 +468,20 @@ def test_bench_sharded_path_two_ranks_one_gpu(gpu, shard):
     lay = j2["config"]["shard_rank0"]
     if shard == "elements":
         assert j2["config"]["elements_per_gpu"] == (1 << 17) and (lay["bit_lo"], lay["bit_hi"]) == (0, 256)
+    elif shard == "bits":
+        assert j2["config"]["elements_per_gpu"] == (1 << 18) and (lay["bit_lo"], lay["bit_hi"]) == (0, 128)
     else:
         assert lay["count"] * (lay["bit_hi"] - lay["bit_lo"]) * 2 == (1 << 18) * 256, lay
     assert j2["result_hex"] == j1["result_hex"] and len(j1["result_hex"]) == 288   # same job, same bytes
+    # the N > 1 extra legs: the plain element split beside the headline's layout, and the host-scalar flow per rank - each
+    # checked by one exchange of the ranks' partials against the headline result
+    alt, flow = j2["alt_layout_elements"], j2["hbm_flow"]
+    assert "error" not in alt and "error" not in flow, (alt, flow)
+    if (lay["bit_lo"], lay["bit_hi"]) == (0, 256):
+        assert alt.get("same_as_headline")
+    else:
+        assert alt["shard_rank0"]["count"] == (1 << 17) and alt["ms_per_step"] > 0
+    assert flow["shard_rank0"]["ranges"] == 1 and flow["result_check"]["ok"] and flow["ms_per_msm_steady"] > 0
 
 
 def test_bench_native_exchange_next_to_torch_process_group(gpu):

@@ -127,6 +127,7 @@ def test_layouts_with_window_tables(gpu, orc, curve, logn):
             vs = DeviceBuffer.__new__(DeviceBuffer); vs.device_id = 0; vs.ptr = ds.ptr + l["first"] * 32; vs.nbytes = l["count"] * 32
             vp = DeviceBuffer.__new__(DeviceBuffer); vp.device_id = 0; vp.ptr = dp.ptr + l["first"] * ps; vp.nbytes = l["count"] * ps
             tab.set_scalar_range(l["bit_lo"], l["bit_hi"])
+            assert tab.prepare_window_table(l["count"], (0, l["first"] * ps))     # this range's own table beside the others'
             got = run_msm(tab, None, vs, l["count"], hbm=(0, l["first"] * ps))
             info = tab.window_table_info()
             assert info["bytes"] > 0 and info["windows"] * info["window_bits"] >= l["bit_hi"] - l["bit_lo"] + 1, (l, info)

@@ -52,6 +52,8 @@ def collect():
     return r, cl.get_api()
 
 
+if os.environ.get("TABLE"):
+    cl.prepare_window_table(cnt, (0, 0))     # built beside the tasks; waited for here
 submit(); tinfo = cl.window_table_info(); submit(); r0, _ = collect(); collect()
 t0 = time.perf_counter()
 pend, out = 0, []
