@@ -468,7 +468,10 @@ def main():
                                      "peak": round(peak, 0), "frac": round(mads / (acc_avg_ms * 1e-3) / peak, 4),
                                      "peak_source": "calibration kernel on this device, this run (50 ms of independent multiply-add chains, "
                                                     "4 waves per SIMD)" if calib else "constant measured on another box",
-                                     "peak_reference_boxes": 3.1e13, "multiply_adds_per_launch": mads}
+                                     "peak_reference_boxes": 3.1e13, "multiply_adds_per_launch": mads,
+                                     "multiply_adds_source": "3542 per bucket addition = the v_mad_u64_u32 count of k_accumulate<Fq_BLS381>'s loop in the "
+                                                             "shipped gfx950 code object (tests/test_isa_counts.py disassembles it), x one addition per "
+                                                             "element and occupied window"}
     clock = {"nominal_mhz": calib["nominal_clock_mhz"] if calib else None, "sclk_mhz_timed_steps": sclk_rec,
              "mad_calibration": calib}
 
