@@ -47,6 +47,23 @@ int use_device(int device_id) {
     return BLZ_OK;
 }
 
+int env_int(const char* name, int dflt) {
+    const char* s = getenv(name);
+    return s && *s ? atoi(s) : dflt;
+}
+
+int plan_override(const char* key, int dflt) {
+    const char* s = getenv("BLAZE_MSM_PLAN");
+    if (!s || !*s) return dflt;
+    const size_t kl = strlen(key);
+    for (const char* p = s; *p;) {
+        while (*p == ',' || *p == ' ') ++p;
+        if (strncmp(p, key, kl) == 0 && p[kl] == '=') return atoi(p + kl + 1);
+        while (*p && *p != ',') ++p;
+    }
+    return dflt;
+}
+
 int wait_timeout_ms() {
     const char* s = getenv("BLAZE_WAIT_TIMEOUT_MS");
     int v = s && *s ? atoi(s) : 120000;
@@ -168,8 +185,17 @@ int launch_stall(hipStream_t st, uint32_t max_ms, void** token) {
     int dev = 0, khz = 0;
     BLZ_HIP(hipGetDevice(&dev), BLZ_ERR_UNKNOWN);
     if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000;   // 100 MHz
+    // one pinned page per process, 64 flags handed out in turn (a flag cannot be freed - nobody knows when its kernel has read
+    // it for the last time - so none is allocated per call)
+    static std::mutex mu;
+    static uint32_t* pool = nullptr;
+    static unsigned next = 0;
     uint32_t* flag = nullptr;
-    BLZ_HIP(hipHostMalloc((void**)&flag, 64), BLZ_ERR_UNKNOWN);
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!pool) BLZ_HIP(hipHostMalloc((void**)&pool, 64 * 64), BLZ_ERR_UNKNOWN);
+        flag = pool + 16 * (next++ % 64u);
+    }
     *flag = 1u;
     hipLaunchKernelGGL(k_stall, dim3(1), dim3(1), 0, st, flag, (uint64_t)max_ms * (uint64_t)khz);
     BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);

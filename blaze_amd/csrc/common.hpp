@@ -52,6 +52,22 @@ inline int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+// Runtime switches.  The shipped library reads EIGHT environment variables (README.md lists them; tests/test_host_logic.py
+// compares that table with what the sources read): BLAZE_LOG, BLAZE_WAIT_TIMEOUT_MS, BLAZE_COMM_TIMEOUT_MS, BLAZE_SHARD,
+// BLAZE_SORT_HIDE, BLAZE_MSM_PIECES, BLAZE_MSM_PLAN (+ BLAZE_HIP_LIB in the Python mirror).  Everything else that was ever
+// swept - sort geometry, segment sizes, kernel variants that lost their A/B runs - is a compile-time experiment: a build
+// with -DBLZ_EXPERIMENT_KNOBS (tools/ only) reads the same names from the environment, the shipped build folds the defaults.
+int env_int(const char* name, int dflt);
+#ifdef BLZ_EXPERIMENT_KNOBS
+inline int exp_knob(const char* name, int dflt) { return env_int(name, dflt); }
+#else
+inline int exp_knob(const char*, int dflt) { return dflt; }
+#endif
+// BLAZE_MSM_PLAN="c=13,L=64,split_ns=0,table_c=26": overrides of the window planner for tests and sweeps (c: uniform window
+// width; L: unit length; split_ns: the planner's price of a split top window - 0 lets mixed widths appear at sizes the
+// oracle can check; table_c: window width of window tables).  Absent keys keep the planner's own choice.
+int plan_override(const char* key, int dflt);
+
 // number of usable devices, 0 if the runtime cannot see any
 int device_count();
 // make `device_id` current; BLZ_ERR_FILE if it does not exist (the reference unwraps the open()
@@ -70,9 +86,9 @@ int sync_device_bounded(const char* what);   // every stream of the current devi
 bool wait_timed_out();   // the last sync_*_bounded of this thread ended on its deadline
 void wait_clear();       // forget it (before a call that may fail without ever reaching a wait)
 
-// Test hook behind blz_test_*_stall: a one-lane kernel on `st` that spins until the host clears *token (pinned host
-// memory, leaked on purpose: nobody knows when the kernel has read it for the last time) or max_ms have passed on the
-// device's wall clock - the cap keeps a failing test from wedging the GPU for good.
+// Test hook behind blz_test_*_stall: a one-lane kernel on `st` that spins until the host clears *token (a slot of one pinned
+// page the process keeps) or max_ms have passed on the device's wall clock - the cap keeps a failing test from wedging the GPU
+// for good.
 int launch_stall(hipStream_t st, uint32_t max_ms, void** token);
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (current device, kernel): the opt-in for more than
@@ -115,7 +131,7 @@ struct ArenaExtent {
     uint64_t dirty_lo = 0, dirty_hi = 0;   // byte span (relative to start) whose points are stale in the shadow
     hipEvent_t shadow_ready = nullptr;     // recorded after the last conversion; consumers on other streams wait
     bool shadow_recorded = false;          // shadow_ready has been recorded at least once since the shadow was (re)built
-    // window tables (msm_impl.cuh k_build_window_table; opt-in per handle): for the points [first, +npts) of the grid at `phase`
+    // window tables (msm_impl.hip.hpp k_build_window_table; opt-in per handle): for the points [first, +npts) of the grid at `phase`
     // the W multiples 2^(lo + c j) P, j < W, in the shadow's point format, point-major.  One per (bases, scalar range) that
     // a handle asked for - the ranks of a job sharded by scalar chunk each tabulate their own range - at most
     // MAX_TABLES per extent.  Any write into the extent drops them all.

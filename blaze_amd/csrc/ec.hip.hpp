@@ -6,7 +6,7 @@
 // repeats a 256-element tile (tests/msm/mod.rs:337-354) so equal / opposite operands meet in the
 // same bucket constantly.
 #pragma once
-#include "field.cuh"
+#include "field.hip.hpp"
 
 namespace blz {
 

@@ -6,8 +6,8 @@
 // quad_perm broadcasts (one v_mov_dpp per limb).  Doubling = 3 rounds, addition = 4 rounds.
 // All 4 lanes of a quad must be active and hold identical inputs; outputs are identical on all 4.
 #pragma once
-#include "ec.cuh"
-#include "ec_rr.cuh"
+#include "ec.hip.hpp"
+#include "ec_rr.hip.hpp"
 
 namespace blz {
 
@@ -121,7 +121,7 @@ __device__ __noinline__ void quad_add(XYZZ<F>& acc, const XYZZ<F>& q, uint32_t l
 }
 
 // ------------------------------------------------------------------------------------------------
-// The same quad-cooperative group law on the reduced-radix field (ec_rr.cuh) for the curves that have one.  The tail is
+// The same quad-cooperative group law on the reduced-radix field (ec_rr.hip.hpp) for the curves that have one.  The tail is
 // a chain of sequential point operations on ONE wave, and a single wave issues a vector instruction every four cycles at
 // best: what counts is the instruction count of a field product - 576 (multiply-add / add-carry pairs) on 32-bit limbs,
 // about 480 on 28-bit limbs.  k_finish is 250 doublings in sequence and dominates the latency of a small MSM (2^13

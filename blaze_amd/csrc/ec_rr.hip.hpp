@@ -1,15 +1,15 @@
-// Mixed addition on y^2 = x^3 + b in XYZZ coordinates over the reduced-radix field (field_rr.cuh): the hot
-// loop of the bucket accumulation.  Same formulas as ec.cuh (EFD madd-2008-s / mdbl-2008-s-1), same
+// Mixed addition on y^2 = x^3 + b in XYZZ coordinates over the reduced-radix field (field_rr.hip.hpp): the hot
+// loop of the bucket accumulation.  Same formulas as ec.hip.hpp (EFD madd-2008-s / mdbl-2008-s-1), same
 // completeness (infinity, P + P, P - P), different arithmetic: no carry chains, no conditional
 // subtractions; every intermediate's limb and value bounds are carried in its type and checked at
 // compile time (Frr<Q, F, V>: limbs < F 2^B, value < V m).
 //
 // Cost in v_mad_u64_u32 (NL = 14): 6 products x 392 + 2 squarings x 301 + 1 fused sum of two products x 588
-// = 3542 per mixed add, against 2844 multiply-add PAIRS (v_mad_u64_u32 + v_addc_co_u32) in ec.cuh.
+// = 3542 per mixed add, against 2844 multiply-add PAIRS (v_mad_u64_u32 + v_addc_co_u32) in ec.hip.hpp.
 // NL = 9 (BN254): 6 x 162 + 2 x 126 + 243 + 9 (the quotient reduction of X3) = 1476, against 1280 pairs on 8 x 32 bits.
 #pragma once
-#include "field_rr.cuh"
-#include "ec.cuh"
+#include "field_rr.hip.hpp"
+#include "ec.hip.hpp"
 #include <type_traits>
 
 namespace blz {
@@ -73,7 +73,7 @@ BLZ_DEV bool ptrr_is_inf(const XYZZRR<Q>& p) { return rr_all_zero(p.zz); }
 // Bounds in the comments: (limb factor, value factor), loose budget first, tight budget after the bar.
 
 // 2 (x, y) for an affine point whose y may be the lazy negation 4m - y.  By value and out of line: the rare
-// P + P branch must not force the hot loop's accumulator into scratch (see ec.cuh's pt_mdbl_val).
+// P + P branch must not force the hot loop's accumulator into scratch (see ec.hip.hpp's pt_mdbl_val).
 // TAG: one copy per calling kernel (a shared out-of-line callee is compiled for its most permissive caller and
 // then sets the register count of every kernel that reaches it).
 template <class Q, int TAG = 0>
@@ -131,8 +131,8 @@ BLZ_DEV void ptrr_madd(XYZZRR<Q>& acc, const AffineRR<Q>& q, bool neg) {
     }
     const auto P = rr_tn(P0);                          // | (1, 6)
     const auto R = rr_tn(R0);                          // | (1, 6)
-    // independent products go in pairs (field_rr.cuh rr_mul_pair: two column chains per wave), ordered so that every
-    // input coordinate dies as early as possible (see ec.cuh's pt_madd)
+    // independent products go in pairs (field_rr.hip.hpp rr_mul_pair: two column chains per wave), ordered so that every
+    // input coordinate dies as early as possible (see ec.hip.hpp's pt_madd)
     rr_sqr_pair(PP, P, t, R);
     rr_mul_pair(acc.zz, acc.zz, PP, PPP, P, PP);       // ZZ3, PPP
     rr_mul_pair(acc.zzz, acc.zzz, PPP, Qv, acc.x, PP); // ZZZ3, Q
@@ -260,7 +260,7 @@ BLZ_DEV void ptrr_store(uint32_t* base, size_t idx, const XYZZRR<Q>& a) {
     rr_store(q + 3 * S, a.zzz);
 }
 
-// accumulator -> ec.cuh's XYZZ over the 32-bit twin field (Montgomery R32, lazy [0, 2m)); infinity stays
+// accumulator -> ec.hip.hpp's XYZZ over the 32-bit twin field (Montgomery R32, lazy [0, 2m)); infinity stays
 // literal zero
 template <class F>
 BLZ_DEV void ptrr_to_xyzz32(XYZZ<F>& r, const XYZZRR<typename F::RR>& a) {

@@ -2,7 +2,7 @@
 // Montgomery radix Rrr = 2^(B NL)  (BLS12-377/381 Fq: 14 x 28 bits, bucket accumulation and first reduce level;
 // the three scalar fields: 9 x 29 bits, the 2^27 NTT).
 //
-// Why a second representation.  With full 32-bit limbs (field.cuh) a column sum of 32x32 products
+// Why a second representation.  With full 32-bit limbs (field.hip.hpp) a column sum of 32x32 products
 // needs 64 + log2(count) bits, so every v_mad_u64_u32 is followed by a v_addc_co_u32 that folds its
 // carry-out into a third accumulator word: 2 issue slots per multiply-add, and both are "long"
 // (VOP3-class) instructions that issue at half the rate of a plain 32-bit add on this chip.  With B-bit
@@ -24,7 +24,7 @@
 // rr_sub<J>(a, b): a - b + 2^J m, b normalised with Vb <= 2^(J-1): Frr<Q, Fa + 2, Va + 2^J>.
 // Values are never canonical in flight; zero tests are done modulo m on demand (rr_is_zero).
 #pragma once
-#include "field.cuh"
+#include "field.hip.hpp"
 
 namespace blz {
 
@@ -575,7 +575,7 @@ BLZ_DEV void rr_to_mont_from_words(Frr<Q, 1, 2>& r, const uint32_t (&w)[Q::N32])
     for (int i = 0; i < Q::NL; ++i) k.v[i] = Q::RR2[i];
     rr_mul(r, x, k);
 }
-// x Rrr (normalised) -> x R32 as 32-bit words in the lazy range [0, 2m) of field.cuh's twin field
+// x Rrr (normalised) -> x R32 as 32-bit words in the lazy range [0, 2m) of field.hip.hpp's twin field
 template <class Q, int V>
 BLZ_DEV void rr_to_mont32_words(uint32_t (&w)[Q::N32], const Frr<Q, 1, V>& a) {
     Frr<Q, 1, 1> k;

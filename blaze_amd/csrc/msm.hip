@@ -15,8 +15,8 @@
 // 32 B LE, entries u32, bucket partials AoS XYZZ (4N dwords).  The arithmetic (v_mad_u64_u32) bounds
 // the dominant kernels, not HBM.
 #include "msm_engine.hpp"
-#include "field.cuh"
-#include "msm_digits.cuh"
+#include "field.hip.hpp"
+#include "msm_digits.hip.hpp"
 
 namespace blz {
 
@@ -40,14 +40,14 @@ size_t mont_point_bytes(int curve) { return curve == BLZ_BN254 ? 64 : 128; }
 // Layouts searched: W windows, the lowest k of width cmin+1, the next W-1-k of width cmin, and a top
 // window of max(cmin, what is left of sbits+1) bits (its upper bits are zero for canonical scalars, so
 // its signed digits never go negative; only 2^(real bits) of its buckets are occupied).  k = 0 with a
-// top window of cmin bits is the uniform plan; BLAZE_MSM_C forces that one.
+// top window of cmin bits is the uniform plan; BLAZE_MSM_PLAN c= forces that one.
 MsmPlan make_plan(uint32_t npts, int sbits, int ebits, int force_c) {
     MsmPlan best;
     double best_cost = 1e300;
     if (ebits <= 0 || ebits > sbits) ebits = sbits;
     const double t_entry = 0.163, t_bucket = 0.62, t_empty = 0.03, t_hot = 0.01;
     const int need = sbits + 1;
-    const double t_split = (double)msm_env_int("BLAZE_MSM_SPLIT_NS", 6000);  // tests set 0: mixed widths at any size
+    const double t_split = (double)plan_override("split_ns", 6000);  // BLAZE_MSM_PLAN: tests set 0 - mixed widths at any size
     for (int cmin = 3; cmin <= 23; ++cmin) {
         if (force_c > 0 && cmin != force_c) continue;
         for (int W = 1; W <= MSM_MAX_W; ++W) {
@@ -122,13 +122,13 @@ MsmPlan make_plan(uint32_t npts, int sbits, int ebits, int force_c) {
     return best;
 }
 
-// Window-table plans (msm_engine.hpp MsmPlan::table, msm_impl.cuh k_build_window_table).  Costs fitted to the round-3 kernels on the table
+// Window-table plans (msm_engine.hpp MsmPlan::table, msm_impl.hip.hpp k_build_window_table).  Costs fitted to the round-3 kernels on the table
 // shape: 0.130 ns per entry (one mixed addition; the sort is hidden), 0.34 ns per bucket slot (two full additions in the
 // level-0 reduce - 12.6 ms for the 2^25 buckets of c = 26 - scans, unit lists).  2^26 bases: c = 26, 10 windows (671 M
 // additions instead of the 805 M of the 12-window plan without a table: 106.6 ms per MSM against 116.2; c = 24, 11 windows:
 // 108.7); 2^24: c = 24 (30.0 against 33.2 ms); 2^23: c = 22 (17.2 against 18.3 ms).
 int table_window_bits(uint32_t npts, int need_bits) {
-    const int forced = msm_env_int("BLAZE_MSM_TABLE_C", 0);
+    const int forced = plan_override("table_c", 0);
     int best = 0;
     double best_cost = 1e300;
     for (int c = 16; c <= 26; ++c) {
@@ -421,10 +421,6 @@ __global__ __launch_bounds__(256) void k_unit_order(const uint32_t* __restrict__
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-int msm_env_int(const char* name, int dflt) {
-    const char* s = getenv(name);
-    return s && *s ? atoi(s) : dflt;
-}
 
 static const MsmCurveOps* ops_for(int curve, int repr = 0) {
     switch (curve) {
@@ -461,10 +457,8 @@ int MsmEngine::init(int device_id, int curve_id, int precompute_factor) {
     curve = curve_id;
     repr = 0;
     if (curve == BLZ_BN254) {
-        // BLAZE_BN254_REPR = rr | w32 overrides the choice by precompute factor (A/B runs)
-        const char* e = getenv("BLAZE_BN254_REPR");
-        if (e && *e) repr = strcmp(e, "w32") == 0 ? 1 : 0;
-        else repr = precompute_factor > 1 ? 1 : 0;
+        // (experiment builds: BLAZE_BN254_REPR = 0 | 1 overrides the choice by precompute factor)
+        repr = exp_knob("BLAZE_BN254_REPR", precompute_factor > 1 ? 1 : 0) ? 1 : 0;
     }
     if (!ops_for(curve, repr)) return fail(BLZ_ERR_INVALID_PARAM, "unknown curve %d", curve);
     BLZ_TRY(use_device(device));
@@ -565,7 +559,7 @@ static const int kScalarFieldBits[3] = {253, 255, 254};  // bit length of r (BLS
 
 MsmPlan MsmEngine::plan_for(uint32_t npts, int sbits) const {
     const int ebits = sbits == 256 ? kScalarFieldBits[curve] : sbits;
-    return make_plan(npts, sbits, ebits, msm_env_int("BLAZE_MSM_C", 0));
+    return make_plan(npts, sbits, ebits, plan_override("c", 0));
 }
 
 MsmPlan MsmEngine::plan_for_range(uint32_t npts, int bit_lo, int bit_hi) const {
@@ -573,7 +567,7 @@ MsmPlan MsmEngine::plan_for_range(uint32_t npts, int bit_lo, int bit_hi) const {
     int ebits = kScalarFieldBits[curve] - bit_lo;   // real bits of canonical scalars inside the range
     if (ebits > vbits) ebits = vbits;
     if (ebits < 1) ebits = 1;
-    MsmPlan P = make_plan(npts, vbits, ebits, msm_env_int("BLAZE_MSM_C", 0));
+    MsmPlan P = make_plan(npts, vbits, ebits, plan_override("c", 0));
     P.base_bit = bit_lo;
     return P;
 }
@@ -586,7 +580,7 @@ MsmPlan MsmEngine::plan_for_range(uint32_t npts, int bit_lo, int bit_hi) const {
 // A task of ONE piece is the classic pipeline: sort stage (hidden underneath the other slot's accumulation when there is
 // one), k_accumulate into per-unit sums, unit folds, bucket reduce over sums[unit_off[g]].  A task of SEVERAL pieces sorts
 // and accumulates piece by piece over the same bucket space: the bucket sums live in `bucket_sums`, indexed by bucket;
-// k_accumulate_cont resumes a bucket's sum where the previous piece left it (msm_impl.cuh), runs longer than L go through the
+// k_accumulate_cont resumes a bucket's sum where the previous piece left it (msm_impl.hip.hpp), runs longer than L go through the
 // unit folds and k_merge_buckets, and the reduce reads bucket_sums through the identity map.
 int MsmEngine::begin(uint32_t npts, int sbits, int* slot_out, int table_c, int bit_lo, int bit_hi, int nslices, bool phased) {
     BLZ_TRY(use_device(device));
@@ -605,10 +599,10 @@ int MsmEngine::begin(uint32_t npts, int sbits, int* slot_out, int table_c, int b
     // (a window table of a ranged handle holds 2^(lo + c j) P: the plan covers hi - lo bits + the carry, no closing doublings)
     MsmPlan P = table_c > 0 ? make_table_plan(npts, table_c, ranged ? bit_hi - bit_lo + 1 : 257)
                 : ranged    ? plan_for_range(npts, bit_lo, bit_hi)
-                            : make_plan(npts, sbits, ebits, msm_env_int("BLAZE_MSM_C", 0));
+                            : make_plan(npts, sbits, ebits, plan_override("c", 0));
     if (P.c == 0) return fail(BLZ_ERR_INVALID_PARAM, "no window plan for npts=%u sbits=%d%s", npts, sbits, table_c > 0 ? " (window table)" : "");
     if (P.table && (sbits != 256 || !msm_sort3t_ok(P))) return fail(BLZ_ERR_INVALID_PARAM, "window-table task outside the sort's range (c=%d)", P.c);
-    P.L = (uint32_t)msm_env_int("BLAZE_MSM_L", (int)P.L);
+    P.L = (uint32_t)plan_override("L", (int)P.L);
     if (P.L < 1) P.L = 1;
     if (P.L > (uint32_t)MAX_L) P.L = MAX_L;
     const uint64_t G = P.G;
@@ -629,16 +623,16 @@ int MsmEngine::begin(uint32_t npts, int sbits, int* slot_out, int table_c, int b
     // with its sort already done.  Its outputs are per slot (SortBufs); the scratch the sorts share is protected by
     // chaining every sort stage behind the one before (last_sort_done).  BLAZE_SORT_HIDE: 0 never, 1 when the other slot
     // is busy (default), 2 the three-level sort always (on the main stream when there is nothing to hide under: tests).
-    const int hide_env = msm_env_int("BLAZE_SORT_HIDE", 1);
+    const int hide_env = env_int("BLAZE_SORT_HIDE", 1);
     const MsmSlot& O = slots[(slot + 1) % MSM_QUEUE_DEPTH];
     bool s3 = P.table || (hide_env != 0 && nslices == 1 && msm_sort3_ok(P, sbits));   // (a table task has no other sort)
     bool fits = true;
     if (s3 && hide_env == 1 && !P.table) {
         // the three-level sort gives one block a whole level-2 bin: fine for the near-uniform digits of real scalars, a
         // cliff for inputs that pile entries into a few buckets (the reference harness repeats a 256-point tile).  The
-        // handle's last tasks say which kind it is being fed: stats_h[1] is their largest bucket.
-        const uint64_t mean = max_entries / (G ? G : 1) + 1;
-        if ((uint64_t)S.stats_h[1] > 64 * mean + 4096 || (uint64_t)O.stats_h[1] > 64 * mean + 4096) s3 = false;
+        // handle's last two COLLECTED tasks say which kind it is being fed (finish(): their largest bucket against their own
+        // mean - judged when the host has waited for the task, never read from a copy that may still be in flight)
+        if (recent_hot[0] || recent_hot[1]) s3 = false;
     }
     if (s3 && hide_env == 1) {
         // ... and the sort only hides if its waves fit BESIDE the accumulation's: two of those per SIMD (registers are
@@ -834,7 +828,7 @@ int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int 
         return BLZ_OK;
     }
     // resident inputs: one piece (BLAZE_MSM_PIECES = n forces n: tests of the piecewise path at sizes the oracle checks)
-    int pieces = msm_env_int("BLAZE_MSM_PIECES", 1);
+    int pieces = env_int("BLAZE_MSM_PIECES", 1);
     int slot = -1;
     BLZ_TRY(begin(npts, sbits, &slot, table_c, bit_lo, bit_hi, pieces, false));
     if (slot_out) *slot_out = slot;
@@ -862,6 +856,10 @@ int MsmEngine::finish(int slot, uint8_t* out) {
     if (S.plan.c) {
         BLZ_LOG(2, "msm: units=%u max_bucket=%u entries=%u", S.stats_h[0], S.stats_h[1], S.stats_h[2]);
         if ((uint64_t)S.stats_h[0] > S.max_units) return fail(BLZ_ERR_UNKNOWN, "unit count %u exceeds its bound", S.stats_h[0]);
+        // hot-bucket guard of begin(): this task's largest bucket against the mean of the sort that produced it
+        const uint64_t mean = (uint64_t)S.stats_h[2] / (S.plan.G ? S.plan.G : 1) + 1;
+        recent_hot[1] = recent_hot[0];
+        recent_hot[0] = (uint64_t)S.stats_h[1] > 64 * mean + 4096;
     }
     memcpy(out, S.result_h, 3 * fq_bytes(curve));
     float t = 0;

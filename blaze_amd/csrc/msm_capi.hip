@@ -130,7 +130,7 @@ int arena_points_mont(blz_msm* h, uint64_t pos, uint32_t npts, const void** out)
     return BLZ_OK;
 }
 
-// Window table of the `npts` bases at arena offset `pos` (msm_impl.cuh k_build_window_table, MsmPlan::table), kept with the
+// Window table of the `npts` bases at arena offset `pos` (msm_impl.hip.hpp k_build_window_table, MsmPlan::table), kept with the
 // extent, dropped by any write into it.  *out stays null - and the task takes the plain path - while the table is not to be
 // had: it is still being built, there is no memory for it, a base has even order, or the task is over a sub-range whose
 // best window width is not the table's.
@@ -145,7 +145,7 @@ int arena_points_mont(blz_msm* h, uint64_t pos, uint32_t npts, const void** out)
 // the first task launched after the last chunk has completed adopts the table.  blz_msm_prepare_window_table enqueues ALL the
 // remaining chunks at once for a host that would rather pay the build now.  Results are bit-identical either way
 // (tests/test_gpu_msm_table.py).
-constexpr uint32_t TABLE_BUILD_CHUNK = 3u << 16;   // bases per launch = the build kernel's lanes (msm_impl.cuh TABLE_BUILD_BLOCKS x 64)
+constexpr uint32_t TABLE_BUILD_CHUNK = 3u << 16;   // bases per launch = the build kernel's lanes (msm_impl.hip.hpp TABLE_BUILD_BLOCKS x 64)
 constexpr int TABLE_CHUNKS_PER_TASK = 2;           // ~18 ms on top of a 2^26 task's 117: 171 tasks until a 2^26 table is there
 int arena_points_table(blz_msm* h, uint64_t pos, uint32_t npts, const void** out, int* c_out, int chunk_budget) {
     *out = nullptr;
@@ -443,14 +443,14 @@ int stage_common(blz_msm* h, bool have_points, const void* points, size_t points
     // carried from piece to piece).  Link and multiplier work at the same time; what is left on the critical path behind the
     // last byte is the last piece's accumulation, the bucket reduce and the tail.
     const int sbits = h->pf == 1 ? 256 : 32;
-    if (!on_device && !has_hbm && h->armed && npts > 0 && msm_env_int("BLAZE_DMA_OVERLAP", 1) != 0) {
+    if (!on_device && !has_hbm && h->armed && npts > 0 && exp_knob("BLAZE_DMA_OVERLAP", 1) != 0) {
         const size_t mp = mont_point_bytes(h->curve), ps = point_size(h), sb = (size_t)sbits / 8;
         BLZ_TRY(h->scalars_buf[set].reserve(scalars_len));
         BLZ_TRY(h->points_raw[set].reserve(want_pts));
         BLZ_TRY(h->points_mont.reserve((size_t)npts * mp));
         // pieces of >= 2^19 points (64 MiB of host bytes: 1.2 ms of link), at most 16.  Measured (profiles/r04_dma_pieces.txt):
         // 2^22 elements 22.6 ms in one piece, 16.2 / 15.35 / 17.1 in 4 / 8 / 16; 2^26 270.8, 191.8 / 178.3 / 171.5
-        int pieces = msm_env_int("BLAZE_DMA_PIECES", 0);
+        int pieces = env_int("BLAZE_MSM_PIECES", 0);   // (the same switch forces the piece count of device-resident tasks, msm.hip run())
         if (pieces <= 0) {
             pieces = (int)(npts >> 19);
             if (pieces > 16) pieces = 16;
@@ -549,8 +549,7 @@ int blz_msm_new(int device_id, int mem_type, int is_precompute, int curve, blz_m
     h->mem_type = mem_type;
     h->pf = is_precompute ? BLZ_PRECOMPUTE_FACTOR : BLZ_PRECOMPUTE_FACTOR_BASE;
     h->curve = curve;
-    h->window_table = msm_env_int("BLAZE_MSM_TABLE", 0);
-    if (h->window_table < 0 || h->window_table > 2) h->window_table = 0;
+    h->window_table = 0;   // opt-in: blz_msm_set_window_table
     int rc = h->eng.init(device_id, curve, (int)h->pf);
     if (rc == BLZ_OK && hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess)
         rc = fail(BLZ_ERR_UNKNOWN, "copy stream creation failed");

@@ -9,7 +9,7 @@ namespace blz {
 // trade (12 windows over 257 bits: 3 x 22 + 8 x 21 + 23 bits hold 18.9 M bucket slots, 12 x 22 hold
 // 25.2 M).  Bucket g of window w is boff[w] + (|digit| - 1).  Downstream of the sort the bucket space is
 // flat; the bucket reduce walks it as Wv "virtual windows" of V = 2^(cmin-1) buckets each (every
-// window's bucket count is a multiple of V) and k_finish stitches them (msm_impl.cuh).
+// window's bucket count is a multiple of V) and k_finish stitches them (msm_impl.hip.hpp).
 constexpr int MSM_MAX_W = 96;
 struct MsmPlan {
     uint32_t npts = 0;   // points in the sum (n * precompute_factor)
@@ -22,7 +22,7 @@ struct MsmPlan {
     int Wv = 0;          // G / V
     uint64_t G = 0;      // bucket slots
     uint32_t L = 0;      // max run length handled by one accumulate unit
-    // Window-table tasks (msm_impl.cuh k_build_window_table): the points array holds, per base, its W multiples 2^(c j) P (point-major), so
+    // Window-table tasks (msm_impl.hip.hpp k_build_window_table): the points array holds, per base, its W multiples 2^(c j) P (point-major), so
     // every window's digit d of base i is an addition of +-table[i W + j] into bucket |d| - 1 of ONE bucket set shared
     // by all windows: boff[w] = 0 for every window, G = 2^(c-1), entries carry i W + j.  The reduce sees a single window.
     bool table = false;
@@ -118,6 +118,7 @@ struct MsmEngine {
     MsmPlan last_plan;
     float last_ms[8] = {};
     bool last_sort_hidden = false;   // of the last task collected by finish(): its sort stage ran on sort_stream
+    bool recent_hot[2] = {false, false};   // the last two collected tasks piled entries into a few buckets (begin()'s guard)
     uint32_t sort_slices = 1, sort_nc = 0;  // geometry of the last LDS sort (msm_sort.hip)
     int sort_cl = 0;
     void* sort_inter_fine = nullptr;  // u16 fine digits of the sort intermediate (second half of `inter`)
@@ -130,7 +131,7 @@ struct MsmEngine {
     MsmPlan plan_for(uint32_t npts, int sbits) const;   // the plan run() will use (host-side only)
     // raw wire-format points (x||y canonical LE) -> Montgomery AoS at mont_point_bytes() stride (never in place)
     int points_to_mont(const void* d_raw, void* d_mont, uint32_t npts);
-    // window table of npts wire-format points (msm_impl.cuh k_build_window_table): see MsmCurveOps::build_table
+    // window table of npts wire-format points (msm_impl.hip.hpp k_build_window_table): see MsmCurveOps::build_table
     int build_table(const void* d_raw, void* d_table, uint32_t npts, int c, int W, int base_shift, void* scratch, uint32_t* flag,
                     hipStream_t st);
     size_t table_scratch_bytes(int W) const;
@@ -150,8 +151,7 @@ struct MsmEngine {
 };
 
 size_t fq_bytes(int curve);
-size_t mont_point_bytes(int curve);  // stride of the Montgomery point array the pipeline reads (msm_impl.cuh MONT_STRIDE)
-int msm_env_int(const char* name, int dflt);
+size_t mont_point_bytes(int curve);  // stride of the Montgomery point array the pipeline reads (msm_impl.hip.hpp MONT_STRIDE)
 // two-level LDS-privatised digit sort (msm_sort.hip): fills count[], then (after the scan) entries[]
 int msm_sort_lds(MsmEngine& E, const void* d_scalars, uint32_t npts, int sbits);
 // three-level, small-footprint digit sort built to run underneath another task's k_accumulate (msm_sort3.hip): fills
@@ -183,7 +183,7 @@ struct MsmCurveOps {
     int partial_dwords;   // dwords of one unit / bucket sum in `partial`
     // VGPRs of k_accumulate as compiled (hipFuncGetAttributes): what the hidden sort has to fit beside
     int (*accumulate_vgprs)();
-    // window table of npts wire-format points (msm_impl.cuh k_build_window_table): table[i W + j] = 2^(base_shift + c j) P_i in the
+    // window table of npts wire-format points (msm_impl.hip.hpp k_build_window_table): table[i W + j] = 2^(base_shift + c j) P_i in the
     // Montgomery point format, on `st`; scratch: table_scratch_bytes(W) bytes; *flag (device u32) is set when a multiple came
     // out as infinity
     int (*build_table)(MsmEngine&, const void* d_raw, void* d_table, uint32_t npts, int c, int W, int base_shift, void* scratch,

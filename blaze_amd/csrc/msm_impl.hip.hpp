@@ -3,9 +3,9 @@
 // instantiations compile in parallel.  See msm.hip for the pipeline overview.
 #pragma once
 #include "msm_engine.hpp"
-#include "ec.cuh"
-#include "ec_rr.cuh"
-#include "ec_quad.cuh"
+#include "ec.hip.hpp"
+#include "ec_rr.hip.hpp"
+#include "ec_quad.hip.hpp"
 #include <type_traits>
 
 namespace blz {
@@ -17,7 +17,7 @@ namespace blz {
 // ------------------------------------------------------------------------------------------------
 template <class F>
 constexpr int MONT_STRIDE = 2 * F::N > 16 ? 32 : 2 * F::N;  // dwords per Montgomery point
-// Fields with a reduced-radix twin (USE_RR, ec_rr.cuh: the two BLS base fields) run the bucket accumulation in
+// Fields with a reduced-radix twin (USE_RR, ec_rr.hip.hpp: the two BLS base fields) run the bucket accumulation in
 // it: their Montgomery point copy holds 2 x NL limbs of B bits (x R_rr, y R_rr: 112 of the line's 128 bytes) and
 // k_accumulate converts a unit's sum to the 32-bit form once, when it stores it.
 
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void k_points_to_mont(const uint32_t* __restri
 // ONE bucket set, so the bucket count no longer multiplies with the window count and the windows can be as wide as
 // the entries-per-bucket ratio allows: 2^26 bases run 10 windows of 26 bits (671 M additions, 2^25 buckets) instead of
 // 12 windows of 21 - 23 bits (805 M additions, 12 x 2^21 buckets).  Costs W x the memory of the bases and, once per
-// load, this kernel: one lane per base walks the c (W - 1) doublings (32-bit XYZZ arithmetic, ec.cuh), parks the
+// load, this kernel: one lane per base walks the c (W - 1) doublings (32-bit XYZZ arithmetic, ec.hip.hpp), parks the
 // W - 1 unnormalised multiples and the running products of their ZZZ in a lane-private scratch row, inverts the
 // last product once and normalises on the way back (Montgomery's trick inside the lane).
 // A base whose multiple comes out as infinity (only a point of even order can: none in the r-torsion) cannot be
@@ -293,7 +293,7 @@ BLZ_DEV void accumulate_body(const uint32_t* __restrict__ pts, const uint32_t* _
         }
     }
     if constexpr (USE_RR<F>) {
-        // reduced-radix arithmetic (ec_rr.cuh): 2 waves per SIMD reach 95 % of the multiplier's rate
+        // reduced-radix arithmetic (ec_rr.hip.hpp): 2 waves per SIMD reach 95 % of the multiplier's rate
         // (profiles/r02_mul_variants.txt), which leaves 256 VGPRs: room for the next point's prefetch
         using Q = typename F::RR;
         XYZZRR<Q> acc;
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(128, 3) void k_combine_units(const uint32_t* __rest
     // k_combine_buckets' (below); this tree only folds the hot ones - none at all in most tasks
     const uint32_t max_units = (stats[1] + L - 1) / L;
     if (stride >= max_units || max_units <= thr) return;
-    // One DPP quad per 16 consecutive entries of the full-unit list (ec_quad.cuh): it scans them for
+    // One DPP quad per 16 consecutive entries of the full-unit list (ec_quad.hip.hpp): it scans them for
     // group leaders (at most two: a bucket's full units are contiguous in the list) and folds each
     // leader's group.  The chain of up to 15 additions is sequential and only hot buckets have any, so
     // latency is what counts: 4 dependent product rounds per add instead of 14, and every lane of a wave
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(64, FIRST ? 2 : 3) void k_reduce_level(const uint32
                                                      uint32_t T, int W, int shift, uint32_t* __restrict__ outA,
                                                      uint32_t* __restrict__ outC) {
     // level 0 (FIRST): one lane per segment, throughput-bound.  Upper levels: one DPP quad per
-    // segment (ec_quad.cuh), because there the sequential chain, not the work, is the cost.
+    // segment (ec_quad.hip.hpp), because there the sequential chain, not the work, is the cost.
     // The upper levels (and k_finish) are a few waves of sequential work on the tail stream, underneath the next task's
     // accumulation: raised wave priority, or they crawl (k_finish 1.8 ms alone, 3.0 ms underneath) - and the host, which
     // hands out the next-but-one task when this one's result arrives, enqueues that task's hidden sort too late for it
@@ -537,7 +537,7 @@ __global__ __launch_bounds__(64, FIRST ? 2 : 3) void k_reduce_level(const uint32
     store_xyzz(outC, (size_t)w * T + t, cs);
 }
 
-// level 0 on the reduced-radix field (ec_rr.cuh): the bucket sums arrive in it straight from k_accumulate, the two
+// level 0 on the reduced-radix field (ec_rr.hip.hpp): the bucket sums arrive in it straight from k_accumulate, the two
 // running sums stay in it, and only the segment's two results are converted to the 32-bit form the upper levels
 // (DPP quads) work in.  20 % fewer multiply-adds than the 32-bit full add, and no conversion per bucket.
 #ifndef BLZ_REDUCE_RR_WAVES
@@ -568,12 +568,12 @@ __global__ __launch_bounds__(64, BLZ_REDUCE_RR_WAVES) void k_reduce_level0_rr(co
         }
         ptrr_add<Q, 3>(s, run);  // weights i + 1 at the first level
     }
-    ptrr_store(outA, (size_t)w * T + t, run);   // the upper levels and k_finish work in the reduced radix too (ec_quad.cuh)
+    ptrr_store(outA, (size_t)w * T + t, run);   // the upper levels and k_finish work in the reduced radix too (ec_quad.hip.hpp)
     ptrr_store(outC, (size_t)w * T + t, s);
 }
 
 // upper levels on the reduced-radix field: one DPP quad per segment, as k_reduce_level<F, false>, with the quad group law
-// of ec_quad.cuh's second half (the chain of a segment is sequential: the latency of a field product is the cost)
+// of ec_quad.hip.hpp's second half (the chain of a segment is sequential: the latency of a field product is the cost)
 template <class F>
 __global__ __launch_bounds__(64, 2) void k_reduce_level_rr(const uint32_t* __restrict__ inA, const uint32_t* __restrict__ inC, uint32_t M,
                                                           uint32_t SEG, uint32_t T, int W, int shift, uint32_t* __restrict__ outA,
@@ -670,7 +670,7 @@ using FinishOps = std::conditional_t<USE_RR<F>, FinishOpsRR<F>, FinishOps32<F>>;
 template <class F>
 __global__ __launch_bounds__(64, USE_RR<F> ? 2 : 3) void k_finish(const uint32_t* __restrict__ vsumA, const uint32_t* __restrict__ vsumC,
                                                   FinishPlan fp, uint32_t* __restrict__ out) {
-    // one wave; every DPP quad runs the same chain cooperatively (ec_quad.cuh), lane 0 emits
+    // one wave; every DPP quad runs the same chain cooperatively (ec_quad.hip.hpp), lane 0 emits
     if (blockIdx.x != 0) return;
     __builtin_amdgcn_s_setprio(BLZ_TAIL_PRIO);   // (see k_reduce_level)
     using Ops = FinishOps<F>;
@@ -948,7 +948,7 @@ int run_accumulate_t(MsmEngine& E, const void* d_pts, uint32_t U, int slice) {
     // lane-per-bucket fold below is the throughput-bound answer.
     uint32_t hot_start = (uint32_t)P.G;
     if constexpr (USE_RR<F>) {
-        if (!P.table && slice < 0 && P.ebits > 0 && msm_env_int("BLAZE_FOLD_HOT", 1) != 0) {
+        if (!P.table && slice < 0 && P.ebits > 0 && exp_knob("BLAZE_FOLD_HOT", 1) != 0) {
             int lowest = -1, off = 0;
             bool any = false;
             int offs[MSM_MAX_W];
@@ -1026,8 +1026,8 @@ int run_reduce_t(MsmEngine& E, const void* sums, const void* unit_off_v) {
     // segment t by shifts.
     uint32_t seg0_auto = 64;
     while (seg0_auto > 8 && G / seg0_auto < 262144) seg0_auto >>= 1;
-    const uint32_t SEG0 = (uint32_t)msm_env_int("BLAZE_MSM_SEG", (int)seg0_auto);
-    const uint32_t SEGU = (uint32_t)msm_env_int("BLAZE_MSM_SEG_UPPER", 8);
+    const uint32_t SEG0 = (uint32_t)exp_knob("BLAZE_MSM_SEG", (int)seg0_auto);
+    const uint32_t SEGU = (uint32_t)exp_knob("BLAZE_MSM_SEG_UPPER", 8);
     uint32_t M = P.Bw;
     int level = 0, shift = 0;
     const uint32_t* curA = (const uint32_t*)sums;

@@ -5,7 +5,7 @@
 // memory of a typical box but fits the 288 GB of HBM, so it is built where it is used
 // (SURVEY.md 8(f) rank 4).  One lane per base: 7 x (32 doublings + normalisation).
 #include "common.hpp"
-#include "ec.cuh"
+#include "ec.hip.hpp"
 
 namespace blz {
 

@@ -17,7 +17,7 @@
 //                     scatter cursor, bucket-major LDS stage, slot-major copy-out to the final runs
 // HBM traffic: scalars read twice (32 B each), 8 B/entry written + read twice, 4 B/entry written.
 #include "msm_engine.hpp"
-#include "msm_digits.cuh"
+#include "msm_digits.hip.hpp"
 
 namespace blz {
 
@@ -485,7 +485,7 @@ static SortGeom make_geom(const MsmPlan& P) {
         cmin = P.width[w] < cmin ? P.width[w] : cmin;
         cmax = P.width[w] > cmax ? P.width[w] : cmax;
     }
-    const int cl_pref = msm_env_int("BLAZE_SORT_CL", 11);
+    const int cl_pref = exp_knob("BLAZE_SORT_CL", 11);
     int cl = cmin - 1 < cl_pref ? cmin - 1 : cl_pref;    // every window needs >= 1 coarse bin
     while ((P.G >> cl) > 24576u && cl < cmin - 1) ++cl;
     g.cl = cl;
@@ -503,7 +503,7 @@ int msm_sort_lds(MsmEngine& E, const void* d_scalars, uint32_t npts, int sbits) 
     SortGeom g = make_geom(P);
     if (g.cl > 12 || g.NC > 24576u) return fail(BLZ_ERR_UNKNOWN, "sort geometry out of range (c=%d W=%d)", P.c, P.W);
     // points per block: enough entries per block to amortise the NC-sized LDS sweeps, enough blocks to fill the chip
-    uint32_t ppb = (uint32_t)(((uint64_t)g.NC * (uint32_t)msm_env_int("BLAZE_SORT_EPB", 64) + P.W - 1) / P.W);
+    uint32_t ppb = (uint32_t)(((uint64_t)g.NC * (uint32_t)exp_knob("BLAZE_SORT_EPB", 64) + P.W - 1) / P.W);
     if (ppb < 4096) ppb = 4096;
     if (ppb > 65536) ppb = 65536;
     ppb = (ppb + SORT_THREADS - 1) / SORT_THREADS * SORT_THREADS;
@@ -529,7 +529,7 @@ int msm_sort_lds(MsmEngine& E, const void* d_scalars, uint32_t npts, int sbits) 
     else hipLaunchKernelGGL(k_coarse_count<1>, dim3(nblk), dim3(SORT_THREADS), lds, st, sc, npts, g, coarse_count);
     hipLaunchKernelGGL(k_coarse_scan, dim3(1), dim3(1024), 0, st, coarse_count, g.NC, coarse_off);
     // BLAZE_SORT_STAGED=0 selects the unstaged coarse scatter (kept for A/B measurements)
-    if (msm_env_int("BLAZE_SORT_STAGED", 1) != 0 && g.chmax <= 11 && g.cl <= 12) {
+    if (exp_knob("BLAZE_SORT_STAGED", 1) != 0 && g.chmax <= 11 && g.cl <= 12) {
         BLZ_TRY(ensure_dynamic_lds((const void*)k_coarse_scatter_staged<8>, 96 * 1024));
         BLZ_TRY(ensure_dynamic_lds((const void*)k_coarse_scatter_staged<1>, 96 * 1024));
         const size_t lds_cs = ((size_t)3 << g.chmax) * 4 + (size_t)CS_PTS * 8;
@@ -562,7 +562,7 @@ int msm_sort_lds_scatter(MsmEngine& E) {
     uint32_t* coarse_off = E.coarse.as<uint32_t>() + E.sort_nc;
     BLZ_TRY(ensure_dynamic_lds((const void*)k_fine_scatter, 158 * 1024));
     // staging entries per round (6 bytes each): what is left of the LDS after the two per-bucket arrays
-    size_t budget = (size_t)msm_env_int("BLAZE_SORT_FS_KB", 157) * 1024 - ((size_t)2 << E.sort_cl) * 4;
+    size_t budget = (size_t)exp_knob("BLAZE_SORT_FS_KB", 157) * 1024 - ((size_t)2 << E.sort_cl) * 4;
     uint32_t round_cap = (uint32_t)(budget / 6);
     if (round_cap > (uint32_t)FS_ROUND) round_cap = FS_ROUND;
     round_cap &= ~1023u;

@@ -25,7 +25,7 @@
 // Used when another task of the handle is in flight (msm.hip run()); a task with nothing to hide under keeps the
 // two-level sort, which is faster when it has the chip to itself.  BLAZE_SORT_HIDE = 0 never / 2 always (tests).
 #include "msm_engine.hpp"
-#include "msm_digits.cuh"
+#include "msm_digits.hip.hpp"
 
 namespace blz {
 
@@ -483,7 +483,7 @@ int msm_sort3(MsmEngine& E, const void* d_scalars, uint32_t npts) {
     MsmEngine::SortBufs& B = E.sb();
     S3Geom g;
     g.W = P.W;
-    g.prio = msm_env_int("BLAZE_SORT_PRIO", 3);
+    g.prio = exp_knob("BLAZE_SORT_PRIO", 3);
     g.NB1 = (uint32_t)(P.G >> S3_SH1);
     uint32_t bit = 0;
     for (int w = 0; w < P.W; ++w) {
@@ -537,7 +537,7 @@ int msm_sort3(MsmEngine& E, const void* d_scalars, uint32_t npts) {
 }
 
 // ================================================================================================ window-table tasks
-// The same three levels for plans whose windows share ONE bucket set (MsmPlan::table, msm_impl.cuh k_build_window_table): W windows of c bits,
+// The same three levels for plans whose windows share ONE bucket set (MsmPlan::table, msm_impl.hip.hpp k_build_window_table): W windows of c bits,
 // G = 2^(c-1) buckets, an entry carries (base * W + window) | sign.  What changes against the kernels above:
 //   * every window scatters into the same <= 256 level-1 bins (bucket >> sh1, sh1 = c - 9), so the level-1 remainder is up
 //     to 17 bits wide: 16 travel in the u16 side array, the lowest one (xs = 1) in bit 30 of the index word (indices stay
@@ -848,7 +848,7 @@ static S3TGeom s3t_geometry(const MsmPlan& P, uint32_t npts) {
     S3TGeom g;
     g.W = P.W;
     g.c = P.c;
-    g.prio = msm_env_int("BLAZE_SORT_PRIO", 3);
+    g.prio = exp_knob("BLAZE_SORT_PRIO", 3);
     g.sh1 = (uint32_t)(P.c - 1 - 8);
     g.NB1 = (uint32_t)(P.G >> g.sh1);   // 256
     // final-level bins of about 6 K entries (uniform digits: entries per bucket = npts W / G)

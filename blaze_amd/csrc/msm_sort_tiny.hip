@@ -12,7 +12,7 @@
 // Same outputs, bit for bit the same buckets as the big path (the order of a bucket's entries differs; the group law does
 // not care).  Chosen by msm.hip run() when msm_sort_tiny_ok().
 #include "msm_engine.hpp"
-#include "msm_digits.cuh"
+#include "msm_digits.hip.hpp"
 
 namespace blz {
 
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(TINY_THREADS) void k_sort_tiny(const uint32_t* __re
 }
 
 bool msm_sort_tiny_ok(const MsmPlan& P, uint32_t npts, int sbits) {
-    if (msm_env_int("BLAZE_SORT_TINY", 1) == 0) return false;
+    if (exp_knob("BLAZE_SORT_TINY", 1) == 0) return false;
     if (P.table || P.W < 1 || (sbits != 256 && sbits != 32)) return false;
     if (P.G == 0 || P.G > TINY_MAX_G || npts > TINY_MAX_PTS || P.L < 1 || P.L > TINY_MAX_L) return false;
     return true;

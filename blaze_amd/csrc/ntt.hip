@@ -53,7 +53,7 @@ struct blz_ntt {
     const NttFieldOps* ops = nullptr;
     int logn = 27;
     int inverse = 0;
-    bool force_generic = false;  // BLAZE_NTT_GENERIC=1: radix-2-in-LDS kernel for every pass (A/B runs)
+    bool force_generic = false;  // (experiment builds, BLAZE_NTT_GENERIC=1: radix-2-in-LDS kernel for every pass)
     NttGeom geom{};
     int cols_log[3] = {0, 0, 0};
     hipStream_t stream = nullptr;
@@ -125,10 +125,8 @@ int ntt_setup(blz_ntt* h) {
     h->T.t2 = p; p += 512 * 8;
     h->T.ninv = h->inverse ? p : nullptr;
     // the boundary table exists only where all three passes run the 512-point kernel (2^27), so that the factor it
-    // splits off is re-joined by the same kernel in pass 2; BLAZE_NTT_TABLE=0 keeps the stepping chain (A/B runs)
-    const char* envt = getenv("BLAZE_NTT_TABLE");
-    const char* envr = getenv("BLAZE_NTT_RR");
-    const bool want_ta = lc == 9 && !h->force_generic && !(envt && *envt == '0') && !(envr && *envr == '0');
+    // splits off is re-joined by the same kernel in pass 2
+    const bool want_ta = lc == 9 && !h->force_generic && exp_knob("BLAZE_NTT_TABLE", 1) != 0;
     BLZ_TRY(h->tables_rr.reserve(NTT_RR_TABLE_BYTES + (want_ta ? NTT_RR_BOUNDARY_BYTES : 0)));
     {
         uint32_t* q = h->tables_rr.as<uint32_t>();
@@ -139,9 +137,9 @@ int ntt_setup(blz_ntt* h) {
         h->TR.fin = h->inverse ? q : nullptr; q += NTT_RR_ENTRY_DWORDS;
         h->TR.ts2 = q; q += 2 * 512 * NTT_RR_ENTRY_DWORDS;   // Shoup entries
         h->TR.tA = want_ta ? q : nullptr;
-        // pass 1 tile order (ntt_rr.cuh); BLAZE_NTT_SWZ=0: the plain order (A/B runs)
-        const char* envs = getenv("BLAZE_NTT_SWZ");
-        h->TR.swz = (la == 9 && lb == 9) ? (envs && *envs ? (uint32_t)atoi(envs) : 4u) : 0u;   // BLAZE_NTT_SWZ: 0 plain, 1 + s (s <= 5); default s = 3
+        // pass 1 tile order (ntt_rr.hip.hpp): 0 plain, 1 + s: 2^s adjacent column groups back to back (s = 3), + 16 b: b bits of
+        // i1 walked first (default 7)
+        h->TR.swz = (la == 9 && lb == 9) ? (uint32_t)exp_knob("BLAZE_NTT_SWZ", 4) : 0u;
         if ((h->TR.swz & 15u) > 6u) h->TR.swz = 6u;
     }
     BLZ_TRY(h->ops->setup(h->stream, h->T, h->TR, h->geom, h->inverse));
@@ -186,7 +184,7 @@ int blz_ntt_new_field(int device_id, int field, int log_size, int inverse, blz_n
     h->ops = ops;
     h->logn = log_size;
     h->inverse = inverse ? 1 : 0;
-    { const char* e = getenv("BLAZE_NTT_GENERIC"); h->force_generic = e && *e == '1'; }
+    h->force_generic = exp_knob("BLAZE_NTT_GENERIC", 0) != 0;
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&h->ev0);

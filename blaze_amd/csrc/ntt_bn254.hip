@@ -1,5 +1,5 @@
 // NTT kernels over the scalar field of BN254 (one translation unit per field).
-#include "ntt_impl.cuh"
+#include "ntt_impl.hip.hpp"
 
 namespace blz {
 const NttFieldOps& ntt_ops_bn254() {

@@ -12,10 +12,10 @@ struct NttTables {  // all Montgomery form, device memory
     uint32_t* ninv;      // n^-1 (Montgomery) for the inverse transform, else nullptr
 };
 
-// reduced-radix twiddle tables of the 512-point kernel (ntt_rr.cuh): entries of 10 dwords (27-bit limbs), Montgomery
+// reduced-radix twiddle tables of the 512-point kernel (ntt_rr.hip.hpp): entries of 10 dwords (27-bit limbs), Montgomery
 // R_rr, < 2m
 struct NttTablesRR {
-    // wpass and tA hold SHOUP entries (canonical twiddle | floor(twiddle R_rr / m): 2 x 10 dwords, field_rr.cuh
+    // wpass and tA hold SHOUP entries (canonical twiddle | floor(twiddle R_rr / m): 2 x 10 dwords, field_rr.hip.hpp
     // rr_mul_shoup), ts2 too (the step of pass 2's boundary twiddle: a constant); t0 / t1 / t2 / fin stay Montgomery (R_rr)
     uint32_t* wpass[3];
     uint32_t* t0;
@@ -23,10 +23,10 @@ struct NttTablesRR {
     uint32_t* t2;
     uint32_t* fin;   // closing factor of the last pass: n^-1 R_rr (inverse) or nullptr (forward: no product)
     uint32_t* tA;    // w^(A e), e < 2^18 (n / 512 entries, 10 MiB), or nullptr: the boundary factor after pass 1 that
-                     // does not depend on the column, read instead of stepped (2^27 transforms only; ntt_rr.cuh)
+                     // does not depend on the column, read instead of stepped (2^27 transforms only; ntt_rr.hip.hpp)
     uint32_t* ts2;   // w^(64 C i0), i0 < 512: the step of pass 2's boundary factor along a lane's rows (one per column)
     uint32_t swz;    // 0: plain tile order; 1 + s: pass 1 walks its tiles in the channel-spreading order with 2^s adjacent column
-                     // groups back to back (2^27 transforms; ntt_rr.cuh)
+                     // groups back to back (2^27 transforms; ntt_rr.hip.hpp)
 };
 constexpr size_t NTT_RR_BOUNDARY_ENTRIES = (size_t)1 << 18;
 constexpr size_t NTT_RR_ENTRY_DWORDS = 10;

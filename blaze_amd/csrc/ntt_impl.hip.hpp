@@ -2,8 +2,8 @@
 // field keeps the build parallel).  Design notes: ntt.hip.
 #pragma once
 #include "ntt_engine.hpp"
-#include "field.cuh"
-#include "ntt_rr.cuh"
+#include "field.hip.hpp"
+#include "ntt_rr.hip.hpp"
 
 namespace blz {
 
@@ -66,7 +66,7 @@ BLZ_DEV void tw_pow(E& r, const NttTables& T, uint32_t e) {
 }
 
 // Data arithmetic of the transform.  Fields with head-room (P::LAZY: BLS12-377 / BN254 Fr) already
-// multiply without a final subtraction; BLS12-381 Fr gets the wide-lazy forms of field.cuh: data live
+// multiply without a final subtraction; BLS12-381 Fr gets the wide-lazy forms of field.hip.hpp: data live
 // in [0, 2m), twiddles stay canonical, only the last pass reduces to the wire format.
 template <class E> struct NttOps;
 template <class Fr>
@@ -226,179 +226,8 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const uint32_t* __rest
 }
 
 
-// ------------------------------------------------------------------------------------------------
-// 512-point passes, register resident: 512 = 8 * 8 * 8.  A lane holds 8 elements (64 VGPRs) and runs
-// a whole 8-point DFT (three radix-2 stages, 5 non-trivial twiddles) in registers; the tile goes
-// through LDS only twice (between the three radix-8 steps) instead of once per radix-2 stage, the
-// loads come straight from global memory and the last step stores straight to it with the
-// inter-pass twiddle applied by stepping along the lane's own 8 outputs.  PMC counters of the
-// radix-2-in-LDS kernel: VALU busy 22 %, 44 % of wave cycles parked on barriers / waitcnt, 58 % of
-// LDS cycles bank conflicts.  COLS = 4 columns x 512 rows per 256-lane block (80 KiB of LDS), two
-// blocks per CU so one block's global traffic overlaps the other's arithmetic.
-// ------------------------------------------------------------------------------------------------
-constexpr int N8_COLS_LOG = 2;
-constexpr int N8_COLS = 1 << N8_COLS_LOG;
-constexpr int N8_THREADS = 64 * N8_COLS;
-constexpr uint32_t N8_RS = N8_COLS * 8 + 8;  // padded row stride in dwords
-
-// in-register 8-point DFT, decimation in time: a[] must hold x[0],x[4],x[2],x[6],x[1],x[5],x[3],x[7];
-// output natural order.  w1,w2,w3 = w8, w8^2, w8^3 (Montgomery).
-template <class E>
-BLZ_DEV void bfly(E& u, E& v) {
-    E s, d;
-    NttOps<E>::add(s, u, v);
-    NttOps<E>::sub(d, u, v);
-    u = s;
-    v = d;
-}
-template <class E>
-BLZ_DEV void dft8(E (&a)[8], const E& w1, const E& w2, const E& w3) {
-    bfly(a[0], a[1]); bfly(a[2], a[3]); bfly(a[4], a[5]); bfly(a[6], a[7]);
-    NttOps<E>::mul(a[3], a[3], w2);
-    NttOps<E>::mul(a[7], a[7], w2);
-    bfly(a[0], a[2]); bfly(a[1], a[3]); bfly(a[4], a[6]); bfly(a[5], a[7]);
-    NttOps<E>::mul(a[5], a[5], w1);
-    NttOps<E>::mul(a[6], a[6], w2);
-    NttOps<E>::mul(a[7], a[7], w3);
-    bfly(a[0], a[4]); bfly(a[1], a[5]); bfly(a[2], a[6]); bfly(a[3], a[7]);
-}
-// order in which a DIT 8-point DFT wants its inputs
-__device__ constexpr int BR8[8] = {0, 4, 2, 6, 1, 5, 3, 7};
-
-template <class Fr, int PASS>
-__global__ __launch_bounds__(N8_THREADS, 2) void k_ntt512(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
-                                                         NttGeom g, NttTables T) {
-    using E = Fp<Fr>;
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const uint32_t A = 1u << g.logA, B = 1u << g.logB, C = 1u << g.logC;
-    uint64_t col_base, fixed, in_base, in_rstride, in_cstride;
-    const uint64_t tile = blockIdx.x;
-    uint32_t col, n2;  // this lane's column and its index in [0,64)
-    if (PASS == 1) {   // rows i2 (stride AB), cols i0 (stride 1), fixed i1
-        uint64_t tiles_per = A >> N8_COLS_LOG;
-        fixed = tile / tiles_per;
-        col_base = (tile % tiles_per) << N8_COLS_LOG;
-        in_base = col_base + (uint64_t)A * fixed;
-        in_rstride = (uint64_t)A * B;
-        in_cstride = 1;
-        col = threadIdx.x & (N8_COLS - 1);
-        n2 = threadIdx.x >> N8_COLS_LOG;
-    } else if (PASS == 2) {  // rows i1 (stride A), cols i0, fixed k2
-        uint64_t tiles_per = A >> N8_COLS_LOG;
-        fixed = tile / tiles_per;
-        col_base = (tile % tiles_per) << N8_COLS_LOG;
-        in_base = col_base + (uint64_t)A * B * fixed;
-        in_rstride = A;
-        in_cstride = 1;
-        col = threadIdx.x & (N8_COLS - 1);
-        n2 = threadIdx.x >> N8_COLS_LOG;
-    } else {  // rows i0 (stride 1, contiguous), cols k2 (stride AB), fixed k1
-        uint64_t tiles_per = C >> N8_COLS_LOG;
-        fixed = tile / tiles_per;
-        col_base = (tile % tiles_per) << N8_COLS_LOG;
-        in_base = (uint64_t)A * fixed + (uint64_t)A * B * col_base;
-        in_rstride = 1;
-        in_cstride = (uint64_t)A * B;
-        // column fastest, like the other passes: a wave reads 16 consecutive rows (512 B) of each of the
-        // 4 columns and - what matters - stores 4 adjacent k2 (128 B) per row instead of 64 lone 32-B
-        // pieces 8 MiB apart (row-fastest lanes: 7.1 ms for this pass)
-        col = threadIdx.x & (N8_COLS - 1);
-        n2 = threadIdx.x >> N8_COLS_LOG;
-    }
-    // the step of the inter-pass twiddle chain, w^(64 m), depends on the column only: 4 lanes compute
-    // it once per tile and leave it in the padding element of tile row `col` (the tile is exactly half of
-    // the CU's LDS: there is no room behind it); one table product less for the other 252 lanes
-    uint32_t* lds_step = lds + N8_COLS * 8;   // + col * N8_RS
-    if (PASS != 3 && n2 == 0) {
-        const uint64_t m = PASS == 1 ? col_base + col + ((uint64_t)fixed << g.logA) : (col_base + col) << g.logC;
-        E st;
-        tw_pow(st, T, (uint32_t)(64u * m));
-        lds_store(lds_step, col * N8_RS, st);
-    }
-    const uint32_t* wp = T.wpass[PASS - 1];  // w512^j, j < 512
-    E w1, w2, w3;
-    fp_load(w1, wp + 64 * 8);
-    fp_load(w2, wp + 128 * 8);
-    fp_load(w3, wp + 192 * 8);
-    E a[8];
-    // ---- step 1: 8-point DFTs over n1 (rows 64 n1 + n2), straight from global memory
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        uint32_t row = 64u * BR8[j] + n2;
-        fp_load(a[j], in + (in_base + row * in_rstride + col * in_cstride) * 8);
-        if (PASS == g.wire_pass) NttOps<E>::wire_in(a[j]);
-    }
-    dft8(a, w1, w2, w3);
-#pragma unroll
-    for (int k1 = 0; k1 < 8; ++k1) {
-        if (k1 != 0 && n2 != 0) {  // * w512^(n2 k1)
-            E w;
-            fp_load(w, wp + (size_t)(n2 * k1) * 8);
-            NttOps<E>::mul(a[k1], a[k1], w);
-        }
-        lds_store(lds, (64u * k1 + n2) * N8_RS + col * 8, a[k1]);
-    }
-    __syncthreads();
-    // ---- step 2a: lane (k1, n2', col): 8-point DFTs over n1' (rows 64 k1 + 8 n1' + n2')
-    {
-        const uint32_t k1 = n2 >> 3, n2p = n2 & 7u;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) lds_load(a[j], lds, (64u * k1 + 8u * BR8[j] + n2p) * N8_RS + col * 8);
-        dft8(a, w1, w2, w3);
-        __syncthreads();
-#pragma unroll
-        for (int k1p = 0; k1p < 8; ++k1p) {
-            if (k1p != 0 && n2p != 0) {  // * w64^(n2' k1') = w512^(8 n2' k1')
-                E w;
-                fp_load(w, wp + (size_t)(8u * n2p * k1p) * 8);
-                NttOps<E>::mul(a[k1p], a[k1p], w);
-            }
-            lds_store(lds, (64u * k1 + 8u * k1p + n2p) * N8_RS + col * 8, a[k1p]);
-        }
-    }
-    __syncthreads();
-    // ---- step 2b: lane (k1, k1', col): 8-point DFTs over n2' (rows 64 k1 + 8 k1' + n2'), outputs
-    // k = k1 + 8 k1' + 64 k2' go to global memory with the inter-pass twiddle
-    {
-        const uint32_t k1 = n2 >> 3, k1p = n2 & 7u;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) lds_load(a[j], lds, (64u * k1 + 8u * k1p + BR8[j]) * N8_RS + col * 8);
-        dft8(a, w1, w2, w3);
-        const uint32_t kb = k1 + 8u * k1p;  // output row of a[k2'] is kb + 64 k2'
-        E w, step;
-        bool tw = false;
-        if (PASS == 1) {
-            // x(i0, i1, k2 = row) *= w^(row * (i0 + A i1)),  m = i0 + A i1 < 2^18
-            const uint64_t m = col_base + col + ((uint64_t)fixed << g.logA);
-            tw = m != 0;
-            if (tw) { tw_pow(w, T, (uint32_t)(kb * m)); lds_load(step, lds_step, col * N8_RS); }
-        } else if (PASS == 2) {
-            // x(i0, k1 = row, k2) *= w^(C i0 row)
-            const uint64_t m = (col_base + col) << g.logC;
-            tw = m != 0;
-            if (tw) { tw_pow(w, T, (uint32_t)(kb * m)); lds_load(step, lds_step, col * N8_RS); }
-        }
-        E sc;
-        if (PASS == 3 && T.ninv) fp_load(sc, T.ninv);
-#pragma unroll
-        for (int k2p = 0; k2p < 8; ++k2p) {
-            const uint32_t row = kb + 64u * k2p;
-            uint64_t oaddr;
-            if (PASS == 3) {
-                if (T.ninv) NttOps<E>::mul(a[k2p], a[k2p], sc);  // inverse transform: * n^-1
-                NttOps<E>::canon(a[k2p]);                        // the wire format is canonical
-                oaddr = (col_base + col) + (uint64_t)C * fixed + (uint64_t)C * B * row;
-            } else {
-                if (tw) {
-                    if (k2p != 0 || kb != 0) NttOps<E>::mul(a[k2p], a[k2p], w);
-                    if (k2p != 7) fp_mul(w, w, step);   // twiddle x twiddle: stays canonical
-                }
-                oaddr = in_base + row * in_rstride + col;
-            }
-            fp_store(out + oaddr * 8, a[k2p]);
-        }
-    }
-}
+// (The 512-point passes - 512 = 8 * 8 * 8 in registers, two LDS exchanges - live in ntt_rr.hip.hpp on the reduced-radix field;
+// their 32-bit-limb predecessor k_ntt512 lost every A/B run since round 2 and was removed in round 4.)
 
 // ------------------------------------------------------------------------------------------------
 // host launchers
@@ -417,7 +246,7 @@ int ntt_setup_t(hipStream_t st, NttTables& T, NttTablesRR& TR, const NttGeom& g,
     hipLaunchKernelGGL(k_ntt_table<Fr>, dim3(2), dim3(256), 0, st, T.t0, 512, l, (uint64_t)1, inverse);
     hipLaunchKernelGGL(k_ntt_table<Fr>, dim3(2), dim3(256), 0, st, T.t1, 512, l, (uint64_t)512, inverse);
     hipLaunchKernelGGL(k_ntt_table<Fr>, dim3(2), dim3(256), 0, st, T.t2, 512, l, (uint64_t)1 << 18, inverse);
-    // the same tables in the reduced radix for the 512-point kernel (ntt_rr.cuh)
+    // the same tables in the reduced radix for the 512-point kernel (ntt_rr.hip.hpp)
     static_assert(rr_stride<typename Fr::RR>() == NTT_RR_ENTRY_DWORDS, "table entry size");
     for (int i = 0; i < 3; ++i)
         hipLaunchKernelGGL(k_ntt_table_to_shoup<Fr>, dim3(2), dim3(256), 0, st, T.wpass[i], TR.wpass[i], lrs[i] ? (1 << lrs[i]) : 1);
@@ -438,30 +267,13 @@ int ntt_pass_t(hipStream_t st, const void* in, void* out, const NttGeom& g, cons
                bool force_generic) {
     int lr = PASS == 1 ? g.logC : PASS == 2 ? g.logB : g.logA;
     const int cols_avail = PASS == 3 ? g.logC : g.logA;  // extent of the tile's column index
-    // BLAZE_NTT_RR=0: the 32-bit-limb 512-point kernel (kept for A/B measurements)
-    static const bool use_rr = []() { const char* e = getenv("BLAZE_NTT_RR"); return !(e && *e == '0'); }();
-    if (lr == 9 && cols_avail >= NR_COLS_LOG && !force_generic && use_rr) {
-        static const bool half = []() { const char* e = getenv("BLAZE_NTT_HALF"); return !(e && *e == '0'); }();
-        const size_t ldsr = (size_t)(half ? 256 : 512) * NR_COLS * rr_stride<typename Fr::RR>() * 4;
+    if (lr == 9 && cols_avail >= NR_COLS_LOG && !force_generic) {
+        // the tile goes through the LDS in two halves: 256 rows x 4 columns x 40 bytes
+        const size_t ldsr = (size_t)256 * NR_COLS * rr_stride<typename Fr::RR>() * 4;
         const uint64_t tilesr = (1ull << g.logn) >> (9 + NR_COLS_LOG);
-        if (half) {
-            BLZ_TRY(ensure_dynamic_lds((const void*)k_ntt512_rr<Fr, PASS, true>, 160 * 1024));
-            hipLaunchKernelGGL((k_ntt512_rr<Fr, PASS, true>), dim3((unsigned)tilesr), dim3(NR_THREADS), ldsr, st, (const uint32_t*)in,
-                               (uint32_t*)out, g, TR);
-        } else {
-            BLZ_TRY(ensure_dynamic_lds((const void*)k_ntt512_rr<Fr, PASS, false>, 160 * 1024));
-            hipLaunchKernelGGL((k_ntt512_rr<Fr, PASS, false>), dim3((unsigned)tilesr), dim3(NR_THREADS), ldsr, st, (const uint32_t*)in,
-                               (uint32_t*)out, g, TR);
-        }
-        BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
-        return BLZ_OK;
-    }
-    if (lr == 9 && cols_avail >= N8_COLS_LOG && !force_generic) {
-        BLZ_TRY(ensure_dynamic_lds((const void*)k_ntt512<Fr, PASS>, 160 * 1024));
-        size_t lds8 = (size_t)512 * N8_RS * 4;
-        uint64_t tiles8 = (1ull << g.logn) >> (9 + N8_COLS_LOG);
-        hipLaunchKernelGGL((k_ntt512<Fr, PASS>), dim3((unsigned)tiles8), dim3(N8_THREADS), lds8, st, (const uint32_t*)in,
-                           (uint32_t*)out, g, T);
+        BLZ_TRY(ensure_dynamic_lds((const void*)k_ntt512_rr<Fr, PASS>, 160 * 1024));
+        hipLaunchKernelGGL((k_ntt512_rr<Fr, PASS>), dim3((unsigned)tilesr), dim3(NR_THREADS), ldsr, st, (const uint32_t*)in,
+                           (uint32_t*)out, g, TR);
         BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
         return BLZ_OK;
     }

@@ -1,5 +1,5 @@
-// The 512-point NTT pass (k_ntt512 of ntt_impl.cuh) on the reduced-radix scalar field: 9 limbs of 29 bits
-// (field_rr.cuh; curve_constants.h Fr_*_RR).  Same decomposition (512 = 8 * 8 * 8, a lane holds 8 elements, two
+// The 512-point NTT pass (k_ntt512 of ntt_impl.hip.hpp) on the reduced-radix scalar field: 9 limbs of 29 bits
+// (field_rr.hip.hpp; curve_constants.h Fr_*_RR).  Same decomposition (512 = 8 * 8 * 8, a lane holds 8 elements, two
 // LDS exchanges per pass - the first across the block, the second inside a wave - inter-pass twiddle stepped along the
 // lane's outputs), different arithmetic:
 //   * a field product is 162 v_mad_u64_u32 (+ 17 shifts, 9 quotient digits) instead of 128 x (v_mad_u64_u32 +
@@ -15,12 +15,12 @@
 //     limb and no 64-bit column sum can overflow anywhere in the three DFT steps.
 // Data in HBM stay 32-byte words (canonical on the wire, < 2m between passes); tile elements in LDS and table
 // entries are rr_stride = 10 dwords apart (9 used).  Round 3: every product by a TABLE twiddle - the five inside an
-// 8-point DFT, the in-tile twiddles, the boundary table of pass 1 - is a Shoup product (field_rr.cuh rr_mul_shoup: the
+// 8-point DFT, the in-tile twiddles, the boundary table of pass 1 - is a Shoup product (field_rr.hip.hpp rr_mul_shoup: the
 // table holds the canonical twiddle and its quotient floor(t R_rr / m), 2 x 10 dwords; 143 multiply-adds and no
 // quotient-digit chain against 153); the stepped boundary twiddles of pass 2 and the closing factor of the inverse
 // transform stay Montgomery products (their tables hold t R_rr mod m).
 #pragma once
-#include "field_rr.cuh"
+#include "field_rr.hip.hpp"
 #include "ntt_engine.hpp"
 
 namespace blz {
@@ -93,7 +93,7 @@ BLZ_DEV void rr_mul_n(Frr<Q, 1, 2>& r, const Frr<Q, Fa, Va>& a, const Frr<Q, Fb,
     if constexpr (rr_cols_ok<Q>(Fa * Fb)) rr_mul(r, a, b);
     else rr_mul(r, rr_norm(a), b);
 }
-// ... and by a table twiddle in Shoup form (field_rr.cuh rr_mul_shoup): the plain product, no Montgomery factor
+// ... and by a table twiddle in Shoup form (field_rr.hip.hpp rr_mul_shoup): the plain product, no Montgomery factor
 template <class Q, int Fa, int Va>
 BLZ_DEV void rr_mul_n(Frr<Q, 1, 2>& r, const Frr<Q, Fa, Va>& a, const RRShoup<Q>& t) {
     if constexpr (rr_cols_ok<Q>(Fa)) rr_mul_shoup(r, a, t);
@@ -315,14 +315,14 @@ constexpr int NR_COLS_LOG = 2;
 constexpr int NR_COLS = 1 << NR_COLS_LOG;
 constexpr int NR_THREADS = 64 * NR_COLS;
 
-// HALF: the tile goes through the LDS in two halves, so that a block needs 40 KiB instead of 80 and THREE blocks share a CU
+// The tile goes through the LDS in two halves, so that a block needs 40 KiB instead of 80 and THREE blocks share a CU
 // (the registers allow three waves per SIMD; with a whole tile in the LDS two blocks are all that fit, and the waves then
 // wait ~30 % of their time at the barriers and the tile loads with nobody to take the multiplier).  Both exchanges move
 // outputs K = 0..3 first and K = 4..7 second: the consumers of an output K of the first exchange are the lanes with
 // k1 = K - waves 0 and 1 for the first half, waves 2 and 3 for the second - and of the second exchange the lanes with
 // k1' = K of the same wave.  Costs: three more block barriers and four outputs kept in registers across a half.
-template <class Fr, int PASS, bool HALF>
-__global__ __launch_bounds__(NR_THREADS, HALF ? 3 : 2) void k_ntt512_rr(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, NttGeom g,
+template <class Fr, int PASS>
+__global__ __launch_bounds__(NR_THREADS, 3) void k_ntt512_rr(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, NttGeom g,
                                                             NttTablesRR T) {
     using Q = typename Fr::RR;
     constexpr uint32_t ES = rr_stride<Q>();  // element stride in LDS and in the tables (dwords)
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(NR_THREADS, HALF ? 3 : 2) void k_ntt512_rr(const ui
     }
     const uint32_t* wp = T.wpass[PASS - 1];  // w512^j, j < 512, Shoup entries (canonical value | quotient)
     constexpr uint32_t ES2 = rr_shoup_stride<Q>();
-    using WT = RRShoup<Q>;     // table twiddles: Shoup products (field_rr.cuh): 143 multiply-adds, no Montgomery factor
+    using WT = RRShoup<Q>;     // table twiddles: Shoup products (field_rr.hip.hpp): 143 multiply-adds, no Montgomery factor
     using W = Frr<Q, 1, 2>;    // stepped twiddles (Montgomery form) and data
     RRShoupU<Q> w1, w2, w3;   // the w8 powers inside the 8-point DFTs: the same for every lane, kept in SGPRs
     {
@@ -400,23 +400,7 @@ __global__ __launch_bounds__(NR_THREADS, HALF ? 3 : 2) void k_ntt512_rr(const ui
     auto o1 = dft8_rr<Q>(a1, w1, w2, w3);
     const uint32_t k1 = n2 >> 3, n2p = n2 & 7u;
     W a2[8];
-    if constexpr (!HALF) {
-        BLZ_RR_FOR8(o1, {   // * w512^(n2 k1); the un-twiddled output (k1 = 0) is brought below 2m without a product
-            W t;
-            if constexpr (K == 0) {
-                t = rr_reduce2m(X);
-            } else {
-                WT w;
-                rr_load_shoup<Q>(w, wp + (size_t)(n2 * K) * ES2);
-                rr_mul_n(t, X, w);
-            }
-            rr_lds_store(lds, (64u * K + n2) * RS + col * ES, t);
-        })
-        __syncthreads();
-        // ---- step 2a: lane (k1, n2', col): 8-point DFTs over n1' (rows 64 k1 + 8 n1' + n2')
-#pragma unroll
-        for (int j = 0; j < 8; ++j) rr_lds_load(a2[j], lds, (64u * k1 + 8u * BR[j] + n2p) * RS + col * ES);
-    } else {
+    {
         // first half: outputs K = 0..3 at rows 64 K + n2, read by the lanes with k1 < 4 (waves 0, 1); second half:
         // K = 4..7 at rows 64 (K - 4) + n2, read by waves 2, 3
         W keep[4];
@@ -450,27 +434,7 @@ __global__ __launch_bounds__(NR_THREADS, HALF ? 3 : 2) void k_ntt512_rr(const ui
     auto o2 = dft8_rr<Q>(a2, w1, w2, w3);
     const uint32_t k1p = n2 & 7u;
     W a3[8];
-    if constexpr (!HALF) {
-        // no barrier: the lane overwrites exactly the 8 elements it has just read (rows 64 k1 + 8 j + n2', its column)
-        BLZ_RR_FOR8(o2, {   // * w64^(n2' k1') = w512^(8 n2' k1')
-            W t;
-            if constexpr (K == 0) {
-                t = rr_reduce2m(X);
-            } else {
-                WT w;
-                rr_load_shoup<Q>(w, wp + (size_t)(8u * n2p * K) * ES2);
-                rr_mul_n(t, X, w);
-            }
-            rr_lds_store(lds, (64u * k1 + 8u * K + n2p) * RS + col * ES, t);
-        })
-        // the second exchange stays inside the 32 lanes that share k1 (n2 = 8 k1 + 0..7, four columns): one wave, whose LDS
-        // operations complete in order - a wave-level fence instead of a block barrier
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-        for (int j = 0; j < 8; ++j) rr_lds_load(a3[j], lds, (64u * k1 + 8u * k1p + BR[j]) * RS + col * ES);
-    } else {
+    {
         // a wave's 64 rows of the half tile: (k1 & 1) 32 + 8 (K mod 4) + n2'; readers k1' < 4 first, then k1' >= 4
         const uint32_t wrow = (threadIdx.x >> 6) * 64u + (k1 & 1u) * 32u;
         W keep[4];

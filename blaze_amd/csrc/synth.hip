@@ -3,7 +3,7 @@
 // result of any size is one scalar multiplication on the CPU (oracle: orc_index_weighted_sum);
 // with pf = 8 element i carries B_{i,j} = 2^(32 j) P_i, the table tests/msm/mod.rs:360-380 builds.
 #include "common.hpp"
-#include "ec.cuh"
+#include "ec.hip.hpp"
 
 namespace blz {
 

@@ -1,7 +1,7 @@
 // Element-wise kernels over the device field / group primitives, so tests can compare each of them
 // with the CPU oracle (include/blaze_hip.h "test hooks").  Not on the MSM/NTT product path.
 #include "common.hpp"
-#include "ec_rr.cuh"
+#include "ec_rr.hip.hpp"
 
 namespace blz {
 
@@ -32,7 +32,7 @@ __global__ __launch_bounds__(64) void k_test_field(int op, const uint32_t* a, co
             }
             break;
         case 10: case 11: case 12: case 13: case 14: case 15:
-            // the reduced-radix twin (field_rr.cuh): product, square, fused sum of products on lazy operands,
+            // the reduced-radix twin (field_rr.hip.hpp): product, square, fused sum of products on lazy operands,
             // carry propagation, zero tests; operands go in through the wire-word conversion and come back
             // through the 32-bit Montgomery form, so both conversions are under test as well
             if constexpr (USE_RR<P>) {
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(64) void k_test_ec(int op, const uint32_t* p, const
             }
             pt_add(acc, qq);
         } break;
-        case 4: case 5:   // the reduced-radix mixed add of the bucket accumulation (ec_rr.cuh); 5 subtracts
+        case 4: case 5:   // the reduced-radix mixed add of the bucket accumulation (ec_rr.hip.hpp); 5 subtracts
             if constexpr (USE_RR<F>) {
                 if (!(fl & 2)) {
                     using QQ = typename F::RR;

@@ -31,7 +31,7 @@ def test_field_ops(gpu, curve, field):
     bb = b"".join(x.to_bytes(nb, "little") for x in b)
     ops = {0: lambda x, y: x * y % m, 1: lambda x, y: (x + y) % m, 2: lambda x, y: (x - y) % m,
            3: lambda x, y: pow(x, -1, m) if x else 0, 4: lambda x, y: x * x % m}
-    if field == 0 or curve != "BLS381":   # lazy-range fields have the fused sum of two products (ec.cuh's Y3)
+    if field == 0 or curve != "BLS381":   # lazy-range fields have the fused sum of two products (ec.hip.hpp's Y3)
         ops[5] = lambda x, y: (x * y + (x + y) * (x - y)) % m
         ops[6] = lambda x, y: (x * y - (x + y) * (x - y)) % m
     if True:   # reduced-radix twins: the BLS base fields (14 x 28 bits); BN254's base field and every scalar field (9 x 29)

@@ -85,8 +85,7 @@ def test_window_plans_agree(gpu, orc, curve, monkeypatch):
     n = 3000
     pts, sc, exp = orc.input_generator(curve, n, 1, 77)
     for c, L in ((4, 256), (9, 3), (13, 16), (16, 256)):
-        monkeypatch.setenv("BLAZE_MSM_C", str(c))
-        monkeypatch.setenv("BLAZE_MSM_L", str(L))
+        monkeypatch.setenv("BLAZE_MSM_PLAN", f"c={c},L={L}")
         cl = msm_client(curve, 1)
         assert run_msm(cl, pts, sc, n) == exp, f"c={c} L={L}"
         assert cl.get_api()["window_bits"] == c
@@ -597,10 +596,10 @@ def test_randomised_small_cases(gpu, orc):
 @pytest.mark.parametrize("pf", [1, 8])
 def test_mixed_window_widths_small(gpu, orc, curve, pf, monkeypatch):
     """Two window widths + a top window (the plan large inputs get) forced at small sizes, where the
-    oracle can check every byte: BLAZE_MSM_SPLIT_NS=0 removes the model's charge for stitching virtual
+    oracle can check every byte: BLAZE_MSM_PLAN=split_ns=0 removes the model's charge for stitching virtual
     windows in k_finish."""
     import ctypes as C
-    monkeypatch.setenv("BLAZE_MSM_SPLIT_NS", "0")
+    monkeypatch.setenv("BLAZE_MSM_PLAN", "split_ns=0")
     mixed = 0
     for n in (700, 5000, 40000):
         out, wd = (C.c_uint32 * 4)(), (C.c_uint8 * 96)()
@@ -703,7 +702,7 @@ def test_non_canonical_scalars(gpu, orc, curve, monkeypatch):
         sc[32 * i: 32 * i + 32] = v.to_bytes(32, "little")
     exp = orc.msm_naive(curve, pts, bytes(sc), n, 1)
     for split in ("6000", "0"):
-        monkeypatch.setenv("BLAZE_MSM_SPLIT_NS", split)
+        monkeypatch.setenv("BLAZE_MSM_PLAN", f"split_ns={split}")
         cl = msm_client(curve, 1)
         assert run_msm(cl, pts, bytes(sc), n) == exp, f"{curve} split={split}"
         cl.close()
@@ -850,7 +849,7 @@ def test_dma_pieces_host_buffers(gpu, orc, curve, pf, n, monkeypatch):
     """DMA mode with host buffers and a task already armed: the task is enqueued piece by piece while its bytes cross the
     link (msm_capi.hip stage_common; the reference streams interleaved chunks of scalars and points while the card computes,
     msm_api.rs:175-202).  Forced to 1 / 4 / 5 / 16 pieces at oracle-checkable sizes (ragged last piece, pieces of whole
-    16-point groups), uniform scalars; then two tasks in flight, and the same handle with the overlap switched off."""
+    16-point groups), uniform scalars; then two tasks in flight, and the whole-staging path of an unarmed set_data."""
     pts, sc, _ = orc.input_generator(curve, n, pf, 777 + pf)
     rng = np.random.default_rng(n)
     sc = bytearray(rng.integers(0, 256, size=32 * n, dtype=np.uint8).tobytes())
@@ -862,7 +861,7 @@ def test_dma_pieces_host_buffers(gpu, orc, curve, pf, n, monkeypatch):
     exp2 = orc.msm_pippenger(curve, pts, sc2, n, pf, threads=8)
     p = MSMParams(n, None)
     for pieces in ("1", "4", "5", "16"):
-        monkeypatch.setenv("BLAZE_DMA_PIECES", pieces)
+        monkeypatch.setenv("BLAZE_MSM_PIECES", pieces)
         cl = msm_client(curve, pf)
         assert run_msm(cl, pts, sc, n) == exp, f"{curve} pf={pf} pieces={pieces}"
         cl.initialize(p); cl.start_process(); cl.set_data(MSMInput(pts, sc, p))
@@ -871,9 +870,11 @@ def test_dma_pieces_host_buffers(gpu, orc, curve, pf, n, monkeypatch):
         cl.wait_result(); assert cl.result().result == exp2
         assert run_msm(cl, pts, sc2, n) == exp2
         cl.close()
-    monkeypatch.setenv("BLAZE_DMA_OVERLAP", "0")
+    monkeypatch.delenv("BLAZE_MSM_PIECES")
+    # set_data before start_process (README.md:71-74 omits start_process): nothing is armed, the inputs are staged whole
     cl = msm_client(curve, pf)
-    assert run_msm(cl, pts, sc, n) == exp
+    cl.initialize(p); cl.set_data(MSMInput(pts, sc, p)); cl.start_process(); cl.wait_result()
+    assert cl.result().result == exp
     cl.close()
 
 
@@ -934,3 +935,34 @@ def test_hidden_sort_fits_under_the_accumulation(gpu, curve):
     cl.close(); dp.free(); ds.free()
     assert hidden and all(hidden), hidden
     assert ratios and max(ratios) < 0.85, ratios
+
+
+def test_switches_hip_lib_and_log(gpu, orc, tmp_path):
+    """BLAZE_HIP_LIB points the Python mirror at another copy of the library; BLAZE_LOG=2 makes the library say what it
+    planned.  A fresh interpreter with both set runs one small MSM against the oracle's bytes."""
+    import shutil
+    import subprocess
+    import sys
+
+    src = os.path.join(os.path.dirname(HERE), "blaze_amd", "lib", "libblaze_hip.so")
+    alt = tmp_path / "libblaze_hip_copy.so"
+    shutil.copy(src, alt)
+    n = 300
+    pts, sc, exp = orc.input_generator("BLS381", n, 1, 11)
+    (tmp_path / "pts.bin").write_bytes(bytes(pts))
+    (tmp_path / "sc.bin").write_bytes(bytes(sc))
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import blaze_amd\n"
+        "from gpu_util import msm_client, run_msm\n"
+        "pts = open(%r, 'rb').read(); sc = open(%r, 'rb').read()\n"
+        "cl = msm_client('BLS381', 1)\n"
+        "print('RESULT', run_msm(cl, pts, sc, %d).hex())\n"
+        "print('LIB', blaze_amd.lib()._name)\n"
+    ) % (os.path.dirname(HERE), HERE, str(tmp_path / "pts.bin"), str(tmp_path / "sc.bin"), n)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BLAZE_HIP_LIB=str(alt), BLAZE_LOG="2"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert f"RESULT {exp.hex()}" in r.stdout
+    assert f"LIB {alt}" in r.stdout
+    assert "[blaze_hip] msm plan: npts=300" in r.stderr, r.stderr[-500:]

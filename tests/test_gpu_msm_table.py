@@ -172,7 +172,7 @@ def test_tasks_in_flight_and_geometries(gpu, orc, curve, logn, c, monkeypatch):
     linearity, and equal to the plain path's bytes."""
     n = (1 << logn) - 4321
     if c:
-        monkeypatch.setenv("BLAZE_MSM_TABLE_C", str(c))
+        monkeypatch.setenv("BLAZE_MSM_PLAN", f"table_c={c}")
     dp, ds0 = synth(curve, n, seed=21)
     ds1 = DeviceBuffer(0, n * 32)
     blaze_amd._lib.check(blaze_amd.lib().blz_synth_scalars(0, int(Curve[curve]), ds1.ptr, n, 22))

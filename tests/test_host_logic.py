@@ -78,3 +78,31 @@ def test_window_plan_invariants():
     assert L.blz_msm_plan(1, 1 << 26, 0, out, None) == 0 and out[0] in (20, 21, 22)
     assert L.blz_msm_plan(7, 10, 0, out, None) != 0
     assert L.blz_msm_plan(1, 0, 0, out, None) != 0
+
+
+def test_readme_switch_table_is_what_the_sources_read():
+    """at most eight runtime switches, and README.md's table is exactly the set of environment variables
+    the shipped sources read (everything else sits behind exp_knob(), which only an experiment build turns into getenv)."""
+    import glob
+    import os
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    readme = open(os.path.join(root, "README.md")).read()
+    table = readme[readme.index("<!-- switches:begin -->"): readme.index("<!-- switches:end -->")]
+    documented = set(re.findall(r"^\| `(BLAZE_[A-Z0-9_]+)`", table, flags=re.M))
+    read = set()
+    for path in glob.glob(os.path.join(root, "blaze_amd", "csrc", "*")):
+        if not path.endswith((".hip", ".hpp", ".h", ".inc")):
+            continue
+        src = open(path).read()
+        read |= set(re.findall(r'(?<![a-z_])getenv\("(BLAZE_[A-Z0-9_]+)"\)', src))
+        read |= set(re.findall(r'(?<![a-z_])env_int\("(BLAZE_[A-Z0-9_]+)"', src))
+    for path in glob.glob(os.path.join(root, "blaze_amd", "*.py")):
+        read |= set(re.findall(r'environ(?:\.get\(|\[)"(BLAZE_[A-Z0-9_]+)"', open(path).read()))
+    assert read == documented, (sorted(read - documented), sorted(documented - read))
+    assert len(documented) <= 8
+    # ... and no experiment knob reaches the environment in the shipped build
+    hpp = open(os.path.join(root, "blaze_amd", "csrc", "common.hpp")).read()
+    assert "#ifdef BLZ_EXPERIMENT_KNOBS" in hpp and "inline int exp_knob(const char*, int dflt) { return dflt; }" in hpp
+    assert "BLZ_EXPERIMENT_KNOBS" not in open(os.path.join(root, "blaze_amd", "csrc", "Makefile")).read().replace("EXTRA=-DBLZ_EXPERIMENT_KNOBS", "")

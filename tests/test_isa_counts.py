@@ -32,7 +32,7 @@ def _bench_constant(pattern: str) -> int:
 
 def test_accumulate_loop_multiply_adds(disasm):
     """One bucket addition (mixed XYZZ add on 14 x 28-bit limbs) = 6 products x 392 + 2 squarings x 301 + one fused sum of two
-    products x 588 = 3542 multiply-adds (ec_rr.cuh): the loop of k_accumulate<Fq_BLS381> that walks a unit's run holds exactly
+    products x 588 = 3542 multiply-adds (ec_rr.hip.hpp): the loop of k_accumulate<Fq_BLS381> that walks a unit's run holds exactly
     that many, and bench.py's roofline.integer_issue multiplies by the same number."""
     assert 6 * 392 + 2 * 301 + 588 == 3542
     # (BLS12-377's q is 1 mod 2^28: its quotient digits are negations, 14 multiply-adds less in each of the 9 reductions)
@@ -53,7 +53,7 @@ def test_ntt_pass_multiply_adds(disasm):
     assert sum(want) == _bench_constant(r"multiply_adds_per_lane\D+(\d+)") or sum(want) == 16242
     got = []
     for p in (1, 2, 3):
-        ins = function_instructions(disasm, f"_ZN3blz11k_ntt512_rrINS_9Fr_BLS381ELi{p}ELb1EEEvPKjPjNS_7NttGeomENS_11NttTablesRRE")
+        ins = function_instructions(disasm, f"_ZN3blz11k_ntt512_rrINS_9Fr_BLS381ELi{p}EEEvPKjPjNS_7NttGeomENS_11NttTablesRRE")
         got.append(count(ins, "v_mad_u64_u32"))
     assert abs(got[1] - want[1]) <= 8, (got, want)
     assert want[0] <= got[0] <= want[0] + 19 * 153 + 8 * 143, (got, want)     # + the stepping chain of a transform without the boundary table

@@ -1,4 +1,4 @@
-"""CPU model checks of the reduced-radix arithmetic the device code relies on (field_rr.cuh), over the constants
+"""CPU model checks of the reduced-radix arithmetic the device code relies on (field_rr.hip.hpp), over the constants
 tools/gen_constants.py emits: the borrow-form multiples of m, the column-sum and value bounds of the three DFT
 steps' types, and the one-digit quotient estimate of rr_reduce2m.  No GPU, no oracle: plain integers."""
 import importlib.util

@@ -53,7 +53,7 @@ def field_struct(name, m, n, extra=""):
 def rr_struct(name, m, n32, B, NL):
     """Reduced-radix twin of a field: NL limbs of B bits in 32-bit registers, Montgomery radix
     Rrr = 2^(B NL).  Limbs leave 32 - B spare bits (carry-free add / sub) and the 64-bit column sums of
-    v_mad_u64_u32 never overflow, so a 32x32 multiply-add is ONE instruction (field_rr.cuh)."""
+    v_mad_u64_u32 never overflow, so a 32x32 multiply-add is ONE instruction (field_rr.hip.hpp)."""
     Rrr = 1 << (B * NL)
     assert Rrr > (m << 5), "value head-room of the lazy range"
     nk = min(14, B * NL - m.bit_length() - 1)  # multiples 2^j m that still fit NL limbs
@@ -77,7 +77,7 @@ def rr_struct(name, m, n32, B, NL):
     out.append(f"    static constexpr uint32_t RR2[{NL}] = {{{L(Rrr * Rrr % m)}}};  // Rrr^2 mod m")
     out.append(f"    static constexpr uint32_t TO32[{NL}] = {{{L((1 << (32 * n32)) % m)}}};  // 2^(32 N32) mod m, plain: x Rrr -> x R32")
     out.append(f"    static constexpr uint32_t FROM32[{NL}] = {{{L(Rrr * Rrr * pow(1 << (32 * n32), -1, m) % m)}}};  // Rrr^2 / R32: x R32 -> x Rrr")
-    out.append(f"    static constexpr uint32_t MBAR[{NL}] = {{{L(Rrr - m)}}};  // Rrr - m: the Shoup product's x w - q m as a sum (field_rr.cuh)")
+    out.append(f"    static constexpr uint32_t MBAR[{NL}] = {{{L(Rrr - m)}}};  // Rrr - m: the Shoup product's x w - q m as a sum (field_rr.hip.hpp)")
     out.append(f"    static constexpr uint32_t T2M = 0x{(2 * m) >> (B * (NL - 1)):08x}u;  // top limb of 2m: a value whose top limb is below it is < 2m")
     # K m in "borrow form" for carry-free subtraction a - b + K m: limb i gains 2^B, limb i + 1 loses 1,
     # so every limb but the top is >= 2^B - 1 >= any normalised limb of b, and the top limb is
@@ -131,7 +131,7 @@ def main():
         extra.append(f"    static constexpr uint32_t GY[{nq}] = {{{limbs(gy * Rq % q, nq)}}};  // generator y, Montgomery")
         if f"Fq_{name}" in RR:
             o.append(rr_struct(f"Fq_{name}_RR", q, nq, *RR[f"Fq_{name}"]))
-            extra.append(f"    using RR = Fq_{name}_RR;  // reduced-radix twin (field_rr.cuh)")
+            extra.append(f"    using RR = Fq_{name}_RR;  // reduced-radix twin (field_rr.hip.hpp)")
         else:
             extra.append("    using RR = void;")
         o.append(field_struct(f"Fq_{name}", q, nq, "\n".join(extra)))
@@ -144,7 +144,7 @@ def main():
         extra.append(f"    static constexpr uint32_t ROOT_INV[8] = {{{limbs(pow(root, -1, r) * Rr % r, 8)}}};  // its inverse, Montgomery")
         if f"Fr_{name}" in RR:
             o.append(rr_struct(f"Fr_{name}_RR", r, 8, *RR[f"Fr_{name}"]))
-            extra.append(f"    using RR = Fr_{name}_RR;  // reduced-radix twin (field_rr.cuh), used by the 2^27 NTT")
+            extra.append(f"    using RR = Fr_{name}_RR;  // reduced-radix twin (field_rr.hip.hpp), used by the 2^27 NTT")
         else:
             extra.append("    using RR = void;")
         o.append(field_struct(f"Fr_{name}", r, 8, "\n".join(extra)))

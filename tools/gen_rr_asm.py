@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Emit blaze_amd/csrc/rr_gen.inc: inline-asm column batches of the reduced-radix multiplier
-(field_rr.cuh).  One function = one asm statement = all products of one kind in one column, chained on the
+(field_rr.hip.hpp).  One function = one asm statement = all products of one kind in one column, chained on the
 64-bit column accumulator with v_mad_u64_u32 (its carry-out, which the column bound rules out, goes to vcc):
 
     rr_ab<NL, K>(acc, a, b)      acc += sum_{i+j=K} a_i b_j
@@ -60,7 +60,7 @@ def emit_qm(NL, K):
 
 def emit_as(NL, K):
     """full column of a (VGPRs) times a wave-uniform constant s (SGPR operands): the q * (2^(B NL) - m) half of the
-    Shoup product (field_rr.cuh rr_mul_shoup)"""
+    Shoup product (field_rr.hip.hpp rr_mul_shoup)"""
     ilo = 0 if K < NL else K - NL + 1
     ihi = K if K < NL else NL - 1
     idx = list(range(ilo, ihi + 1))
@@ -111,7 +111,7 @@ def emit_abqm(NL, K):
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
     dst = os.path.join(here, "..", "blaze_amd", "csrc", "rr_gen.inc")
-    out = ["// GENERATED by tools/gen_rr_asm.py - do not edit.  Included by field_rr.cuh inside namespace blz.\n",
+    out = ["// GENERATED by tools/gen_rr_asm.py - do not edit.  Included by field_rr.hip.hpp inside namespace blz.\n",
            "template <int NL, int K> BLZ_DEV void rr_ab(uint64_t& acc, const uint32_t (&a)[NL], const uint32_t (&b)[NL]);",
            "template <int NL, int K> BLZ_DEV void rr_sq(uint64_t& acc, const uint32_t (&a)[NL], const uint32_t (&a2)[NL]);",
            "template <int NL, int K> BLZ_DEV void rr_qm(uint64_t& acc, const uint32_t (&q)[NL], const uint32_t (&m)[NL]);",

@@ -4,7 +4,7 @@
 // per-wave time divided by the waves per SIMD is the throughput cost per instruction pair.
 // Build: hipcc --offload-arch=gfx950 -O3 tools/mac_issue.hip -o mac_issue
 #include <hip/hip_runtime.h>
-#include "field.cuh"   // -I blaze_amd/csrc: the real multiplier, timed the same way
+#include "field.hip.hpp"   // -I blaze_amd/csrc: the real multiplier, timed the same way
 #include <cstdio>
 #include <cstdint>
 #include <vector>

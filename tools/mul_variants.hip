@@ -1,6 +1,6 @@
 // Field-multiplier alternatives on gfx950, timed the same way:
-//   A  32-bit limbs, product scanning, v_mad_u64_u32 + v_addc_co_u32 per multiply-add (field.cuh, shipped r01)
-//   B  reduced radix 14 x 28 bits, v_mad_u64_u32 only, one 64-bit column accumulator (field_rr.cuh)
+//   A  32-bit limbs, product scanning, v_mad_u64_u32 + v_addc_co_u32 per multiply-add (field.hip.hpp, shipped r01)
+//   B  reduced radix 14 x 28 bits, v_mad_u64_u32 only, one 64-bit column accumulator (field_rr.hip.hpp)
 //   C  reduced radix 13 x 30 bits, two-phase (a*b columns normalised, then the reduction columns)
 //   D  instruction-mix model of the DFMA hi/lo multiplier (8 x 52-bit limbs: 2 v_fma_f64 + 1 v_add_f64 +
 //      2 v_lshl_add_u64 per limb product) - NOT a functional multiplier, only its issue cost
@@ -11,7 +11,7 @@
 // >= 5 ms kernel; the shader clock is derived from s_memtime / s_memrealtime (100 MHz) in the same run.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I blaze_amd/csrc tools/mul_variants.hip -o build/mul_variants
 #include <hip/hip_runtime.h>
-#include "field_rr.cuh"
+#include "field_rr.hip.hpp"
 #include <cstdio>
 #include <cstdint>
 #include <vector>

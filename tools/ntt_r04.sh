@@ -1,3 +1,4 @@
+# (historical: BLAZE_NTT_HALF existed only while the two kernels were compared in round 4; the whole-tile kernel is gone)
 # Round 4: per-pass kernel times and SQ / traffic counters of the 2^27 NTT, whole-tile exchange (BLAZE_NTT_HALF=0, the round-3
 # kernel) against the half-tile exchange (=1).  Output: gpurun_out/ntt_r04_half{0,1}.txt
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT

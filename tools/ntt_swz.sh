@@ -1,3 +1,4 @@
+# (needs an experiment build: make -C blaze_amd/csrc OUT=../lib/libblaze_hip_x.so OBJDIR=../../build/obj_x EXTRA=-DBLZ_EXPERIMENT_KNOBS; BLAZE_HIP_LIB=...)
 # Dev tool: pass-1 tile order sweep.  BLAZE_NTT_SWZ = (1 + s) + 16 b: 2^s adjacent column groups back to back, then b bits of i1.
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 for v in "$@"; do

@@ -6,7 +6,7 @@
 // Montgomery chain (same residues) before it is timed.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I blaze_amd/csrc tools/shoup_probe.hip -o build/shoup_probe
 #include <hip/hip_runtime.h>
-#include "field_rr.cuh"
+#include "field_rr.hip.hpp"
 #include <cstdio>
 #include <cstdint>
 #include <vector>

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Dev tool: sweep the window size c (BLAZE_MSM_C: uniform windows) per problem size against the planner's own choice
+"""Dev tool: sweep the window size c (BLAZE_MSM_PLAN=c=..: uniform windows) per problem size against the planner's own choice
 (mixed widths); prints the throughput-relevant part of the device pipeline (sort + accumulation + bucket reduce; the
 finish step hides under the next task) and the full latency."""
 import sys, os
@@ -16,9 +16,9 @@ for logn in [int(x) for x in sys.argv[1:]]:
     row = []
     for c in [0] + list(range(max(8, logn - 7), min(23, logn - 2) + 1)):
         if c:
-            os.environ["BLAZE_MSM_C"] = str(c)
+            os.environ["BLAZE_MSM_PLAN"] = f"c={c}"
         else:
-            os.environ.pop("BLAZE_MSM_C", None)
+            os.environ.pop("BLAZE_MSM_PLAN", None)
         cl = MSMClient(MSMInit(PointMemoryType.DMA, False, Curve.BLS381), dc)
         best = (1e9, 1e9)
         for rep in range(3):
