@@ -442,18 +442,41 @@ int stage_common(blz_msm* h, bool have_points, const void* points, size_t points
     // (MsmEngine::begin / sort_slice / accumulate_slice / end: the pieces share one bucket space and the bucket sums are
     // carried from piece to piece).  Link and multiplier work at the same time; what is left on the critical path behind the
     // last byte is the last piece's accumulation, the bucket reduce and the tail.
+    // The reference's HBM flow (bases resident in the arena, the scalars a host Vec<u8> with every task:
+    // tests/integration_msm_hbm.rs:57-100) goes the same way when the handle is idle: a lone task's 2 GiB of scalars would
+    // otherwise cross the link with the chip doing nothing (38 of 163 ms at 2^26); in a stream of tasks the whole upload
+    // already hides under the previous task's accumulation, and the task keeps its one-piece form (hidden sort, no
+    // carried sums).
     const int sbits = h->pf == 1 ? 256 : 32;
-    if (!on_device && !has_hbm && h->armed && npts > 0 && exp_knob("BLAZE_DMA_OVERLAP", 1) != 0) {
+    const bool dma_pieces = !on_device && !has_hbm && h->armed && npts > 0 && exp_knob("BLAZE_DMA_OVERLAP", 1) != 0;
+    const bool hbm_pieces = !on_device && has_hbm && h->armed && npts > 0 && (npts >= (1u << 22) || env_int("BLAZE_MSM_PIECES", 0) > 1) &&
+                            h->in_flight.empty() && !wants_table(h) &&
+                            exp_knob("BLAZE_DMA_OVERLAP", 1) != 0;
+    if (dma_pieces || hbm_pieces) {
         const size_t mp = mont_point_bytes(h->curve), ps = point_size(h), sb = (size_t)sbits / 8;
         BLZ_TRY(h->scalars_buf[set].reserve(scalars_len));
-        BLZ_TRY(h->points_raw[set].reserve(want_pts));
-        BLZ_TRY(h->points_mont.reserve((size_t)npts * mp));
-        // pieces of >= 2^19 points (64 MiB of host bytes: 1.2 ms of link), at most 16.  Measured (profiles/r04_dma_pieces.txt):
-        // 2^22 elements 22.6 ms in one piece, 16.2 / 15.35 / 17.1 in 4 / 8 / 16; 2^26 270.8, 191.8 / 178.3 / 171.5
+        const void* arena_mont = nullptr;
+        if (dma_pieces) {
+            BLZ_TRY(h->points_raw[set].reserve(want_pts));
+            BLZ_TRY(h->points_mont.reserve((size_t)npts * mp));
+        } else {
+            BLZ_TRY(arena_points_mont(h, h->staged_arena_pos, npts, &arena_mont));   // (stale spans are converted on the main stream)
+        }
+        // pieces of >= 2^19 points with their scalars (64 MiB of host bytes: 1.2 ms of link), at most 16.
+        // Measured (profiles/r04_dma_pieces.txt): 2^22 elements 22.6 ms in one piece, 16.2 / 15.35 / 17.1 in 4 / 8 / 16; 2^26
+        // 270.8, 191.8 / 178.3 / 171.5
         int pieces = env_int("BLAZE_MSM_PIECES", 0);   // (the same switch forces the piece count of device-resident tasks, msm.hip run())
         if (pieces <= 0) {
-            pieces = (int)(npts >> 19);
-            if (pieces > 16) pieces = 16;
+            if (dma_pieces) {
+                pieces = (int)(npts >> 19);
+                if (pieces > 16) pieces = 16;
+            } else {
+                // scalars alone: the link is a quarter of the task, and every piece pays the sort stage's passes over the
+                // bucket space again (not hidden here) - 2^26: 163.7 ms whole, 158.5 / 145.4 / 181.8 in 16 / 8 / 32 pieces
+                pieces = (int)(npts >> 23);
+                if (pieces > 8) pieces = 8;
+                if (pieces < 2) pieces = 2;
+            }
         }
         if (pieces < 1) pieces = 1;
         int slot = -1;
@@ -479,11 +502,15 @@ int stage_common(blz_msm* h, bool have_points, const void* points, size_t points
             char* d_sc = (char*)h->scalars_buf[set].p + (size_t)p0 * sb;
             rc = copy_in(d_sc, (const char*)scalars + (size_t)p0 * sb, (size_t)np * sb, "set_data: host -> device copy of the scalars");
             if (rc == BLZ_OK) rc = h->eng.sort_slice(slot, k, d_sc, np);
-            char* d_raw = (char*)h->points_raw[set].p + (size_t)p0 * ps;
-            char* d_mont = (char*)h->points_mont.p + (size_t)p0 * mp;
-            if (rc == BLZ_OK) rc = copy_in(d_raw, (const char*)points + (size_t)p0 * ps, (size_t)np * ps, "set_data: host -> device copy of the points");
-            if (rc == BLZ_OK) rc = h->eng.points_to_mont(d_raw, d_mont, np);
-            if (rc == BLZ_OK) rc = h->eng.accumulate_slice(slot, k, d_mont);
+            if (dma_pieces) {
+                char* d_raw = (char*)h->points_raw[set].p + (size_t)p0 * ps;
+                char* d_mont = (char*)h->points_mont.p + (size_t)p0 * mp;
+                if (rc == BLZ_OK) rc = copy_in(d_raw, (const char*)points + (size_t)p0 * ps, (size_t)np * ps, "set_data: host -> device copy of the points");
+                if (rc == BLZ_OK) rc = h->eng.points_to_mont(d_raw, d_mont, np);
+                if (rc == BLZ_OK) rc = h->eng.accumulate_slice(slot, k, d_mont);
+            } else if (rc == BLZ_OK) {
+                rc = h->eng.accumulate_slice(slot, k, (const char*)arena_mont + (size_t)p0 * mp);
+            }
         }
         if (rc == BLZ_OK) rc = h->eng.end(slot);
         if (rc != BLZ_OK) {
@@ -491,7 +518,7 @@ int stage_common(blz_msm* h, bool have_points, const void* points, size_t points
             return rc;
         }
         h->d_scalars = h->scalars_buf[set].p;
-        h->d_points_mont = h->points_mont.p;
+        h->d_points_mont = dma_pieces ? h->points_mont.p : arena_mont;
         h->staged_n = n;
         h->set_used[set] = true;
         h->staged_set = -1;

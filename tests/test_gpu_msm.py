@@ -937,6 +937,39 @@ def test_hidden_sort_fits_under_the_accumulation(gpu, curve):
     assert ratios and max(ratios) < 0.85, ratios
 
 
+@pytest.mark.parametrize("curve,pf", [("BLS381", 1), ("BN254", 8)])
+def test_hbm_flow_pieces_host_scalars(gpu, orc, curve, pf, monkeypatch):
+    """The reference's HBM flow (bases loaded into the arena once, the scalars a host buffer with every task,
+    tests/integration_msm_hbm.rs:57-100): an idle handle enqueues such a task piece by piece while the scalars cross the link;
+    with another task in flight it keeps the one-piece form.  Forced to 5 pieces at an oracle-checkable size; lone tasks,
+    then two in flight (the second one whole), then a ranged handle."""
+    n = 20011
+    pts, sc, exp = orc.input_generator(curve, n, pf, 31 + pf)
+    sc2 = bytes(sc[96:]) + bytes(sc[:96])
+    exp2 = orc.msm_pippenger(curve, pts, sc2, n, pf, threads=8)
+    blaze_amd._lib.check(blaze_amd.lib().blz_arena_release(0))
+    monkeypatch.setenv("BLAZE_MSM_PIECES", "5")
+    cl = msm_client(curve, pf, PointMemoryType.HBM)
+    cl.load_data_to_hbm(pts, 0x1000, 0)
+    p = MSMParams(n, (0x1000, 0))
+    assert run_msm(cl, None, sc, n, hbm=(0x1000, 0)) == exp
+    assert run_msm(cl, None, sc2, n, hbm=(0x1000, 0)) == exp2
+    cl.initialize(p); cl.start_process(); cl.set_data(MSMInput(None, sc, p))
+    cl.initialize(p); cl.start_process(); cl.set_data(MSMInput(None, sc2, p))
+    cl.wait_result(); assert cl.result().result == exp
+    cl.wait_result(); assert cl.result().result == exp2
+    if pf == 1:
+        cl.set_scalar_range(64, 192)
+        part = run_msm(cl, None, sc, n, hbm=(0x1000, 0))
+        plain = msm_client(curve, 1)
+        plain.set_scalar_range(64, 192)
+        monkeypatch.setenv("BLAZE_MSM_PIECES", "1")
+        assert part == run_msm(plain, pts, sc, n)
+        plain.close()
+    cl.close()
+    blaze_amd._lib.check(blaze_amd.lib().blz_arena_release(0))
+
+
 def test_switches_hip_lib_and_log(gpu, orc, tmp_path):
     """BLAZE_HIP_LIB points the Python mirror at another copy of the library; BLAZE_LOG=2 makes the library say what it
     planned.  A fresh interpreter with both set runs one small MSM against the oracle's bytes."""
