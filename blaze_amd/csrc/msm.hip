@@ -474,6 +474,10 @@ int MsmEngine::init(int device_id, int curve_id, int precompute_factor) {
         BLZ_HIP(hipEventCreateWithFlags(&S.ev_l0, hipEventDisableTiming), BLZ_ERR_UNKNOWN);
         BLZ_HIP(hipEventCreateWithFlags(&S.ev_done, hipEventDisableTiming), BLZ_ERR_UNKNOWN);
         BLZ_HIP(hipEventCreateWithFlags(&S.ev_sorted, hipEventDisableTiming), BLZ_ERR_UNKNOWN);
+        for (int i = 0; i < 2; ++i) {
+            BLZ_HIP(hipEventCreateWithFlags(&S.ev_sorted_pp[i], hipEventDisableTiming), BLZ_ERR_UNKNOWN);
+            BLZ_HIP(hipEventCreateWithFlags(&S.ev_acc_pp[i], hipEventDisableTiming), BLZ_ERR_UNKNOWN);
+        }
         BLZ_HIP(hipEventCreate(&S.ev_s0), BLZ_ERR_UNKNOWN);
         BLZ_HIP(hipEventCreate(&S.ev_s1), BLZ_ERR_UNKNOWN);
         BLZ_HIP(hipHostMalloc((void**)&S.result_h, 256), BLZ_ERR_UNKNOWN);
@@ -509,6 +513,10 @@ bool MsmEngine::destroy() {
         if (S.ev_l0) (void)hipEventDestroy(S.ev_l0);
         if (S.ev_done) (void)hipEventDestroy(S.ev_done);
         if (S.ev_sorted) (void)hipEventDestroy(S.ev_sorted);
+        for (int i = 0; i < 2; ++i) {
+            if (S.ev_sorted_pp[i]) (void)hipEventDestroy(S.ev_sorted_pp[i]);
+            if (S.ev_acc_pp[i]) (void)hipEventDestroy(S.ev_acc_pp[i]);
+        }
         if (S.ev_s0) (void)hipEventDestroy(S.ev_s0);
         if (S.ev_s1) (void)hipEventDestroy(S.ev_s1);
         if (S.result_h) (void)hipHostFree(S.result_h);
@@ -644,7 +652,15 @@ int MsmEngine::begin(uint32_t npts, int sbits, int* slot_out, int table_c, int b
         if (av > 0 && sv > 0 && 2 * ((av + 7) & ~7) + ((sv + 7) & ~7) > 512 - 32) fits = false;
         if (!fits && !P.table) s3 = false;
     }
-    const bool hide = s3 && O.busy && hide_env != 0 && fits;
+    bool hide = s3 && O.busy && hide_env != 0 && fits;
+    // pieces of a task on an otherwise idle handle: piece k + 1 sorts underneath the accumulation of piece k (ping-pong over
+    // the two slots' sort buffers); same conditions as hiding a task's sort
+    bool pingpong = false;
+    if (nslices > 1 && hide_env != 0 && !O.busy && !P.table && msm_sort3_ok(P, sbits) && !(recent_hot[0] || recent_hot[1])) {
+        const int av = ops->accumulate_vgprs(), sv = msm_sort3_max_vgprs();   // (k_accumulate_cont shares k_accumulate's register cap)
+        if (!(av > 0 && sv > 0 && 2 * ((av + 7) & ~7) + ((sv + 7) & ~7) > 512 - 32)) pingpong = true;
+    }
+    if (pingpong) { s3 = true; hide = true; }
 
     cur = slot;
     if (slot_out) *slot_out = slot;
@@ -659,15 +675,20 @@ int MsmEngine::begin(uint32_t npts, int sbits, int* slot_out, int table_c, int b
     S.max_units = max_units;
     S.use_s3 = s3 && (hide || hide_env == 2 || P.table);
     S.sort_hidden = hide;
+    S.pingpong = pingpong;
+    S.acc_pp_recorded[0] = S.acc_pp_recorded[1] = false;
     S.phased = phased;
     S.task_inputs_event = inputs_event;
     S.accum_timed = false;
     BLZ_HIP(hipEventRecord(S.ev[0], st), BLZ_ERR_UNKNOWN);
-    BLZ_TRY(sbuf[slot].count.reserve((G + 1) * 4 + 16));
-    BLZ_TRY(sbuf[slot].off.reserve((G + 2) * 4));
-    BLZ_TRY(sbuf[slot].unit_off.reserve((G + 2) * 4));
+    for (int b = 0; b < MSM_QUEUE_DEPTH; ++b) {
+        if (b != slot && !pingpong) continue;
+        BLZ_TRY(sbuf[b].count.reserve((G + 1) * 4 + 16));
+        BLZ_TRY(sbuf[b].off.reserve((G + 2) * 4));
+        BLZ_TRY(sbuf[b].unit_off.reserve((G + 2) * 4));
+        BLZ_TRY(sbuf[b].entries.reserve(max_entries * 4));
+    }
     BLZ_TRY(blocksums.reserve((size_t)((G + 1 + SCAN_TILE - 1) / SCAN_TILE) * 8));
-    BLZ_TRY(sbuf[slot].entries.reserve(max_entries * 4));
     if (nslices > 1) {
         const size_t sum_bytes = (size_t)ops->partial_dwords * 4;
         BLZ_TRY(bucket_sums.reserve((G + 1) * sum_bytes));
@@ -693,13 +714,24 @@ int MsmEngine::sort_slice(int slot, int sl, const void* d_scalars, uint32_t np) 
     const uint64_t G = P.G;
     const uint32_t nscan = (uint32_t)((G + 1 + SCAN_TILE - 1) / SCAN_TILE);
     hipStream_t st = stream;
+    MsmSlot& O = slots[(slot + 1) % MSM_QUEUE_DEPTH];
+    sb_sel = S.pingpong ? (slot + sl) % MSM_QUEUE_DEPTH : slot;
     SortBufs& B = sb();
     const bool hide = S.sort_hidden;
     sort_st = hide ? sort_stream : st;
     hipStream_t ss = sort_st;
     if (last_sort_done) BLZ_HIP(hipStreamWaitEvent(ss, last_sort_done, 0), BLZ_ERR_UNKNOWN);
-    // this slot's previous task must have let go of its sort outputs (its level-0 reduce read unit_off last)
-    if (hide && S.l0_recorded) BLZ_HIP(hipStreamWaitEvent(ss, S.ev_l0, 0), BLZ_ERR_UNKNOWN);
+    if (hide) {
+        // whoever read this buffer set last must have let go of it: the accumulation two pieces back (ping-pong), else the
+        // slot's previous task (its level-0 reduce read unit_off last) - and the OTHER slot's last task too if that was a
+        // ping-pong task, which borrowed this slot's set
+        if (S.pingpong && S.acc_pp_recorded[sl & 1]) {
+            BLZ_HIP(hipStreamWaitEvent(ss, S.ev_acc_pp[sl & 1], 0), BLZ_ERR_UNKNOWN);
+        } else {
+            if (S.l0_recorded) BLZ_HIP(hipStreamWaitEvent(ss, S.ev_l0, 0), BLZ_ERR_UNKNOWN);
+            if (O.pingpong && O.l0_recorded) BLZ_HIP(hipStreamWaitEvent(ss, O.ev_l0, 0), BLZ_ERR_UNKNOWN);
+        }
+    }
     BLZ_HIP(hipEventRecord(S.ev_s0, ss), BLZ_ERR_UNKNOWN);   // ev_s0 .. ev_s1: the sort stage, whichever stream it is on
     dim3 b256(256);
     const char* sc_s = (const char*)d_scalars;
@@ -737,8 +769,9 @@ int MsmEngine::sort_slice(int slot, int sl, const void* d_scalars, uint32_t np) 
     // from `stats`; the host copy below is for the log line, the sanity check of finish() and the hot-bucket guard.
     BLZ_HIP(hipMemcpyAsync(S.stats_h, B.stats.p, 16, hipMemcpyDeviceToHost, ss), BLZ_ERR_READ);
     if (!tiny) BLZ_TRY(launch_fill_units(E, (uint32_t)S.max_units));
-    BLZ_HIP(hipEventRecord(S.ev_sorted, ss), BLZ_ERR_UNKNOWN);
-    last_sort_done = S.ev_sorted;
+    hipEvent_t sorted = S.pingpong ? S.ev_sorted_pp[sl & 1] : S.ev_sorted;
+    BLZ_HIP(hipEventRecord(sorted, ss), BLZ_ERR_UNKNOWN);
+    last_sort_done = sorted;
     BLZ_HIP(hipEventRecord(S.ev_s1, ss), BLZ_ERR_UNKNOWN);
     // run() (inputs all there before the task began): the staged inputs have been consumed once the LAST sort has read
     // the scalars - and, in DMA mode, once the to-Montgomery pass, which msm_capi.hip enqueued on the MAIN stream ahead of
@@ -762,9 +795,14 @@ int MsmEngine::accumulate_slice(int slot, int sl, const void* d_pts) {
     cur = slot;
     last_plan = S.plan;
     sort_st = S.sort_hidden ? sort_stream : stream;
-    if (S.sort_hidden) BLZ_HIP(hipStreamWaitEvent(stream, S.ev_sorted, 0), BLZ_ERR_UNKNOWN);
+    sb_sel = S.pingpong ? (slot + sl) % MSM_QUEUE_DEPTH : slot;
+    if (S.sort_hidden) BLZ_HIP(hipStreamWaitEvent(stream, S.pingpong ? S.ev_sorted_pp[sl & 1] : S.ev_sorted, 0), BLZ_ERR_UNKNOWN);
     BLZ_TRY(ops->run_accumulate(*this, d_pts, (uint32_t)S.max_units, S.slices > 1 ? sl : -1));
     if (S.slices > 1) BLZ_TRY(ops->merge_buckets(*this));
+    if (S.pingpong) {
+        BLZ_HIP(hipEventRecord(S.ev_acc_pp[sl & 1], stream), BLZ_ERR_UNKNOWN);
+        S.acc_pp_recorded[sl & 1] = true;
+    }
     return BLZ_OK;
 }
 
@@ -782,6 +820,7 @@ int MsmEngine::end(int slot) {
         BLZ_HIP(hipEventRecord(S.task_inputs_event, stream), BLZ_ERR_UNKNOWN);
         S.task_inputs_event = nullptr;
     }
+    sb_sel = slot;
     if (S.slices > 1) {
         hipLaunchKernelGGL(k_iota, dim3(1024), dim3(256), 0, stream, bucket_ident.as<uint32_t>(), S.plan.G + 2);
         BLZ_TRY(ops->run_reduce(*this, bucket_sums.p, bucket_ident.p));

@@ -74,6 +74,13 @@ struct MsmSlot {
     uint32_t npts = 0, pts_per_slice = 0;
     int sbits = 0, bit_lo = 0, bit_hi = 0;
     hipEvent_t task_inputs_event = nullptr;   // the caller's inputs_event, until it has been recorded
+    // A piecewise task on an otherwise idle handle sorts piece k + 1 UNDERNEATH the accumulation of piece k, like a stream
+    // of tasks does: the pieces alternate between this slot's SortBufs and the other slot's (which nobody uses while that
+    // slot is idle), sorts on sort_stream, one pair of events per buffer set.
+    bool pingpong = false;
+    hipEvent_t ev_sorted_pp[2] = {nullptr, nullptr};   // piece's sort stage complete (index: piece & 1)
+    hipEvent_t ev_acc_pp[2] = {nullptr, nullptr};      // the accumulation that read the piece's sort outputs is through
+    bool acc_pp_recorded[2] = {false, false};
 };
 
 struct MsmEngine {
@@ -97,7 +104,8 @@ struct MsmEngine {
         DevBuf range_scalars;   // scalar-range tasks: words [bit_lo / 32, bit_hi / 32) of every scalar, zero-extended to 32 bytes
     };
     SortBufs sbuf[MSM_QUEUE_DEPTH];
-    SortBufs& sb() { return sbuf[cur]; }
+    int sb_sel = 0;                // the set the piece being enqueued uses: its slot's, or (ping-pong pieces) the other slot's
+    SortBufs& sb() { return sbuf[sb_sel]; }
     hipStream_t sort_stream = nullptr;   // hidden sorts
     hipStream_t sort_st = nullptr;       // the stream the CURRENT task's sort stage is being enqueued on (stream or sort_stream)
     hipEvent_t last_sort_done = nullptr; // sorts share their scratch (coarse, inter, inter2, ...): each waits for the one before

@@ -380,9 +380,9 @@ __global__ __launch_bounds__(128, USE_RR<F> ? BLZ_ACC_RR_WAVES : 3) __attribute_
                                                     uint32_t* __restrict__ partial) {
     accumulate_body<F, false>(pts, entries, off, unit_off, unit_bucket, unit_order, stats, L, partial, nullptr, false);
 }
-// the piecewise twin (no register cap: no sort is ever hidden underneath it)
+// the piecewise twin (same register cap: the next piece's sort hides underneath it)
 template <class F>
-__global__ __launch_bounds__(128, USE_RR<F> ? BLZ_ACC_RR_WAVES : 3) void k_accumulate_cont(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ entries,
+__global__ __launch_bounds__(128, USE_RR<F> ? BLZ_ACC_RR_WAVES : 3) __attribute__((amdgpu_num_vgpr(BLZ_ACC_VGPR_CAP))) void k_accumulate_cont(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ entries,
                                                     const uint32_t* __restrict__ off, const uint32_t* __restrict__ unit_off,
                                                     const uint32_t* __restrict__ unit_bucket,
                                                     const uint32_t* __restrict__ unit_order,
