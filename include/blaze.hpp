@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <optional>
 #include <stdexcept>
+#include <array>
 #include <string>
 #include <utility>
 #include <vector>
@@ -128,6 +129,20 @@ class MSMClient : public DriverPrimitive<MSMInit, MSMParams, MSMInput, MSMResult
     // resident-base window table (blaze_hip.h): opt-in, bases in the arena, precompute_factor 1
     void set_scalar_range(uint32_t bit_lo, uint32_t bit_hi) { check(blz_msm_set_scalar_range(h_, bit_lo, bit_hi)); }   // one shard of a job split by scalar chunk
     void set_window_table(int mode) { check(blz_msm_set_window_table(h_, mode)); }   // 0 off, 1 where it pays, 2 always
+    // enqueue the table's build for the bases at hbm_addr (it is paced by the tasks otherwise) and wait up to wait_ms for it
+    // (0: not at all, < 0: the library's wait deadline); true: the table is in place
+    bool prepare_window_table(uint32_t nof_elements, std::pair<uint64_t, uint64_t> hbm_addr = {0, 0}, int wait_ms = -1) {
+        int ready = 0;
+        check(blz_msm_prepare_window_table(h_, nof_elements, hbm_addr.first, hbm_addr.second, wait_ms, &ready));
+        return ready != 0;
+    }
+    // {first element, count, bit_lo, bit_hi, ranges, compute us, link us, device MiB} of `rank`: the split priced with the flow's
+    // transfers (flags: BLZ_SHARD_SCALARS_FROM_HOST | BLZ_SHARD_BASES_FROM_HOST)
+    static std::array<uint32_t, 8> shard_layout_ex(int curve, uint32_t nof_elements, int nranks, int rank, uint32_t flags) {
+        std::array<uint32_t, 8> out{};
+        check(blz_msm_shard_layout_ex(curve, nof_elements, nranks, rank, flags, out.data()));
+        return out;
+    }
     void comm_init(int rank, int nranks, const std::vector<uint8_t>& id) { check(blz_msm_comm_init(h_, rank, nranks, id.data())); }
     std::vector<uint8_t> all_gather_combine(const std::vector<uint8_t>& partial) {
         std::vector<uint8_t> out(result_size_);
