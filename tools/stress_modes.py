@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Dev tool: long-lived clients fed a random mix of task kinds - plain, resident-base window table (arena bases, sub-ranges,
-rewrites that drop the table), scalar ranges - at random sizes, two in flight, every result checked through linearity
+rewrites that drop the table), scalar ranges, host buffers (DMA mode and the HBM flow with host scalars: tasks enqueued piece by
+piece, BLAZE_MSM_PIECES drawn per task) - at random sizes, two in flight, every result checked through linearity
 (P_i = (i + 1) G).  python3 tools/stress_modes.py [iterations] [seed]"""
 import os
 import random
@@ -22,12 +23,13 @@ rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 9)
 L = blaze_amd.lib()
 NMAX = 1 << 21
 curves = ("BLS381", "BLS377", "BN254")
-host_sc, dev = {}, {}
+host_sc, host_pts, dev = {}, {}, {}
 L.blz_arena_release(0)
 for c in curves:
     dp, ds = synth(c, NMAX, seed=13)
     dev[c] = (dp, ds)
     host_sc[c] = np.frombuffer(ds.download(), dtype=np.uint8).reshape(NMAX, 32).copy()
+    host_pts[c] = bytes(dp.download())
 
 
 class View(blaze_amd.DeviceBuffer):
@@ -49,6 +51,7 @@ def expected(c, first, n, lo, hi):
 
 plain = {c: msm_client(c, 1) for c in curves}
 table = {c: msm_client(c, 1, PointMemoryType.HBM) for c in curves}
+hbm = {c: msm_client(c, 1, PointMemoryType.HBM) for c in curves}
 ARENA = {c: (i + 1) << 32 for i, c in enumerate(curves)}   # one flat arena per device: every curve's bases at their own address
 for c in curves:
     table[c].set_window_table(2)
@@ -71,7 +74,13 @@ def collect(cl, key):
 
 for it in range(iters):
     c = rng.choice(curves)
-    kind = rng.choice(("plain", "table", "table", "range", "range", "rewrite", "table+range"))
+    kind = rng.choice(("plain", "table", "table", "range", "range", "rewrite", "table+range", "dma_host", "dma_host", "hbm_host", "hbm_host",
+                       "dma_host+range", "pieces"))
+    pc = rng.choice(("", "", "1", "2", "3", "8", "16"))
+    if pc:
+        os.environ["BLAZE_MSM_PIECES"] = pc
+    else:
+        os.environ.pop("BLAZE_MSM_PIECES", None)
     n = rng.choice([1, 63, 4096, 100001, 1 << 18, (1 << 19) + 5, 1 << 20, NMAX])
     first = 0 if n == NMAX else rng.randrange(0, NMAX - n) & ~3
     dp, ds = dev[c]
@@ -86,7 +95,20 @@ for it in range(iters):
         cl.load_data_to_hbm(View(dp, at * ps[c], m * ps[c]), ARENA[c], at * ps[c])
         continue
     lo, hi = 0, 256
-    if kind in ("table", "table+range"):
+    if kind == "hbm_host":
+        # the reference's HBM flow: bases in the arena, the scalars a host buffer (an idle handle enqueues it piece by piece)
+        cl, key = hbm[c], ("h", c)
+        params = MSMParams(n, (ARENA[c], first * ps[c]))
+        inp = MSMInput(None, host_sc[c][first:first + n].tobytes(), params)
+    elif kind in ("dma_host", "dma_host+range"):
+        cl, key = plain[c], ("p", c)
+        if kind == "dma_host+range":
+            a, b = sorted(rng.sample(range(0, 9), 2))
+            lo, hi = 32 * a, 32 * b
+        cl.set_scalar_range(lo, hi)
+        params = MSMParams(n, None)
+        inp = MSMInput(host_pts[c][first * ps[c]:(first + n) * ps[c]], host_sc[c][first:first + n].tobytes(), params)
+    elif kind in ("table", "table+range"):
         cl, key = table[c], ("t", c)
         if kind == "table+range":
             a, b = sorted(rng.sample(range(0, 9), 2))
@@ -110,7 +132,7 @@ for it in range(iters):
     if it % 20 == 19:
         print(f"iter {it + 1}: {time.time() - t0:.1f} s, mismatches so far {bad}", flush=True)
 for (k, c), lst in pending.items():
-    cl = table[c] if k == "t" else plain[c]
+    cl = table[c] if k == "t" else hbm[c] if k == "h" else plain[c]
     while lst:
         collect(cl, (k, c))
 print("mismatches:", bad)
