@@ -6,6 +6,7 @@
 #include "ec.hip.hpp"
 #include "ec_rr.hip.hpp"
 #include "ec_quad.hip.hpp"
+#include "ec_row.hip.hpp"
 #include <type_traits>
 
 namespace blz {
@@ -719,6 +720,61 @@ __global__ __launch_bounds__(64, USE_RR<F> ? 2 : 3) void k_finish(const uint32_t
     }
 }
 
+// The same walk with ONE point spread over the wave (ec_row.hip.hpp: a limb per lane, the four products of a formula round on
+// the four DPP rows): a doubling costs ~1.5 us instead of the quad law's ~5, and the ~255 of them are the whole kernel.  For
+// the curves on the loose 28-bit budget (BLS12-377 / 381); BN254 keeps the quad walk.
+template <class F>
+__global__ __launch_bounds__(64, 2) void k_finish_row(const uint32_t* __restrict__ vsumA, const uint32_t* __restrict__ vsumC, FinishPlan fp,
+                                                      uint32_t* __restrict__ out) {
+    using Q = typename F::RR;
+    if (blockIdx.x != 0) return;
+    __builtin_amdgcn_s_setprio(BLZ_TAIL_PRIO);
+    __shared__ uint32_t sh[4][16];
+    const RowCtx<Q> c = row_ctx<Q>();
+    RowPt acc;
+    rowpt_set_inf(acc);
+    int pos = 0;
+    bool started = false;
+    for (int w = fp.W - 1; w >= 0; --w) {
+        const int v0 = fp.v0[w], m = fp.m[w], off = fp.off[w];
+        if (m > 1) {
+            RowPt t, u;
+            rowpt_set_inf(t);
+            rowpt_set_inf(u);
+            for (int j = m - 1; j >= 1; --j) {
+                RowPt a;
+                rowpt_load<Q>(c, a, vsumA, (size_t)(v0 + j));
+                rowpt_add<Q>(c, t, a);
+                rowpt_add<Q>(c, u, t);
+            }
+            const int o2 = off + fp.logV;
+            if (started) for (int d = 0; d < pos - o2; ++d) rowpt_dbl<Q>(c, acc);
+            rowpt_add<Q>(c, acc, u);
+            pos = o2;
+            started = true;
+        }
+        RowPt cs;
+        rowpt_load<Q>(c, cs, vsumC, (size_t)v0);
+        for (int j = 1; j < m; ++j) {
+            RowPt a;
+            rowpt_load<Q>(c, a, vsumC, (size_t)(v0 + j));
+            rowpt_add<Q>(c, cs, a);
+        }
+        if (started) for (int d = 0; d < pos - off; ++d) rowpt_dbl<Q>(c, acc);
+        rowpt_add<Q>(c, acc, cs);
+        pos = off;
+        started = true;
+    }
+    for (int d = 0; d < pos; ++d) rowpt_dbl<Q>(c, acc);
+    XYZZRR<Q> r;
+    rowpt_export<Q>(c, acc, sh, r);
+    if (threadIdx.x == 0) {
+        XYZZ<F> o;
+        ptrr_to_xyzz32<F>(o, r);
+        emit_result(out, o);
+    }
+}
+
 template <class F>
 __global__ void k_emit_infinity(uint32_t* __restrict__ out) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -1095,7 +1151,16 @@ int run_reduce_t(MsmEngine& E, const void* sums, const void* unit_off_v) {
             off += P.width[w];
         }
     }
-    hipLaunchKernelGGL(k_finish<F>, dim3(1), dim3(64), 0, st, curA, curC, fp, E.slot_result(E.cur));
+    bool row_walk = false;
+    if constexpr (USE_RR<F>) row_walk = !RR_TIGHT<typename F::RR> && exp_knob("BLAZE_FINISH_ROW", 1) != 0;
+    if (row_walk) {
+        if constexpr (USE_RR<F>) {
+            if constexpr (!RR_TIGHT<typename F::RR>)
+                hipLaunchKernelGGL(k_finish_row<F>, dim3(1), dim3(64), 0, st, curA, curC, fp, E.slot_result(E.cur));
+        }
+    } else {
+        hipLaunchKernelGGL(k_finish<F>, dim3(1), dim3(64), 0, st, curA, curC, fp, E.slot_result(E.cur));
+    }
     BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
     BLZ_HIP(hipEventRecord(S.ev[4], st), BLZ_ERR_UNKNOWN);
     BLZ_HIP(hipMemcpyAsync(S.result_h, E.slot_result(E.cur), 12 * F::N, hipMemcpyDeviceToHost, st), BLZ_ERR_READ);
