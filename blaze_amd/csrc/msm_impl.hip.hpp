@@ -250,6 +250,9 @@ BLZ_DEV void store_xyzz(uint32_t* base, size_t idx, const XYZZ<F>& a) {
 // (msm.hip run()).  BLS12-381 compiles to 194 on its own; BLS12-377 to 206 (same code, other constants), which left its
 // sorts in the open (+4 ms per MSM) until this cap: 200 registers and 8 more spilled dwords outside the inner loop.
 // The attribute counts in units of the pre-gfx90a file (the backend doubles it for the unified 512-register file): 100 = 200.
+#ifndef BLZ_ACC_W32_WAVES
+#define BLZ_ACC_W32_WAVES 3
+#endif
 #ifndef BLZ_ACC_VGPR_CAP
 #define BLZ_ACC_VGPR_CAP 100
 #endif
@@ -373,7 +376,7 @@ BLZ_DEV void accumulate_body(const uint32_t* __restrict__ pts, const uint32_t* _
 }
 
 template <class F>
-__global__ __launch_bounds__(128, USE_RR<F> ? BLZ_ACC_RR_WAVES : 3) __attribute__((amdgpu_num_vgpr(BLZ_ACC_VGPR_CAP))) void k_accumulate(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ entries,
+__global__ __launch_bounds__(128, USE_RR<F> ? BLZ_ACC_RR_WAVES : BLZ_ACC_W32_WAVES) __attribute__((amdgpu_num_vgpr(BLZ_ACC_VGPR_CAP))) void k_accumulate(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ entries,
                                                     const uint32_t* __restrict__ off, const uint32_t* __restrict__ unit_off,
                                                     const uint32_t* __restrict__ unit_bucket,
                                                     const uint32_t* __restrict__ unit_order,

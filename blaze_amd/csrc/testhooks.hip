@@ -2,6 +2,7 @@
 // with the CPU oracle (include/blaze_hip.h "test hooks").  Not on the MSM/NTT product path.
 #include "common.hpp"
 #include "ec_rr.hip.hpp"
+#include "ec_row.hip.hpp"
 
 namespace blz {
 
@@ -182,6 +183,89 @@ struct Tmp {
     }
 };
 
+// ops 20..24: the row-cooperative field arithmetic of ec_row.hip.hpp (a limb per lane, 16 lanes per element, four elements per
+// wave).  Operands go in through the lane form's conversions and the results come back through them, so what is compared with
+// the oracle is the value.  24 is a self-check of the carry machinery on SYNTHETIC limb patterns (random Montgomery forms
+// practically never hold a run of 0xfffffff limbs): limbs drawn from {0, 1, MASK, MASK - 1, 2^28, 2^28 + 3, lazy ...} by the
+// input bits, weak normalisation + exact resolve against a serial carry loop; the result is 1 (agree) or 0.
+template <class P>
+__global__ __launch_bounds__(64) void k_test_row(int op, const uint32_t* a, const uint32_t* b, uint32_t* out, uint32_t n) {
+    if constexpr (USE_RR<P>) {
+        using Q = typename P::RR;
+        if constexpr (!RR_TIGHT<Q> && Q::B == 28) {
+            __shared__ uint32_t sh[2][4][16];
+            const RowCtx<Q> c = row_ctx<Q>();
+            // this row's element; the zero test (23) is wave-wide - the tail's rows are replicas - so it takes one element per wave
+            const uint32_t e = op == 23 ? blockIdx.x : blockIdx.x * 4u + c.row;
+            const uint32_t ee = e < n ? e : n - 1;
+            Fp<P> x, y;
+            fp_load(x, a + (size_t)ee * P::N);
+            fp_load(y, b + (size_t)ee * P::N);
+            uint32_t xl = 0, yl = 0;
+            if (op == 24) {
+                // limb li from 3 bits of the inputs
+                const uint32_t bits = (x.v[c.li % P::N] >> (3u * (c.li / P::N))) ^ (y.v[(c.li * 5u) % P::N] >> 7);
+                const uint32_t pat[8] = {0u, 1u, Q::MASK, Q::MASK - 1u, 1u << 28, (1u << 28) + 3u, 15u * (1u << 28) + Q::MASK, (7u << 28) + 1u};
+                xl = c.li < (uint32_t)Q::NL ? pat[bits & 7u] : 0u;
+                if (c.li == (uint32_t)Q::NL - 1u) xl &= 0xffffu;   // the top limb stays small (value bound)
+            } else {
+                Frr<Q, 1, 2> xr, yr;
+                rr_to_mont_from_words<Q>(xr, x.v);
+                rr_to_mont_from_words<Q>(yr, y.v);
+                if ((threadIdx.x & 15u) == 0u) {
+#pragma unroll
+                    for (int i = 0; i < Q::NL; ++i) { sh[0][c.row][i] = xr.v[i]; sh[1][c.row][i] = yr.v[i]; }
+                    sh[0][c.row][14] = sh[0][c.row][15] = sh[1][c.row][14] = sh[1][c.row][15] = 0u;
+                }
+                __syncthreads();
+                xl = sh[0][c.row][c.li];
+                yl = sh[1][c.row][c.li];
+                __syncthreads();
+            }
+            uint32_t r = 0;
+            if (op == 20) r = row_mul<Q>(c, xl, yl);
+            else if (op == 21) r = row_mul<Q>(c, row_norm<Q>(c, xl + (c.km2 - yl) + 2u * (c.km2 - yl)), yl);   // (x - 3y + 12m) y
+            else if (op == 22) {   // (x - y + 32m)(x + y): the 32m constant, a lazy operand on each side (F = 5 and 2: 11 <= 18)
+                r = row_mul<Q>(c, xl + (c.km5 - yl), xl + yl);
+            } else if (op == 23) {   // 1 if x == y else 0 (Montgomery one / zero), through the filter and the exact test
+                const uint32_t d = row_norm<Q>(c, xl + (c.km2 - yl));
+                const bool z = row_is_zero<Q>(c, d);
+                const bool eq = row_maybe_equal<Q>(c, d) && z;
+                r = z != eq ? (c.li == 0u ? 7u : 0u) : eq ? c.one : 0u;
+            } else if (op == 24) {
+                r = row_resolve<Q>(c, row_norm<Q>(c, xl));
+            }
+            if (op != 24) r = row_resolve<Q>(c, r);
+            sh[0][c.row][c.li] = r;
+            sh[1][c.row][c.li] = xl;
+            __syncthreads();
+            if (c.li == 0u && e < n && (op != 23 || c.row == 0u)) {
+                Fp<P> o;
+                if (op == 24) {
+                    uint64_t carry = 0;
+                    bool same = true;
+                    for (int i = 0; i < Q::NL; ++i) {
+                        const uint64_t t = (uint64_t)sh[1][c.row][i] + carry;
+                        const uint32_t want = i + 1 < Q::NL ? (uint32_t)t & Q::MASK : (uint32_t)t;
+                        carry = i + 1 < Q::NL ? t >> Q::B : 0;
+                        same = same && want == sh[0][c.row][i];
+                    }
+                    fp_zero(o);
+                    o.v[0] = same ? 1u : 0u;
+                    fp_store(out + (size_t)e * P::N, o);
+                } else {
+                    Frr<Q, 1, 2> rr;
+#pragma unroll
+                    for (int i = 0; i < Q::NL; ++i) rr.v[i] = sh[0][c.row][i];
+                    rr_to_mont32_words<Q>(o.v, rr);
+                    fp_from_mont(o, o);
+                    fp_store(out + (size_t)e * P::N, o);
+                }
+            }
+        }
+    }
+}
+
 template <class P>
 int test_field_t(int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n) {
     Tmp tmp;
@@ -190,8 +274,13 @@ int test_field_t(int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_
     BLZ_TRY(tmp.alloc(&da, bytes)); BLZ_TRY(tmp.alloc(&db, bytes)); BLZ_TRY(tmp.alloc(&dout, bytes));
     BLZ_HIP(hipMemcpy(da, a, bytes, hipMemcpyHostToDevice), BLZ_ERR_WRITE);
     BLZ_HIP(hipMemcpy(db, b, bytes, hipMemcpyHostToDevice), BLZ_ERR_WRITE);
-    hipLaunchKernelGGL(k_test_field<P>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, op, (const uint32_t*)da,
-                       (const uint32_t*)db, (uint32_t*)dout, (uint32_t)n);
+    if (op >= 20 && op <= 24) {
+        BLZ_HIP(hipMemset(dout, 0, bytes), BLZ_ERR_UNKNOWN);   // (fields without the row arithmetic answer zero)
+        hipLaunchKernelGGL(k_test_row<P>, dim3((unsigned)(op == 23 ? n : (n + 3) / 4)), dim3(64), 0, 0, op, (const uint32_t*)da, (const uint32_t*)db,
+                           (uint32_t*)dout, (uint32_t)n);
+    } else
+        hipLaunchKernelGGL(k_test_field<P>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, op, (const uint32_t*)da,
+                           (const uint32_t*)db, (uint32_t*)dout, (uint32_t)n);
     BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
     BLZ_HIP(hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost), BLZ_ERR_READ);
     return BLZ_OK;

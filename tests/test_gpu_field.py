@@ -41,6 +41,12 @@ def test_field_ops(gpu, curve, field):
         ops[13] = lambda x, y: (x - 3 * y) * y % m
         ops[14] = lambda x, y: 1 if x == y else 0
         ops[15] = lambda x, y: (x - 3 * y) * x % m
+    if field == 0 and curve != "BN254":   # the row-cooperative arithmetic of the tail (ec_row.hip.hpp): the BLS base fields
+        ops[20] = lambda x, y: x * y % m
+        ops[21] = lambda x, y: (x - 3 * y) * y % m
+        ops[22] = lambda x, y: (x - y) * (x + y) % m
+        ops[23] = lambda x, y: 1 if x == y else 0
+        ops[24] = lambda x, y: 1            # carry machinery self-check on synthetic limb patterns
     for op, fn in ops.items():
         cnt = n if op != 3 else 200  # inversion is slow on one lane; sample
         out = C.create_string_buffer(cnt * nb)
