@@ -484,7 +484,7 @@ def main():
     # after it, reached by every rank whatever happened to it (N > 1: the ranks' tasks are timed without the 144-byte exchange)
     if hbm_mode and not args.no_extras and os.environ.get("BLAZE_BENCH_TABLE", "1") == "1":
         wd.arm(900, "window-table leg")
-        terr, tdt, tinfo, first_ms, tkernel, n_before, until_ms, paced_ms = None, -1.0, {"bytes": 0, "window_bits": 0, "windows": 0, "build_ms": 0.0}, 0.0, 0.0, 0, 0.0, 0.0
+        terr, tdt, tinfo, first_ms, tkernel, n_before, until_ms, paced_ms, alloc_ms = None, -1.0, {"bytes": 0, "window_bits": 0, "windows": 0, "build_ms": 0.0}, 0.0, 0.0, 0, 0.0, 0.0, 0.0
         k_t = args.steps
         tcl = None
         try:
@@ -521,6 +521,12 @@ def main():
             tsubmit()                       # (a fresh handle's first task pays its workspace allocations: not the table's doing)
             tcollect()
             tcl.set_window_table(True)
+            # the table's allocation (80 GiB: 0.3 ms on a clean device, seconds when the driver first has to scrub memory an
+            # earlier process freed - and a hipMalloc stalls every HIP call of the process, on any thread) belongs with the load:
+            # prepare_window_table without a wait allocates and enqueues the first chunks
+            t1 = time.perf_counter()
+            tcl.prepare_window_table(n_loc, (0, 0), 0)
+            alloc_ms = (time.perf_counter() - t1) * 1e3
             t1 = time.perf_counter()
             tsubmit()
             first = tcollect()
@@ -568,7 +574,7 @@ def main():
                 table_rec = {"ms_per_step": round(tdt / k_t * 1e3, 3), "msm_per_s": round(k_t / tdt, 4), "steps": k_t,
                              "used": tinfo["bytes"] > 0, "table_bytes_per_gpu": tinfo["bytes"], "window_bits": tinfo["window_bits"],
                              "windows": tinfo["windows"], "build_ms": round(tinfo["build_ms"], 1),
-                             "first_task_ms": round(first_ms, 1), "ms_per_task_while_building": round(paced_ms, 1),
+                             "prepare_no_wait_ms": round(alloc_ms, 1), "first_task_ms": round(first_ms, 1), "ms_per_task_while_building": round(paced_ms, 1),
                              "tasks_on_the_plain_path": n_before, "prepare_wait_ms": round(until_ms, 1), "kernel_ms": round(tkernel, 3),
                              "result_check": "this rank's result bytes equal its result in the headline loop (which the oracle checked"
                                              + (" after the exchange)" if multi else ")"),
