@@ -563,6 +563,16 @@ int MsmEngine::build_table(const void* d_raw, void* d_table, uint32_t npts, int 
 }
 size_t MsmEngine::table_scratch_bytes(int W) const { return ops_for(curve, repr)->table_scratch_bytes(W); }
 
+// do the hidden sort's waves (sv VGPRs) fit on a SIMD beside the accumulation's (av VGPRs each, as many as fit)?  Measured: the
+// sort runs beside 2 x 200 + 72 = 472 registers and waits for the accumulation to END behind 2 x 208 + 72 = 488.
+static bool sort_fits_beside(int av, int sv) {
+    const int a = (av + 7) & ~7, s = (sv + 7) & ~7;
+    int waves = 512 / a;
+    if (waves > 4) waves = 4;
+    if (waves < 1) waves = 1;
+    return waves * a + s <= 512 - 32;
+}
+
 static const int kScalarFieldBits[3] = {253, 255, 254};  // bit length of r (BLS12-377 / 381 / BN254)
 
 MsmPlan MsmEngine::plan_for(uint32_t npts, int sbits) const {
@@ -648,8 +658,10 @@ int MsmEngine::begin(uint32_t npts, int sbits, int* slot_out, int table_c, int b
         // registers, and waits for the accumulation to END behind 2 x 206 (-> 208) + 72 = 488 and 2 x 211 (-> 216) + 72 = 504 -
         // the SIMD does not hand out all 512.  A build whose k_accumulate grew past that still works, it just sorts in
         // the open (round 3 saw 211 VGPRs cost 4 ms per step before this check existed).
+        // (the SIMD runs as many accumulation waves as their allocation admits: two of the reduced-radix kernels', three of
+        // the 32-bit-limb kernel's, whose allocation is padded to 136 for exactly this purpose)
         const int av = ops->accumulate_vgprs(), sv = P.table ? msm_sort3t_max_vgprs() : msm_sort3_max_vgprs();
-        if (av > 0 && sv > 0 && 2 * ((av + 7) & ~7) + ((sv + 7) & ~7) > 512 - 32) fits = false;
+        if (av > 0 && sv > 0 && !sort_fits_beside(av, sv)) fits = false;
         if (!fits && !P.table) s3 = false;
     }
     bool hide = s3 && O.busy && hide_env != 0 && fits;
@@ -658,7 +670,7 @@ int MsmEngine::begin(uint32_t npts, int sbits, int* slot_out, int table_c, int b
     bool pingpong = false;
     if (nslices > 1 && hide_env != 0 && !O.busy && !P.table && msm_sort3_ok(P, sbits) && !(recent_hot[0] || recent_hot[1])) {
         const int av = ops->accumulate_vgprs(), sv = msm_sort3_max_vgprs();   // (k_accumulate_cont shares k_accumulate's register cap)
-        if (!(av > 0 && sv > 0 && 2 * ((av + 7) & ~7) + ((sv + 7) & ~7) > 512 - 32)) pingpong = true;
+        if (!(av > 0 && sv > 0 && !sort_fits_beside(av, sv))) pingpong = true;
     }
     if (pingpong) { s3 = true; hide = true; }
 
@@ -747,7 +759,7 @@ int MsmEngine::sort_slice(int slot, int sl, const void* d_scalars, uint32_t np) 
     // a small task's whole sort stage - digits, bucket scan, entries, unit lists - is one block's work (msm_sort_tiny.hip)
     const bool tiny = !S.use_s3 && S.slices == 1 && msm_sort_tiny_ok(P, np, S.sbits);
     if (S.use_s3) {
-        BLZ_TRY(P.table ? msm_sort3t(E, sc_s, np) : msm_sort3(E, sc_s, np));   // count[] and entries[] in one go
+        BLZ_TRY(P.table ? msm_sort3t(E, sc_s, np) : msm_sort3(E, sc_s, np, S.sbits));   // count[] and entries[] in one go
     } else if (tiny) {
         BLZ_TRY(msm_sort_tiny(E, sc_s, np, S.sbits, (uint32_t)S.max_units));
     } else {

@@ -166,7 +166,7 @@ int msm_sort_lds(MsmEngine& E, const void* d_scalars, uint32_t npts, int sbits);
 // count[] and entries[] of the current slot's SortBufs on E.sort_st; msm_sort3_ok: does the plan qualify
 bool msm_sort3_ok(const MsmPlan& P, int sbits);
 int msm_sort3_max_vgprs();   // the largest register count among the three-level sort's kernels (0 if unknown)
-int msm_sort3(MsmEngine& E, const void* d_scalars, uint32_t npts);
+int msm_sort3(MsmEngine& E, const void* d_scalars, uint32_t npts, int sbits);
 // the same sort for window-table plans (shared bucket set, entries = point * W + window)
 bool msm_sort3t_ok(const MsmPlan& P);
 int msm_sort3t_max_vgprs();

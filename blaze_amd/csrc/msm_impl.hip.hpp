@@ -250,8 +250,10 @@ BLZ_DEV void store_xyzz(uint32_t* base, size_t idx, const XYZZ<F>& a) {
 // (msm.hip run()).  BLS12-381 compiles to 194 on its own; BLS12-377 to 206 (same code, other constants), which left its
 // sorts in the open (+4 ms per MSM) until this cap: 200 registers and 8 more spilled dwords outside the inner loop.
 // The attribute counts in units of the pre-gfx90a file (the backend doubles it for the unified 512-register file): 100 = 200.
+// waves per SIMD of the 32-bit-limb kernel (BN254 precompute handles): 2 like the reduced-radix kernels - measured equal to 3
+// (config 3: 82.9 against 82.8 ms) - so that the register cap applies and the next task's sort fits beside it
 #ifndef BLZ_ACC_W32_WAVES
-#define BLZ_ACC_W32_WAVES 3
+#define BLZ_ACC_W32_WAVES 2
 #endif
 #ifndef BLZ_ACC_VGPR_CAP
 #define BLZ_ACC_VGPR_CAP 100
@@ -354,6 +356,10 @@ BLZ_DEV void accumulate_body(const uint32_t* __restrict__ pts, const uint32_t* _
 #endif
         ptrr_store(dst, didx, acc);
     } else {
+        // The 32-bit-limb kernel needs only ~125 VGPRs and would run four waves per SIMD - no registers left for the hidden
+        // sort's waves (4 x 128 + 72 > 512).  Naming v135 as clobbered makes the allocation 136: three waves, 3 x 136 + 72 = 480.
+        // (amdgpu_waves_per_eu's maximum is a hint to the register allocator; it does not pad the allocation.)
+        asm volatile("" ::: "v135");
         XYZZ<F> acc;
         pt_set_inf(acc);
         if constexpr (CONT) {
@@ -386,7 +392,7 @@ __global__ __launch_bounds__(128, USE_RR<F> ? BLZ_ACC_RR_WAVES : BLZ_ACC_W32_WAV
 }
 // the piecewise twin (same register cap: the next piece's sort hides underneath it)
 template <class F>
-__global__ __launch_bounds__(128, USE_RR<F> ? BLZ_ACC_RR_WAVES : 3) __attribute__((amdgpu_num_vgpr(BLZ_ACC_VGPR_CAP))) void k_accumulate_cont(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ entries,
+__global__ __launch_bounds__(128, USE_RR<F> ? BLZ_ACC_RR_WAVES : BLZ_ACC_W32_WAVES) __attribute__((amdgpu_num_vgpr(BLZ_ACC_VGPR_CAP))) void k_accumulate_cont(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ entries,
                                                     const uint32_t* __restrict__ off, const uint32_t* __restrict__ unit_off,
                                                     const uint32_t* __restrict__ unit_bucket,
                                                     const uint32_t* __restrict__ unit_order,

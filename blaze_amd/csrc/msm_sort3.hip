@@ -76,6 +76,8 @@ __device__ __forceinline__ uint32_t s3_block_excl_scan(uint32_t v, uint32_t* wav
 }
 
 // ---------------------------------------------------------------------------------------------- level 1
+// NW: 32-bit words per scalar - 8 (256-bit scalars) or 1 (the 32-bit chunks of a precompute handle: pf = 8)
+template <int NW>
 __global__ __launch_bounds__(S3_THREADS, 4) void k3_l1_count(const uint32_t* __restrict__ scalars, uint32_t npts, S3Geom g,
                                                             uint32_t* __restrict__ cnt1) {
     const int prio = g.prio;
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(S3_THREADS, 4) void k3_l1_count(const uint32_t* __r
     uint32_t end = base + S3_CNT_PTS;
     if (end > npts) end = npts;
     for (uint32_t p0 = base + threadIdx.x; p0 < end; p0 += 4 * S3_THREADS) {
-        ScalarWords<8> sw[4];
+        ScalarWords<NW> sw[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const uint32_t p = p0 + u * S3_THREADS;
@@ -139,15 +141,16 @@ __global__ __launch_bounds__(S3_THREADS) void k3_scan_small(const uint32_t* __re
     if (threadIdx.x == 0) off[n] = total;
 }
 
+template <int NW>
 __global__ __launch_bounds__(S3_THREADS, 4) void k3_l1_scatter(const uint32_t* __restrict__ scalars, uint32_t npts, S3Geom g,
                                                               uint32_t* __restrict__ cur1, uint32_t* __restrict__ o_idx,
                                                               uint16_t* __restrict__ o_rem) {
     const int prio = g.prio;
     S3_PRIO();
     extern __shared__ __attribute__((aligned(16))) uint32_t sh[];
-    uint32_t* sc = sh;                                          // [8][S3_PB]: word j of the lane's scalar u at j * PB + u * 256 + tid
-    uint2* stage = reinterpret_cast<uint2*>(sh + 8 * S3_PB);    // [S3_PB]
-    uint32_t* hist = sh + 10 * S3_PB;                           // [256]
+    uint32_t* sc = sh;                                          // [NW][S3_PB]: word j of the lane's scalar u at j * PB + u * 256 + tid
+    uint2* stage = reinterpret_cast<uint2*>(sh + NW * S3_PB);   // [S3_PB]
+    uint32_t* hist = sh + (NW + 2) * S3_PB;                     // [256]
     uint32_t* lstart = hist + 256;
     uint32_t* gbase = lstart + 256;
     __shared__ uint32_t wave_tot[4];
@@ -157,15 +160,19 @@ __global__ __launch_bounds__(S3_THREADS, 4) void k3_l1_scatter(const uint32_t* _
 #pragma unroll
     for (int u = 0; u < S3_T; ++u) {
         const uint32_t p = base + u * S3_THREADS + tid;
-        uint4 a = make_uint4(0, 0, 0, 0), b = make_uint4(0, 0, 0, 0);
-        if (p < npts) {
-            const uint4* q = reinterpret_cast<const uint4*>(scalars) + 2 * (size_t)p;
-            a = q[0];
-            b = q[1];
-        }
         const uint32_t i = u * S3_THREADS + tid;
-        sc[0 * S3_PB + i] = a.x; sc[1 * S3_PB + i] = a.y; sc[2 * S3_PB + i] = a.z; sc[3 * S3_PB + i] = a.w;
-        sc[4 * S3_PB + i] = b.x; sc[5 * S3_PB + i] = b.y; sc[6 * S3_PB + i] = b.z; sc[7 * S3_PB + i] = b.w;
+        if constexpr (NW == 8) {
+            uint4 a = make_uint4(0, 0, 0, 0), b = make_uint4(0, 0, 0, 0);
+            if (p < npts) {
+                const uint4* q = reinterpret_cast<const uint4*>(scalars) + 2 * (size_t)p;
+                a = q[0];
+                b = q[1];
+            }
+            sc[0 * S3_PB + i] = a.x; sc[1 * S3_PB + i] = a.y; sc[2 * S3_PB + i] = a.z; sc[3 * S3_PB + i] = a.w;
+            sc[4 * S3_PB + i] = b.x; sc[5 * S3_PB + i] = b.y; sc[6 * S3_PB + i] = b.z; sc[7 * S3_PB + i] = b.w;
+        } else {
+            sc[i] = p < npts ? scalars[p] : 0u;
+        }
     }
     uint32_t carry = 0;   // bit u: the carry of the lane's scalar u into the next window
     for (int w = 0; w < g.W; ++w) {
@@ -178,8 +185,8 @@ __global__ __launch_bounds__(S3_THREADS, 4) void k3_l1_scatter(const uint32_t* _
 #pragma unroll
         for (int u = 0; u < S3_T; ++u) {
             const uint32_t i = u * S3_THREADS + tid;
-            const uint32_t lo = j < 8 ? sc[j * S3_PB + i] : 0u;
-            const uint32_t hi = j + 1 < 8 ? sc[(j + 1) * S3_PB + i] : 0u;
+            const uint32_t lo = j < (uint32_t)NW ? sc[j * S3_PB + i] : 0u;
+            const uint32_t hi = j + 1 < (uint32_t)NW ? sc[(j + 1) * S3_PB + i] : 0u;
             const uint32_t raw = (shb ? __builtin_amdgcn_alignbit(hi, lo, shb) : lo) & mask;
             const uint32_t v = raw + ((carry >> u) & 1u);
             int d;
@@ -432,7 +439,10 @@ __global__ __launch_bounds__(S3_THREADS, 4) void k3_l3(const uint32_t* __restric
         __syncthreads();
         for (uint32_t t = tid; t < s; t += S3_THREADS) entries[a + t] = out[t];
     } else {
-        // a bin beyond the registers (hot buckets): count, then place entry by entry
+        // a bin beyond the registers - the precompute shapes (2^29 points of 32-bit scalars in 2 x 2^16 buckets: a million
+        // entries per bin, 8192 per bucket), hot buckets (the reference harness's repeated tile): count the whole bin, then
+        // place it chunk by chunk - S3_R3 entries ranked in LDS, staged in bucket order, copied out as one contiguous piece
+        // per bucket (a bucket's piece of a chunk is contiguous in the stage and at the bucket's cursor in entries[])
         for (uint32_t i = a + tid; i < b; i += S3_THREADS) atomicAdd(&hist[i_lo[i]], 1u);
         __syncthreads();
         const uint32_t v = tid < 128 ? hist[tid] : 0u;
@@ -440,19 +450,60 @@ __global__ __launch_bounds__(S3_THREADS, 4) void k3_l3(const uint32_t* __restric
         const uint32_t excl = s3_block_excl_scan(v, wave_tot, &total);
         if (tid < 128) {
             count[((size_t)j << 7) + tid] = v;
-            cursor[tid] = excl;
+            cursor[tid] = excl;      // where the bucket's next piece goes, relative to a
         }
-        __syncthreads();
-        for (uint32_t i = a + tid; i < b; i += S3_THREADS) {
-            const uint32_t pos = atomicAdd(&cursor[i_lo[i]], 1u);
-            entries[a + pos] = i_idx[i];
+        // (half the entries per lane of the one-pass path: this path must not raise the kernel's register count - the sort
+        // only hides beside the accumulation at <= 72 VGPRs)
+        constexpr int TB = S3_T3 / 2;
+        constexpr uint32_t RB = S3_THREADS * TB;
+        __shared__ uint32_t chist[128], cstart[128];
+        __shared__ uint8_t cbkt[RB];
+        for (uint32_t c0 = a; c0 < b; c0 += RB) {
+            const uint32_t c1 = c0 + RB < b ? c0 + RB : b;
+            if (tid < 128) chist[tid] = 0;
+            __syncthreads();
+            uint32_t ex[TB], ky[TB];
+#pragma unroll
+            for (int t = 0; t < TB; ++t) {
+                const uint32_t i = c0 + t * S3_THREADS + tid;
+                ky[t] = 0xffffffffu;
+                ex[t] = 0;
+                if (i < c1) {
+                    ky[t] = i_lo[i];
+                    ex[t] = i_idx[i];
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < TB; ++t)
+                if (ky[t] != 0xffffffffu) ky[t] |= atomicAdd(&chist[ky[t]], 1u) << 8;
+            __syncthreads();
+            const uint32_t cv = tid < 128 ? chist[tid] : 0u;
+            uint32_t ctotal;
+            const uint32_t cexcl = s3_block_excl_scan(cv, wave_tot, &ctotal);
+            if (tid < 128) cstart[tid] = cexcl;
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < TB; ++t)
+                if (ky[t] != 0xffffffffu) {
+                    const uint32_t slot = cstart[ky[t] & 127u] + (ky[t] >> 8);
+                    out[slot] = ex[t];
+                    cbkt[slot] = (uint8_t)(ky[t] & 127u);
+                }
+            __syncthreads();
+            for (uint32_t slot = tid; slot < ctotal; slot += S3_THREADS) {
+                const uint32_t bk = cbkt[slot];
+                entries[a + cursor[bk] + (slot - cstart[bk])] = out[slot];
+            }
+            __syncthreads();
+            if (tid < 128) cursor[tid] += chist[tid];
+            __syncthreads();
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------- host
 bool msm_sort3_ok(const MsmPlan& P, int sbits) {
-    if (sbits != 256 || P.W < 1) return false;
+    if ((sbits != 256 && sbits != 32) || P.W < 1) return false;
     for (int w = 0; w < P.W; ++w)
         if (P.width[w] < S3_SH1 + 1 || P.width[w] > 23) return false;   // every window a whole number of level-1 bins, <= 256 of them
     if ((P.G >> S3_SH1) > S3_MAXNB1 || (P.G & ((1u << S3_SH1) - 1u))) return false;
@@ -464,8 +515,8 @@ int msm_sort3_max_vgprs() {
     static int cached = -1;
     if (cached >= 0) return cached;
     int mx = 0;
-    const void* ks[] = {(const void*)k3_l1_count, (const void*)k3_l1_scatter, (const void*)k3_l2_count, (const void*)k3_l2_scatter,
-                        (const void*)k3_l3};
+    const void* ks[] = {(const void*)k3_l1_count<8>, (const void*)k3_l1_scatter<8>, (const void*)k3_l1_count<1>, (const void*)k3_l1_scatter<1>,
+                        (const void*)k3_l2_count, (const void*)k3_l2_scatter, (const void*)k3_l3};
     for (const void* k : ks) {
         hipFuncAttributes a;
         if (hipFuncGetAttributes(&a, k) != hipSuccess) {
@@ -477,7 +528,7 @@ int msm_sort3_max_vgprs() {
     return cached = mx;
 }
 
-int msm_sort3(MsmEngine& E, const void* d_scalars, uint32_t npts) {
+int msm_sort3(MsmEngine& E, const void* d_scalars, uint32_t npts, int sbits) {
     const MsmPlan& P = E.last_plan;
     hipStream_t st = E.sort_st;
     MsmEngine::SortBufs& B = E.sb();
@@ -520,11 +571,18 @@ int msm_sort3(MsmEngine& E, const void* d_scalars, uint32_t npts) {
 
     BLZ_HIP(hipMemsetAsync(cnt1, 0, (size_t)(NB1 + 2) * 4, st), BLZ_ERR_UNKNOWN);
     BLZ_HIP(hipMemsetAsync(cnt2, 0, (size_t)(NB2 + 2) * 4, st), BLZ_ERR_UNKNOWN);
-    hipLaunchKernelGGL(k3_l1_count, dim3((npts + S3_CNT_PTS - 1) / S3_CNT_PTS), blk, 0, st, sc, npts, g, cnt1);
+    const int NW = sbits == 256 ? 8 : 1;
+    if (NW == 8) hipLaunchKernelGGL(k3_l1_count<8>, dim3((npts + S3_CNT_PTS - 1) / S3_CNT_PTS), blk, 0, st, sc, npts, g, cnt1);
+    else hipLaunchKernelGGL(k3_l1_count<1>, dim3((npts + S3_CNT_PTS - 1) / S3_CNT_PTS), blk, 0, st, sc, npts, g, cnt1);
     hipLaunchKernelGGL(k3_scan_small, dim3(1), blk, 0, st, cnt1, NB1, off1, cur1, g.prio);
-    const size_t lds1 = (size_t)(10 * S3_PB + 3 * 256) * 4;
-    BLZ_TRY(ensure_dynamic_lds((const void*)k3_l1_scatter, (int)lds1));
-    hipLaunchKernelGGL(k3_l1_scatter, dim3((npts + S3_PB - 1) / S3_PB), blk, lds1, st, sc, npts, g, cur1, i1_idx, i1_rem);
+    const size_t lds1 = (size_t)((NW + 2) * S3_PB + 3 * 256) * 4;
+    if (NW == 8) {
+        BLZ_TRY(ensure_dynamic_lds((const void*)k3_l1_scatter<8>, (int)lds1));
+        hipLaunchKernelGGL(k3_l1_scatter<8>, dim3((npts + S3_PB - 1) / S3_PB), blk, lds1, st, sc, npts, g, cur1, i1_idx, i1_rem);
+    } else {
+        BLZ_TRY(ensure_dynamic_lds((const void*)k3_l1_scatter<1>, (int)lds1));
+        hipLaunchKernelGGL(k3_l1_scatter<1>, dim3((npts + S3_PB - 1) / S3_PB), blk, lds1, st, sc, npts, g, cur1, i1_idx, i1_rem);
+    }
     hipLaunchKernelGGL(k3_slice_map, dim3(1), blk, 0, st, off1, NB1, S3_SLICE2, map, nitems, g.prio);
     hipLaunchKernelGGL(k3_l2_count, dim3(max_items), blk, 0, st, i1_rem, off1, map, nitems, cnt2, g.prio);
     hipLaunchKernelGGL(k3_scan_a, dim3(nsb), blk, 0, st, cnt2, NB2, bsum, g.prio);

@@ -878,15 +878,18 @@ def test_dma_pieces_host_buffers(gpu, orc, curve, pf, n, monkeypatch):
     cl.close()
 
 
-@pytest.mark.parametrize("curve,logn", [("BLS381", 19), ("BLS381", 20), ("BLS377", 22), ("BN254", 21)])
-def test_hidden_three_level_sort(gpu, orc, curve, logn, monkeypatch):
+@pytest.mark.parametrize("curve,logn,pf", [("BLS381", 19, 1), ("BLS381", 20, 1), ("BLS377", 22, 1), ("BN254", 21, 1),
+                                            ("BN254", 18, 8), ("BN254", 20, 8), ("BLS381", 19, 8)])
+def test_hidden_three_level_sort(gpu, orc, curve, logn, pf, monkeypatch):
     """The digit sort of a task submitted while another is in flight runs on its own stream, underneath that task's
     accumulation, with the three-level small-footprint kernels (msm_sort3.hip).  Same digits, same buckets: every result
     must equal the oracle's (linearity over P_i = (i + 1) G) whichever sort produced the buckets - the two-level sort on
     the main stream (BLAZE_SORT_HIDE=0), the three-level sort on the main stream (=2), and the default mix where the
     first task of a burst is sorted in the open and the following ones hidden - and the three modes agree byte for byte."""
+    # (pf = 8: the 32-bit chunks of a precompute handle - 2 windows of 17 bits, 2^17 buckets with thousands of entries each: the
+    # final level places its bins chunk by chunk)
     n = (1 << logn) - 12345            # ragged: the last level-1 block and the last slices are partial
-    dp, ds0 = synth(curve, n, seed=11)
+    dp, ds0 = synth(curve, n, pf=pf, seed=11)
     ds1 = DeviceBuffer(0, n * 32)
     blaze_amd._lib.check(blaze_amd.lib().blz_synth_scalars(0, int(Curve[curve]), ds1.ptr, n, 12))
     exp = []
@@ -896,7 +899,7 @@ def test_hidden_three_level_sort(gpu, orc, curve, logn, monkeypatch):
     params = MSMParams(n, None)
     for mode in ("0", "2", "1"):
         monkeypatch.setenv("BLAZE_SORT_HIDE", mode)
-        cl = msm_client(curve, 1)
+        cl = msm_client(curve, pf)
         got = []
         order = [0, 1, 1, 0, 1, 0]
         for k, which in enumerate(order):
@@ -904,7 +907,7 @@ def test_hidden_three_level_sort(gpu, orc, curve, logn, monkeypatch):
             if k >= 1:
                 cl.wait_result(); got.append(cl.result().result)
         cl.wait_result(); got.append(cl.result().result)
-        assert got == [exp[w] for w in order], f"{curve} 2^{logn} BLAZE_SORT_HIDE={mode}"
+        assert got == [exp[w] for w in order], f"{curve} 2^{logn} pf={pf} BLAZE_SORT_HIDE={mode}"
         cl.close()
     for b in (dp, ds0, ds1):
         b.free()
