@@ -9,7 +9,9 @@
 //   k_accumulate   one lane per unit: gathers its run of points, XYZZ mixed adds   [phase 1]
 //   k_combine_units   only when a bucket needed more than one unit
 //   k_reduce_level Sum_b b*S_b per virtual window by segmented running sums        [phase 2]
-//   k_finish       stitch virtual windows, Horner over windows, one inversion, Z=1|y|x  [phase 3]
+//   k_finish(_row) stitch virtual windows, Horner over windows, one inversion, Z=1|y|x  [phase 3]
+// A task is enqueued in steps - begin / per piece sort_slice + accumulate_slice / end - so that host buffers can be handed to
+// the device piece by piece while they cross the PCIe link (pieces share one bucket space: k_accumulate_cont).
 //
 // HBM layout: points AoS Montgomery (one 128-B line per BLS point, 64 B per BN254 point), scalars raw
 // 32 B LE, entries u32, bucket partials AoS XYZZ (4N dwords).  The arithmetic (v_mad_u64_u32) bounds
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(256) void k_extract_range(const uint32_t* __restric
     }
 }
 
-// p[i] = i: the "every bucket has exactly one sum, at its own index" unit_off of slice-major tasks
+// p[i] = i: the "every bucket has exactly one sum, at its own index" unit_off of piecewise tasks (begin() / end())
 __global__ __launch_bounds__(256) void k_iota(uint32_t* __restrict__ p, uint64_t n) {
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) p[i] = (uint32_t)i;
 }
@@ -917,7 +919,7 @@ int MsmEngine::finish(int slot, uint8_t* out) {
     (void)hipEventElapsedTime(&t, S.ev[0], S.ev[4]); last_ms[0] = t;
     last_ms[1] = 0;
     if (S.accum_timed && S.plan.c) {
-        if (S.slices > 1) {   // slice-major task: the sum of the slices' k_accumulate launches
+        if (S.slices > 1) {   // piecewise task: the sum of the pieces' k_accumulate_cont launches
             for (int i = 0; i < S.slices; ++i)
                 if (hipEventElapsedTime(&t, S.slice_ev[2 * i], S.slice_ev[2 * i + 1]) == hipSuccess) last_ms[1] += t;
         } else {

@@ -51,7 +51,7 @@ struct blz_msm {
     ncclComm_t comm = nullptr;
     int comm_rank = 0, comm_size = 0;
     DevBuf comm_buf;   // [send: one partial | recv: comm_size partials]
-    // resident-base window table (blz_msm_set_window_table; BLAZE_MSM_TABLE sets the default of new handles)
+    // resident-base window table (blz_msm_set_window_table; off for new handles)
     int window_table = 0;   // 0 off, 1 where it pays (the BLS curves), 2 always
     // scalar range of this handle's tasks (blz_msm_set_scalar_range): bits [range_lo, range_hi) of every scalar; 0, 0 = all
     int range_lo = 0, range_hi = 0;

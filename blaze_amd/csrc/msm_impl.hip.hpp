@@ -985,7 +985,7 @@ int run_accumulate_t(MsmEngine& E, const void* d_pts, uint32_t U, int slice) {
     MsmSlot& S = E.slots[E.cur];
     const MsmPlan& P = E.last_plan;
     BLZ_TRY(E.partial.reserve(((size_t)U + 1) * 4 * partial_dwords<F>()));
-    if (slice <= 0) BLZ_HIP(hipEventRecord(S.ev[1], st), BLZ_ERR_UNKNOWN);   // (slice-major: the FIRST slice's sort stage is done)
+    if (slice <= 0) BLZ_HIP(hipEventRecord(S.ev[1], st), BLZ_ERR_UNKNOWN);   // (piecewise task: the FIRST piece's sort stage is done)
     S.accum_timed = true;
     // ev5..ev6 (or the slice's pair) bracket the dominant kernel alone
     BLZ_HIP(hipEventRecord(slice < 0 ? S.ev[5] : S.slice_ev[2 * slice], st), BLZ_ERR_UNKNOWN);

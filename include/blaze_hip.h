@@ -165,23 +165,24 @@ int blz_msm_plan(int curve, uint32_t nof_elements, int is_precompute, uint32_t o
  * MSMInit.is_precompute, msm_api.rs:40-50, which costs 16 window passes per element where the plain path needs 12).
  * enable: 0 off, 1 on where it was measured to pay (BLS12-377 / BLS12-381; BN254's 64-byte points are already
  * gathered at the memory system's rate and lose 4 % with a table, so 1 leaves BN254 on the plain path), 2 always.
- * With it, a pf = 1 handle whose bases live in the arena (hbm_point_addr) builds, on the first task over a
- * range of bases, the table of their window multiples 2^(c j) P, j < W = ceil(257 / c) - synchronously, about 2 s for
- * 2^26 BLS12-381 bases, W x the memory of the Montgomery copy (2^26: 10 x 8 GiB) - and keeps it with the arena
- * extent until the next write into it.  Tasks over those bases then add every window's digit into ONE bucket set:
+ * With it, a pf = 1 handle whose bases live in the arena (hbm_point_addr) builds the table of their window multiples
+ * 2^(c j) P, j < W = ceil(257 / c) - 3.1 s of the chip for 2^26 BLS12-381 bases, paced by the tasks (below), W x the memory
+ * of the Montgomery copy (2^26: 10 x 8 GiB) - and keeps it with the arena extent until the next write into it.  Tasks over
+ * those bases then add every window's digit into ONE bucket set:
  * 10 windows of 26 bits at 2^26 (671 M bucket additions, 2^25 buckets) instead of 12 windows of 21-23 bits (805 M).
  * Results are bit-identical to the plain path's.  Falls back to the plain path (silently; BLAZE_LOG=1 says why) when
  * the table does not fit the free memory, when a base has even order (a multiple at infinity cannot be tabulated;
  * never the case in the r-torsion), or for a task over a sub-range that wants a different window width.
  * A handle with a scalar range (blz_msm_set_scalar_range) tabulates 2^(bit_lo + c j) P for the windows of its range.
- * The default of new handles is BLAZE_MSM_TABLE (0).  No other value of `enable` is accepted (InvalidPrimitiveParam). */
+ * New handles start with 0 (off).  No other value of `enable` is accepted (InvalidPrimitiveParam). */
 int blz_msm_set_window_table(blz_msm* h, int enable);
-/* The table is built BESIDE the tasks, never inside one: the first task over bases that have none enqueues the build (chunks
- * of bases on a lowest-priority stream of the device) and takes the plain path, like every task until the build has
- * completed; the next task adopts the table.  Results are bit-identical either way.  A host that wants the table in place
- * before its first task - or wants the build to overlap something else - calls this after load_data_to_hbm: it enqueues the
- * build for the nof_elements bases at hbm_addr + hbm_off and waits up to wait_ms (0: not at all; < 0: BLAZE_WAIT_TIMEOUT_MS)
- * for it; *ready = 1 when the table is in place, 0 otherwise (still building, not opted in, no memory, a base of even
+/* The table's build is never one lump inside a task: it is cut into chunks of 196 608 bases (~9 ms of the chip), every task
+ * launched over the bases first enqueues two of them on its own stream and takes the plain path, like every task until the
+ * last chunk has completed; the next task adopts the table.  Results are bit-identical either way.  A host that wants the
+ * table in place before its first task calls this after load_data_to_hbm: it allocates the table (do this with the load: an
+ * 80 GiB hipMalloc takes 0.3 ms on a clean device and seconds on one that has memory to scrub), enqueues the first chunks
+ * (wait_ms = 0) or ALL the remaining ones (wait_ms != 0) for the nof_elements bases at hbm_addr + hbm_off and waits up to
+ * wait_ms (< 0: BLAZE_WAIT_TIMEOUT_MS) for the build; *ready = 1 when the table is in place, 0 otherwise (still building, not opted in, no memory, a base of even
  * order, another handle's table serves the extent). */
 int blz_msm_prepare_window_table(blz_msm* h, uint32_t nof_elements, uint64_t hbm_addr, uint64_t hbm_off, int wait_ms, int* ready);
 /* out = {table bytes, window bits c, windows W, build time in microseconds} of the table the handle's last HBM task
