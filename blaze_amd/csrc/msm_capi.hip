@@ -470,6 +470,9 @@ int stage_common(blz_msm* h, bool have_points, const void* points, size_t points
             if (dma_pieces) {
                 pieces = (int)(npts >> 19);
                 if (pieces > 16) pieces = 16;
+                // with another task in flight the link is the bound whatever the pieces do, and every piece costs it the
+                // ~150 us of launches between two copies: fewer, larger pieces (2^22: 10.4 against 10.8 ms per MSM)
+                if (!h->in_flight.empty() && pieces > 4) pieces = 4;
             } else {
                 // scalars alone: the link is a quarter of the task, and every piece pays the sort stage's passes over the
                 // bucket space again (not hidden here) - 2^26: 163.7 ms whole, 158.5 / 145.4 / 181.8 in 16 / 8 / 32 pieces

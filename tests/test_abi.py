@@ -99,3 +99,26 @@ def test_cpp_host_mirror_compiles_and_fails_loudly_without_gpu(tmp_path):
     exe = _build_cpp_example(tmp_path)
     p = subprocess.run([exe, "a", "b", "1", "c"], capture_output=True, text=True)
     assert p.returncode == 1 and "kind 7" in p.stderr
+
+
+def test_shard_layout_candidates_and_plan_override_are_host_side():
+    """blz_msm_shard_layout_ex / _candidate need no device: argument checks, and the estimates scale as documented."""
+    import ctypes as C
+
+    import blaze_amd
+    L = blaze_amd.lib()
+    out = (C.c_uint32 * 8)()
+    assert L.blz_msm_shard_layout_ex(1, 1 << 20, 0, 0, 0, out) == 4          # no ranks
+    assert L.blz_msm_shard_layout_ex(1, 1 << 20, 4, 0, 0, None) == 4
+    assert L.blz_msm_shard_layout_candidate(1, 1 << 20, 4, 0, 0, 3, out) == 4   # 3 ranges do not divide 4 ranks
+    assert L.blz_msm_shard_layout_candidate(1, 1 << 20, 4, 0, 0, 8, out) == 4
+    assert L.blz_msm_shard_layout_candidate(1, 1 << 26, 8, 5, 1, 2, out) == 0
+    first, count, lo, hi, R, comp_us, link_us, mib = list(out)
+    assert (first, count, lo, hi, R) == (2 * (1 << 24), 1 << 24, 128, 256, 2)     # rank 5 = chunk 2, range 1
+    assert abs(link_us - (1 << 24) * 32 / 56.3e3) < 2 and mib == (1 << 24) * (96 + 128 + 32) >> 20 and comp_us > 0
+    # more ranks than elements: the ranks' rectangles still tile the job
+    area = 0
+    for r in range(8):
+        assert L.blz_msm_shard_layout_ex(0, 3, 8, r, 0, out) == 0
+        area += out[1] * (out[3] - out[2])
+    assert area == 3 * 256
