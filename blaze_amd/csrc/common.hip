@@ -74,8 +74,8 @@ static thread_local bool g_wait_timed_out = false;
 bool wait_timed_out() { return g_wait_timed_out; }
 void wait_clear() { g_wait_timed_out = false; }
 
-// poll `query` (hipSuccess = done, hipErrorNotReady = pending) against the deadline.  The first 200 us spin
-// (a small task's tail is a few hundred microseconds: a sleeping wait would double its latency), then 50 us naps.
+// poll `query` (hipSuccess = done, hipErrorNotReady = pending) against the deadline.  The first 3 ms spin (a small task -
+// the reference's default 8192 elements - is done within 2 ms, and a nap oversleeps by ~60 us), then 50 us naps.
 template <class Q>
 static int bounded_wait(Q&& query, const char* what) {
     g_wait_timed_out = false;
@@ -94,7 +94,7 @@ static int bounded_wait(Q&& query, const char* what) {
             return fail(BLZ_ERR_UNKNOWN, "%s timed out after %d ms (BLAZE_WAIT_TIMEOUT_MS): the device task did not complete; "
                         "the handle accepts only reset / free now", what, limit_ms);
         }
-        if (dt < std::chrono::microseconds(200)) std::this_thread::yield();
+        if (dt < std::chrono::microseconds(3000)) std::this_thread::yield();
         else std::this_thread::sleep_for(std::chrono::microseconds(50));
     }
 }

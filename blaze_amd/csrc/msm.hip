@@ -17,6 +17,7 @@
 // 32 B LE, entries u32, bucket partials AoS XYZZ (4N dwords).  The arithmetic (v_mad_u64_u32) bounds
 // the dominant kernels, not HBM.
 #include "msm_engine.hpp"
+#include <mutex>
 #include "field.hip.hpp"
 #include "msm_digits.hip.hpp"
 
@@ -43,13 +44,12 @@ size_t mont_point_bytes(int curve) { return curve == BLZ_BN254 ? 64 : 128; }
 // window of max(cmin, what is left of sbits+1) bits (its upper bits are zero for canonical scalars, so
 // its signed digits never go negative; only 2^(real bits) of its buckets are occupied).  k = 0 with a
 // top window of cmin bits is the uniform plan; BLAZE_MSM_PLAN c= forces that one.
-MsmPlan make_plan(uint32_t npts, int sbits, int ebits, int force_c) {
+static MsmPlan search_plan(uint32_t npts, int sbits, int ebits, int force_c, int split_ns) {
     MsmPlan best;
     double best_cost = 1e300;
-    if (ebits <= 0 || ebits > sbits) ebits = sbits;
     const double t_entry = 0.163, t_bucket = 0.62, t_empty = 0.03, t_hot = 0.01;
     const int need = sbits + 1;
-    const double t_split = (double)plan_override("split_ns", 6000);  // BLAZE_MSM_PLAN: tests set 0 - mixed widths at any size
+    const double t_split = (double)split_ns;
     for (int cmin = 3; cmin <= 23; ++cmin) {
         if (force_c > 0 && cmin != force_c) continue;
         for (int W = 1; W <= MSM_MAX_W; ++W) {
@@ -122,6 +122,33 @@ MsmPlan make_plan(uint32_t npts, int sbits, int ebits, int force_c) {
         best.L = L;
     }
     return best;
+}
+
+// The search walks a few hundred thousand layouts (0.2 - 0.6 ms of host time): a task of 8192 elements - the reference's
+// default size - is done on the device in 1.9 ms and asks for its plan twice (set_data's check, begin()), so the last few
+// answers are kept.  Keyed on everything the search reads.
+MsmPlan make_plan(uint32_t npts, int sbits, int ebits, int force_c) {
+    if (ebits <= 0 || ebits > sbits) ebits = sbits;
+    const int split_ns = plan_override("split_ns", 6000);  // BLAZE_MSM_PLAN: tests set 0 - mixed widths at any size
+    struct Memo {
+        uint32_t npts = 0;
+        int sbits = 0, ebits = 0, force_c = 0, split_ns = 0;
+        MsmPlan plan;
+    };
+    static std::mutex mu;
+    static Memo memo[16];
+    static unsigned next = 0;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (const Memo& m : memo)
+            if (m.sbits == sbits && m.npts == npts && m.ebits == ebits && m.force_c == force_c && m.split_ns == split_ns) return m.plan;
+    }
+    const MsmPlan P = search_plan(npts, sbits, ebits, force_c, split_ns);
+    std::lock_guard<std::mutex> lk(mu);
+    Memo& m = memo[next++ % 16];
+    m.npts = npts; m.sbits = sbits; m.ebits = ebits; m.force_c = force_c; m.split_ns = split_ns;
+    m.plan = P;
+    return P;
 }
 
 // Window-table plans (msm_engine.hpp MsmPlan::table, msm_impl.hip.hpp k_build_window_table).  Costs fitted to the round-3 kernels on the table

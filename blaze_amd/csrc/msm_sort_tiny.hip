@@ -88,7 +88,8 @@ __global__ __launch_bounds__(TINY_THREADS) void k_sort_tiny(const uint32_t* __re
     }
     if (mx) atomicMax(&mx_sh, mx);
     uint64_t total;
-    uint64_t run = tiny_block_scan(mine, wave_tot, &total);
+    const uint64_t run0 = tiny_block_scan(mine, wave_tot, &total);
+    uint64_t run = run0;
     for (uint32_t b = g0; b < g1; ++b) {
         const uint32_t c = cnt[b];
         const uint32_t o = (uint32_t)(run & 0xffffffffu), u = (uint32_t)(run >> 32);
@@ -135,10 +136,13 @@ __global__ __launch_bounds__(TINY_THREADS) void k_sort_tiny(const uint32_t* __re
         lenhist[i] = lh[i];
         lenhist[TINY_MAX_L + 1 + i] = lcur[i] + lh[i];   // (the big path leaves its end-of-bin cursors there; nobody reads them)
     }
+    run = run0;
     for (uint32_t b = g0; b < g1; ++b) {
-        // (cnt[b] is the END of bucket b's run now; its size from the offsets this thread wrote above)
-        const uint32_t o = off[b], c = cnt[b] - o, u0 = unit_off[b];
+        // (cnt[b] is the END of bucket b's run now; its start and first unit are the scan's running values again - not read back
+        // from off[] / unit_off[]: a dependent global load per bucket, ~2 us each on this one-block kernel)
+        const uint32_t o = (uint32_t)(run & 0xffffffffu), c = cnt[b] - o, u0 = (uint32_t)(run >> 32);
         const uint32_t nfull = c / L, rem = c - nfull * L;
+        run += (uint64_t)c | ((uint64_t)((c + L - 1) / L) << 32);
         if (nfull) {
             const uint32_t pos = atomicAdd(&lcur[L], nfull);
             for (uint32_t k = 0; k < nfull; ++k) unit_order[pos + k] = u0 + k;

@@ -26,13 +26,20 @@ L.blz_arena_release(0)
 cl = MSMClient(MSMInit(PointMemoryType.HBM, False, Curve[curve]), DriverClient(0))
 cl.load_data_to_hbm(dp, 0, 0)
 params = MSMParams(n, (0, 0))
-ts, dev = [], []
+ts, dev, calls = [], [], []
+inp = MSMInput(None, ds, params)
 for k in range(reps + 2):
     t0 = time.perf_counter()
-    cl.initialize(params); cl.start_process(); cl.set_data(MSMInput(None, ds, params)); cl.wait_result(); cl.result()
+    cl.initialize(params); t1 = time.perf_counter()
+    cl.start_process(); t2 = time.perf_counter()
+    cl.set_data(inp); t3 = time.perf_counter()
+    cl.wait_result(); t4 = time.perf_counter()
+    cl.result(); t5 = time.perf_counter()
     if k >= 2:
-        ts.append((time.perf_counter() - t0) * 1e3)
+        ts.append((t5 - t0) * 1e3)
+        calls.append([(b - a) * 1e3 for a, b in ((t0, t1), (t1, t2), (t2, t3), (t3, t4), (t4, t5))])
         dev.append(cl.get_api()["total_ms"])
 a = cl.get_api()
 print(f"{curve} 2^{logn} one at a time: wall {statistics.median(ts):.3f} ms, device pipeline {statistics.median(dev):.3f} ms "
+      f"[calls: " + " ".join(f"{n} {statistics.median(c[i] for c in calls):.3f}" for i, n in enumerate(("initialize", "start", "set_data", "wait", "result"))) + "] "
       f"(sort {a['sort_ms']:.2f}, accumulate {a['accumulate_kernel_ms']:.2f}, reduce {a['phase2_reduce_ms']:.2f}, finish {a['phase3_final_ms']:.2f})")
