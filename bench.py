@@ -796,6 +796,8 @@ def main():
             stream(cl3, prm3, None, s3, 2)
             dt3, outs3, apis3 = stream(cl3, prm3, None, s3, 4)
             k3 = statistics.mean(a_["accumulate_kernel_ms"] for a_ in apis3)
+            if os.environ.get("BENCH_DEBUG"):
+                print("[bench debug] config 3 tasks:", [{k_: round(v_, 2) for k_, v_ in a_.items() if k_.endswith("_ms")} for a_ in apis3], file=sys.stderr, flush=True)
             bytes3 = n3 * (32 + 8 * 64)
             chk3 = None
             if not args.no_check:

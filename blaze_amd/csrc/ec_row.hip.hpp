@@ -134,6 +134,19 @@ BLZ_DEV void rowpt_load(const RowCtx<Q>& c, RowPt& p, const uint32_t* base, size
     p.zz = in ? q[2 * S + i] : 0u;
     p.zzz = in ? q[3 * S + i] : 0u;
 }
+// ... and back in the same layout, limbs as they are (weakly normalised): read by rowpt_load only - the quad law of
+// ec_quad.hip.hpp wants limbs below 2^28 and coordinates below 2m
+template <class Q>
+BLZ_DEV void rowpt_store(const RowCtx<Q>& c, uint32_t* base, size_t idx, const RowPt& p) {
+    constexpr int S = rr_stride<Q>();
+    uint32_t* q = base + idx * 4 * S;
+    if (c.row == 0u && c.li < (uint32_t)Q::NL) {
+        q[c.li] = p.x;
+        q[S + c.li] = p.y;
+        q[2 * S + c.li] = p.zz;
+        q[3 * S + c.li] = p.zzz;
+    }
+}
 
 // x = 0 (mod m)?  x lazy, value < 2^11 m.  Exact: the product by one is < 2m and normalised - it is 0 or m
 template <class Q>

@@ -617,6 +617,56 @@ __global__ __launch_bounds__(64, 2) void k_reduce_level_rr(const uint32_t* __res
     ptrr_store(outC, (size_t)w * T + t, cs);
 }
 
+// A level whose segments are FEW (a small task's every level; a large task's last ones): the chain of a segment is what the
+// level costs, and the row law of ec_row.hip.hpp - one point spread over the wave, an addition in ~3 us against the quad law's
+// ~6 and a lone lane's ~12 - runs it two to four times faster: one segment per wave.  Same sums as k_reduce_level0_rr (LEVEL0:
+// bucket sums through unit_off, weights i + 1) and k_reduce_level_rr (weights i, the carried C sums, `shift` doublings).  The
+// results stay in the row law's weakly normalised form, so from the first level that takes this kernel every later level and
+// the Horner walk (k_finish_row) take the row law too (run_reduce_t).
+template <class F, bool LEVEL0>
+__global__ __launch_bounds__(64, 4) void k_reduce_level_row(const uint32_t* __restrict__ inA, const uint32_t* __restrict__ inC,
+                                                           const uint32_t* __restrict__ unit_off, uint32_t M, uint32_t SEG, uint32_t T, int W,
+                                                           int shift, uint32_t* __restrict__ outA, uint32_t* __restrict__ outC) {
+    using Q = typename F::RR;
+    __builtin_amdgcn_s_setprio(BLZ_TAIL_PRIO);
+    const uint32_t tid = blockIdx.x;   // (one wave per block)
+    if (tid >= T * (uint32_t)W) return;
+    const uint32_t w = tid / T, t = tid - w * T;
+    const uint32_t lo = t * SEG;
+    uint32_t hi = lo + SEG;
+    if (hi > M) hi = M;
+    const RowCtx<Q> c = row_ctx<Q>();
+    RowPt run, s, cs;
+    rowpt_set_inf(run);
+    rowpt_set_inf(s);
+    rowpt_set_inf(cs);
+    for (uint32_t i = hi; i-- > lo;) {
+        const size_t idx = (size_t)w * M + i;
+        RowPt a;
+        if constexpr (LEVEL0) {
+            const uint32_t u0 = unit_off[idx], u1 = unit_off[idx + 1];
+            if (u1 > u0) {
+                rowpt_load<Q>(c, a, inA, u0);
+                rowpt_add<Q>(c, run, a);
+            }
+            rowpt_add<Q>(c, s, run);
+        } else {
+            RowPt cc;
+            rowpt_load<Q>(c, a, inA, idx);
+            rowpt_load<Q>(c, cc, inC, idx);
+            rowpt_add<Q>(c, cs, cc);
+            rowpt_add<Q>(c, run, a);
+            if (i != lo) rowpt_add<Q>(c, s, run);
+        }
+    }
+    if constexpr (!LEVEL0) {
+        for (int d = 0; d < shift; ++d) rowpt_dbl<Q>(c, s);
+        rowpt_add<Q>(c, cs, s);
+    }
+    rowpt_store<Q>(c, outA, (size_t)w * T + t, run);
+    rowpt_store<Q>(c, outC, (size_t)w * T + t, LEVEL0 ? s : cs);
+}
+
 // ------------------------------------------------------------------------------------------------
 // phase 3: Horner over the window sums, normalise, emit Z | Y | X canonical little-endian
 // (layout read back by tests/msm/mod.rs:397-399).  Infinity: Z = 0, Y = 1, X = 0.
@@ -1095,6 +1145,10 @@ int run_reduce_t(MsmEngine& E, const void* sums, const void* unit_off_v) {
     const uint32_t SEGU = (uint32_t)exp_knob("BLAZE_MSM_SEG_UPPER", 8);
     uint32_t M = P.Bw;
     int level = 0, shift = 0;
+    // the Horner walk and the levels of few segments run on the row law (ec_row.hip.hpp) where the curve has it
+    bool row_walk = false, row_levels = false;
+    if constexpr (USE_RR<F>) row_walk = !RR_TIGHT<typename F::RR> && exp_knob("BLAZE_FINISH_ROW", 1) != 0;
+    const uint32_t row_max = (uint32_t)exp_knob("BLAZE_REDUCE_ROW_MAX", 4096);
     const uint32_t* curA = (const uint32_t*)sums;
     const uint32_t* curC = nullptr;
     for (;;) {
@@ -1107,7 +1161,25 @@ int run_reduce_t(MsmEngine& E, const void* sums, const void* unit_off_v) {
         BLZ_TRY(oA.reserve((size_t)T * P.Wv * 4 * partial_dwords<F>()));   // (reduced-radix accumulators where the curve has them)
         BLZ_TRY(oC.reserve((size_t)T * P.Wv * 4 * partial_dwords<F>()));
         uint32_t nthreads = T * (uint32_t)P.Wv;
-        if (level == 0) {
+        // few segments: one per wave on the row law, from here to the end (k_reduce_level_row)
+        if (row_walk && nthreads <= row_max) row_levels = true;
+        if (row_levels) {
+            if constexpr (USE_RR<F>) {
+                if constexpr (!RR_TIGHT<typename F::RR>) {
+                    if (level == 0)
+                        hipLaunchKernelGGL((k_reduce_level_row<F, true>), dim3(nthreads), dim3(64), 0, st, curA, curC, unit_off, M, SEG, T, P.Wv,
+                                           shift, oA.as<uint32_t>(), oC.as<uint32_t>());
+                    else
+                        hipLaunchKernelGGL((k_reduce_level_row<F, false>), dim3(nthreads), dim3(64), 0, st, curA, curC, unit_off, M, SEG, T, P.Wv,
+                                           shift, oA.as<uint32_t>(), oC.as<uint32_t>());
+                }
+            }
+            if (level == 0) {
+                BLZ_HIP(hipEventRecord(S.ev_l0, st), BLZ_ERR_UNKNOWN);
+                st = E.tail_stream;
+                BLZ_HIP(hipStreamWaitEvent(st, S.ev_l0, 0), BLZ_ERR_UNKNOWN);
+            }
+        } else if (level == 0) {
             if constexpr (USE_RR<F>)
                 hipLaunchKernelGGL(k_reduce_level0_rr<F>, dim3((nthreads + 63) / 64), dim3(64), 0, st, curA, unit_off, M,
                                    SEG, T, P.Wv, oA.as<uint32_t>(), oC.as<uint32_t>());
@@ -1160,8 +1232,6 @@ int run_reduce_t(MsmEngine& E, const void* sums, const void* unit_off_v) {
             off += P.width[w];
         }
     }
-    bool row_walk = false;
-    if constexpr (USE_RR<F>) row_walk = !RR_TIGHT<typename F::RR> && exp_knob("BLAZE_FINISH_ROW", 1) != 0;
     if (row_walk) {
         if constexpr (USE_RR<F>) {
             if constexpr (!RR_TIGHT<typename F::RR>)

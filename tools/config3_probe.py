@@ -14,6 +14,12 @@ curve = sys.argv[2] if len(sys.argv) > 2 else "BN254"
 n = 1 << logn
 dp, ds = synth(curve, n, pf=8)
 blaze_amd.lib().blz_arena_release(0)
+# (PRE_CLIENTS=k: k other handles created - and, PRE_CLOSE=1, closed - first: where do this handle's streams land among the
+# process's hardware queues?)
+pre = [msm_client("BLS381", 1) for _ in range(int(os.environ.get("PRE_CLIENTS", "0")))]
+if os.environ.get("PRE_CLOSE", "0") == "1":
+    for c_ in pre:
+        c_.close()
 cl = msm_client(curve, 8, PointMemoryType.HBM)
 cl.load_data_to_hbm(dp, 0, 0)
 dp.free()
@@ -32,6 +38,13 @@ for _ in range(6):
     submit(); r, a = collect(); assert r == r0; done.append(time.perf_counter()); apis.append(a)
 r, a = collect(); done.append(time.perf_counter()); apis.append(a)
 gaps = [(b - a_) * 1e3 for a_, b in zip(done, done[1:])]
+# bench.py's config 3 key: bursts of four tasks, two in flight, from an idle handle (the ramp and the last tail included)
+bursts = []
+for _ in range(3):
+    t = time.perf_counter()
+    submit(); submit(); collect(); submit(); collect(); submit(); collect(); collect()
+    bursts.append((time.perf_counter() - t) * 1e3 / 4)
+    hidden = blaze_amd.lib().blz_msm_last_sort_hidden
 print(json.dumps({"config": f"2^{logn} {curve} pf=8, pieces={os.environ.get('BLAZE_MSM_PIECES', 'auto')}", "lone_ms": round(min(lone), 2),
-                  "two_in_flight_ms_per_msm": round(statistics.median(gaps), 2), "accumulate_kernel_ms": round(apis[-2]["accumulate_kernel_ms"], 2),
+                  "two_in_flight_ms_per_msm": round(statistics.median(gaps), 2), "gaps": [round(g, 1) for g in gaps], "burst_of_4_ms_per_msm": [round(b, 1) for b in bursts], "accumulate_kernel_ms": round(apis[-2]["accumulate_kernel_ms"], 2),
                   "phases": {k: round(v, 2) for k, v in apis[-2].items() if k.endswith("_ms")}}))

@@ -21,7 +21,7 @@ from gpu_util import msm_client, synth  # noqa: E402
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 120
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 9)
 L = blaze_amd.lib()
-NMAX = 1 << 21
+NMAX = 1 << int(os.environ.get("STRESS_LOG_NMAX", "21"))   # (2^24: the piecewise paths at their default piece counts)
 curves = ("BLS381", "BLS377", "BN254")
 host_sc, host_pts, dev = {}, {}, {}
 L.blz_arena_release(0)
@@ -81,7 +81,7 @@ for it in range(iters):
         os.environ["BLAZE_MSM_PIECES"] = pc
     else:
         os.environ.pop("BLAZE_MSM_PIECES", None)
-    n = rng.choice([1, 63, 4096, 100001, 1 << 18, (1 << 19) + 5, 1 << 20, NMAX])
+    n = rng.choice([1, 63, 4096, 100001, 1 << 18, (1 << 19) + 5, 1 << 20, NMAX // 2 + 12, NMAX])
     first = 0 if n == NMAX else rng.randrange(0, NMAX - n) & ~3
     dp, ds = dev[c]
     if kind == "rewrite":
