@@ -894,12 +894,13 @@ def main():
                             "unit": "GB/s", "frac": round(nb / (k * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
                             "algorithmic_bytes": nb, "traffic": None}}
         # The resource the passes saturate, beside the prescribed HBM figure: 32-bit integer multiply issue.  Per lane (8 elements)
-        # and pass the 512-point kernel does 37 / 46 / 29 field products: Shoup products by table twiddles at
-        # 143 v_mad_u64_u32, Montgomery products (pass 2's stepped boundary twiddle: 8 applications + 2 to start the chain) at 153,
-        # and a 9-multiply-add quotient reduction for each un-twiddled output: 5309 + 6696 + 4237 = 16 242 per lane
-        # (tests/test_isa_counts.py counts them in the code object), n / 8 lanes per pass.
+        # and pass the 512-point kernel does 37 / 37 / 29 field products: Shoup products by table twiddles at
+        # 143 v_mad_u64_u32, Montgomery products (pass 2's boundary factors, read from the per-element table) at 153, and a
+        # 9-multiply-add quotient reduction for each un-twiddled output: 5309 + 5389 + 4237 = 14 935 per lane
+        # (tests/test_isa_counts.py counts them in the code object; round 3 and most of round 4: 16 242, pass 2 stepping its
+        # factors), n / 8 lanes per pass.
         if NTT_LOG == 27:
-            ntt_mads = (37 * 143 + 2 * 9) + (36 * 143 + 10 * 153 + 2 * 9) + (29 * 143 + 10 * 9)
+            ntt_mads = (37 * 143 + 2 * 9) + (29 * 143 + 8 * 153 + 2 * 9) + (29 * 143 + 10 * 9)
             mads_t = ntt_mads * (nn // 8)
             peak_i = calib["mad_lane_ops_per_s"] if calib else 3.1e13
             ntt["roofline"]["integer_issue"] = {"unit": "v_mad_u64_u32 lane-ops/s", "achieved": round(mads_t / (k * 1e-3), 0), "peak": round(peak_i, 0),

@@ -59,7 +59,7 @@ struct blz_ntt {
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;  // host<->buffer traffic, concurrent with the compute stream
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    DevBuf buf[2], scratch, tables, tables_rr;
+    DevBuf buf[2], scratch, tables, tables_rr, table_b;
     NttTables T{};
     NttTablesRR TR{};
     bool in_flight = false;
@@ -137,6 +137,14 @@ int ntt_setup(blz_ntt* h) {
         h->TR.fin = h->inverse ? q : nullptr; q += NTT_RR_ENTRY_DWORDS;
         h->TR.ts2 = q; q += 2 * 512 * NTT_RR_ENTRY_DWORDS;   // Shoup entries
         h->TR.tA = want_ta ? q : nullptr;
+        // pass 2's boundary factors, one per element (4 GiB at 2^27: the transform's buffers are 8): only beside tA, whose
+        // split of pass 1's factor it completes
+        const bool want_tb = want_ta && exp_knob("BLAZE_NTT_TB", 1) != 0;
+        h->TR.tB = nullptr;
+        if (want_tb) {
+            BLZ_TRY(h->table_b.reserve(ntt_bytes(h)));
+            h->TR.tB = h->table_b.as<uint32_t>();
+        }
         // pass 1 tile order (ntt_rr.hip.hpp): 0 plain, 1 + s: 2^s adjacent column groups back to back (s = 3), + 16 b: b bits of
         // i1 walked first (default 7)
         h->TR.swz = (la == 9 && lb == 9) ? (uint32_t)exp_knob("BLAZE_NTT_SWZ", 4) : 0u;
@@ -207,7 +215,7 @@ void blz_ntt_free(blz_ntt* h) {
         delete h;
         return;
     }
-    h->buf[0].release(); h->buf[1].release(); h->scratch.release(); h->tables.release(); h->tables_rr.release();
+    h->buf[0].release(); h->buf[1].release(); h->scratch.release(); h->tables.release(); h->tables_rr.release(); h->table_b.release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);

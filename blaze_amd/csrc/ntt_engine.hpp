@@ -25,6 +25,8 @@ struct NttTablesRR {
     uint32_t* tA;    // w^(A e), e < 2^18 (n / 512 entries, 10 MiB), or nullptr: the boundary factor after pass 1 that
                      // does not depend on the column, read instead of stepped (2^27 transforms only; ntt_rr.hip.hpp)
     uint32_t* ts2;   // w^(64 C i0), i0 < 512: the step of pass 2's boundary factor along a lane's rows (one per column)
+    uint32_t* tB;    // pass 2's boundary factor of EVERY element, w^((C k1 + k2) i0) R_rr mod m as 8 words at the element's own index
+                     // (n x 32 bytes: 4 GiB at 2^27), or nullptr: stepped along the lane's rows (ntt_rr.hip.hpp)
     uint32_t swz;    // 0: plain tile order; 1 + s: pass 1 walks its tiles in the channel-spreading order with 2^s adjacent column
                      // groups back to back (2^27 transforms; ntt_rr.hip.hpp)
 };

@@ -258,6 +258,8 @@ int ntt_setup_t(hipStream_t st, NttTables& T, NttTablesRR& TR, const NttGeom& g,
     if (TR.tA)
         hipLaunchKernelGGL((k_ntt_table_rr_pow<Fr, NTT_TA_SHOUP>), dim3((unsigned)(NTT_RR_BOUNDARY_ENTRIES / 256)), dim3(256), 0, st, TR.tA,
                            (uint32_t)NTT_RR_BOUNDARY_ENTRIES, l, (uint64_t)1 << g.logA, inverse);
+    if (TR.tB)
+        hipLaunchKernelGGL(k_ntt_table_b<Fr>, dim3((unsigned)(n / 256)), dim3(256), 0, st, TR.tB, g, TR);   // (after t0 / t1 / t2: same stream)
     BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
     return BLZ_OK;
 }
@@ -271,9 +273,15 @@ int ntt_pass_t(hipStream_t st, const void* in, void* out, const NttGeom& g, cons
         // the tile goes through the LDS in two halves: 256 rows x 4 columns x 40 bytes
         const size_t ldsr = (size_t)256 * NR_COLS * rr_stride<typename Fr::RR>() * 4;
         const uint64_t tilesr = (1ull << g.logn) >> (9 + NR_COLS_LOG);
-        BLZ_TRY(ensure_dynamic_lds((const void*)k_ntt512_rr<Fr, PASS>, 160 * 1024));
-        hipLaunchKernelGGL((k_ntt512_rr<Fr, PASS>), dim3((unsigned)tilesr), dim3(NR_THREADS), ldsr, st, (const uint32_t*)in,
-                           (uint32_t*)out, g, TR);
+        if (PASS == 2 && TR.tB) {
+            BLZ_TRY(ensure_dynamic_lds((const void*)k_ntt512_rr<Fr, 2, true>, 160 * 1024));
+            hipLaunchKernelGGL((k_ntt512_rr<Fr, 2, true>), dim3((unsigned)tilesr), dim3(NR_THREADS), ldsr, st, (const uint32_t*)in,
+                               (uint32_t*)out, g, TR);
+        } else {
+            BLZ_TRY(ensure_dynamic_lds((const void*)k_ntt512_rr<Fr, PASS>, 160 * 1024));
+            hipLaunchKernelGGL((k_ntt512_rr<Fr, PASS>), dim3((unsigned)tilesr), dim3(NR_THREADS), ldsr, st, (const uint32_t*)in,
+                               (uint32_t*)out, g, TR);
+        }
         BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
         return BLZ_OK;
     }

@@ -25,6 +25,8 @@
 
 namespace blz {
 
+constexpr int NTT_RR_COLS_LOG = 2;   // columns per tile of k_ntt512_rr (256 lanes: 64 rows x 4 columns)
+
 template <class T> struct rr_bounds;
 template <class Q, int F, int V>
 struct rr_bounds<Frr<Q, F, V>> {
@@ -303,6 +305,29 @@ BLZ_DEV void tw_pow_rr(Frr<Q, 1, 2>& r, const NttTablesRR& T, uint32_t e) {
     if (e2) { rr_load(a, T.t2 + (size_t)e2 * ES); rr_mul(r, r, a); }
 }
 
+// tB: pass 2's boundary factor w^((C k1 + k2) i0) (with the column part of pass 1's, see k_ntt512_rr) of every element,
+// canonical Montgomery form packed in 32 bytes, IN THE ORDER PASS 2 CONSUMES THEM: entry ((tile 8 + K) 256 + thread) is the
+// factor of output K of that lane of that tile, so a wave reads 2 KiB in one piece per output and the table streams through once
+// (at the element's own index - rows 16 KiB apart, 128 bytes each, like the data - the pass gained 8 % instead of 14 %)
+template <class Fr>
+__global__ void k_ntt_table_b(uint32_t* __restrict__ out, NttGeom g, NttTablesRR T) {
+    using Q = typename Fr::RR;
+    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >> g.logn) return;
+    const uint32_t thread = (uint32_t)(idx & 255u), K = (uint32_t)((idx >> 8) & 7u);
+    const uint64_t tile = idx >> 11;
+    const uint64_t tiles_per = (1ull << g.logA) >> NTT_RR_COLS_LOG;
+    const uint32_t k2 = (uint32_t)(tile / tiles_per);
+    const uint32_t i0 = (uint32_t)((tile % tiles_per) << NTT_RR_COLS_LOG) + (thread & ((1u << NTT_RR_COLS_LOG) - 1u));
+    const uint32_t n2 = thread >> NTT_RR_COLS_LOG;
+    const uint32_t k1 = (n2 >> 3) + 8u * (n2 & 7u) + 64u * K;   // the lane's output row (k_ntt512_rr: kb + 64 K)
+    Frr<Q, 1, 2> w;
+    tw_pow_rr<Q>(w, T, ((k1 << g.logC) + k2) * i0);
+    Fp<Fr> y;
+    rr_to_words<Q>(y.v, rr_canon(w));
+    fp_store(out + idx * 8, y);
+}
+
 // the boundary table tA (2^18 entries, read once per element after pass 1) as Shoup entries (20 MiB) or Montgomery ones
 // (10 MiB, -DBLZ_NTT_TA_SHOUP=0).  Same-box: pass 1 5.48 ms with Shoup entries, 5.59 with Montgomery ones - and 5.49 before
 // any product of the pass was a Shoup product: pass 1 is bound by its access pattern (rows 8 MiB apart), not by its products.
@@ -311,7 +336,7 @@ BLZ_DEV void tw_pow_rr(Frr<Q, 1, 2>& r, const NttTablesRR& T, uint32_t e) {
 #endif
 constexpr bool NTT_TA_SHOUP = BLZ_NTT_TA_SHOUP != 0;
 
-constexpr int NR_COLS_LOG = 2;
+constexpr int NR_COLS_LOG = NTT_RR_COLS_LOG;
 constexpr int NR_COLS = 1 << NR_COLS_LOG;
 constexpr int NR_THREADS = 64 * NR_COLS;
 
@@ -321,7 +346,7 @@ constexpr int NR_THREADS = 64 * NR_COLS;
 // outputs K = 0..3 first and K = 4..7 second: the consumers of an output K of the first exchange are the lanes with
 // k1 = K - waves 0 and 1 for the first half, waves 2 and 3 for the second - and of the second exchange the lanes with
 // k1' = K of the same wave.  Costs: three more block barriers and four outputs kept in registers across a half.
-template <class Fr, int PASS>
+template <class Fr, int PASS, bool TABB = false>   // TABB: pass 2 reads its boundary factors from the per-element table tB
 __global__ __launch_bounds__(NR_THREADS, 3) void k_ntt512_rr(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, NttGeom g,
                                                             NttTablesRR T) {
     using Q = typename Fr::RR;
@@ -481,6 +506,7 @@ __global__ __launch_bounds__(NR_THREADS, 3) void k_ntt512_rr(const uint32_t* __r
     // not involve the index pass 2 transforms over, joins pass 2's own factor: w^(i0 (C k1 + k2)), still one
     // geometric sequence along the lane's rows.
     const bool split = T.tA != nullptr;
+    constexpr bool tabB = PASS == 2 && TABB;
     W w, step;
     WT step_s;
     if (PASS == 1) {
@@ -492,9 +518,14 @@ __global__ __launch_bounds__(NR_THREADS, 3) void k_ntt512_rr(const uint32_t* __r
         }
     } else if (PASS == 2) {
         // x(i0, k1 = row, k2) *= w^(C i0 row)   [split: * w^(i0 k2) as well; k2 = fixed]
-        const uint64_t i0 = col_base + col;
-        tw_pow_rr<Q>(w, T, (uint32_t)((((uint64_t)kb << g.logC) + (split ? fixed : 0)) * i0));
-        rr_load_shoup<Q>(step_s, T.ts2 + (size_t)i0 * ES2);   // w^(64 C i0): a Shoup entry - w (Montgomery form) times a plain constant stays in Montgomery form
+        // With the table tB (2^27 transforms) the factor of every element is READ at the element's own index: 8 products per
+        // lane instead of 8 + 7 (the stepping chain) + 2 (its first term from the 512-entry tables), for 4 GiB more traffic
+        // on a pass the multiplier bounds.
+        if constexpr (!tabB) {
+            const uint64_t i0 = col_base + col;
+            tw_pow_rr<Q>(w, T, (uint32_t)((((uint64_t)kb << g.logC) + (split ? fixed : 0)) * i0));
+            rr_load_shoup<Q>(step_s, T.ts2 + (size_t)i0 * ES2);   // w^(64 C i0): a Shoup entry - w (Montgomery form) times a plain constant stays in Montgomery form
+        }
     } else if (T.fin) {
         rr_load(w, T.fin);   // inverse transform: n^-1; a forward transform closes with the product-free reduction
     }
@@ -513,6 +544,12 @@ __global__ __launch_bounds__(NR_THREADS, 3) void k_ntt512_rr(const uint32_t* __r
                 rr_load(wa, T.tA + (size_t)(row * (uint32_t)fixed) * ES);
                 rr_mul_n(t, X, wa);
             }
+        } else if constexpr (tabB) {
+            Fp<Fr> tw;
+            fp_load(tw, T.tB + (((uint64_t)tile * 8u + K) * NR_THREADS + threadIdx.x) * 8);
+            Frr<Q, 1, 1> wa;
+            rr_from_words<Q>(wa, tw.v);
+            rr_mul_n(t, X, wa);
         } else {
             rr_mul_n(t, X, w);
         }
@@ -523,7 +560,7 @@ __global__ __launch_bounds__(NR_THREADS, 3) void k_ntt512_rr(const uint32_t* __r
             fp_csub_const<Fr, Fr::MOD>(y);   // < 2m -> canonical: the wire format
             oaddr = (col_base + col) + (uint64_t)C * fixed + (uint64_t)C * B * row;
         } else {
-            if (K != 7 && !(PASS == 1 && split)) {   // twiddle x twiddle
+            if (K != 7 && !(PASS == 1 && split) && !(PASS == 2 && tabB)) {   // twiddle x twiddle
                 if (PASS == 2) rr_mul_shoup(w, w, step_s);
                 else rr_mul(w, w, step);
             }

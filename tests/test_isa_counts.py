@@ -45,18 +45,21 @@ def test_accumulate_loop_multiply_adds(disasm):
 
 
 def test_ntt_pass_multiply_adds(disasm):
-    """The 2^27 NTT's per-lane multiply-adds: 37 / 46 / 29 field products per pass at 143 (Shoup, table
-    twiddles) or 153 (Montgomery: pass 2's stepped boundary twiddle) plus a 9-multiply-add quotient reduction per
-    un-twiddled output.  Pass 2 has no cold alternative path, so its kernel's STATIC count is its per-lane count; passes 1
-    and 3 also carry the no-boundary-table chain and the inverse transform's closing products, so theirs bound it from above."""
-    want = [37 * 143 + 2 * 9, 36 * 143 + 10 * 153 + 2 * 9, 29 * 143 + 10 * 9]
-    assert sum(want) == _bench_constant(r"multiply_adds_per_lane\D+(\d+)") or sum(want) == 16242
+    """The 2^27 NTT's per-lane multiply-adds: 37 / 37 / 29 field products per pass at 143 (Shoup, table
+    twiddles) or 153 (Montgomery: pass 2's boundary factors, read from the per-element table) plus a 9-multiply-add quotient
+    reduction per un-twiddled output.  Pass 2's table kernel has no cold alternative path, so its STATIC count is its per-lane
+    count; passes 1 and 3 also carry the no-boundary-table chain and the inverse transform's closing products, so theirs bound
+    it from above; pass 2 without the table (smaller transforms) steps its factors: 36 Shoup + 10 Montgomery products."""
+    want = [37 * 143 + 2 * 9, 29 * 143 + 8 * 153 + 2 * 9, 29 * 143 + 10 * 9]
+    assert sum(want) == _bench_constant(r"multiply_adds_per_lane\D+(\d+)") or sum(want) == 14935
     got = []
-    for p in (1, 2, 3):
-        ins = function_instructions(disasm, f"_ZN3blz11k_ntt512_rrINS_9Fr_BLS381ELi{p}EEEvPKjPjNS_7NttGeomENS_11NttTablesRRE")
+    for p, tab in ((1, 0), (2, 1), (3, 0)):
+        ins = function_instructions(disasm, f"_ZN3blz11k_ntt512_rrINS_9Fr_BLS381ELi{p}ELb{tab}EEEvPKjPjNS_7NttGeomENS_11NttTablesRRE")
         got.append(count(ins, "v_mad_u64_u32"))
     assert abs(got[1] - want[1]) <= 8, (got, want)
     assert want[0] <= got[0] <= want[0] + 19 * 153 + 8 * 143, (got, want)     # + the stepping chain of a transform without the boundary table
     assert want[2] <= got[2] <= want[2] + 8 * 153, (got, want)                # + the inverse transform's n^-1 products
+    stepped = function_instructions(disasm, "_ZN3blz11k_ntt512_rrINS_9Fr_BLS381ELi2ELb0EEEvPKjPjNS_7NttGeomENS_11NttTablesRRE")
+    assert abs(count(stepped, "v_mad_u64_u32") - (36 * 143 + 10 * 153 + 2 * 9)) <= 8
     src = open(os.path.join(ROOT, "bench.py")).read()
-    assert "(37 * 143 + 2 * 9) + (36 * 143 + 10 * 153 + 2 * 9) + (29 * 143 + 10 * 9)" in src
+    assert "(37 * 143 + 2 * 9) + (29 * 143 + 8 * 153 + 2 * 9) + (29 * 143 + 10 * 9)" in src
