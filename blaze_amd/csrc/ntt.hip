@@ -142,8 +142,9 @@ int ntt_setup(blz_ntt* h) {
         const bool want_tb = want_ta && exp_knob("BLAZE_NTT_TB", 1) != 0;
         h->TR.tB = nullptr;
         if (want_tb) {
-            BLZ_TRY(h->table_b.reserve(ntt_bytes(h)));
-            h->TR.tB = h->table_b.as<uint32_t>();
+            // (an optimisation, not a need: a device too full for it steps the factors as smaller transforms do)
+            if (h->table_b.reserve(ntt_bytes(h)) == BLZ_OK) h->TR.tB = h->table_b.as<uint32_t>();
+            else BLZ_LOG(1, "NTT: no memory for the boundary-factor table (%zu bytes): pass 2 steps its factors", ntt_bytes(h));
         }
         // pass 1 tile order (ntt_rr.hip.hpp): 0 plain, 1 + s: 2^s adjacent column groups back to back (s = 3), + 16 b: b bits of
         // i1 walked first (default 7)
