@@ -948,6 +948,27 @@ __global__ __launch_bounds__(64, 2) void k_combine_buckets_wave(const uint32_t* 
     if (lane == 0) ptrr_store(partial, u0, acc);
 }
 
+// The same fold on the row law (ec_row.hip.hpp) for the tasks whose whole tail runs on it (small_row_tail: every reduce level is a
+// row level): one wave per bucket adds the bucket's units in sequence, ~3 us per addition - against ~20 us per ROUND of the
+// shuffle tree above and k_fold_hot's 0.09 ms for the 16-unit buckets of a 2^13 task's top window - and leaves the sum, in
+// the row law's weakly normalised form (read by k_reduce_level_row only), in the bucket's first unit.
+template <class F>
+__global__ __launch_bounds__(64, 4) void k_combine_buckets_row(const uint32_t* __restrict__ unit_off, uint32_t thr, uint32_t* __restrict__ partial) {
+    using Q = typename F::RR;
+    const uint64_t g = blockIdx.x;
+    const uint32_t u0 = unit_off[g], U = unit_off[g + 1] - u0;
+    if (U < 2 || U > thr) return;   // (uniform over the wave; longer buckets were folded by k_combine_units' tree)
+    const RowCtx<Q> c = row_ctx<Q>();
+    RowPt acc;
+    rowpt_load<Q>(c, acc, partial, u0);
+    for (uint32_t u = 1; u < U; ++u) {
+        RowPt a;
+        rowpt_load<Q>(c, a, partial, u0 + u);
+        rowpt_add<Q>(c, acc, a);
+    }
+    rowpt_store<Q>(c, partial, u0, acc);
+}
+
 // ... and for the windows the PLAN knows to be hot - the top windows of a small or mid-sized task hold the last few bits of
 // the scalars: 2^18 elements in 20 windows of 13 bits leave 8 bits for the top one, 256 buckets of 1024 entries = 64 units
 // each; 2^16 in 22 x 12: 3 bits, 8 buckets of 512 units - eight waves take a bucket: every wave folds chunks of 64 units by
@@ -1029,6 +1050,25 @@ __global__ __launch_bounds__(128, 2) void k_merge_buckets(const uint32_t* __rest
 }
 
 // phase 1 after a digit sort: at most U units (the real count is in E.sb().stats on the device)
+// level 0's segment length (run_reduce_t) and whether the task's reduce runs on the row law from level 0 on
+inline uint32_t reduce_seg0(const MsmPlan& P) {
+    uint32_t seg0_auto = 64;
+    while (seg0_auto > 8 && P.G / seg0_auto < 262144) seg0_auto >>= 1;
+    return (uint32_t)exp_knob("BLAZE_MSM_SEG", (int)seg0_auto);
+}
+inline uint32_t reduce_row_max() { return (uint32_t)exp_knob("BLAZE_REDUCE_ROW_MAX", 4096); }
+template <class F>
+bool small_row_tail(const MsmPlan& P) {
+    if constexpr (USE_RR<F>) {
+        if constexpr (!RR_TIGHT<typename F::RR>) {
+            if (exp_knob("BLAZE_FINISH_ROW", 1) == 0) return false;
+            const uint32_t seg0 = reduce_seg0(P);
+            return (uint64_t)((P.Bw + seg0 - 1) / seg0) * (uint64_t)P.Wv <= reduce_row_max();
+        }
+    }
+    return false;
+}
+
 template <class F>
 int run_accumulate_t(MsmEngine& E, const void* d_pts, uint32_t U, int slice) {
     hipStream_t st = E.stream;
@@ -1062,8 +1102,11 @@ int run_accumulate_t(MsmEngine& E, const void* d_pts, uint32_t U, int slice) {
     // leave it alone.  Only for a small suffix of a larger space: where EVERY window is like that (the precompute shapes) the
     // lane-per-bucket fold below is the throughput-bound answer.
     uint32_t hot_start = (uint32_t)P.G;
+    // a task whose reduce runs on the row law from level 0 on folds its buckets on it too (k_combine_buckets_row, every bucket of
+    // up to 64 units, the plan's hot windows included)
+    const bool row_fold = slice < 0 && thr != 0 && small_row_tail<F>(P);
     if constexpr (USE_RR<F>) {
-        if (!P.table && slice < 0 && P.ebits > 0 && exp_knob("BLAZE_FOLD_HOT", 1) != 0) {
+        if (!row_fold && !P.table && slice < 0 && P.ebits > 0 && exp_knob("BLAZE_FOLD_HOT", 1) != 0) {
             int lowest = -1, off = 0;
             bool any = false;
             int offs[MSM_MAX_W];
@@ -1096,7 +1139,13 @@ int run_accumulate_t(MsmEngine& E, const void* d_pts, uint32_t U, int slice) {
             hipLaunchKernelGGL(k_fold_hot<F>, dim3((uint32_t)(P.G - hot_start)), dim3(512), 0, st, E.sb().unit_off.as<uint32_t>(), hot_start,
                                E.partial.as<uint32_t>());
     }
-    if (thr && hot_start > 0) {
+    if (row_fold) {
+        if constexpr (USE_RR<F>) {
+            if constexpr (!RR_TIGHT<typename F::RR>)
+                hipLaunchKernelGGL(k_combine_buckets_row<F>, dim3((uint32_t)P.G), dim3(64), 0, st, E.sb().unit_off.as<uint32_t>(), thr,
+                                   E.partial.as<uint32_t>());
+        }
+    } else if (thr && hot_start > 0) {
         bool wave = false;
         if constexpr (USE_RR<F>) wave = hot_start <= 32768;   // small bucket spaces: one wave per bucket (latency), else one lane (throughput)
         if (wave) {
@@ -1139,16 +1188,14 @@ int run_reduce_t(MsmEngine& E, const void* sums, const void* unit_off_v) {
     // run on the tail stream).  Same-box sweeps, profiles/r03_seg_sweep.txt: 17.8 M bucket slots (the 2^26 plan) 64 best; 12.6 M: 32 (61.9 against 62.9 ms per MSM);
     // 5 - 7 M: 16 (17.2 against 17.8); 2.1 M (2^22): 8 (10.1 against 11.1).  Powers of two only: the upper levels weigh
     // segment t by shifts.
-    uint32_t seg0_auto = 64;
-    while (seg0_auto > 8 && G / seg0_auto < 262144) seg0_auto >>= 1;
-    const uint32_t SEG0 = (uint32_t)exp_knob("BLAZE_MSM_SEG", (int)seg0_auto);
+    const uint32_t SEG0 = reduce_seg0(P);
     const uint32_t SEGU = (uint32_t)exp_knob("BLAZE_MSM_SEG_UPPER", 8);
     uint32_t M = P.Bw;
     int level = 0, shift = 0;
     // the Horner walk and the levels of few segments run on the row law (ec_row.hip.hpp) where the curve has it
     bool row_walk = false, row_levels = false;
     if constexpr (USE_RR<F>) row_walk = !RR_TIGHT<typename F::RR> && exp_knob("BLAZE_FINISH_ROW", 1) != 0;
-    const uint32_t row_max = (uint32_t)exp_knob("BLAZE_REDUCE_ROW_MAX", 4096);
+    const uint32_t row_max = reduce_row_max();
     const uint32_t* curA = (const uint32_t*)sums;
     const uint32_t* curC = nullptr;
     for (;;) {

@@ -20,6 +20,7 @@ constexpr int TINY_THREADS = 1024;
 constexpr uint32_t TINY_MAX_G = 24576;        // 96 KiB of LDS for the histogram / cursor
 constexpr uint32_t TINY_MAX_PTS = 20480;      // scalars (pf = 8: 32-bit chunks) one block walks twice: 0.25 ms at 2^13, 0.46 at 2^14, 0.87 at 2^15 - where the big path (0.6 ms flat) is the faster one again
 constexpr uint32_t TINY_MAX_L = 1024;
+constexpr uint32_t TINY_ONE_BLOCK_PTS = 2048;  // up to here the one-block kernel (one launch, histogram in the LDS) is the faster one
 
 struct TinyGeom {
     int W;
@@ -156,6 +157,113 @@ __global__ __launch_bounds__(TINY_THREADS) void k_sort_tiny(const uint32_t* __re
     }
 }
 
+// The same stage for the upper half of the range (more than TINY_ONE_BLOCK_PTS scalars): the digit walks - 8 scalars x 26 windows
+// per lane, twice, ~30 instructions per digit - were 0.2 of the 0.24 ms on the ONE CU the block runs on; here they spread
+// over up to 16 blocks with the histogram and the cursors in global memory (k_tiny_hist, k_tiny_place), and one block does
+// the scans and the unit lists in between (k_tiny_scan: phases B and D above, from the global histogram).  Three launches.
+template <int SW>
+__global__ __launch_bounds__(TINY_THREADS) void k_tiny_hist(const uint32_t* __restrict__ scalars, uint32_t npts, TinyGeom g, uint32_t* __restrict__ count) {
+    for (uint32_t p = blockIdx.x * TINY_THREADS + threadIdx.x; p < npts; p += gridDim.x * TINY_THREADS) {
+        ScalarWords<SW> sw;
+        sw.load(scalars, p);
+        uint32_t carry = 0;
+        for (int w = 0; w < g.W; ++w) {
+            const int cw = g.width[w];
+            const int d = sw.next(cw, (1u << cw) - 1u, 1u << (cw - 1), carry);
+            if (d != 0) atomicAdd(&count[g.boff[w] + (uint32_t)(d < 0 ? -d : d) - 1u], 1u);
+        }
+    }
+}
+template <int SW>
+__global__ __launch_bounds__(TINY_THREADS) void k_tiny_place(const uint32_t* __restrict__ scalars, uint32_t npts, TinyGeom g, uint32_t* __restrict__ cursor,
+                                                             uint32_t* __restrict__ entries) {
+    for (uint32_t p = blockIdx.x * TINY_THREADS + threadIdx.x; p < npts; p += gridDim.x * TINY_THREADS) {
+        ScalarWords<SW> sw;
+        sw.load(scalars, p);
+        uint32_t carry = 0;
+        for (int w = 0; w < g.W; ++w) {
+            const int cw = g.width[w];
+            const int d = sw.next(cw, (1u << cw) - 1u, 1u << (cw - 1), carry);
+            if (d != 0) {
+                const uint32_t pos = atomicAdd(&cursor[g.boff[w] + (uint32_t)(d < 0 ? -d : d) - 1u], 1u);
+                entries[pos] = p | (d < 0 ? 0x80000000u : 0u);
+            }
+        }
+    }
+}
+// count[] holds the histogram on entry and the buckets' start offsets (the cursors of k_tiny_place) on exit
+__global__ __launch_bounds__(TINY_THREADS) void k_tiny_scan(TinyGeom g, uint32_t* __restrict__ count, uint32_t* __restrict__ off,
+                                                            uint32_t* __restrict__ unit_off, uint32_t* __restrict__ unit_bucket,
+                                                            uint32_t* __restrict__ unit_order, uint32_t* __restrict__ lenhist, uint32_t* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t cnt[];   // [G]: the histogram
+    __shared__ uint64_t wave_tot[TINY_THREADS / 64];
+    __shared__ uint32_t lh[TINY_MAX_L + 1], lcur[TINY_MAX_L + 1];
+    __shared__ uint32_t mx_sh;
+    const uint32_t tid = threadIdx.x, G = g.G, L = g.L;
+    for (uint32_t i = tid; i < G; i += TINY_THREADS) cnt[i] = count[i];
+    for (uint32_t i = tid; i <= L; i += TINY_THREADS) lh[i] = 0;
+    if (tid == 0) mx_sh = 0;
+    __syncthreads();
+    const uint32_t chunk = (G + TINY_THREADS - 1) / TINY_THREADS;
+    const uint32_t g0 = tid * chunk, g1 = g0 + chunk < G ? g0 + chunk : G;
+    uint64_t mine = 0;
+    uint32_t mx = 0;
+    for (uint32_t b = g0; b < g1; ++b) {
+        const uint32_t c = cnt[b];
+        mine += (uint64_t)c | ((uint64_t)((c + L - 1) / L) << 32);
+        mx = c > mx ? c : mx;
+    }
+    if (mx) atomicMax(&mx_sh, mx);
+    uint64_t total;
+    const uint64_t run0 = tiny_block_scan(mine, wave_tot, &total);
+    uint64_t run = run0;
+    for (uint32_t b = g0; b < g1; ++b) {
+        const uint32_t c = cnt[b];
+        const uint32_t o = (uint32_t)(run & 0xffffffffu), u = (uint32_t)(run >> 32);
+        off[b] = o;
+        unit_off[b] = u;
+        count[b] = o;   // cursor
+        const uint32_t nfull = c / L, rem = c - nfull * L;
+        if (nfull) atomicAdd(&lh[L], nfull);
+        if (rem) atomicAdd(&lh[rem], 1u);
+        for (uint32_t k = 0; k < nfull + (rem ? 1u : 0u); ++k) unit_bucket[u + k] = b;
+        run += (uint64_t)c | ((uint64_t)((c + L - 1) / L) << 32);
+    }
+    if (tid == 0) {
+        off[G] = (uint32_t)(total & 0xffffffffu);
+        unit_off[G] = (uint32_t)(total >> 32);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t r = 0;
+        for (int len = (int)L; len >= 0; --len) {
+            lcur[len] = r;
+            r += lh[len];
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i <= L; i += TINY_THREADS) {
+        lenhist[i] = lh[i];
+        lenhist[TINY_MAX_L + 1 + i] = lcur[i] + lh[i];
+    }
+    run = run0;
+    for (uint32_t b = g0; b < g1; ++b) {
+        const uint32_t c = cnt[b], u0 = (uint32_t)(run >> 32);
+        const uint32_t nfull = c / L, rem = c - nfull * L;
+        if (nfull) {
+            const uint32_t pos = atomicAdd(&lcur[L], nfull);
+            for (uint32_t k = 0; k < nfull; ++k) unit_order[pos + k] = u0 + k;
+        }
+        if (rem) unit_order[atomicAdd(&lcur[rem], 1u)] = u0 + nfull;
+        run += (uint64_t)c | ((uint64_t)((c + L - 1) / L) << 32);
+    }
+    if (tid == 0) {
+        stats[0] = (uint32_t)(total >> 32);
+        stats[1] = mx_sh;
+        stats[2] = (uint32_t)(total & 0xffffffffu);
+    }
+}
+
 bool msm_sort_tiny_ok(const MsmPlan& P, uint32_t npts, int sbits) {
     if (exp_knob("BLAZE_SORT_TINY", 1) == 0) return false;
     if (P.table || P.W < 1 || (sbits != 256 && sbits != 32)) return false;
@@ -181,7 +289,19 @@ int msm_sort_tiny(MsmEngine& E, const void* d_scalars, uint32_t npts, int sbits,
     BLZ_TRY(B.lenhist.reserve(2 * (TINY_MAX_L + 1) * 4));
     const size_t lds = (size_t)g.G * 4;
     const uint32_t* sc = (const uint32_t*)d_scalars;
-    if (sbits == 256) {
+    if (npts > TINY_ONE_BLOCK_PTS && exp_knob("BLAZE_SORT_TINY_BLOCKS", 1) != 0) {
+        uint32_t nb = (npts + TINY_THREADS - 1) / TINY_THREADS;
+        if (nb > 16) nb = 16;
+        uint32_t* count = B.count.as<uint32_t>();
+        BLZ_HIP(hipMemsetAsync(count, 0, (size_t)g.G * 4, st), BLZ_ERR_UNKNOWN);
+        BLZ_TRY(ensure_dynamic_lds((const void*)k_tiny_scan, (int)lds));
+        if (sbits == 256) hipLaunchKernelGGL(k_tiny_hist<8>, dim3(nb), dim3(TINY_THREADS), 0, st, sc, npts, g, count);
+        else hipLaunchKernelGGL(k_tiny_hist<1>, dim3(nb), dim3(TINY_THREADS), 0, st, sc, npts, g, count);
+        hipLaunchKernelGGL(k_tiny_scan, dim3(1), dim3(TINY_THREADS), lds, st, g, count, B.off.as<uint32_t>(), B.unit_off.as<uint32_t>(),
+                           B.unit_bucket.as<uint32_t>(), B.unit_order.as<uint32_t>(), B.lenhist.as<uint32_t>(), B.stats.as<uint32_t>());
+        if (sbits == 256) hipLaunchKernelGGL(k_tiny_place<8>, dim3(nb), dim3(TINY_THREADS), 0, st, sc, npts, g, count, B.entries.as<uint32_t>());
+        else hipLaunchKernelGGL(k_tiny_place<1>, dim3(nb), dim3(TINY_THREADS), 0, st, sc, npts, g, count, B.entries.as<uint32_t>());
+    } else if (sbits == 256) {
         BLZ_TRY(ensure_dynamic_lds((const void*)k_sort_tiny<8>, (int)lds));
         hipLaunchKernelGGL(k_sort_tiny<8>, dim3(1), dim3(TINY_THREADS), lds, st, sc, npts, g, B.count.as<uint32_t>(), B.off.as<uint32_t>(),
                            B.unit_off.as<uint32_t>(), B.entries.as<uint32_t>(), B.unit_bucket.as<uint32_t>(), B.unit_order.as<uint32_t>(),
