@@ -1056,7 +1056,7 @@ inline uint32_t reduce_seg0(const MsmPlan& P) {
     while (seg0_auto > 8 && P.G / seg0_auto < 262144) seg0_auto >>= 1;
     return (uint32_t)exp_knob("BLAZE_MSM_SEG", (int)seg0_auto);
 }
-inline uint32_t reduce_row_max() { return (uint32_t)exp_knob("BLAZE_REDUCE_ROW_MAX", 4096); }
+inline uint32_t reduce_row_max() { return (uint32_t)exp_knob("BLAZE_REDUCE_ROW_MAX", 8192); }
 template <class F>
 bool small_row_tail(const MsmPlan& P) {
     if constexpr (USE_RR<F>) {
@@ -1105,8 +1105,9 @@ int run_accumulate_t(MsmEngine& E, const void* d_pts, uint32_t U, int slice) {
     // a task whose reduce runs on the row law from level 0 on folds its buckets on it too (k_combine_buckets_row, every bucket of
     // up to 64 units, the plan's hot windows included)
     const bool row_fold = slice < 0 && thr != 0 && small_row_tail<F>(P);
+    double hot_units = 0;   // units per bucket of the hottest window the plan predicts
     if constexpr (USE_RR<F>) {
-        if (!row_fold && !P.table && slice < 0 && P.ebits > 0 && exp_knob("BLAZE_FOLD_HOT", 1) != 0) {
+        if (!P.table && slice < 0 && P.ebits > 0 && exp_knob("BLAZE_FOLD_HOT", 1) != 0) {
             int lowest = -1, off = 0;
             bool any = false;
             int offs[MSM_MAX_W];
@@ -1123,8 +1124,12 @@ int run_accumulate_t(MsmEngine& E, const void* d_pts, uint32_t U, int slice) {
                 if (!hot && entries > 0) break;       // a normal window: the suffix ends above it
                 lowest = w;
                 any = any || hot;
+                if (hot && entries / active / (double)P.L > hot_units) hot_units = entries / active / (double)P.L;
             }
             if (any && lowest > 0 && P.G - P.boff[lowest] <= 16384) hot_start = P.boff[lowest];
+            // (the row fold adds a bucket's units in sequence, ~3 us each: it takes the hot windows too while that chain stays
+            // below k_fold_hot's ~0.1 ms - the 16-unit buckets of a 2^13 task's top window; the 512-unit ones of 2^16 do not)
+            if (row_fold && hot_units <= 24.0) hot_start = (uint32_t)P.G;
         }
     }
     // (64-bit stride: with BLAZE_MSM_L < 8 and close to 2^31 points, maxunits exceeds 2^28 and a u32 stride would
@@ -1141,9 +1146,11 @@ int run_accumulate_t(MsmEngine& E, const void* d_pts, uint32_t U, int slice) {
     }
     if (row_fold) {
         if constexpr (USE_RR<F>) {
-            if constexpr (!RR_TIGHT<typename F::RR>)
-                hipLaunchKernelGGL(k_combine_buckets_row<F>, dim3((uint32_t)P.G), dim3(64), 0, st, E.sb().unit_off.as<uint32_t>(), thr,
-                                   E.partial.as<uint32_t>());
+            if constexpr (!RR_TIGHT<typename F::RR>) {
+                if (hot_start > 0)
+                    hipLaunchKernelGGL(k_combine_buckets_row<F>, dim3(hot_start), dim3(64), 0, st, E.sb().unit_off.as<uint32_t>(), thr,
+                                       E.partial.as<uint32_t>());
+            }
         }
     } else if (thr && hot_start > 0) {
         bool wave = false;

@@ -202,8 +202,12 @@ __global__ __launch_bounds__(SORT_THREADS) void k_coarse_scatter(const uint32_t*
 constexpr int CS_THREADS = BLZ_CS_THREADS;
 constexpr int CS_T = BLZ_CS_T;
 constexpr int CS_PTS = CS_THREADS * CS_T;  // 8192 points per block: 64 KiB of staging
+constexpr int CS_T_SMALL = 2;             // inputs of up to CS_SMALL_PTS points: 1024 per block
+constexpr uint32_t CS_SMALL_PTS = 1u << 19;
 
-template <int SW>
+// (T scalars per lane: 16 where the input fills the chip with blocks of 8192 points, 2 below that - 2^16 points were 8 blocks
+// walking 22 windows for 0.38 ms of a 2.4 ms MSM)
+template <int SW, int T>
 __global__ __launch_bounds__(CS_THREADS) void k_coarse_scatter_staged(const uint32_t* __restrict__ scalars, uint32_t npts,
                                                                       SortGeom g, uint32_t* __restrict__ coarse_cursor,
                                                                       uint32_t* __restrict__ inter_idx,
@@ -214,16 +218,16 @@ __global__ __launch_bounds__(CS_THREADS) void k_coarse_scatter_staged(const uint
     uint32_t* hist = sh;              // [nb] counts of this window
     uint32_t* lstart = sh + nbmax;       // [nb] first stage slot of the bin
     uint32_t* gbase = sh + 2 * nbmax;    // [nb] reserved global position of the bin's run
-    uint2* stage = reinterpret_cast<uint2*>(sh + 3 * nbmax);  // [CS_PTS]
+    uint2* stage = reinterpret_cast<uint2*>(sh + 3 * nbmax);  // [CS_THREADS * T]
     __shared__ uint32_t wave_tot[CS_THREADS / 64];
     __shared__ uint32_t total_sh;
     const uint32_t tid = threadIdx.x;
-    const uint32_t base = blockIdx.x * (uint32_t)CS_PTS;
+    const uint32_t base = blockIdx.x * (uint32_t)(CS_THREADS * T);
     const uint32_t fmask = (1u << g.cl) - 1u;
-    ScalarWords<SW> sw[CS_T];
-    uint32_t carry[CS_T];
+    ScalarWords<SW> sw[T];
+    uint32_t carry[T];
 #pragma unroll
-    for (int u = 0; u < CS_T; ++u) {
+    for (int u = 0; u < T; ++u) {
         uint32_t p = base + u * CS_THREADS + tid;
         sw[u].load(scalars, p < npts ? p : 0u);
         carry[u] = 0;
@@ -233,9 +237,9 @@ __global__ __launch_bounds__(CS_THREADS) void k_coarse_scatter_staged(const uint
         const uint32_t per = nb > (uint32_t)CS_THREADS ? nb / CS_THREADS : 1u;  // bins per lane in the scan
         for (uint32_t i = tid; i < nb; i += CS_THREADS) hist[i] = 0;
         __syncthreads();
-        uint32_t key[CS_T], rk[CS_T];  // key = fine | bin << 12 | sign << 31;  rk = rank in the bin, ~0 = no entry
+        uint32_t key[T], rk[T];  // key = fine | bin << 12 | sign << 31;  rk = rank in the bin, ~0 = no entry
 #pragma unroll
-        for (int u = 0; u < CS_T; ++u) {
+        for (int u = 0; u < T; ++u) {
             int d = next_digit(sw[u], g, w, carry[u]);
             rk[u] = ~0u;
             key[u] = 0;
@@ -278,7 +282,7 @@ __global__ __launch_bounds__(CS_THREADS) void k_coarse_scatter_staged(const uint
         }
         __syncthreads();
 #pragma unroll
-        for (int u = 0; u < CS_T; ++u) {
+        for (int u = 0; u < T; ++u) {
             if (rk[u] != ~0u) {
                 uint32_t bin = (key[u] >> 12) & 0x7ffffu;
                 uint32_t p = base + u * CS_THREADS + tid;
@@ -530,14 +534,21 @@ int msm_sort_lds(MsmEngine& E, const void* d_scalars, uint32_t npts, int sbits) 
     hipLaunchKernelGGL(k_coarse_scan, dim3(1), dim3(1024), 0, st, coarse_count, g.NC, coarse_off);
     // BLAZE_SORT_STAGED=0 selects the unstaged coarse scatter (kept for A/B measurements)
     if (exp_knob("BLAZE_SORT_STAGED", 1) != 0 && g.chmax <= 11 && g.cl <= 12) {
-        BLZ_TRY(ensure_dynamic_lds((const void*)k_coarse_scatter_staged<8>, 96 * 1024));
-        BLZ_TRY(ensure_dynamic_lds((const void*)k_coarse_scatter_staged<1>, 96 * 1024));
-        const size_t lds_cs = ((size_t)3 << g.chmax) * 4 + (size_t)CS_PTS * 8;
-        const uint32_t nblk_cs = (npts + CS_PTS - 1) / CS_PTS;
-        if (sbits == 256)
-            hipLaunchKernelGGL(k_coarse_scatter_staged<8>, dim3(nblk_cs), dim3(CS_THREADS), lds_cs, st, sc, npts, g, coarse_count, inter_idx, inter_fine);
-        else
-            hipLaunchKernelGGL(k_coarse_scatter_staged<1>, dim3(nblk_cs), dim3(CS_THREADS), lds_cs, st, sc, npts, g, coarse_count, inter_idx, inter_fine);
+        const bool small = npts <= CS_SMALL_PTS;
+        const uint32_t pts_blk = (uint32_t)CS_THREADS * (small ? CS_T_SMALL : CS_T);
+        const uint32_t nblk_cs = (npts + pts_blk - 1) / pts_blk;
+        const size_t lds_cs = ((size_t)3 << g.chmax) * 4 + (size_t)pts_blk * 8;
+        BLZ_TRY(ensure_dynamic_lds((const void*)k_coarse_scatter_staged<8, CS_T>, 96 * 1024));
+        BLZ_TRY(ensure_dynamic_lds((const void*)k_coarse_scatter_staged<1, CS_T>, 96 * 1024));
+        BLZ_TRY(ensure_dynamic_lds((const void*)k_coarse_scatter_staged<8, CS_T_SMALL>, 96 * 1024));
+        BLZ_TRY(ensure_dynamic_lds((const void*)k_coarse_scatter_staged<1, CS_T_SMALL>, 96 * 1024));
+        if (sbits == 256) {
+            if (small) hipLaunchKernelGGL((k_coarse_scatter_staged<8, CS_T_SMALL>), dim3(nblk_cs), dim3(CS_THREADS), lds_cs, st, sc, npts, g, coarse_count, inter_idx, inter_fine);
+            else hipLaunchKernelGGL((k_coarse_scatter_staged<8, CS_T>), dim3(nblk_cs), dim3(CS_THREADS), lds_cs, st, sc, npts, g, coarse_count, inter_idx, inter_fine);
+        } else {
+            if (small) hipLaunchKernelGGL((k_coarse_scatter_staged<1, CS_T_SMALL>), dim3(nblk_cs), dim3(CS_THREADS), lds_cs, st, sc, npts, g, coarse_count, inter_idx, inter_fine);
+            else hipLaunchKernelGGL((k_coarse_scatter_staged<1, CS_T>), dim3(nblk_cs), dim3(CS_THREADS), lds_cs, st, sc, npts, g, coarse_count, inter_idx, inter_fine);
+        }
     } else if (sbits == 256)
         hipLaunchKernelGGL(k_coarse_scatter<8>, dim3(nblk), dim3(SORT_THREADS), lds, st, sc, npts, g, coarse_count, inter_idx, inter_fine);
     else
