@@ -772,7 +772,7 @@ def main():
     # ---- the other two BASELINE configs on this GPU (extra keys): config 3 - 2^26 BN254, precompute
     # factor 8, the 2^29 bases (32 GiB) resident in the device arena, scalars-only set_data - and one rank's task of config 4 -
     # rank 0 of 8 of a 2^26 BLS12-377 job as blz_msm_shard_layout cuts it.  Each checked against the oracle by linearity.
-    cfg3 = cfg4 = None
+    cfg3 = cfg4 = lone_small = None
     if rank == 0 and world == 1 and not multi and not args.no_extras and hbm_mode and LOG_N == 26:
         def weighted_expect(curve_name, sc_bytes, count, first):
             import oracle
@@ -859,6 +859,42 @@ def main():
             raise
         except Exception as e:   # noqa: BLE001
             cfg4 = {"error": f"{type(e).__name__}: {e}"}
+        # ---- lone small tasks (extra key): the reference's own tests run MSM_SIZE = 8192 elements, one task at
+        # a time (tests/integration_msm.rs:149-207).  Device-resident inputs, wall clock of initialize .. result, median of 15.
+        wd.arm(300, "lone small MSMs")
+        try:
+            lone_small = {"what": "one BLS12-381 MSM at a time over device-resident inputs (bases in the arena), wall ms of initialize -> start_process -> "
+                                  "set_data -> wait_result -> result, median of 15; 2^13 = the reference's default MSM_SIZE", "ms": {}}
+            c5 = Curve["BLS381"]
+            for lg in (13, 16, 20):
+                n5 = 1 << lg
+                p5 = DeviceBuffer(dev, n5 * 96)
+                s5 = DeviceBuffer(dev, n5 * 32)
+                check(L.blz_synth_points(dev, int(c5), p5.ptr, n5, 1, 0))
+                check(L.blz_synth_scalars_at(dev, int(c5), s5.ptr, n5, 0x5A11 + lg, 0))
+                cl5 = MSMClient(MSMInit(PointMemoryType.HBM, False, c5), DriverClient(dev))
+                cl5.load_data_to_hbm(p5, 0, 0)
+                p5.free()
+                prm5 = MSMParams(n5, (0, 0))
+                inp5 = MSMInput(None, s5, prm5)
+                ts5, out5 = [], None
+                for k5 in range(18):
+                    t5 = time.perf_counter()
+                    cl5.initialize(prm5); cl5.start_process(); cl5.set_data(inp5); cl5.wait_result()
+                    out5 = cl5.result().result
+                    if k5 >= 3:
+                        ts5.append((time.perf_counter() - t5) * 1e3)
+                if not args.no_check and out5 != weighted_expect("BLS381", s5.download(), n5, 0):
+                    raise SystemExit(f"bench: the lone 2^{lg} result is WRONG")
+                lone_small["ms"][f"2^{lg}"] = round(statistics.median(ts5), 3)
+                cl5.close()
+                s5.free()
+                L.blz_arena_release(dev)
+            lone_small["result_check"] = None if args.no_check else {"ok": True, "method": "each size: result == (sum_i s_i (i+1) mod r) G, CPU oracle"}
+        except SystemExit:
+            raise
+        except Exception as e:   # noqa: BLE001
+            lone_small = {"error": f"{type(e).__name__}: {e}"}
         wd.disarm()
 
     # ---- NTT 2^27 latency (replica per rank; rank 0 reports), timed like benches/ntt_bench.rs:34-39
@@ -983,7 +1019,7 @@ def main():
                        "sort_hidden_under_previous_accumulation": bool(api.get("sort_hidden", 0))},
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_ref_semantics": cpu_ref, "result_check": check_rec,
             "ntt_2e27": ntt, "clock": clock, "exchange_native": native, "window_table": table_rec, "alt_layout_elements": alt_rec, "hbm_flow": hbm_flow, "config2_dma": cfg2,
-            "config3_bn254_pf8": cfg3, "config4_rank_task": cfg4,
+            "config3_bn254_pf8": cfg3, "config4_rank_task": cfg4, "lone_small_msm": lone_small,
             "phases_ms": {k: round(v, 3) for k, v in api.items() if k.endswith("_ms")},
         }
         if os.environ.get("BLAZE_BENCH_EMIT_RESULT") == "1":
