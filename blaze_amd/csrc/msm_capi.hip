@@ -476,9 +476,10 @@ int stage_common(blz_msm* h, bool have_points, const void* points, size_t points
             } else {
                 // scalars alone: the link is a quarter of the task, and every piece pays the sort stage's passes over the
                 // bucket space again (not hidden here) - 2^26: 163.7 ms whole, 158.5 / 145.4 / 181.8 in 16 / 8 / 32 pieces
+                // (2^22 .. 2^24 lone tasks: 14.25 / 25.6 / 46.2 ms whole, 13.3 / 23.6 / 42.5 in two pieces, 12.7 / 22.5 / 40.6 in four)
                 pieces = (int)(npts >> 23);
                 if (pieces > 8) pieces = 8;
-                if (pieces < 2) pieces = 2;
+                if (pieces < 4) pieces = 4;
             }
         }
         if (pieces < 1) pieces = 1;
