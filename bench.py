@@ -110,10 +110,10 @@ class SclkSampler:
     """Shader clock of this rank's GPU while the timed steps run, read from the driver's sysfs table
     (pp_dpm_sclk marks the current level with '*'); None when the box does not expose it."""
 
-    def __init__(self, torch, dev):
+    def __init__(self, torch, dev, period=0.05):
         import glob
 
-        self.path, self.samples, self.stop_flag, self.thread = None, [], False, None
+        self.path, self.samples, self.stop_flag, self.thread, self.period = None, [], False, None, period
         try:
             pr = torch.cuda.get_device_properties(dev)
             cand = "/sys/bus/pci/devices/%04x:%02x:%02x.0/pp_dpm_sclk" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
@@ -146,7 +146,7 @@ class SclkSampler:
                         self.samples.append(v)
                 except Exception:
                     return
-                time.sleep(0.05)
+                time.sleep(self.period)
 
         self.thread = threading.Thread(target=loop, daemon=True)
         self.thread.start()
@@ -158,7 +158,7 @@ class SclkSampler:
         if not self.samples:
             return None
         return {"min": min(self.samples), "mean": round(statistics.mean(self.samples), 1), "max": max(self.samples),
-                "samples": len(self.samples), "source": "pp_dpm_sclk (driver sysfs), sampled every 50 ms over the timed steps"}
+                "samples": len(self.samples), "source": f"pp_dpm_sclk (driver sysfs), sampled every {int(self.period * 1e3)} ms over the timed steps"}
 
 
 def main():
@@ -914,7 +914,11 @@ def main():
         nc.set_data(NTTInput(0, d_in))
         d_in.free()
         kms, wall = [], []
+        sclk_ntt = None
         for i in range(2 + 10):
+            if i == 2:   # the shader clock while the timed transforms run (the passes are power-limited like the MSM's accumulation)
+                sclk_ntt = SclkSampler(torch, dev, period=0.01)
+                sclk_ntt.start()
             t1 = time.perf_counter()
             nc.initialize(NttInit())
             nc.start_process(0)
@@ -923,12 +927,14 @@ def main():
             if i >= 2:
                 kms.append(nc.last_kernel_ms())
                 wall.append(w)
+        sclk_ntt_rec = sclk_ntt.stop() if sclk_ntt is not None else None
         nb = 2 * 32 * nn
         k = statistics.median(kms)
         ntt = {"log_size": NTT_LOG, "ms": round(statistics.median(wall), 3), "kernel_ms": round(k, 3), "samples": 10,
                "roofline": {"bound": "hbm", "achieved": round(nb / (k * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": round(nb / (k * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
-                            "algorithmic_bytes": nb, "traffic": None}}
+                            "algorithmic_bytes": nb, "traffic": None},
+               "sclk_mhz_timed_transforms": sclk_ntt_rec}
         # The resource the passes saturate, beside the prescribed HBM figure: 32-bit integer multiply issue.  Per lane (8 elements)
         # and pass the 512-point kernel does 37 / 37 / 29 field products: Shoup products by table twiddles at
         # 143 v_mad_u64_u32, Montgomery products (pass 2's boundary factors, read from the per-element table) at 153, and a
