@@ -469,6 +469,7 @@ int stage_common(blz_msm* h, bool have_points, const void* points, size_t points
         if (pieces <= 0) {
             if (dma_pieces) {
                 pieces = (int)(npts >> 19);
+                if (npts >= (1u << 20) && npts <= (1u << 21)) pieces = (int)(npts >> 18);   // 2^20: 5.49 ms in 2 pieces, 5.23 in 4; 2^21: 8.47 in 4, 8.25 in 8
                 if (pieces > 16) pieces = 16;
                 // with another task in flight the link is the bound whatever the pieces do, and every piece costs it the
                 // ~150 us of launches between two copies: fewer, larger pieces (2^22: 10.4 against 10.8 ms per MSM)
