@@ -946,7 +946,7 @@ def test_hidden_sort_runs_beside_the_accumulation_on_a_reopened_handle(gpu):
     stream's queue - every result right, every "hidden" sort waiting for the accumulation it should have run beneath (config 3
     in bench.py: 91 -> 111 ms per MSM).  The sort, tail and exchange streams are high-priority streams now (queues of their
     own: MsmEngine::init).  Guard: after two handles were opened and closed, a stream of 2^24 tasks still takes about its
-    accumulation per task (collided: + the whole sort stage, ~1.3 x)."""
+    accumulation per task (collided: + the whole sort stage, ~1.35 x)."""
     import time
 
     for _ in range(2):
@@ -968,7 +968,9 @@ def test_hidden_sort_runs_beside_the_accumulation_on_a_reopened_handle(gpu):
     cl.close(); dp.free(); ds.free()
     gaps = sorted((b - a) * 1e3 for a, b in zip(done[2:], done[3:]))
     assert all(hidden[2:]), hidden
-    assert gaps[len(gaps) // 2] < 1.2 * max(acc[2:]), (gaps, acc)
+    # (measured: 1.11 - 1.12 with the sort hidden - the points' to-Montgomery pass and the level-0 reduce are in the gap too - and
+    # 1.35+ with the sort stage in the open)
+    assert gaps[len(gaps) // 2] < 1.27 * max(acc[2:]), (gaps, acc)
 
 
 @pytest.mark.parametrize("curve,pf", [("BLS381", 1), ("BN254", 8)])
