@@ -232,6 +232,23 @@ BLZ_DEV void rowpt_add(const RowCtx<Q>& c, RowPt& acc, const RowPt& q) {
     acc.zzz = ZZZ3;
 }
 
+// ... in ec_rr.hip.hpp's accumulator form (exact limbs, Y below 2m by a product with R mod m: XYZZRR's bounds), for readers on
+// either law
+template <class Q>
+BLZ_DEV void rowpt_store_strict(const RowCtx<Q>& c, uint32_t* base, size_t idx, const RowPt& p) {
+    constexpr int S = rr_stride<Q>();
+    const bool inf = rowpt_is_inf(p);
+    const uint32_t y = inf ? 0u : row_mul<Q>(c, p.y, c.one);
+    const uint32_t ex = row_resolve<Q>(c, inf ? 0u : p.x), ey = row_resolve<Q>(c, y), ezz = row_resolve<Q>(c, p.zz), ezzz = row_resolve<Q>(c, inf ? 0u : p.zzz);
+    uint32_t* q = base + idx * 4 * S;
+    if (c.row == 0u && c.li < (uint32_t)Q::NL) {
+        q[c.li] = ex;
+        q[S + c.li] = ey;
+        q[2 * S + c.li] = ezz;
+        q[3 * S + c.li] = ezzz;
+    }
+}
+
 // the point as ec_rr.hip.hpp's accumulator, on lane 0 (via LDS: 4 x 16 dwords).  Y is brought below 2m by a product with R mod m.
 template <class Q>
 BLZ_DEV void rowpt_export(const RowCtx<Q>& c, const RowPt& p, uint32_t (*sh)[16], XYZZRR<Q>& out) {

@@ -952,7 +952,7 @@ __global__ __launch_bounds__(64, 2) void k_combine_buckets_wave(const uint32_t* 
 // row level): one wave per bucket adds the bucket's units in sequence, ~3 us per addition - against ~20 us per ROUND of the
 // shuffle tree above and k_fold_hot's 0.09 ms for the 16-unit buckets of a 2^13 task's top window - and leaves the sum, in
 // the row law's weakly normalised form (read by k_reduce_level_row only), in the bucket's first unit.
-template <class F>
+template <class F, bool STRICT>   // STRICT: the sum leaves in the accumulator form every reader takes (level 0 on the thread-level law)
 __global__ __launch_bounds__(64, 4) void k_combine_buckets_row(const uint32_t* __restrict__ unit_off, uint32_t thr, uint32_t* __restrict__ partial) {
     using Q = typename F::RR;
     const uint64_t g = blockIdx.x;
@@ -966,7 +966,48 @@ __global__ __launch_bounds__(64, 4) void k_combine_buckets_row(const uint32_t* _
         rowpt_load<Q>(c, a, partial, u0 + u);
         rowpt_add<Q>(c, acc, a);
     }
-    rowpt_store<Q>(c, partial, u0, acc);
+    if constexpr (STRICT) rowpt_store_strict<Q>(c, partial, u0, acc);
+    else rowpt_store<Q>(c, partial, u0, acc);
+}
+
+// k_fold_hot on the row law: sixteen waves take a hot bucket, wave w adds the units w, w + 16, ... in sequence (~3 us each: 32 of
+// the 512 units a 2^16 task's top buckets hold), the sixteen sums meet in the LDS and four rounds of pairwise additions leave
+// the bucket's sum, in the accumulator form, in its first unit: 0.33 -> 0.1 ms at 2^16.
+template <class F>
+__global__ __launch_bounds__(1024, 1) void k_fold_hot_row(const uint32_t* __restrict__ unit_off, uint32_t hot_start, uint32_t* __restrict__ partial) {
+    using Q = typename F::RR;
+    __shared__ uint32_t sh[16][4][16];
+    const uint64_t g = (uint64_t)hot_start + blockIdx.x;
+    const uint32_t u0 = unit_off[g], U = unit_off[g + 1] - u0;
+    if (U < 2) return;   // (uniform over the block)
+    const uint32_t wave = threadIdx.x >> 6;
+    const RowCtx<Q> c = row_ctx<Q>();
+    RowPt acc;
+    rowpt_set_inf(acc);
+    for (uint32_t u = wave; u < U; u += 16u) {
+        RowPt a;
+        rowpt_load<Q>(c, a, partial, u0 + u);
+        rowpt_add<Q>(c, acc, a);
+    }
+    for (uint32_t r = 8; r >= 1; r >>= 1) {
+        if (wave >= r && wave < 2u * r && c.row == 0u) {
+            sh[wave][0][c.li] = acc.x;
+            sh[wave][1][c.li] = acc.y;
+            sh[wave][2][c.li] = acc.zz;
+            sh[wave][3][c.li] = acc.zzz;
+        }
+        __syncthreads();
+        if (wave < r) {
+            RowPt o;
+            o.x = sh[wave + r][0][c.li];
+            o.y = sh[wave + r][1][c.li];
+            o.zz = sh[wave + r][2][c.li];
+            o.zzz = sh[wave + r][3][c.li];
+            rowpt_add<Q>(c, acc, o);
+        }
+        __syncthreads();
+    }
+    if (wave == 0) rowpt_store_strict<Q>(c, partial, u0, acc);
 }
 
 // ... and for the windows the PLAN knows to be hot - the top windows of a small or mid-sized task hold the last few bits of
@@ -1102,10 +1143,15 @@ int run_accumulate_t(MsmEngine& E, const void* d_pts, uint32_t U, int slice) {
     // leave it alone.  Only for a small suffix of a larger space: where EVERY window is like that (the precompute shapes) the
     // lane-per-bucket fold below is the throughput-bound answer.
     uint32_t hot_start = (uint32_t)P.G;
-    // a task whose reduce runs on the row law from level 0 on folds its buckets on it too (k_combine_buckets_row, every bucket of
-    // up to 64 units, the plan's hot windows included)
-    const bool row_fold = slice < 0 && thr != 0 && small_row_tail<F>(P);
-    double hot_units = 0;   // units per bucket of the hottest window the plan predicts
+    // Where the curve has the row law (ec_row.hip.hpp), a task of up to 2^17 bucket slots and units folds its buckets on it: one wave per bucket
+    // (k_combine_buckets_row, buckets of up to 64 units), sixteen per bucket of the plan's hot windows (k_fold_hot_row).  The
+    // sums leave in the accumulator form unless everything behind them runs on the row law too (small_row_tail).
+    bool row_law = false;
+    if constexpr (USE_RR<F>) row_law = !RR_TIGHT<typename F::RR> && exp_knob("BLAZE_FINISH_ROW", 1) != 0 && exp_knob("BLAZE_FOLD_ROW", 1) != 0;
+    // (a latency tool: chip-wide the row law adds ~5 x slower than one lane per point - 2^18 elements, 82 K buckets of four units:
+    // 0.41 ms against the lane-per-bucket fold's 0.19 - so only while the units to fold are few)
+    const bool row_fold = row_law && slice < 0 && thr != 0 && P.G <= (1u << 17) && (uint64_t)P.npts * P.W / P.L <= (1u << 17);
+    const bool row_tail = row_fold && small_row_tail<F>(P);
     if constexpr (USE_RR<F>) {
         if (!P.table && slice < 0 && P.ebits > 0 && exp_knob("BLAZE_FOLD_HOT", 1) != 0) {
             int lowest = -1, off = 0;
@@ -1124,12 +1170,8 @@ int run_accumulate_t(MsmEngine& E, const void* d_pts, uint32_t U, int slice) {
                 if (!hot && entries > 0) break;       // a normal window: the suffix ends above it
                 lowest = w;
                 any = any || hot;
-                if (hot && entries / active / (double)P.L > hot_units) hot_units = entries / active / (double)P.L;
             }
             if (any && lowest > 0 && P.G - P.boff[lowest] <= 16384) hot_start = P.boff[lowest];
-            // (the row fold adds a bucket's units in sequence, ~3 us each: it takes the hot windows too while that chain stays
-            // below k_fold_hot's ~0.1 ms - the 16-unit buckets of a 2^13 task's top window; the 512-unit ones of 2^16 do not)
-            if (row_fold && hot_units <= 24.0) hot_start = (uint32_t)P.G;
         }
     }
     // (64-bit stride: with BLAZE_MSM_L < 8 and close to 2^31 points, maxunits exceeds 2^28 and a u32 stride would
@@ -1140,16 +1182,31 @@ int run_accumulate_t(MsmEngine& E, const void* d_pts, uint32_t U, int slice) {
                            E.sb().lenhist.as<uint32_t>() + P.L, E.sb().stats.as<uint32_t>(), P.L, (uint32_t)stride, thr, hot_start,
                            E.partial.as<uint32_t>());
     if constexpr (USE_RR<F>) {
-        if (hot_start < P.G)
-            hipLaunchKernelGGL(k_fold_hot<F>, dim3((uint32_t)(P.G - hot_start)), dim3(512), 0, st, E.sb().unit_off.as<uint32_t>(), hot_start,
-                               E.partial.as<uint32_t>());
+        if (hot_start < P.G) {
+            bool done = false;
+            if constexpr (!RR_TIGHT<typename F::RR>) {
+                if (row_law) {
+                    hipLaunchKernelGGL(k_fold_hot_row<F>, dim3((uint32_t)(P.G - hot_start)), dim3(1024), 0, st, E.sb().unit_off.as<uint32_t>(), hot_start,
+                                       E.partial.as<uint32_t>());
+                    done = true;
+                }
+            }
+            if (!done)
+                hipLaunchKernelGGL(k_fold_hot<F>, dim3((uint32_t)(P.G - hot_start)), dim3(512), 0, st, E.sb().unit_off.as<uint32_t>(), hot_start,
+                                   E.partial.as<uint32_t>());
+        }
     }
     if (row_fold) {
         if constexpr (USE_RR<F>) {
             if constexpr (!RR_TIGHT<typename F::RR>) {
-                if (hot_start > 0)
-                    hipLaunchKernelGGL(k_combine_buckets_row<F>, dim3(hot_start), dim3(64), 0, st, E.sb().unit_off.as<uint32_t>(), thr,
-                                       E.partial.as<uint32_t>());
+                if (hot_start > 0) {
+                    if (row_tail)
+                        hipLaunchKernelGGL((k_combine_buckets_row<F, false>), dim3(hot_start), dim3(64), 0, st, E.sb().unit_off.as<uint32_t>(), thr,
+                                           E.partial.as<uint32_t>());
+                    else
+                        hipLaunchKernelGGL((k_combine_buckets_row<F, true>), dim3(hot_start), dim3(64), 0, st, E.sb().unit_off.as<uint32_t>(), thr,
+                                           E.partial.as<uint32_t>());
+                }
             }
         }
     } else if (thr && hot_start > 0) {
