@@ -1137,7 +1137,10 @@ int run_accumulate_t(MsmEngine& E, const void* d_pts, uint32_t U, int slice) {
     if (full_bound > U) full_bound = U;
     // where the plan itself says that buckets hold several units each (mean run > L / 2), the lane-per-bucket fold takes
     // every bucket of up to 64 units and the tree only the hot ones beyond
-    const uint32_t thr = ((uint64_t)P.npts * P.W / (P.G ? P.G : 1) > P.L / 2) ? 64u : 0u;
+    // (... and for every task of up to 2^22 points: one window of such a task can be twice as dense as the mean - the top real
+    // window of 255-bit scalars below r covers 0x39f6 of its 2^15 buckets at c = 16 - and the quad tree, built for a handful of
+    // hot buckets, spent 0.48 ms of a 4.8 ms 2^20 task on its 14 K two-unit buckets; one pass over the unit offsets is nothing here)
+    const uint32_t thr = ((uint64_t)P.npts * P.W / (P.G ? P.G : 1) > P.L / 2 || P.npts <= (1u << 22)) ? 64u : 0u;
     // The windows the plan knows to be hot (the top ones, where the scalars' bits run out: a few buckets with long runs):
     // a suffix [hot_start, G) of the bucket space goes to k_fold_hot - eight waves per bucket - and the two folds below
     // leave it alone.  Only for a small suffix of a larger space: where EVERY window is like that (the precompute shapes) the
