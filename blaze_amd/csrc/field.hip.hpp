@@ -435,7 +435,7 @@ BLZ_DEV bool fp_eq(const Fp<P>& a, const Fp<P>& b) {
 
 // ------------------------------------------------------------------------------------------
 // Inversion: binary extended Euclid on plain integers (shifts, adds, compares only).  On one lane it
-// is ~60 k instructions against ~510 k for Fermat's a^(m-2) (570 Montgomery products), and the
+// is ~25 k instructions (Kaliski's form, below) against ~510 k for Fermat's a^(m-2) (570 Montgomery products), and the
 // inversions of this library all sit on single-lane latency paths (final normalisation of an MSM,
 // combine of multi-GPU partials, table set-up).  Data-dependent trip count; not constant time (the
 // inputs are public).  Input and output in Montgomery form; inverse of 0 is 0.
@@ -481,41 +481,106 @@ BLZ_DEV void mp_sub_mod(uint32_t (&x)[P::N], const uint32_t (&y)[P::N]) {
     for (int i = 0; i < P::N; ++i) x[i] = add_cc(x[i], P::MOD[i] & mask, c);
 }
 
+// bit length of the modulus
 template <class P>
-__device__ __noinline__ void fp_inv(Fp<P>& r, const Fp<P>& a_in) {
-    constexpr int N = P::N;
+constexpr int mp_mod_bits() {
+    int top = P::N - 1;
+    while (top > 0 && P::MOD[top] == 0) --top;
+    int b = 0;
+    for (uint32_t x = P::MOD[top]; x; x >>= 1) ++b;
+    return 32 * top + b;
+}
+template <int N>
+BLZ_DEV void mp_shl1(uint32_t (&a)[N]) {
+#pragma unroll
+    for (int i = N - 1; i > 0; --i) a[i] = (a[i] << 1) | (a[i - 1] >> 31);
+    a[0] <<= 1;
+}
+// the plain integer 2^d (d < 32 N) as a field operand
+template <class P>
+BLZ_DEV void fp_pow2(Fp<P>& r, int d) {
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) r.v[i] = (d >> 5) == i ? 1u << (d & 31) : 0u;
+}
+
+// Kaliski's almost inverse (round 4; the extended Euclid with a modular halving per step that stood here was ~60 k instructions,
+// 0.16 ms of every lone task's 0.68 ms Horner kernel): the cofactors r, s are only ever added and doubled - no reduction
+// inside the loop, they stay below 2m - and the loop leaves A^-1 2^k mod m with n <= k <= 2n (n = bit length of m); the power of
+// two comes off in the Montgomery products that put the result in Montgomery form anyway.  ~25 k instructions.
+template <class P>
+__device__ __noinline__ void fp_inv(Fp<P>& r_out, const Fp<P>& a_in) {
+    constexpr int N = P::N, W = 32 * N, BITS = mp_mod_bits<P>();
+    static_assert(BITS + 1 <= W, "the cofactors reach 2m");
     Fp<P> a = a_in;
     fp_reduce(a);
     uint32_t nz = 0;
 #pragma unroll
     for (int i = 0; i < N; ++i) nz |= a.v[i];
-    if (nz == 0) { fp_zero(r); return; }
-    uint32_t u[N], v[N], x1[N], x2[N];
+    if (nz == 0) { fp_zero(r_out); return; }
+    uint32_t u[N], v[N], r[N], s[N];
 #pragma unroll
-    for (int i = 0; i < N; ++i) { u[i] = a.v[i]; v[i] = P::MOD[i]; x1[i] = i == 0 ? 1u : 0u; x2[i] = 0u; }
-    // invariants: x1 * A == u, x2 * A == v (mod m), A = the input as a plain integer
-    while (!mp_is_one<N>(u) && !mp_is_one<N>(v)) {
-        while ((u[0] & 1u) == 0) { mp_shr1<N>(u, 0); mp_half_mod<P>(x1); }
-        while ((v[0] & 1u) == 0) { mp_shr1<N>(v, 0); mp_half_mod<P>(x2); }
-        if (mp_geq<N>(u, v)) {
-            uint32_t br = 0;
+    for (int i = 0; i < N; ++i) { u[i] = P::MOD[i]; v[i] = a.v[i]; r[i] = 0u; s[i] = i == 0 ? 1u : 0u; }
+    int k = 0;
+    // invariants (A = the input as a plain integer): A r == -u 2^k, A s == v 2^k (mod m); u, v > 0 until v reaches 0 with u = 1
+    for (;;) {
+        uint32_t vz = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) vz |= v[i];
+        if (vz == 0) break;
+        if ((u[0] & 1u) == 0) {
+            mp_shr1<N>(u, 0);
+            mp_shl1<N>(s);
+        } else if ((v[0] & 1u) == 0) {
+            mp_shr1<N>(v, 0);
+            mp_shl1<N>(r);
+        } else if (!mp_geq<N>(v, u)) {   // u > v
+            uint32_t br = 0, c = 0;
 #pragma unroll
             for (int i = 0; i < N; ++i) u[i] = sub_bb(u[i], v[i], br);
-            mp_sub_mod<P>(x1, x2);
+            mp_shr1<N>(u, 0);
+#pragma unroll
+            for (int i = 0; i < N; ++i) r[i] = add_cc(r[i], s[i], c);
+            mp_shl1<N>(s);
         } else {
-            uint32_t br = 0;
+            uint32_t br = 0, c = 0;
 #pragma unroll
             for (int i = 0; i < N; ++i) v[i] = sub_bb(v[i], u[i], br);
-            mp_sub_mod<P>(x2, x1);
-        }
-    }
-    const bool take1 = mp_is_one<N>(u);
-    Fp<P> t, r2;
+            mp_shr1<N>(v, 0);
 #pragma unroll
-    for (int i = 0; i < N; ++i) { t.v[i] = take1 ? x1[i] : x2[i]; r2.v[i] = P::R2[i]; }
-    // t = A^-1 = a^-1 R^-1 (plain);  two products by R^2 give a^-1 R, the Montgomery form of a^-1
+            for (int i = 0; i < N; ++i) s[i] = add_cc(s[i], r[i], c);
+            mp_shl1<N>(r);
+        }
+        ++k;
+    }
+    // r < 2m holds -A^-1 2^k: bring it below m and negate
+    {
+        uint32_t d[N], br = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) d[i] = sub_bb(r[i], P::MOD[i], br);
+        if (br == 0) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) r[i] = d[i];
+        }
+        br = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) r[i] = sub_bb(P::MOD[i], r[i], br);
+    }
+    // x = A^-1 2^k with A = a R: the Montgomery form of a^-1 is a^-1 R = A^-1 R^2 = x 2^(2W - k), and 6 <= 2W - k <= 2W - n.
+    // A Montgomery product by R^2 multiplies by R, one by the plain integer 2^d by 2^d / R (2^d <= 2m: d <= BITS).
+    Fp<P> t, r2, pw;
+#pragma unroll
+    for (int i = 0; i < N; ++i) { t.v[i] = r[i]; r2.v[i] = P::R2[i]; }
+    int d = 2 * W - k;
     fp_mul(t, t, r2);
-    fp_mul(r, t, r2);
+    if (d > BITS) {          // (k within a few bits of n: an input that is nearly a power of two; two more products)
+        const int d1 = d / 2;
+        fp_pow2(pw, d1);
+        fp_mul(t, t, pw);
+        fp_mul(t, t, r2);
+        d -= d1;
+    }
+    fp_pow2(pw, d);
+    fp_mul(r_out, t, pw);
 }
 
 // ------------------------------------------------------------------------------------------

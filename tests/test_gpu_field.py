@@ -59,6 +59,34 @@ def test_field_ops(gpu, curve, field):
 
 
 @pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("field", [0, 1])
+def test_field_inversion_edge_representations(gpu, curve, field):
+    """fp_inv works on the plain integer A = x R mod m behind a Montgomery-form input (Kaliski's almost inverse: A^-1 2^k with
+    n <= k <= 2n, the power of two taken off in the closing Montgomery products - by one product when 2W - k <= n, by three when
+    A is so close to a power of two that k stays within a few bits of n).  The random inputs of test_field_ops never get near
+    those representations: here x is chosen so that A is 1, 2, 3, every power of two, 2^j +- 1, m - 1, m - 2^j, (m +- 1) / 2."""
+    c = pyref.CURVES[curve]
+    m = c["q"] if field == 0 else c["r"]
+    nb = c["fq_bytes"] if field == 0 else 32
+    R = 1 << (8 * nb)
+    Rinv = pow(R, -1, m)
+    bits = m.bit_length()
+    A = [1, 2, 3, m - 1, m - 2, (m - 1) // 2, (m + 1) // 2]
+    for j in range(1, bits):
+        for v in (1 << j, (1 << j) - 1, (1 << j) + 1, m - (1 << j)):
+            if 0 < v < m:
+                A.append(v)
+    xs = [a * Rinv % m for a in A]
+    ab = b"".join(x.to_bytes(nb, "little") for x in xs)
+    out = C.create_string_buffer(len(xs) * nb)
+    rc = gpu.blz_test_field_op(0, c["id"], field, 3, ab, ab, C.cast(out, C.c_void_p), len(xs))
+    assert rc == 0, gpu.blz_last_error_message()
+    got = [int.from_bytes(out.raw[i * nb:(i + 1) * nb], "little") for i in range(len(xs))]
+    bad = [i for i, x in enumerate(xs) if got[i] != pow(x, -1, m)]
+    assert not bad, f"{curve} field={field}: {len(bad)} wrong inverses, first for A={A[bad[0]]:#x}"
+
+
+@pytest.mark.parametrize("curve", CURVES)
 def test_ec_ops(gpu, curve):
     c = pyref.CURVES[curve]
     cid = c["id"]
