@@ -582,6 +582,39 @@ __global__ __launch_bounds__(64, BLZ_REDUCE_RR_WAVES) void k_reduce_level0_rr(co
     ptrr_store(outC, (size_t)w * T + t, s);
 }
 
+// level 0 with one DPP QUAD per segment (ec_quad.hip.hpp) for the sizes in between: too many segments for a wave each
+// (k_reduce_level_row), too few to fill the chip with a lane each - 2^18 elements are 10 240 segments, 160 waves of lanes
+// whose 16-addition chains at ~12 us are the kernel's 0.2 ms; a quad adds in ~6.
+template <class F>
+__global__ __launch_bounds__(64, 2) void k_reduce_level0_quad(const uint32_t* __restrict__ inA, const uint32_t* __restrict__ unit_off, uint32_t M,
+                                                             uint32_t SEG, uint32_t T, int W, uint32_t* __restrict__ outA,
+                                                             uint32_t* __restrict__ outC) {
+    using Q = typename F::RR;
+    const uint32_t gtid = blockIdx.x * 64u + threadIdx.x;
+    const uint32_t tid = gtid >> 2, ql = gtid & 3u;
+    if (tid >= T * (uint32_t)W) return;
+    const uint32_t w = tid / T, t = tid - w * T;
+    const uint32_t lo = t * SEG;
+    uint32_t hi = lo + SEG;
+    if (hi > M) hi = M;
+    XYZZRR<Q> run, s;
+    ptrr_set_inf(run);
+    ptrr_set_inf(s);
+    for (uint32_t i = hi; i-- > lo;) {
+        const size_t idx = (size_t)w * M + i;
+        const uint32_t u0 = unit_off[idx], u1 = unit_off[idx + 1];
+        if (u1 > u0) {   // (uniform over the quad)
+            XYZZRR<Q> a;
+            ptrr_load(a, inA, u0);
+            quadrr_add(run, a, ql);
+        }
+        quadrr_add(s, run, ql);  // weights i + 1 at the first level
+    }
+    if (ql != 0) return;
+    ptrr_store(outA, (size_t)w * T + t, run);
+    ptrr_store(outC, (size_t)w * T + t, s);
+}
+
 // upper levels on the reduced-radix field: one DPP quad per segment, as k_reduce_level<F, false>, with the quad group law
 // of ec_quad.hip.hpp's second half (the chain of a segment is sequential: the latency of a field product is the cost)
 template <class F>
@@ -1294,10 +1327,14 @@ int run_reduce_t(MsmEngine& E, const void* sums, const void* unit_off_v) {
                 BLZ_HIP(hipStreamWaitEvent(st, S.ev_l0, 0), BLZ_ERR_UNKNOWN);
             }
         } else if (level == 0) {
-            if constexpr (USE_RR<F>)
-                hipLaunchKernelGGL(k_reduce_level0_rr<F>, dim3((nthreads + 63) / 64), dim3(64), 0, st, curA, unit_off, M,
-                                   SEG, T, P.Wv, oA.as<uint32_t>(), oC.as<uint32_t>());
-            else
+            if constexpr (USE_RR<F>) {
+                if (nthreads <= (uint32_t)exp_knob("BLAZE_REDUCE_QUAD_MAX", 131072))
+                    hipLaunchKernelGGL(k_reduce_level0_quad<F>, dim3((nthreads * 4 + 63) / 64), dim3(64), 0, st, curA, unit_off, M,
+                                       SEG, T, P.Wv, oA.as<uint32_t>(), oC.as<uint32_t>());
+                else
+                    hipLaunchKernelGGL(k_reduce_level0_rr<F>, dim3((nthreads + 63) / 64), dim3(64), 0, st, curA, unit_off, M,
+                                       SEG, T, P.Wv, oA.as<uint32_t>(), oC.as<uint32_t>());
+            } else
                 hipLaunchKernelGGL((k_reduce_level<F, true>), dim3((nthreads + 63) / 64), dim3(64), 0, st, curA, curC,
                                    unit_off, M, SEG, T, P.Wv, shift, oA.as<uint32_t>(), oC.as<uint32_t>());
             // the rest is a few lanes of sequential work: hand it to the tail stream, so this stream can
