@@ -209,6 +209,9 @@ def main():
         backend = os.environ.get("BLAZE_BENCH_BACKEND", "nccl")
         if os.environ.get("BLAZE_BENCH_ONE_GPU") == "1":
             local_rank = 0
+        ndev = torch.cuda.device_count()
+        if ndev and local_rank >= ndev:   # a launcher that narrows every rank's visibility to its own GPU(s)
+            local_rank %= ndev
         torch.cuda.set_device(local_rank)
         t_pg = int(os.environ.get("BLAZE_BENCH_PG_TIMEOUT_S", "180"))
         wd.arm(t_pg + 30, "process-group rendezvous + first collective")
