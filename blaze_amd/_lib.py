@@ -69,8 +69,12 @@ _SIGS = {
     "blz_msm_precompute_bases_device": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64]),
     "blz_msm_combine_partials": (C.c_int, [C.c_void_p, _u8p, C.c_size_t, _u8p, C.c_size_t]),
     "blz_msm_last_sort_hidden": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "blz_msm_memory_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "blz_msm_set_window_table": (C.c_int, [C.c_void_p, C.c_int]),
     "blz_msm_prepare_window_table": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_int)]),
+    "blz_msm_set_precompute_plan": (C.c_int, [C.c_void_p, C.c_int]),
+    "blz_msm_prepare_precompute_plan": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.POINTER(C.c_int)]),
+    "blz_msm_precompute_plan_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "blz_msm_set_scalar_range": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
     "blz_msm_shard_layout": (C.c_int, [C.c_int, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_uint32)]),
     "blz_msm_shard_layout_ex": (C.c_int, [C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_uint32, C.POINTER(C.c_uint32)]),
@@ -80,6 +84,9 @@ _SIGS = {
     "blz_ntt_new": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "blz_ntt_new_ex": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "blz_ntt_new_field": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "blz_ntt_new_ex2": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "blz_ntt_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "blz_ntt_exchange": (C.c_int, [C.c_void_p, C.c_size_t, _u8p, C.c_size_t, _u8p, C.c_size_t]),
     "blz_ntt_free": (None, [C.c_void_p]),
     "blz_ntt_initialize": (C.c_int, [C.c_void_p]),
     "blz_ntt_set_data": (C.c_int, [C.c_void_p, C.c_size_t, _u8p, C.c_size_t]),

@@ -7,6 +7,7 @@
 // addresses the same bytes through load_data_to_hbm / hbm_point_addr.  The bytes live as long as the holder.
 #include "common.hpp"
 
+#include <atomic>
 #include <cstdlib>
 #include <string>
 
@@ -48,6 +49,11 @@ void arena_free_extent(ArenaExtent& x) {
     arena_drop_table(x);
     if (x.shadow_ready) (void)hipEventDestroy(x.shadow_ready);
     x = ArenaExtent();
+}
+
+uint64_t arena_next_epoch() {
+    static std::atomic<uint64_t> next{1};
+    return next.fetch_add(1);
 }
 
 static void mark_dirty(ArenaExtent& e, uint64_t lo, uint64_t hi) {
@@ -133,6 +139,8 @@ int arena_write(int device_id, uint64_t pos, const void* src, size_t len, bool s
         arena_drop_table(*e);
     }
     e->table_refused = false;
+    e->pcheck = ArenaExtent::PrecompCheck();   // the table check was about the old bytes
+    e->epoch = arena_next_epoch();
     char* dst = (char*)e->raw + (pos - e->start);
     hipError_t he = hipMemcpyAsync(dst, src, len, src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st);
     if (he != hipSuccess)
@@ -236,6 +244,7 @@ int blz_arena_attach(int device_id, const char* path) {
         }
         n.dirty_lo = 0;
         n.dirty_hi = n.len;   // this process has no shadow of it yet
+        n.epoch = arena_next_epoch();
         A.ext.push_back(n);
     }
     return BLZ_OK;

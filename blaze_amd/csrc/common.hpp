@@ -146,7 +146,18 @@ struct ArenaExtent {
     };
     static constexpr size_t MAX_TABLES = 32;
     std::vector<WindowTable> tables;
-    bool table_refused = false;            // a build failed (a base of even order, or no memory): do not retry until the next write
+    bool table_refused = false;            // a build failed (a base of even order, or no memory): no NEW build until the next write
+    // Checked-table plan of precompute handles (msm_capi.hip arena_precompute_check; opt-in per handle): has the caller's x8 table
+    // been compared, element by element, with what precompute_base_* produces (tests/msm/mod.rs:360-380: B_j = 2^32 B_(j-1), B_0
+    // on the curve)?  For the points [first, +npts) of the grid at `phase`; any write into the extent forgets the answer.
+    struct PrecompCheck {
+        int state = 0;                     // 0 not checked, 1 consistent, 2 refuted
+        int curve = -1;
+        uint32_t phase = 0;
+        uint64_t first = 0, npts = 0;
+        float ms = 0;                      // device time of the check
+    } pcheck;
+    uint64_t epoch = 0;                    // changes with every write into the extent (a check that ran unlocked commits only to the bytes it read)
     // A table being built (msm_capi.hip arena_points_table): in chunks, paced by the tasks over these bases (each enqueues a
     // few chunks on its own stream ahead of itself and takes the plain path); the task that finds `done` complete behind the
     // last chunk adopts the table.
@@ -178,6 +189,7 @@ ArenaExtent* arena_find(Arena& a, uint64_t pos, size_t len);
 // write bytes (host or device source) at pos; extends / merges extents as needed; blocking
 int arena_write(int device_id, uint64_t pos, const void* src, size_t len, bool src_is_device, hipStream_t st);
 void arena_free_extent(ArenaExtent& x);
+uint64_t arena_next_epoch();
 void arena_drop_table(ArenaExtent& x);   // the table and a build in flight; the caller has drained the device
 
 }  // namespace blz

@@ -176,6 +176,25 @@ BLZ_DEV void ptrr_aadd(XYZZRR<Q>& acc, const AffineRR<Q>& p, bool negp, const Af
     acc.zzz = PPP;
 }
 
+// p = 2 p for an accumulator that is not the point at infinity (dbl-2008-s-1), inlined: the doubling chains of the table check
+// (msm_impl.hip.hpp k_check_precompute: 32 in a row per lane).  Independent products in pairs, like ptrr_madd.
+template <class Q>
+BLZ_DEV void ptrr_dbl_inl(XYZZRR<Q>& p) {
+    const auto U = rr_tn(rr_add(p.y, p.y));            // (2, 8) | (1, 4)
+    Frr<Q, 1, 2> V, W, S, t, Msq, y3;
+    rr_sqr_pair(V, U, t, p.x);
+    rr_mul_pair(W, U, V, S, p.x, V);
+    const auto M = rr_tn(rr_add(rr_add(t, t), t));     // (3, 6) | (1, 6)
+    rr_sqr(Msq, M);
+    const auto X3 = rr_xfix(rr_sub_twice<2>(Msq, S));  // (1, 10) | (1, 2)
+    const auto D = rr_tn(rr_sub<RR_JX<Q>>(S, X3));     // (3, 34) | (1, 6)
+    const auto nW = rr_neg<2>(W);                      // (2, 4)
+    rr_mul2(y3, M, D, nW, p.y);                        // M (S - X3) - W Y1
+    p.x = rr_as<1, XYZZRR<Q>::VX>(X3);
+    p.y = rr_as<1, XYZZRR<Q>::VY>(y3);
+    rr_mul_pair(p.zz, V, p.zz, p.zzz, W, p.zzz);
+}
+
 // 2 p for an accumulator (dbl-2008-s-1).  By value and out of line, like ptrr_mdbl_val.
 template <class Q, int TAG = 0>
 __device__ __noinline__ XYZZRR<Q> ptrr_dbl_val(XYZZRR<Q> p) {

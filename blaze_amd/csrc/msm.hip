@@ -594,6 +594,15 @@ int MsmEngine::points_to_mont(const void* d_raw, void* d_mont, uint32_t npts) {
     return ops_for(curve, repr)->points_to_mont(*this, d_raw, d_mont, npts);
 }
 
+int MsmEngine::points_to_mont_even(const void* d_raw, void* d_mont, uint32_t nq) {
+    BLZ_TRY(use_device(device));
+    return ops_for(curve, repr)->points_to_mont_even(*this, d_raw, d_mont, nq);
+}
+int MsmEngine::check_precompute(const void* d_raw, uint64_t nelem, uint32_t* flag, hipStream_t st) {
+    BLZ_TRY(use_device(device));
+    return ops_for(curve, 0)->check_precompute(*this, d_raw, nelem, flag, st);   // (reads wire-format points: always on the faster arithmetic)
+}
+
 int MsmEngine::build_table(const void* d_raw, void* d_table, uint32_t npts, int c, int W, int base_shift, void* scratch, uint32_t* flag,
                            hipStream_t st) {
     BLZ_TRY(use_device(device));

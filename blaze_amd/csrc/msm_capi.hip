@@ -56,6 +56,9 @@ struct blz_msm {
     // scalar range of this handle's tasks (blz_msm_set_scalar_range): bits [range_lo, range_hi) of every scalar; 0, 0 = all
     int range_lo = 0, range_hi = 0;
     uint64_t table_info[4] = {0, 0, 0, 0};   // of the last HBM task: table bytes, window bits, windows, build time (us)
+    // checked-table plan of a precompute handle (blz_msm_set_precompute_plan; off for new handles)
+    int precompute_plan = 0;
+    uint64_t pc_info[4] = {0, 0, 0, 0};      // of the last HBM task: took the plan, check state of its bases, check time (us), bytes of the even-base copy
 };
 
 namespace {
@@ -83,7 +86,9 @@ size_t result_size(const blz_msm* h) { return blz_result_size(h->curve); }
 // Resolve the Montgomery-form view of `npts` points stored at arena offset `pos`: (re)builds the part of the
 // extent's shadow that is stale, on this handle's main stream, and orders this stream behind conversions other
 // handles may have enqueued.
-int arena_points_mont(blz_msm* h, uint64_t pos, uint32_t npts, const void** out) {
+int arena_points_mont(blz_msm* h, uint64_t pos, uint32_t npts, const void** out, bool even = false) {
+    // even (checked-table plan of a precompute handle): the copy holds the even bases of every element only - B_0, B_2, B_4, B_6,
+    // contiguous, 4 per element - and *out addresses the copy of the element at `pos`; npts counts the RAW points (8 per element)
     const size_t ps = point_size(h), mp = mont_point_bytes(h->curve);
     const size_t len = (size_t)npts * ps;
     Arena& A = arena_for(h->device);
@@ -94,16 +99,20 @@ int arena_points_mont(blz_msm* h, uint64_t pos, uint32_t npts, const void** out)
                     (unsigned long long)pos, len, h->device);
     const uint32_t phase = (uint32_t)((pos - e->start) % ps);   // where the point grid sits inside the extent
     const size_t cap_pts = (e->cap - phase) / ps, ext_pts = (e->len - phase) / ps;
-    if (e->mont_curve != h->eng.format_id() || e->mont_phase != phase || e->mont_bytes < cap_pts * mp) {
-        // another curve / grid (or the first use): a fresh shadow, everything stale
+    const uint64_t first = (pos - e->start - phase) / ps;
+    if (even && (first & 7u)) return fail(BLZ_ERR_UNKNOWN, "even-base copy asked for a task that does not start on the extent's element grid");
+    const int fmt = h->eng.format_id() | (even ? 1 << 16 : 0);
+    const size_t want_bytes = (even ? (cap_pts / 8) * 4 : cap_pts) * mp;
+    if (e->mont_curve != fmt || e->mont_phase != phase || e->mont_bytes < want_bytes) {
+        // another curve / grid / layout (or the first use): a fresh shadow, everything stale
         if (e->mont) {
             BLZ_TRY(sync_device_bounded("replacing a Montgomery shadow"));   // a task of another handle may still read the old one
             (void)hipFree(e->mont);
             e->mont = nullptr;
         }
-        e->mont_bytes = cap_pts * mp + 16;
+        e->mont_bytes = want_bytes + 16;
         BLZ_HIP(hipMalloc(&e->mont, e->mont_bytes), BLZ_ERR_UNKNOWN);
-        e->mont_curve = h->eng.format_id();   // curve and layout of the copy (BN254 has two: msm_engine.hpp `repr`)
+        e->mont_curve = fmt;   // curve and layout of the copy (BN254 has two: msm_engine.hpp `repr`; bit 16: even bases only)
         e->mont_phase = phase;
         e->dirty_lo = 0;
         e->dirty_hi = e->len;
@@ -120,13 +129,111 @@ int arena_points_mont(blz_msm* h, uint64_t pos, uint32_t npts, const void** out)
         uint64_t lo = e->dirty_lo > phase ? (e->dirty_lo - phase) / ps : 0;
         uint64_t hi = e->dirty_hi > phase ? (e->dirty_hi - phase + ps - 1) / ps : 0;
         if (hi > ext_pts) hi = ext_pts;
-        if (lo < hi)
+        if (even) {
+            // whole elements (an element whose tail has not been loaded yet is converted when the load that completes it dirties it)
+            const uint64_t elo = lo / 8, ehi = hi / 8 < ext_pts / 8 ? (hi + 7) / 8 : ext_pts / 8;
+            if (elo < ehi)
+                BLZ_TRY(h->eng.points_to_mont_even((const char*)e->raw + phase + elo * 8 * ps, (char*)e->mont + elo * 4 * mp, (uint32_t)((ehi - elo) * 4)));
+        } else if (lo < hi) {
             BLZ_TRY(h->eng.points_to_mont((const char*)e->raw + phase + lo * ps, (char*)e->mont + lo * mp, (uint32_t)(hi - lo)));
+        }
         BLZ_HIP(hipEventRecord(e->shadow_ready, h->eng.stream), BLZ_ERR_UNKNOWN);
         e->shadow_recorded = true;
         e->dirty_lo = e->dirty_hi = 0;
     }
-    *out = (const char*)e->mont + (pos - e->start - phase) / ps * mp;
+    *out = (const char*)e->mont + (even ? first / 8 * 4 : first) * mp;
+    if (even) h->pc_info[3] = e->mont_bytes;
+    return BLZ_OK;
+}
+
+// Checked-table plan (msm_impl.hip.hpp k_check_precompute): is the x8 table of the `nelem` elements at arena offset `pos` what
+// precompute_base_* produces?  Answered once per (extent contents, range): the check runs on this handle's main stream (1278 /
+// 3059 multiply-adds per doubling, 224 doublings per element: ~0.7 s for 2^26 BN254 elements, ~1.6 s for BLS) and the caller waits
+// for it - with the arena unlocked; the answer is committed only if no write reached the extent in the meantime (epoch).
+int arena_precompute_check(blz_msm* h, uint64_t pos, uint32_t nelem, bool* ok) {
+    *ok = false;
+    const size_t ps = point_size(h);
+    const size_t len = (size_t)nelem * 8 * ps;
+    Arena& A = arena_for(h->device);
+    uint64_t epoch = 0, first = 0;
+    uint32_t phase = 0;
+    uint32_t* flag = nullptr;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(A.mu);
+        ArenaExtent* e = arena_find(A, pos, len);
+        if (!e)
+            return fail(BLZ_ERR_INVALID_PARAM, "HBM bases: no loaded extent covers [%llu, +%zu) on device %d", (unsigned long long)pos, len, h->device);
+        phase = (uint32_t)((pos - e->start) % ps);
+        first = (pos - e->start - phase) / ps;
+        h->pc_info[1] = 0;
+        if (first & 7u) {
+            BLZ_LOG(1, "precompute plan: the task's bases do not start on the extent's element grid (point %llu): exact path", (unsigned long long)first);
+            return BLZ_OK;
+        }
+        const ArenaExtent::PrecompCheck& C = e->pcheck;
+        if (C.state != 0 && C.curve == h->curve && C.phase == phase && first >= C.first && first + (uint64_t)nelem * 8 <= C.first + C.npts) {
+            *ok = C.state == 1;
+            h->pc_info[1] = (uint64_t)C.state;
+            h->pc_info[2] = (uint64_t)(C.ms * 1000.0f);
+            return BLZ_OK;
+        }
+        if (!A.build_flags && hipMalloc((void**)&A.build_flags, 256 * sizeof(uint32_t)) != hipSuccess) {
+            (void)hipGetLastError();
+            A.build_flags = nullptr;
+            BLZ_LOG(1, "precompute plan: no memory for the check's flag: exact path");
+            return BLZ_OK;
+        }
+        flag = A.build_flags + (A.build_flag_next++ & 255u);
+        epoch = e->epoch;
+        hipStream_t st = h->eng.stream;
+        if (hipEventCreate(&t0) != hipSuccess || hipEventCreate(&t1) != hipSuccess) {
+            if (t0) (void)hipEventDestroy(t0);
+            return fail(BLZ_ERR_UNKNOWN, "event creation failed");
+        }
+        int rc = BLZ_OK;
+        if (hipMemsetAsync(flag, 0, 4, st) != hipSuccess || hipEventRecord(t0, st) != hipSuccess) rc = fail(BLZ_ERR_UNKNOWN, "precompute check: enqueue failed");
+        if (rc == BLZ_OK) rc = h->eng.check_precompute((const char*)e->raw + (pos - e->start), nelem, flag, st);
+        if (rc == BLZ_OK && hipEventRecord(t1, st) != hipSuccess) rc = fail(BLZ_ERR_UNKNOWN, "precompute check: enqueue failed");
+        if (rc != BLZ_OK) {
+            (void)hipEventDestroy(t0);
+            (void)hipEventDestroy(t1);
+            return rc;
+        }
+    }
+    // (the raw bytes cannot go away under the kernel: whoever frees or moves an extent drains the device first)
+    uint32_t flag_h = 1;
+    wait_clear();
+    int rc = sync_event_bounded(t1, "precompute plan: table check");
+    if (rc != BLZ_OK && wait_timed_out()) h->wedged = true;
+    float ms = 0;
+    if (rc == BLZ_OK) {
+        (void)hipEventElapsedTime(&ms, t0, t1);
+        if (hipMemcpy(&flag_h, flag, 4, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(BLZ_ERR_READ, "precompute check: flag read failed");
+    }
+    if (rc == BLZ_OK || !wait_timed_out()) {
+        (void)hipEventDestroy(t0);
+        (void)hipEventDestroy(t1);
+    }
+    BLZ_TRY(rc);
+    std::lock_guard<std::mutex> lk(A.mu);
+    ArenaExtent* e = arena_find(A, pos, len);
+    if (!e || e->epoch != epoch) {
+        BLZ_LOG(1, "precompute plan: the extent was written while its table was being checked: exact path for this task");
+        return BLZ_OK;
+    }
+    ArenaExtent::PrecompCheck& C = e->pcheck;
+    C.state = flag_h ? 2 : 1;
+    C.curve = h->curve;
+    C.phase = phase;
+    C.first = first;
+    C.npts = (uint64_t)nelem * 8;
+    C.ms = ms;
+    *ok = flag_h == 0;
+    h->pc_info[1] = (uint64_t)C.state;
+    h->pc_info[2] = (uint64_t)(ms * 1000.0f);
+    BLZ_LOG(1, "precompute plan: table of %u elements %s (%.1f ms)", nelem,
+            flag_h ? "is NOT B_j = 2^32 B_(j-1) over on-curve bases: exact path (8n points, 32-bit chunks)" : "is consistent: 4n even bases, 64-bit chunks", ms);
     return BLZ_OK;
 }
 
@@ -158,7 +265,7 @@ int arena_points_table(blz_msm* h, uint64_t pos, uint32_t npts, const void** out
     if (!e)
         return fail(BLZ_ERR_INVALID_PARAM, "HBM bases: no loaded extent covers [%llu, +%zu) on device %d",
                     (unsigned long long)pos, len, h->device);
-    if (npts == 0 || e->table_refused) return BLZ_OK;
+    if (npts == 0) return BLZ_OK;
     const uint32_t phase = (uint32_t)((pos - e->start) % ps);
     const uint64_t first = (pos - e->start - phase) / ps;
     const int fmt = h->eng.format_id();
@@ -240,6 +347,8 @@ int arena_points_table(blz_msm* h, uint64_t pos, uint32_t npts, const void** out
         if (t.format == fmt && t.phase == phase && first >= t.first && first + npts <= t.first + t.npts && t.lo == lo && t.hi == hi) T = &t;
     if (T && T->c != want_c) return BLZ_OK;   // a sub-range that wants other windows: the plain path, not a rebuild
     if (!T) {
+        // (a refusal - no memory for a table, a base of even order - stops NEW builds until the next write; tables that are
+        // in place keep being served, and a build in flight keeps being paced)
         if (B.tab) {
             // a build in flight: this launch pays its share if the build is for this handle's bases and range (one build at a
             // time: another's turn comes when this one is through)
@@ -247,6 +356,7 @@ int arena_points_table(blz_msm* h, uint64_t pos, uint32_t npts, const void** out
                 BLZ_TRY(enqueue_chunks(chunk_budget));
             return BLZ_OK;
         }
+        if (e->table_refused) return BLZ_OK;
         if (e->tables.size() >= ArenaExtent::MAX_TABLES) {
             BLZ_LOG(1, "window table: the extent already holds %zu tables: plain path for this handle", e->tables.size());
             return BLZ_OK;
@@ -300,6 +410,8 @@ int arena_points_table(blz_msm* h, uint64_t pos, uint32_t npts, const void** out
             (void)hipGetLastError();
             A.build_flags = nullptr;
             (void)hipFree(tab);
+            if (t0) (void)hipEventDestroy(t0);
+            if (done) (void)hipEventDestroy(done);
             e->table_refused = true;
             return BLZ_OK;
         }
@@ -345,6 +457,52 @@ bool wants_table(const blz_msm* h) {
     return h->pf == 1 && (h->window_table == 2 || (h->window_table == 1 && h->curve != BLZ_BN254));
 }
 
+// BN254 has two arithmetics (msm_engine.hpp `repr`): the 9 x 29-bit reduced radix wins while the accumulation is bound by its
+// multiplier, 32-bit limbs win once it is bound by the reach of the TLB over the gathered copy.  The exact path of a precompute
+// handle always runs on 32-bit limbs (2^29 bases, 32 GiB); the plan's even-base copy is a quarter of that per element, so it
+// takes the reduced radix up to 2^25 elements (8 GiB of even bases) and 32-bit limbs above - measured, same box, ms per MSM in a
+// stream of tasks, reduced radix / 32-bit limbs: 2^20 1.85 / 2.20, 2^22 6.60 / 7.49, 2^24 18.2 / 19.2, 2^26 74.8 / 70.0
+// (exact path: 2.2, 7.2, 24.6, 92.5).  BLAZE_MSM_PLAN pc_repr=0|1 forces one (tests).  Switched only while nothing of the
+// handle is in flight.
+int plan_repr_bn254(uint32_t nelem) {
+    const int forced = plan_override("pc_repr", -1);
+    if (forced == 0 || forced == 1) return forced;
+    return nelem > (1u << 25) ? 1 : 0;
+}
+
+// Which task serves `n` elements whose bases sit in the arena at `pos`: a precompute handle on the checked-table plan whose
+// table is consistent sums 4n even bases over 64-bit chunks; a pf = 1 handle with a window table in place gathers from it;
+// everything else is the plain task over the Montgomery copy.  Resolves h->d_points_mont (shadow pointers are resolved when
+// the task is launched, not when its data was staged: a load by another handle in between may have moved or re-converted
+// the extent).
+int resolve_arena_task(blz_msm* h, uint64_t pos, uint32_t n, bool allow_table, uint32_t* npts, int* sbits, int* table_c) {
+    *npts = n * h->pf;
+    *sbits = h->pf == 1 ? 256 : 32;
+    *table_c = 0;
+    memset(h->table_info, 0, sizeof(h->table_info));
+    memset(h->pc_info, 0, sizeof(h->pc_info));
+    if (h->pf == BLZ_PRECOMPUTE_FACTOR && h->precompute_plan && n > 0) {
+        bool ok = false;
+        BLZ_TRY(arena_precompute_check(h, pos, n, &ok));
+        if (h->curve == BLZ_BN254 && h->in_flight.empty()) h->eng.repr = exp_knob("BLAZE_BN254_REPR", ok ? plan_repr_bn254(n) : 1) ? 1 : 0;
+        if (ok && h->eng.plan_for(n * 4, 64).c != 0) {
+            BLZ_TRY(arena_points_mont(h, pos, n * 8, &h->d_points_mont, true));
+            *npts = n * 4;
+            *sbits = 64;
+            h->pc_info[0] = 1;
+            return BLZ_OK;
+        }
+    }
+    if (allow_table && wants_table(h)) {
+        const void* tab = nullptr;
+        BLZ_TRY(arena_points_table(h, pos, *npts, &tab, table_c, TABLE_CHUNKS_PER_TASK));
+        if (tab) h->d_points_mont = tab;
+        else *table_c = 0;
+    }
+    if (!*table_c) BLZ_TRY(arena_points_mont(h, pos, *npts, &h->d_points_mont));
+    return BLZ_OK;
+}
+
 int launch_if_ready(blz_msm* h) {
     if (!(h->armed && h->data_ready)) return BLZ_OK;
     if (!h->eng.can_accept())
@@ -352,19 +510,10 @@ int launch_if_ready(blz_msm* h) {
     uint32_t npts = h->staged_n * h->pf;
     int sbits = h->pf == 1 ? 256 : 32;
     int slot = 0;
-    // bases in the arena: the shadow pointer is resolved now, not when the data was staged - a load by another
-    // handle in between may have moved or re-converted the extent
     int table_c = 0;
     memset(h->table_info, 0, sizeof(h->table_info));
-    if (h->staged_from_arena) {
-        if (wants_table(h)) {
-            const void* tab = nullptr;
-            BLZ_TRY(arena_points_table(h, h->staged_arena_pos, npts, &tab, &table_c, TABLE_CHUNKS_PER_TASK));
-            if (tab) h->d_points_mont = tab;
-            else table_c = 0;
-        }
-        if (!table_c) BLZ_TRY(arena_points_mont(h, h->staged_arena_pos, npts, &h->d_points_mont));
-    }
+    memset(h->pc_info, 0, sizeof(h->pc_info));
+    if (h->staged_from_arena) BLZ_TRY(resolve_arena_task(h, h->staged_arena_pos, h->staged_n, true, &npts, &sbits, &table_c));
     h->eng.inputs_event = h->staged_set >= 0 ? h->set_free[h->staged_set] : nullptr;
     BLZ_TRY(h->eng.run(h->d_points_mont, h->d_scalars, npts, sbits, &slot, table_c, h->range_lo, h->range_hi));
     if (h->staged_set >= 0) h->set_used[h->staged_set] = true;
@@ -447,21 +596,27 @@ int stage_common(blz_msm* h, bool have_points, const void* points, size_t points
     // otherwise cross the link with the chip doing nothing (38 of 163 ms at 2^26); in a stream of tasks the whole upload
     // already hides under the previous task's accumulation, and the task keeps its one-piece form (hidden sort, no
     // carried sums).
-    const int sbits = h->pf == 1 ? 256 : 32;
+    int sbits = h->pf == 1 ? 256 : 32;
     const bool dma_pieces = !on_device && !has_hbm && h->armed && npts > 0 && exp_knob("BLAZE_DMA_OVERLAP", 1) != 0;
     const bool hbm_pieces = !on_device && has_hbm && h->armed && npts > 0 && (npts >= (1u << 22) || env_int("BLAZE_MSM_PIECES", 0) > 1) &&
                             h->in_flight.empty() && !wants_table(h) &&
                             exp_knob("BLAZE_DMA_OVERLAP", 1) != 0;
     if (dma_pieces || hbm_pieces) {
-        const size_t mp = mont_point_bytes(h->curve), ps = point_size(h), sb = (size_t)sbits / 8;
+        const size_t mp = mont_point_bytes(h->curve), ps = point_size(h);
         BLZ_TRY(h->scalars_buf[set].reserve(scalars_len));
         const void* arena_mont = nullptr;
+        memset(h->table_info, 0, sizeof(h->table_info));
+        memset(h->pc_info, 0, sizeof(h->pc_info));
         if (dma_pieces) {
             BLZ_TRY(h->points_raw[set].reserve(want_pts));
             BLZ_TRY(h->points_mont.reserve((size_t)npts * mp));
         } else {
-            BLZ_TRY(arena_points_mont(h, h->staged_arena_pos, npts, &arena_mont));   // (stale spans are converted on the main stream)
+            // (stale spans are converted on the main stream; a precompute handle on the checked-table plan: 4n even bases, 64-bit chunks)
+            int tc = 0;
+            BLZ_TRY(resolve_arena_task(h, h->staged_arena_pos, n, false, &npts, &sbits, &tc));
+            arena_mont = h->d_points_mont;
         }
+        const size_t sb = (size_t)sbits / 8;
         // pieces of >= 2^19 points with their scalars (64 MiB of host bytes: 1.2 ms of link), at most 16.
         // Measured (profiles/r04_dma_pieces.txt): 2^22 elements 22.6 ms in one piece, 16.2 / 15.35 / 17.1 in 4 / 8 / 16; 2^26
         // 270.8, 191.8 / 178.3 / 171.5
@@ -486,7 +641,6 @@ int stage_common(blz_msm* h, bool have_points, const void* points, size_t points
         if (pieces < 1) pieces = 1;
         int slot = -1;
         h->eng.inputs_event = h->set_free[set];
-        memset(h->table_info, 0, sizeof(h->table_info));
         BLZ_TRY(h->eng.begin(npts, sbits, &slot, 0, h->range_lo, h->range_hi, pieces, true));
         const uint32_t per = h->eng.slots[slot].pts_per_slice;
         pieces = h->eng.slots[slot].slices;
@@ -668,15 +822,60 @@ int blz_msm_prepare_window_table(blz_msm* h, uint32_t nof_elements, uint64_t hbm
         }
         bool building = false;
         {
+            // is the build in flight THIS handle's (its bases, its scalar range)?  Another handle's build is paced by that
+            // handle's tasks: waiting for it here would sit out the whole deadline (one build at a time per extent)
             Arena& A = arena_for(h->device);
             std::lock_guard<std::mutex> lk(A.mu);
-            ArenaExtent* e = arena_find(A, hbm_addr + hbm_off, (size_t)nof_elements * point_size(h));
-            building = e && e->build.tab != nullptr;
+            const size_t ps = point_size(h);
+            const uint64_t pos = hbm_addr + hbm_off;
+            ArenaExtent* e = arena_find(A, pos, (size_t)nof_elements * ps);
+            if (e && e->build.tab != nullptr) {
+                const ArenaExtent::TableBuild& B = e->build;
+                const uint32_t phase = (uint32_t)((pos - e->start) % ps);
+                const uint64_t first = (pos - e->start - phase) / ps;
+                const int lo = h->range_hi ? h->range_lo : 0, hi = h->range_hi ? h->range_hi : 256;
+                building = B.format == h->eng.format_id() && B.phase == phase && first >= B.first && first + nof_elements <= B.first + B.npts &&
+                           B.lo == lo && B.hi == hi;
+            }
         }
-        if (!building) return BLZ_OK;   // refused (no memory, a base of even order), or another handle's table stays
+        if (!building) return BLZ_OK;   // refused (no memory, a base of even order), another handle's table stays, or another handle's build is in flight
         if (std::chrono::steady_clock::now() - t0 >= std::chrono::milliseconds(limit)) return BLZ_OK;
         std::this_thread::sleep_for(std::chrono::microseconds(200));
     }
+}
+
+int blz_msm_set_precompute_plan(blz_msm* h, int enable) {
+    if (!h) return fail(BLZ_ERR_INVALID_PARAM, "null handle");
+    if (enable != 0 && enable != 1) return fail(BLZ_ERR_INVALID_PARAM, "precompute plan mode %d (0 exact path, 1 checked-table plan)", enable);
+    if (enable && h->pf != BLZ_PRECOMPUTE_FACTOR) return fail(BLZ_ERR_INVALID_PARAM, "the checked-table plan is for precompute handles (MSMInit.is_precompute)");
+    h->precompute_plan = enable;
+    return BLZ_OK;
+}
+
+int blz_msm_prepare_precompute_plan(blz_msm* h, uint32_t nof_elements, uint64_t hbm_addr, uint64_t hbm_off, int* consistent) {
+    if (!h) return fail(BLZ_ERR_INVALID_PARAM, "null handle");
+    BLZ_LIVE(h);
+    if (consistent) *consistent = 0;
+    BLZ_TRY(use_device(h->device));
+    if (!h->precompute_plan || nof_elements == 0) return BLZ_OK;
+    if ((uint64_t)nof_elements * h->pf >= (1ull << 31)) return fail(BLZ_ERR_INVALID_PARAM, "too many points");
+    bool ok = false;
+    BLZ_TRY(arena_precompute_check(h, hbm_addr + hbm_off, nof_elements, &ok));
+    if (ok && h->in_flight.empty()) {
+        // the even-base copy too, so that the first task finds it in place
+        if (h->curve == BLZ_BN254) h->eng.repr = exp_knob("BLAZE_BN254_REPR", plan_repr_bn254(nof_elements)) ? 1 : 0;
+        const void* p = nullptr;
+        BLZ_TRY(arena_points_mont(h, hbm_addr + hbm_off, nof_elements * 8, &p, true));
+        BLZ_WAIT(h, sync_stream_bounded(h->eng.stream, "precompute plan: even-base copy"));
+    }
+    if (consistent) *consistent = ok ? 1 : 0;
+    return BLZ_OK;
+}
+
+int blz_msm_precompute_plan_info(blz_msm* h, uint64_t out[4]) {
+    if (!h || !out) return fail(BLZ_ERR_INVALID_PARAM, "null argument");
+    for (int i = 0; i < 4; ++i) out[i] = h->pc_info[i];
+    return BLZ_OK;
 }
 
 int blz_msm_set_scalar_range(blz_msm* h, uint32_t bit_lo, uint32_t bit_hi) {
@@ -934,6 +1133,44 @@ int blz_msm_reset(blz_msm* h) {
 int blz_msm_last_timings(blz_msm* h, float out[8]) {
     if (!h || !out) return fail(BLZ_ERR_INVALID_PARAM, "null argument");
     memcpy(out, h->eng.last_ms, sizeof(float) * 8);
+    return BLZ_OK;
+}
+
+// Device memory behind a handle, in bytes: [0] the engine's workspace (sort intermediates, entries, bucket tables, partial
+// sums, reduce levels: grown to the largest task seen), [1] the handle's staging buffers (host scalars / points of DMA-mode tasks,
+// their Montgomery copy, the exchange buffer), and - shared by every handle of the device - the arena: [2] raw bytes as loaded
+// (allocated capacity), [3] Montgomery copies of the bases, [4] window tables (built, being built, and the builds' scratch rows);
+// [5] the sum.
+int blz_msm_memory_info(blz_msm* h, uint64_t out[6]) {
+    if (!h || !out) return fail(BLZ_ERR_INVALID_PARAM, "null argument");
+    MsmEngine& E = h->eng;
+    uint64_t ws = 0;
+    for (const DevBuf* b : {&E.coarse, &E.inter, &E.inter2, &E.slice_map, &E.partial, &E.blocksums, &E.result, &E.sort3_tabs, &E.bucket_sums, &E.bucket_ident})
+        ws += b->cap;
+    for (const auto& B : E.sbuf)
+        for (const DevBuf* b : {&B.count, &B.off, &B.unit_off, &B.unit_bucket, &B.unit_order, &B.lenhist, &B.entries, &B.stats, &B.range_scalars}) ws += b->cap;
+    for (const auto& S : E.slots)
+        for (const DevBuf* b : {&S.lvlA[0], &S.lvlA[1], &S.lvlC[0], &S.lvlC[1]}) ws += b->cap;
+    uint64_t staging = h->points_mont.cap + h->comm_buf.cap;
+    for (int i = 0; i < 2; ++i) staging += h->scalars_buf[i].cap + h->points_raw[i].cap;
+    uint64_t raw = 0, mont = 0, tables = 0;
+    {
+        Arena& A = arena_for(h->device);
+        std::lock_guard<std::mutex> lk(A.mu);
+        for (const auto& e : A.ext) {
+            if (!e.imported) raw += e.cap;
+            if (e.mont) mont += e.mont_bytes;
+            for (const auto& t : e.tables) tables += t.bytes;
+            if (e.build.tab) tables += e.build.bytes;
+        }
+        tables += A.build_scratch_bytes;
+    }
+    out[0] = ws;
+    out[1] = staging;
+    out[2] = raw;
+    out[3] = mont;
+    out[4] = tables;
+    out[5] = ws + staging + raw + mont + tables;
     return BLZ_OK;
 }
 

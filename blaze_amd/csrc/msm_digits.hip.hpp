@@ -13,6 +13,10 @@ struct ScalarWords {
             const uint4* q = reinterpret_cast<const uint4*>(scalars) + 2 * (size_t)p;
             uint4 a = q[0], b = q[1];
             s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
+        } else if constexpr (SW == 2) {
+            // the 64-bit chunks of a precompute handle on the checked-table plan (msm_capi.hip resolve_precompute_plan)
+            const uint2 a = reinterpret_cast<const uint2*>(scalars)[p];
+            s[0] = a.x; s[1] = a.y;
         } else {
             s[0] = scalars[p];
         }
@@ -29,5 +33,14 @@ struct ScalarWords {
     }
 };
 
+
+// Launch dispatch on the scalar width: SW = 32-bit words per scalar - 8 (256-bit scalars), 2 (the 64-bit chunks of a
+// precompute handle on the checked-table plan) or 1 (its 32-bit chunks on the exact path)
+#define BLZ_SW_DISPATCH(sbits, ...)                                   \
+    do {                                                              \
+        if ((sbits) == 256) { constexpr int SW = 8; __VA_ARGS__; }    \
+        else if ((sbits) == 64) { constexpr int SW = 2; __VA_ARGS__; } \
+        else { constexpr int SW = 1; __VA_ARGS__; }                   \
+    } while (0)
 
 }  // namespace blz

@@ -13,7 +13,7 @@ namespace blz {
 constexpr int MSM_MAX_W = 96;
 struct MsmPlan {
     uint32_t npts = 0;   // points in the sum (n * precompute_factor)
-    int sbits = 256;     // scalar width per point: 256 (pf=1) or 32 (pf=8 chunk)
+    int sbits = 256;     // scalar width per point: 256 (pf=1), 32 (pf=8 chunk) or 64 (pf=8, checked-table plan: two chunks per even base)
     int c = 0;           // widest lower window (reported as window_bits)
     int W = 0;           // windows; their widths sum to >= sbits+1 (signed digits carry into the top one)
     uint8_t width[MSM_MAX_W] = {};     // bits of window w, low to high
@@ -139,6 +139,8 @@ struct MsmEngine {
     MsmPlan plan_for(uint32_t npts, int sbits) const;   // the plan run() will use (host-side only)
     // raw wire-format points (x||y canonical LE) -> Montgomery AoS at mont_point_bytes() stride (never in place)
     int points_to_mont(const void* d_raw, void* d_mont, uint32_t npts);
+    int points_to_mont_even(const void* d_raw, void* d_mont, uint32_t nq);
+    int check_precompute(const void* d_raw, uint64_t nelem, uint32_t* flag, hipStream_t st);
     // window table of npts wire-format points (msm_impl.hip.hpp k_build_window_table): see MsmCurveOps::build_table
     int build_table(const void* d_raw, void* d_table, uint32_t npts, int c, int W, int base_shift, void* scratch, uint32_t* flag,
                     hipStream_t st);
@@ -198,6 +200,11 @@ struct MsmCurveOps {
                        uint32_t* flag, hipStream_t st);
     size_t (*table_scratch_bytes)(int W);
     int (*combine)(MsmEngine&, const uint8_t* partials, size_t count, uint8_t* out, bool on_device);
+    // checked-table plan of precompute handles (msm_impl.hip.hpp k_check_precompute / k_points_to_mont_even):
+    // Montgomery copy of the even bases of nq / 4 elements (raw: 8 wire-format points per element; nq = 4 per element);
+    // *flag (device u32) is raised when the table of nelem elements is not B_j = 2^32 B_(j-1) over on-curve B_0
+    int (*points_to_mont_even)(MsmEngine&, const void* d_raw, void* d_mont, uint32_t nq);
+    int (*check_precompute)(MsmEngine&, const void* d_raw, uint64_t nelem, uint32_t* flag, hipStream_t st);
 };
 const MsmCurveOps& msm_ops_bls377();
 const MsmCurveOps& msm_ops_bls381();

@@ -70,6 +70,100 @@ __global__ __launch_bounds__(256) void k_points_to_mont(const uint32_t* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
+// Checked-table plan of precompute handles (opt-in: blz_msm_set_precompute_plan; msm_capi.hip arena_precompute_check).
+// The reference's precompute mode (MSMInit.is_precompute, msm_api.rs:39-50) has the CALLER supply, per element, the 8 bases
+// B_j = 2^(32 j) P (precompute_base_*: tests/msm/mod.rs:360-380) and the device sums s_j B_j over the 32-bit chunks s_j of the
+// scalar.  Served as the 8n-point MSM it is, that is 16 bucket additions per element (two 17-bit windows per chunk) against 12
+// without the table.  IF the table is what precompute_base_* produces, the same sum is sum_k (s_2k + 2^32 s_(2k+1)) B_2k:
+// 4n points with 64-bit scalars - three windows of 22 / 22 / 21 bits, 12 additions per element into 3 bucket sets of 2^21 +
+// 2^21 + 2^20 slots.  The library cannot take the caller's word for it (a table that is NOT consistent has a defined result
+// too: the exact sum over all 8 bases), so the resident table is checked once per load, base by base:
+//   k_check_precompute      one lane per (element, j in 1..7): 32 doublings of B_(j-1), compared with B_j projectively
+//                           (X3 == x_j ZZ3, Y3 == y_j ZZZ3, ZZ3 != 0: no inversion); the j = 1 lane also checks that B_0 is
+//                           on the curve (then every B_j is, and every evaluation order of the sum gives the same point).
+//                           Any miss raises *flag and the extent stays on the exact path.
+//   k_points_to_mont_even   the Montgomery copy of the even bases only (B_0, B_2, B_4, B_6 of every element, contiguous):
+//                           half the copy's memory, and the 4n-point task gathers from it with plain indices.
+// ------------------------------------------------------------------------------------------------
+template <class F>
+__global__ __launch_bounds__(256) void k_points_to_mont_even(const uint32_t* __restrict__ raw, uint32_t* __restrict__ mont, uint32_t nq) {
+    const uint32_t q = blockIdx.x * 256u + threadIdx.x;
+    if (q >= nq) return;
+    const size_t p = (size_t)(q >> 2) * 8u + (size_t)(q & 3u) * 2u;
+    Fp<F> x, y;
+    fp_load(x, raw + p * 2 * F::N);
+    fp_load(y, raw + p * 2 * F::N + F::N);
+    store_mont_point<F>(mont, q, x, y);
+}
+
+constexpr int TAG_CHECK = 77;
+template <class F>
+__global__ __launch_bounds__(64, 3) void k_check_precompute(const uint32_t* __restrict__ raw, uint64_t nelem, uint32_t* __restrict__ flag) {
+    const uint64_t items = nelem * 7u;
+    for (uint64_t t = (uint64_t)blockIdx.x * 64u + threadIdx.x; t < items; t += (uint64_t)gridDim.x * 64u) {
+        if (*(volatile uint32_t*)flag) return;   // refuted already
+        const uint64_t i = t / 7u;
+        const uint32_t j = (uint32_t)(t - i * 7u) + 1u;
+        const uint32_t* src = raw + (i * 8u + (j - 1u)) * 2 * F::N;
+        const uint32_t* dst = src + 2 * F::N;
+        Fp<F> x0, y0, x1, y1;
+        fp_load(x0, src); fp_load(y0, src + F::N);
+        fp_load(x1, dst); fp_load(y1, dst + F::N);
+        bool ok = true;
+        if (j == 1u) {
+            // B_0 on the curve: y^2 == x^3 + b
+            Fp<F> xm, ym, l, r, b;
+            fp_to_mont(xm, x0);
+            fp_to_mont(ym, y0);
+            fp_sqr(l, ym);
+            fp_sqr(r, xm);
+            fp_mul(r, r, xm);
+#pragma unroll
+            for (int k = 0; k < F::N; ++k) b.v[k] = F::CURVE_B[k];
+            fp_add(r, r, b);
+            ok = fp_eq(l, r);
+        }
+        if constexpr (USE_RR<F>) {
+            using Q = typename F::RR;
+            Frr<Q, 1, 2> ax, ay;
+            AffineRR<Q> bj;
+            rr_to_mont_from_words<Q>(ax, x0.v);
+            rr_to_mont_from_words<Q>(ay, y0.v);
+            rr_to_mont_from_words<Q>(bj.x, x1.v);
+            rr_to_mont_from_words<Q>(bj.y, y1.v);
+            XYZZRR<Q> p = ptrr_mdbl_val<Q, TAG_CHECK>(ax, rr_cneg<2>(ay, false));
+            // (a doubling that reaches infinity - ZZ == 0 mod m - stays there: every later ZZ is a multiple of it)
+#pragma unroll 1
+            for (int d = 1; d < 32; ++d) ptrr_dbl_inl(p);
+            if (rr_is_zero(p.zz)) ok = false;   // 2^32 B_(j-1) is the point at infinity: no affine B_j equals it
+            Frr<Q, 1, 2> U2, S2;
+            rr_mul_pair(U2, bj.x, p.zz, S2, bj.y, p.zzz);
+            const auto P0 = rr_sub<RR_JX<Q>>(U2, p.x);
+            const auto R0 = rr_sub<RR_JY<Q>>(S2, p.y);
+            if (!rr_is_zero(P0) || !rr_is_zero(R0)) ok = false;
+        } else {
+            Affine<F> a, bj;
+            fp_to_mont(a.x, x0);
+            fp_to_mont(a.y, y0);
+            fp_to_mont(bj.x, x1);
+            fp_to_mont(bj.y, y1);
+            XYZZ<F> p;
+            pt_mdbl(p, a);
+            for (int d = 1; d < 32; ++d) { XYZZ<F> t2; pt_dbl(t2, p); p = t2; }
+            if (fp_is_zero(p.zz)) ok = false;
+            Fp<F> U2, S2;
+            fp_mul(U2, bj.x, p.zz);
+            fp_mul(S2, bj.y, p.zzz);
+            if (!fp_eq(U2, p.x) || !fp_eq(S2, p.y)) ok = false;
+        }
+        if (!ok) {
+            atomicOr(flag, 1u);
+            return;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Window table of resident bases (opt-in: blz_msm_set_window_table): table[i W + j] = 2^(c j) P_i, j < W, in the
 // Montgomery point format above.  With the window weights moved into the points, all W windows of a scalar add into
 // ONE bucket set, so the bucket count no longer multiplies with the window count and the windows can be as wide as
@@ -1442,6 +1536,25 @@ int build_table_t(MsmEngine& E, const void* d_raw, void* d_table, uint32_t npts,
     return BLZ_OK;
 }
 
+constexpr uint32_t CHECK_BLOCKS = 256 * 4 * 3;   // 64-lane blocks: three waves on every SIMD
+template <class F>
+int points_to_mont_even_t(MsmEngine& E, const void* d_raw, void* d_mont, uint32_t nq) {
+    if (nq == 0) return BLZ_OK;
+    hipLaunchKernelGGL(k_points_to_mont_even<F>, dim3((nq + 255) / 256), dim3(256), 0, E.stream, (const uint32_t*)d_raw, (uint32_t*)d_mont, nq);
+    BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
+    return BLZ_OK;
+}
+template <class F>
+int check_precompute_t(MsmEngine& E, const void* d_raw, uint64_t nelem, uint32_t* flag, hipStream_t st) {
+    (void)E;
+    if (nelem == 0) return BLZ_OK;
+    const uint64_t want = (nelem * 7u + 63u) / 64u;
+    const uint32_t blocks = (uint32_t)(want < CHECK_BLOCKS ? want : CHECK_BLOCKS);
+    hipLaunchKernelGGL(k_check_precompute<F>, dim3(blocks), dim3(64), 0, st, (const uint32_t*)d_raw, nelem, flag);
+    BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
+    return BLZ_OK;
+}
+
 template <class F>
 int accumulate_vgprs_t() {
     hipFuncAttributes a;
@@ -1465,6 +1578,8 @@ MsmCurveOps make_ops() {
     o.build_table = &build_table_t<F>;
     o.table_scratch_bytes = &table_scratch_bytes_t<F>;
     o.combine = &combine_t<F>;
+    o.points_to_mont_even = &points_to_mont_even_t<F>;
+    o.check_precompute = &check_precompute_t<F>;
     return o;
 }
 

@@ -524,13 +524,12 @@ int msm_sort_lds(MsmEngine& E, const void* d_scalars, uint32_t npts, int sbits) 
     uint32_t* coarse_off = coarse_count + g.NC;
     BLZ_HIP(hipMemsetAsync(coarse_count, 0, (size_t)g.NC * 4, st), BLZ_ERR_UNKNOWN);
     const size_t lds = (size_t)g.NC * 4;
-    BLZ_TRY(ensure_dynamic_lds((const void*)k_coarse_count<8>, 128 * 1024));
-    BLZ_TRY(ensure_dynamic_lds((const void*)k_coarse_count<1>, 128 * 1024));
-    BLZ_TRY(ensure_dynamic_lds((const void*)k_coarse_scatter<8>, 128 * 1024));
-    BLZ_TRY(ensure_dynamic_lds((const void*)k_coarse_scatter<1>, 128 * 1024));
+    BLZ_SW_DISPATCH(sbits, {
+        BLZ_TRY(ensure_dynamic_lds((const void*)k_coarse_count<SW>, 128 * 1024));
+        BLZ_TRY(ensure_dynamic_lds((const void*)k_coarse_scatter<SW>, 128 * 1024));
+    });
     const uint32_t* sc = (const uint32_t*)d_scalars;
-    if (sbits == 256) hipLaunchKernelGGL(k_coarse_count<8>, dim3(nblk), dim3(SORT_THREADS), lds, st, sc, npts, g, coarse_count);
-    else hipLaunchKernelGGL(k_coarse_count<1>, dim3(nblk), dim3(SORT_THREADS), lds, st, sc, npts, g, coarse_count);
+    BLZ_SW_DISPATCH(sbits, hipLaunchKernelGGL(k_coarse_count<SW>, dim3(nblk), dim3(SORT_THREADS), lds, st, sc, npts, g, coarse_count));
     hipLaunchKernelGGL(k_coarse_scan, dim3(1), dim3(1024), 0, st, coarse_count, g.NC, coarse_off);
     // BLAZE_SORT_STAGED=0 selects the unstaged coarse scatter (kept for A/B measurements)
     if (exp_knob("BLAZE_SORT_STAGED", 1) != 0 && g.chmax <= 11 && g.cl <= 12) {
@@ -538,21 +537,15 @@ int msm_sort_lds(MsmEngine& E, const void* d_scalars, uint32_t npts, int sbits) 
         const uint32_t pts_blk = (uint32_t)CS_THREADS * (small ? CS_T_SMALL : CS_T);
         const uint32_t nblk_cs = (npts + pts_blk - 1) / pts_blk;
         const size_t lds_cs = ((size_t)3 << g.chmax) * 4 + (size_t)pts_blk * 8;
-        BLZ_TRY(ensure_dynamic_lds((const void*)k_coarse_scatter_staged<8, CS_T>, 96 * 1024));
-        BLZ_TRY(ensure_dynamic_lds((const void*)k_coarse_scatter_staged<1, CS_T>, 96 * 1024));
-        BLZ_TRY(ensure_dynamic_lds((const void*)k_coarse_scatter_staged<8, CS_T_SMALL>, 96 * 1024));
-        BLZ_TRY(ensure_dynamic_lds((const void*)k_coarse_scatter_staged<1, CS_T_SMALL>, 96 * 1024));
-        if (sbits == 256) {
-            if (small) hipLaunchKernelGGL((k_coarse_scatter_staged<8, CS_T_SMALL>), dim3(nblk_cs), dim3(CS_THREADS), lds_cs, st, sc, npts, g, coarse_count, inter_idx, inter_fine);
-            else hipLaunchKernelGGL((k_coarse_scatter_staged<8, CS_T>), dim3(nblk_cs), dim3(CS_THREADS), lds_cs, st, sc, npts, g, coarse_count, inter_idx, inter_fine);
-        } else {
-            if (small) hipLaunchKernelGGL((k_coarse_scatter_staged<1, CS_T_SMALL>), dim3(nblk_cs), dim3(CS_THREADS), lds_cs, st, sc, npts, g, coarse_count, inter_idx, inter_fine);
-            else hipLaunchKernelGGL((k_coarse_scatter_staged<1, CS_T>), dim3(nblk_cs), dim3(CS_THREADS), lds_cs, st, sc, npts, g, coarse_count, inter_idx, inter_fine);
-        }
-    } else if (sbits == 256)
-        hipLaunchKernelGGL(k_coarse_scatter<8>, dim3(nblk), dim3(SORT_THREADS), lds, st, sc, npts, g, coarse_count, inter_idx, inter_fine);
-    else
-        hipLaunchKernelGGL(k_coarse_scatter<1>, dim3(nblk), dim3(SORT_THREADS), lds, st, sc, npts, g, coarse_count, inter_idx, inter_fine);
+        BLZ_SW_DISPATCH(sbits, {
+            BLZ_TRY(ensure_dynamic_lds((const void*)k_coarse_scatter_staged<SW, CS_T>, 96 * 1024));
+            BLZ_TRY(ensure_dynamic_lds((const void*)k_coarse_scatter_staged<SW, CS_T_SMALL>, 96 * 1024));
+            if (small) hipLaunchKernelGGL((k_coarse_scatter_staged<SW, CS_T_SMALL>), dim3(nblk_cs), dim3(CS_THREADS), lds_cs, st, sc, npts, g, coarse_count, inter_idx, inter_fine);
+            else hipLaunchKernelGGL((k_coarse_scatter_staged<SW, CS_T>), dim3(nblk_cs), dim3(CS_THREADS), lds_cs, st, sc, npts, g, coarse_count, inter_idx, inter_fine);
+        });
+    } else {
+        BLZ_SW_DISPATCH(sbits, hipLaunchKernelGGL(k_coarse_scatter<SW>, dim3(nblk), dim3(SORT_THREADS), lds, st, sc, npts, g, coarse_count, inter_idx, inter_fine));
+    }
     // work list of the fine passes (device-built, no host sync)
     const uint32_t max_slices = (uint32_t)(max_entries / SLICE) + g.NC + 1;
     BLZ_TRY(E.slice_map.reserve(((size_t)max_slices + 2) * 8));

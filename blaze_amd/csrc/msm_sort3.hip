@@ -76,7 +76,8 @@ __device__ __forceinline__ uint32_t s3_block_excl_scan(uint32_t v, uint32_t* wav
 }
 
 // ---------------------------------------------------------------------------------------------- level 1
-// NW: 32-bit words per scalar - 8 (256-bit scalars) or 1 (the 32-bit chunks of a precompute handle: pf = 8)
+// NW: 32-bit words per scalar - 8 (256-bit scalars), 1 (the 32-bit chunks of a precompute handle: pf = 8) or 2 (its 64-bit
+// chunks on the checked-table plan: msm_capi.hip)
 template <int NW>
 __global__ __launch_bounds__(S3_THREADS, 4) void k3_l1_count(const uint32_t* __restrict__ scalars, uint32_t npts, S3Geom g,
                                                             uint32_t* __restrict__ cnt1) {
@@ -170,6 +171,10 @@ __global__ __launch_bounds__(S3_THREADS, 4) void k3_l1_scatter(const uint32_t* _
             }
             sc[0 * S3_PB + i] = a.x; sc[1 * S3_PB + i] = a.y; sc[2 * S3_PB + i] = a.z; sc[3 * S3_PB + i] = a.w;
             sc[4 * S3_PB + i] = b.x; sc[5 * S3_PB + i] = b.y; sc[6 * S3_PB + i] = b.z; sc[7 * S3_PB + i] = b.w;
+        } else if constexpr (NW == 2) {
+            uint2 a = make_uint2(0, 0);
+            if (p < npts) a = reinterpret_cast<const uint2*>(scalars)[p];
+            sc[0 * S3_PB + i] = a.x; sc[1 * S3_PB + i] = a.y;
         } else {
             sc[i] = p < npts ? scalars[p] : 0u;
         }
@@ -503,7 +508,7 @@ __global__ __launch_bounds__(S3_THREADS, 4) void k3_l3(const uint32_t* __restric
 
 // ---------------------------------------------------------------------------------------------- host
 bool msm_sort3_ok(const MsmPlan& P, int sbits) {
-    if ((sbits != 256 && sbits != 32) || P.W < 1) return false;
+    if ((sbits != 256 && sbits != 64 && sbits != 32) || P.W < 1) return false;
     for (int w = 0; w < P.W; ++w)
         if (P.width[w] < S3_SH1 + 1 || P.width[w] > 23) return false;   // every window a whole number of level-1 bins, <= 256 of them
     if ((P.G >> S3_SH1) > S3_MAXNB1 || (P.G & ((1u << S3_SH1) - 1u))) return false;
@@ -516,7 +521,7 @@ int msm_sort3_max_vgprs() {
     if (cached >= 0) return cached;
     int mx = 0;
     const void* ks[] = {(const void*)k3_l1_count<8>, (const void*)k3_l1_scatter<8>, (const void*)k3_l1_count<1>, (const void*)k3_l1_scatter<1>,
-                        (const void*)k3_l2_count, (const void*)k3_l2_scatter, (const void*)k3_l3};
+                        (const void*)k3_l1_count<2>, (const void*)k3_l1_scatter<2>, (const void*)k3_l2_count, (const void*)k3_l2_scatter, (const void*)k3_l3};
     for (const void* k : ks) {
         hipFuncAttributes a;
         if (hipFuncGetAttributes(&a, k) != hipSuccess) {
@@ -571,18 +576,13 @@ int msm_sort3(MsmEngine& E, const void* d_scalars, uint32_t npts, int sbits) {
 
     BLZ_HIP(hipMemsetAsync(cnt1, 0, (size_t)(NB1 + 2) * 4, st), BLZ_ERR_UNKNOWN);
     BLZ_HIP(hipMemsetAsync(cnt2, 0, (size_t)(NB2 + 2) * 4, st), BLZ_ERR_UNKNOWN);
-    const int NW = sbits == 256 ? 8 : 1;
-    if (NW == 8) hipLaunchKernelGGL(k3_l1_count<8>, dim3((npts + S3_CNT_PTS - 1) / S3_CNT_PTS), blk, 0, st, sc, npts, g, cnt1);
-    else hipLaunchKernelGGL(k3_l1_count<1>, dim3((npts + S3_CNT_PTS - 1) / S3_CNT_PTS), blk, 0, st, sc, npts, g, cnt1);
+    BLZ_SW_DISPATCH(sbits, hipLaunchKernelGGL(k3_l1_count<SW>, dim3((npts + S3_CNT_PTS - 1) / S3_CNT_PTS), blk, 0, st, sc, npts, g, cnt1));
     hipLaunchKernelGGL(k3_scan_small, dim3(1), blk, 0, st, cnt1, NB1, off1, cur1, g.prio);
-    const size_t lds1 = (size_t)((NW + 2) * S3_PB + 3 * 256) * 4;
-    if (NW == 8) {
-        BLZ_TRY(ensure_dynamic_lds((const void*)k3_l1_scatter<8>, (int)lds1));
-        hipLaunchKernelGGL(k3_l1_scatter<8>, dim3((npts + S3_PB - 1) / S3_PB), blk, lds1, st, sc, npts, g, cur1, i1_idx, i1_rem);
-    } else {
-        BLZ_TRY(ensure_dynamic_lds((const void*)k3_l1_scatter<1>, (int)lds1));
-        hipLaunchKernelGGL(k3_l1_scatter<1>, dim3((npts + S3_PB - 1) / S3_PB), blk, lds1, st, sc, npts, g, cur1, i1_idx, i1_rem);
-    }
+    BLZ_SW_DISPATCH(sbits, {
+        const size_t lds1 = (size_t)((SW + 2) * S3_PB + 3 * 256) * 4;
+        BLZ_TRY(ensure_dynamic_lds((const void*)k3_l1_scatter<SW>, (int)lds1));
+        hipLaunchKernelGGL(k3_l1_scatter<SW>, dim3((npts + S3_PB - 1) / S3_PB), blk, lds1, st, sc, npts, g, cur1, i1_idx, i1_rem);
+    });
     hipLaunchKernelGGL(k3_slice_map, dim3(1), blk, 0, st, off1, NB1, S3_SLICE2, map, nitems, g.prio);
     hipLaunchKernelGGL(k3_l2_count, dim3(max_items), blk, 0, st, i1_rem, off1, map, nitems, cnt2, g.prio);
     hipLaunchKernelGGL(k3_scan_a, dim3(nsb), blk, 0, st, cnt2, NB2, bsum, g.prio);

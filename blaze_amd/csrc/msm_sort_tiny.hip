@@ -266,7 +266,7 @@ __global__ __launch_bounds__(TINY_THREADS) void k_tiny_scan(TinyGeom g, uint32_t
 
 bool msm_sort_tiny_ok(const MsmPlan& P, uint32_t npts, int sbits) {
     if (exp_knob("BLAZE_SORT_TINY", 1) == 0) return false;
-    if (P.table || P.W < 1 || (sbits != 256 && sbits != 32)) return false;
+    if (P.table || P.W < 1 || (sbits != 256 && sbits != 64 && sbits != 32)) return false;
     if (P.G == 0 || P.G > TINY_MAX_G || npts > TINY_MAX_PTS || P.L < 1 || P.L > TINY_MAX_L) return false;
     return true;
 }
@@ -295,22 +295,17 @@ int msm_sort_tiny(MsmEngine& E, const void* d_scalars, uint32_t npts, int sbits,
         uint32_t* count = B.count.as<uint32_t>();
         BLZ_HIP(hipMemsetAsync(count, 0, (size_t)g.G * 4, st), BLZ_ERR_UNKNOWN);
         BLZ_TRY(ensure_dynamic_lds((const void*)k_tiny_scan, (int)lds));
-        if (sbits == 256) hipLaunchKernelGGL(k_tiny_hist<8>, dim3(nb), dim3(TINY_THREADS), 0, st, sc, npts, g, count);
-        else hipLaunchKernelGGL(k_tiny_hist<1>, dim3(nb), dim3(TINY_THREADS), 0, st, sc, npts, g, count);
+        BLZ_SW_DISPATCH(sbits, hipLaunchKernelGGL(k_tiny_hist<SW>, dim3(nb), dim3(TINY_THREADS), 0, st, sc, npts, g, count));
         hipLaunchKernelGGL(k_tiny_scan, dim3(1), dim3(TINY_THREADS), lds, st, g, count, B.off.as<uint32_t>(), B.unit_off.as<uint32_t>(),
                            B.unit_bucket.as<uint32_t>(), B.unit_order.as<uint32_t>(), B.lenhist.as<uint32_t>(), B.stats.as<uint32_t>());
-        if (sbits == 256) hipLaunchKernelGGL(k_tiny_place<8>, dim3(nb), dim3(TINY_THREADS), 0, st, sc, npts, g, count, B.entries.as<uint32_t>());
-        else hipLaunchKernelGGL(k_tiny_place<1>, dim3(nb), dim3(TINY_THREADS), 0, st, sc, npts, g, count, B.entries.as<uint32_t>());
-    } else if (sbits == 256) {
-        BLZ_TRY(ensure_dynamic_lds((const void*)k_sort_tiny<8>, (int)lds));
-        hipLaunchKernelGGL(k_sort_tiny<8>, dim3(1), dim3(TINY_THREADS), lds, st, sc, npts, g, B.count.as<uint32_t>(), B.off.as<uint32_t>(),
-                           B.unit_off.as<uint32_t>(), B.entries.as<uint32_t>(), B.unit_bucket.as<uint32_t>(), B.unit_order.as<uint32_t>(),
-                           B.lenhist.as<uint32_t>(), B.stats.as<uint32_t>());
+        BLZ_SW_DISPATCH(sbits, hipLaunchKernelGGL(k_tiny_place<SW>, dim3(nb), dim3(TINY_THREADS), 0, st, sc, npts, g, count, B.entries.as<uint32_t>()));
     } else {
-        BLZ_TRY(ensure_dynamic_lds((const void*)k_sort_tiny<1>, (int)lds));
-        hipLaunchKernelGGL(k_sort_tiny<1>, dim3(1), dim3(TINY_THREADS), lds, st, sc, npts, g, B.count.as<uint32_t>(), B.off.as<uint32_t>(),
-                           B.unit_off.as<uint32_t>(), B.entries.as<uint32_t>(), B.unit_bucket.as<uint32_t>(), B.unit_order.as<uint32_t>(),
-                           B.lenhist.as<uint32_t>(), B.stats.as<uint32_t>());
+        BLZ_SW_DISPATCH(sbits, {
+            BLZ_TRY(ensure_dynamic_lds((const void*)k_sort_tiny<SW>, (int)lds));
+            hipLaunchKernelGGL(k_sort_tiny<SW>, dim3(1), dim3(TINY_THREADS), lds, st, sc, npts, g, B.count.as<uint32_t>(), B.off.as<uint32_t>(),
+                               B.unit_off.as<uint32_t>(), B.entries.as<uint32_t>(), B.unit_bucket.as<uint32_t>(), B.unit_order.as<uint32_t>(),
+                               B.lenhist.as<uint32_t>(), B.stats.as<uint32_t>());
+        });
     }
     BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
     return BLZ_OK;

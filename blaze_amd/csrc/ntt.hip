@@ -11,6 +11,10 @@
 // access), runs the radix-2 stages there and applies the inter-pass twiddle on the way out.
 // Data stay in plain canonical form; only twiddles are in Montgomery form (mont_mul(x, tR) = x t),
 // so there is no conversion pass.  Algorithmic traffic 2 x 4 GiB; this 3-pass form moves 3x that.
+#include <atomic>
+#include <string>
+#include <thread>
+
 #include "common.hpp"
 #include "ntt_engine.hpp"
 
@@ -58,6 +62,8 @@ struct blz_ntt {
     int cols_log[3] = {0, 0, 0};
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;  // host<->buffer traffic, concurrent with the compute stream
+    hipStream_t copy_stream2 = nullptr; // blz_ntt_exchange: the host -> device direction, while copy_stream carries device -> host
+    uint32_t flags = 0;                 // blz_ntt_new_ex2
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     DevBuf buf[2], scratch, tables, tables_rr, table_b;
     NttTables T{};
@@ -139,7 +145,7 @@ int ntt_setup(blz_ntt* h) {
         h->TR.tA = want_ta ? q : nullptr;
         // pass 2's boundary factors, one per element (4 GiB at 2^27: the transform's buffers are 8): only beside tA, whose
         // split of pass 1's factor it completes
-        const bool want_tb = want_ta && exp_knob("BLAZE_NTT_TB", 1) != 0;
+        const bool want_tb = want_ta && !(h->flags & BLZ_NTT_NO_FACTOR_TABLE) && exp_knob("BLAZE_NTT_TB", 1) != 0;
         h->TR.tB = nullptr;
         if (want_tb) {
             // (an optimisation, not a need: a device too full for it steps the factors as smaller transforms do)
@@ -179,8 +185,13 @@ int blz_ntt_new_ex(int device_id, int log_size, int inverse, blz_ntt** out) {
 }
 
 int blz_ntt_new_field(int device_id, int field, int log_size, int inverse, blz_ntt** out) {
+    return blz_ntt_new_ex2(device_id, field, log_size, inverse, 0u, out);
+}
+
+int blz_ntt_new_ex2(int device_id, int field, int log_size, int inverse, uint32_t flags, blz_ntt** out) {
     if (!out) return fail(BLZ_ERR_INVALID_PARAM, "null out");
     *out = nullptr;
+    if (flags & ~(uint32_t)BLZ_NTT_NO_FACTOR_TABLE) return fail(BLZ_ERR_INVALID_PARAM, "unknown NTT flags 0x%x", flags);
     const NttFieldOps* ops = ntt_ops_for(field);
     if (!ops) return fail(BLZ_ERR_INVALID_PARAM, "unknown field %d", field);
     if (log_size < 1 || log_size > 27) return fail(BLZ_ERR_INVALID_PARAM, "log_size %d out of range [1,27]", log_size);
@@ -193,9 +204,11 @@ int blz_ntt_new_field(int device_id, int field, int log_size, int inverse, blz_n
     h->ops = ops;
     h->logn = log_size;
     h->inverse = inverse ? 1 : 0;
+    h->flags = flags;
     h->force_generic = exp_knob("BLAZE_NTT_GENERIC", 0) != 0;
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->copy_stream2, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&h->ev0);
     if (e == hipSuccess) e = hipEventCreate(&h->ev1);
     int rc = e == hipSuccess ? ntt_setup(h) : fail(BLZ_ERR_UNKNOWN, "stream/event creation failed: %s", hipGetErrorString(e));
@@ -211,7 +224,8 @@ void blz_ntt_free(blz_ntt* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream && (sync_stream_bounded(h->stream, "free: NTT stream") != BLZ_OK ||
-                      sync_stream_bounded(h->copy_stream, "free: NTT copy stream") != BLZ_OK)) {
+                      sync_stream_bounded(h->copy_stream, "free: NTT copy stream") != BLZ_OK ||
+                      (h->copy_stream2 && sync_stream_bounded(h->copy_stream2, "free: NTT copy stream") != BLZ_OK))) {
         BLZ_LOG(0, "NTT handle freed while its device work is wedged: buffers and streams are leaked");
         delete h;
         return;
@@ -221,6 +235,7 @@ void blz_ntt_free(blz_ntt* h) {
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
+    if (h->copy_stream2) (void)hipStreamDestroy(h->copy_stream2);
     delete h;
 }
 
@@ -304,11 +319,94 @@ static int ntt_result_common(blz_ntt* h, size_t buf, void* out, size_t out_cap, 
 int blz_ntt_result(blz_ntt* h, size_t buf, uint8_t* out, size_t out_cap) { return ntt_result_common(h, buf, out, out_cap, false); }
 int blz_ntt_result_device(blz_ntt* h, size_t buf, void* d_out, size_t out_cap) { return ntt_result_common(h, buf, d_out, out_cap, true); }
 
+// result(buf) and set_data(buf) of the reference's double-buffered loop (tests/integration_ntt.rs:102-136: while the kernel runs
+// on the other buffer the host READS the previous result out of `buf` and WRITES the next input into it) as ONE call that uses
+// the link in both directions at once.  Called one after the other, the two copies are the whole cycle - 76 + 76.5 ms around a
+// hidden 14 ms kernel at 2^27 - and each leaves the opposite direction of the full-duplex link idle.  Here the buffer goes in
+// pieces: piece k leaves for prev_out on copy_stream, and as soon as it has, piece k of next_in lands in its place on
+// copy_stream2, while piece k + 1 is already leaving.  Pageable host memory makes hipMemcpyAsync return only when the runtime
+// has staged the copy, so the two directions are driven by two host threads (the caller's: device -> host; a helper: host ->
+// device, which waits for a piece's departure through a counter).
+constexpr size_t NTT_XCHG_PIECE = (size_t)32 << 20;
+int blz_ntt_exchange(blz_ntt* h, size_t buf, const uint8_t* next_in, size_t in_len, uint8_t* prev_out, size_t out_cap) {
+    if (!h || !next_in || !prev_out) return fail(BLZ_ERR_INVALID_PARAM, "null argument");
+    if (buf > 1) return fail(BLZ_ERR_INVALID_PARAM, "buffer index must be 0 or 1");
+    const size_t total = ntt_bytes(h);
+    if (in_len != total) return fail(BLZ_ERR_INVALID_PARAM, "data length %zu != %zu", in_len, total);
+    if (out_cap < total) return fail(BLZ_ERR_INVALID_PARAM, "output buffer too small");
+    BLZ_NTT_LIVE(h);
+    if (h->in_flight && h->in_flight_buf == (int)buf)
+        return fail(BLZ_ERR_INVALID_PARAM, "buffer %zu is being transformed; call wait_result first", buf);
+    BLZ_TRY(use_device(h->device));
+    char* dbuf = (char*)h->buf[buf].p;
+    const size_t npieces = (total + NTT_XCHG_PIECE - 1) / NTT_XCHG_PIECE;
+    std::atomic<size_t> departed{0};     // pieces [0, departed) are in prev_out
+    std::atomic<bool> abort_in{false};
+    int rc_in = BLZ_OK;
+    bool timed_out_in = false;
+    std::string err_in;
+    const int dev = h->device;
+    hipStream_t st_in = h->copy_stream2;
+    std::thread writer([&, dev, st_in] {
+        if (hipSetDevice(dev) != hipSuccess) { rc_in = BLZ_ERR_FILE; err_in = "hipSetDevice failed on the exchange's helper thread"; return; }
+        for (size_t k = 0; k < npieces; ++k) {
+            while (departed.load(std::memory_order_acquire) <= k) {
+                if (abort_in.load(std::memory_order_acquire)) return;
+                std::this_thread::yield();
+            }
+            const size_t o = k * NTT_XCHG_PIECE, len = total - o < NTT_XCHG_PIECE ? total - o : NTT_XCHG_PIECE;
+            if (hipMemcpyAsync(dbuf + o, next_in + o, len, hipMemcpyHostToDevice, st_in) != hipSuccess) {
+                (void)hipGetLastError();
+                rc_in = BLZ_ERR_WRITE;
+                err_in = "exchange: host -> device copy failed";
+                return;
+            }
+        }
+        blz::wait_clear();
+        rc_in = sync_stream_bounded(st_in, "exchange: copy into the NTT buffer");
+        if (rc_in != BLZ_OK) { err_in = blz_last_error_message(); timed_out_in = blz::wait_timed_out(); }
+    });
+    int rc_out = BLZ_OK;
+    bool timed_out_out = false;
+    for (size_t k = 0; k < npieces && rc_out == BLZ_OK; ++k) {
+        const size_t o = k * NTT_XCHG_PIECE, len = total - o < NTT_XCHG_PIECE ? total - o : NTT_XCHG_PIECE;
+        if (hipMemcpyAsync(prev_out + o, dbuf + o, len, hipMemcpyDeviceToHost, h->copy_stream) != hipSuccess) {
+            (void)hipGetLastError();
+            rc_out = fail(BLZ_ERR_READ, "exchange: device -> host copy failed");
+            break;
+        }
+        // the piece must have LEFT before its place is overwritten: a host-side wait (bounded), which pageable copies have paid already
+        blz::wait_clear();
+        rc_out = sync_stream_bounded(h->copy_stream, "exchange: copy out of the NTT buffer");
+        if (rc_out != BLZ_OK) { timed_out_out = blz::wait_timed_out(); break; }
+        departed.store(k + 1, std::memory_order_release);
+    }
+    if (rc_out != BLZ_OK) abort_in.store(true, std::memory_order_release);
+    writer.join();
+    if (timed_out_in || timed_out_out) h->wedged = true;
+    if (rc_out != BLZ_OK) return rc_out;
+    if (rc_in != BLZ_OK) return fail(rc_in, "%s", err_in.c_str());
+    return BLZ_OK;
+}
+
+// out = {device bytes this handle holds (two transform buffers, scratch, twiddle and factor tables), 1 when pass 2 READS its
+// boundary factors from the per-element table (2^27 transforms with memory for it) / 0 when it steps them, 1 when pass 1 reads the
+// column-independent boundary table, log_size}
+int blz_ntt_info(blz_ntt* h, uint64_t out[4]) {
+    if (!h || !out) return fail(BLZ_ERR_INVALID_PARAM, "null argument");
+    out[0] = (uint64_t)(h->buf[0].cap + h->buf[1].cap + h->scratch.cap + h->tables.cap + h->tables_rr.cap + h->table_b.cap);
+    out[1] = h->TR.tB ? 1u : 0u;
+    out[2] = h->TR.tA ? 1u : 0u;
+    out[3] = (uint64_t)h->logn;
+    return BLZ_OK;
+}
+
 int blz_ntt_reset(blz_ntt* h) {
     if (!h) return fail(BLZ_ERR_INVALID_PARAM, "null handle");
     BLZ_TRY(use_device(h->device));
     BLZ_TRY(sync_stream_bounded(h->stream, "reset: NTT stream"));
     BLZ_TRY(sync_stream_bounded(h->copy_stream, "reset: NTT copy stream"));
+    BLZ_TRY(sync_stream_bounded(h->copy_stream2, "reset: NTT copy stream"));
     h->in_flight = false;
     h->wedged = false;
     return BLZ_OK;

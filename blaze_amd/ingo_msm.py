@@ -211,7 +211,15 @@ class MSMClient(DriverPrimitive[MSMInit, MSMParams, MSMInput, MSMResult]):
         hid = C.c_int(0)
         check(lib().blz_msm_last_sort_hidden(self._h, C.byref(hid)))
         api["sort_hidden"] = int(hid.value)
+        api["device_memory"] = self.memory_info()
         return api
+
+    def memory_info(self) -> dict:
+        """Device bytes behind this client (include/blaze_hip.h blz_msm_memory_info); the arena figures are per device."""
+        m = (C.c_uint64 * 6)()
+        check(lib().blz_msm_memory_info(self._h, m))
+        keys = ["workspace", "staging", "arena_raw", "arena_montgomery", "arena_window_tables", "total"]
+        return dict(zip(keys, [int(x) for x in m]))
 
     def reset(self) -> None:
         check(lib().blz_msm_reset(self._h))
@@ -236,6 +244,26 @@ class MSMClient(DriverPrimitive[MSMInit, MSMParams, MSMInput, MSMResult]):
         ready = C.c_int(0)
         check(lib().blz_msm_prepare_window_table(self._h, nof_elements, hbm_addr[0], hbm_addr[1], wait_ms, C.byref(ready)))
         return bool(ready.value)
+
+    def set_precompute_plan(self, enable) -> None:
+        """Opt a precompute client (MSMInit.is_precompute) in to the checked-table plan (include/blaze_hip.h
+        blz_msm_set_precompute_plan): resident x8 tables are checked once per load against precompute_base_*
+        (tests/msm/mod.rs:360-380) and, if consistent, served as 4n even bases with 64-bit chunks - 12 bucket additions per
+        element instead of 16, identical result bytes.  A table that fails the check keeps the exact path."""
+        check(lib().blz_msm_set_precompute_plan(self._h, int(bool(enable))))
+
+    def prepare_precompute_plan(self, nof_elements: int, hbm_addr=(0, 0)) -> bool:
+        """Run the table check (and build the even-base copy) now; True: tasks over these bases take the plan."""
+        ok = C.c_int(0)
+        check(lib().blz_msm_prepare_precompute_plan(self._h, nof_elements, hbm_addr[0], hbm_addr[1], C.byref(ok)))
+        return bool(ok.value)
+
+    def precompute_plan_info(self) -> dict:
+        """Of the last HBM task: did it take the plan, what the check of its bases said, what the check cost."""
+        out = (C.c_uint64 * 4)()
+        check(lib().blz_msm_precompute_plan_info(self._h, out))
+        return {"used": bool(out[0]), "check": ["unchecked", "consistent", "refuted"][int(out[1])], "check_ms": int(out[2]) / 1000.0,
+                "even_copy_bytes": int(out[3])}
 
     def set_scalar_range(self, bit_lo: int, bit_hi: int) -> None:
         """This client's tasks sum only bits [bit_lo, bit_hi) of every scalar and return 2^bit_lo x that sum: one shard of a

@@ -35,15 +35,17 @@ class NTTClient(DriverPrimitive[NTT, NttInit, NTTInput, bytes]):
 
     _FIELDS = {"BLS377": 0, "BLS381": 1, "BN254": 2}  # enum blz_curve
 
+    NO_FACTOR_TABLE = 1  # include/blaze_hip.h BLZ_NTT_NO_FACTOR_TABLE
+
     def __init__(self, _ptype: NTT, dclient: DriverClient, log_size: int = NTT_LOG_SIZE, inverse: bool = False,
-                 field: str = "BLS381"):
+                 field: str = "BLS381", flags: int = 0):
         self.driver_client = dclient
         self.log_size = log_size
         self.inverse = inverse
         self.field = field
         self.nbytes = NTT_WORD_SIZE << log_size
         h = C.c_void_p()
-        check(lib().blz_ntt_new_field(dclient.id, self._FIELDS[field], log_size, int(inverse), C.byref(h)))
+        check(lib().blz_ntt_new_ex2(dclient.id, self._FIELDS[field], log_size, int(inverse), int(flags), C.byref(h)))
         self._h = h
 
     def close(self):
@@ -94,6 +96,22 @@ class NTTClient(DriverPrimitive[NTT, NttInit, NTTInput, bytes]):
         if nb != self.nbytes:
             raise ValueError(f"result buffer holds {nb} bytes, the transform has {self.nbytes}")
         check(lib().blz_ntt_result(self._h, buf_num, p, self.nbytes))
+
+    def exchange(self, buf_host: int, next_input, out) -> None:
+        """result(buf_host) into `out` and set_data(NTTInput(buf_host, next_input)) as one full-duplex call
+        (include/blaze_hip.h blz_ntt_exchange): what a cycle of ntt_parallel_test_correctness does on the buffer the
+        kernel is not using (tests/integration_ntt.rs:102-136), with both directions of the link busy at once."""
+        pi, ni, _k1 = buf_ptr(next_input)
+        po, no, _k2 = buf_ptr(out)
+        if no < self.nbytes:
+            raise ValueError(f"result buffer holds {no} bytes, the transform has {self.nbytes}")
+        check(lib().blz_ntt_exchange(self._h, buf_host, pi, ni, po, no))
+
+    def info(self) -> dict:
+        """Device bytes this client holds and which pass-2 kernel it runs (include/blaze_hip.h blz_ntt_info)."""
+        v = (C.c_uint64 * 4)()
+        check(lib().blz_ntt_info(self._h, v))
+        return {"device_bytes": int(v[0]), "pass2_factor_table": bool(v[1]), "pass1_boundary_table": bool(v[2]), "log_size": int(v[3])}
 
     def result_device(self, buf_num: int, dst: DeviceBuffer) -> None:
         check(lib().blz_ntt_result_device(self._h, buf_num, dst.ptr, dst.nbytes))

@@ -129,6 +129,26 @@ class MSMClient : public DriverPrimitive<MSMInit, MSMParams, MSMInput, MSMResult
     // resident-base window table (blaze_hip.h): opt-in, bases in the arena, precompute_factor 1
     void set_scalar_range(uint32_t bit_lo, uint32_t bit_hi) { check(blz_msm_set_scalar_range(h_, bit_lo, bit_hi)); }   // one shard of a job split by scalar chunk
     void set_window_table(int mode) { check(blz_msm_set_window_table(h_, mode)); }   // 0 off, 1 where it pays, 2 always
+    // checked-table plan of a precompute client (blaze_hip.h blz_msm_set_precompute_plan): resident x8 tables are checked once per
+    // load against precompute_base_* and, if consistent, served as 4n even bases with 64-bit chunks; identical result bytes
+    void set_precompute_plan(bool enable) { check(blz_msm_set_precompute_plan(h_, enable ? 1 : 0)); }
+    bool prepare_precompute_plan(uint32_t nof_elements, std::pair<uint64_t, uint64_t> hbm_addr = {0, 0}) {
+        int ok = 0;
+        check(blz_msm_prepare_precompute_plan(h_, nof_elements, hbm_addr.first, hbm_addr.second, &ok));
+        return ok != 0;
+    }
+    // device bytes behind this client: {workspace, staging, arena raw, arena Montgomery copies, arena window tables, total}
+    std::array<uint64_t, 6> memory_info() {
+        std::array<uint64_t, 6> out{};
+        check(blz_msm_memory_info(h_, out.data()));
+        return out;
+    }
+    // {took the plan, check state (0 unchecked, 1 consistent, 2 refuted), check us, even-base copy bytes} of the last HBM task
+    std::array<uint64_t, 4> precompute_plan_info() {
+        std::array<uint64_t, 4> out{};
+        check(blz_msm_precompute_plan_info(h_, out.data()));
+        return out;
+    }
     // enqueue the table's build for the bases at hbm_addr (it is paced by the tasks otherwise) and wait up to wait_ms for it
     // (0: not at all, < 0: the library's wait deadline); true: the table is in place
     bool prepare_window_table(uint32_t nof_elements, std::pair<uint64_t, uint64_t> hbm_addr = {0, 0}, int wait_ms = -1) {
@@ -189,9 +209,10 @@ class NTTClient : public DriverPrimitive<NTT, NttInit, NTTInput, std::vector<uin
     DriverClient driver_client;
     // ntt_api.rs:26-31; 2^27 over BLS12-381 Fr, forward, is the reference shape.  `field` (a Curve: the
     // scalar field of that curve) and `inverse` have no reference counterpart.
-    NTTClient(NTT, DriverClient dclient, int log_size = 27, Curve field = Curve::BLS381, bool inverse = false)
+    // flags: BLZ_NTT_NO_FACTOR_TABLE (blaze_hip.h)
+    NTTClient(NTT, DriverClient dclient, int log_size = 27, Curve field = Curve::BLS381, bool inverse = false, uint32_t flags = 0)
         : nbytes_(size_t(32) << log_size), driver_client(dclient) {
-        check(blz_ntt_new_field(dclient.id, int(field), log_size, inverse ? 1 : 0, &h_));
+        check(blz_ntt_new_ex2(dclient.id, int(field), log_size, inverse ? 1 : 0, flags, &h_));
     }
     ~NTTClient() override { blz_ntt_free(h_); }
     NTTClient(const NTTClient&) = delete;
@@ -206,6 +227,18 @@ class NTTClient : public DriverPrimitive<NTT, NttInit, NTTInput, std::vector<uin
         std::vector<uint8_t> out(nbytes_);
         check(blz_ntt_result(h_, buf_num.value(), out.data(), out.size()));
         return out;
+    }
+    // result(buf) into `out` and set_data({buf, next}) as one full-duplex call (blaze_hip.h blz_ntt_exchange): a cycle of the
+    // reference's double-buffered loop (tests/integration_ntt.rs:102-136) on the buffer the kernel is not using
+    void exchange(size_t buf, const std::vector<uint8_t>& next, std::vector<uint8_t>& out) {
+        out.resize(nbytes_);
+        check(blz_ntt_exchange(h_, buf, next.data(), next.size(), out.data(), out.size()));
+    }
+    // {device bytes held, pass 2 reads its factor table, pass 1 boundary table, log_size}
+    std::array<uint64_t, 4> info() {
+        std::array<uint64_t, 4> v{};
+        check(blz_ntt_info(h_, v.data()));
+        return v;
     }
 };
 

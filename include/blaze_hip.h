@@ -150,6 +150,12 @@ int blz_msm_last_timings(blz_msm* h, float out[8]);
  * flight, the sort's kernels fit beside the accumulation's waves: DESIGN.md section 3), else 0.  Diagnostic. */
 int blz_msm_last_sort_hidden(blz_msm* h, int* out);
 
+/* Device memory behind a handle, bytes (get_api, msm_api.rs:324-330, dumps the card's registers; the one figure a GPU host
+ * needs that the card never had to report): out = {engine workspace (grown to the largest task seen), staging buffers of this
+ * handle, arena: raw bytes as loaded (allocated), arena: Montgomery copies of the bases, arena: window tables + build scratch,
+ * total}.  The three arena figures are per DEVICE (every handle of the device reports the same). */
+int blz_msm_memory_info(blz_msm* h, uint64_t out[6]);
+
 /* precompute_base_* (tests/msm/mod.rs:360-380) on the device: for each of the n base points (x||y)
  * write PRECOMPUTE_FACTOR = 8 points P, 2^32 P, ..., 2^224 P contiguously to d_out (n*8 points).
  * The reference builds this table on the host before set_data / load_data_to_hbm. */
@@ -188,6 +194,30 @@ int blz_msm_prepare_window_table(blz_msm* h, uint32_t nof_elements, uint64_t hbm
 /* out = {table bytes, window bits c, windows W, build time in microseconds} of the table the handle's last HBM task
  * used; zeros when it took the plain path */
 int blz_msm_window_table_info(blz_msm* h, uint64_t out[4]);
+
+/* Checked-table plan for precompute handles (opt-in; MSMInit.is_precompute, msm_api.rs:39-50).  The reference's precompute mode
+ * has the CALLER supply, per element, the 8 bases B_j = 2^(32 j) P (precompute_base_*: tests/msm/mod.rs:360-380) and defines the
+ * task as sum_i sum_j s_(i,j) B_(i,j) over the 32-bit chunks of the scalars.  Served literally - the default - that is an 8n-point
+ * MSM of 32-bit scalars: 16 bucket additions per element where the same elements without a table need 12.  With enable = 1 a
+ * handle whose bases live in the arena (hbm_point_addr) CHECKS the table once per load - on the device, base by base: B_(i,0) on the
+ * curve and B_(i,j) == 2^32 B_(i,j-1) for j = 1..7 (32 doublings each, compared projectively; 0.25 s for 2^26 BN254 elements,
+ * about 0.6 s on the BLS curves) - and, if it holds, sums sum_i sum_k (s_(i,2k) + 2^32 s_(i,2k+1)) B_(i,2k) instead: 4n points with 64-bit
+ * scalars, three windows of 22 / 22 / 21 bits, 12 additions per element into 3 shared bucket sets, over a Montgomery copy of
+ * the even bases only (half the copy's memory).  The two sums are the same group element exactly when the check holds, and the
+ * result is emitted normalised (Z = 1), so the bytes are identical to the exact path's.  A table that fails the check (any base
+ * off the curve, any multiple that is not 2^32 times its predecessor, a multiple at infinity) keeps the exact path - silently;
+ * BLAZE_LOG=1 says so, blz_msm_precompute_plan_info reports it.  Any write into the extent forgets the answer and the next task
+ * checks again.  The check runs inside the first set_data / start_process that launches a task over the bases (the call blocks
+ * for it), or in blz_msm_prepare_precompute_plan for a host that wants to pay with the load.  DMA-mode tasks (points with every
+ * task) always take the exact path: they are link-bound, and a check per task would cost more than it saves.
+ * New handles start with 0.  InvalidPrimitiveParam for a handle without is_precompute. */
+int blz_msm_set_precompute_plan(blz_msm* h, int enable);
+/* run the check (and build the even-base copy) now for the nof_elements elements at hbm_addr + hbm_off; *consistent = 1 when
+ * tasks over them will take the plan, 0 otherwise (not opted in, table refuted, bases off the extent's element grid) */
+int blz_msm_prepare_precompute_plan(blz_msm* h, uint32_t nof_elements, uint64_t hbm_addr, uint64_t hbm_off, int* consistent);
+/* out = {1 if the handle's last HBM task took the plan, state of the check of its bases (0 not asked / not checked, 1 consistent,
+ * 2 refuted), device time of the check in microseconds, bytes of the even-base Montgomery copy} */
+int blz_msm_precompute_plan_info(blz_msm* h, uint64_t out[4]);
 
 /* Sharding by scalar chunk (multi-GPU; no reference counterpart - README.md:20-22 leaves the split to a "management
  * layer").  A handle with a scalar range sums only bits [bit_lo, bit_hi) of every scalar it is given and returns
@@ -263,6 +293,15 @@ int blz_ntt_new_ex(int device_id, int log_size, int inverse, blz_ntt** out);
  * two-adicity 47; BN254 Fr, generator 5, two-adicity 28).  The bitstream the
  * reference drives is built for one field; here the kernels are instantiated per field. */
 int blz_ntt_new_field(int device_id, int field, int log_size, int inverse, blz_ntt** out);
+/* same, with flags.  BLZ_NTT_NO_FACTOR_TABLE: never allocate the per-element boundary-factor table of a 2^27 transform's
+ * second pass (n x 32 bytes: 4 GiB beside the handle's 12 GiB of buffers): the pass steps the factors along each lane's rows
+ * instead - the kernel a memory-tight device gets anyway (the table is an optimisation worth ~2 %, allocated when it fits) and the
+ * one every smaller transform runs.  blz_ntt_info says which one a handle got. */
+#define BLZ_NTT_NO_FACTOR_TABLE 1u
+int blz_ntt_new_ex2(int device_id, int field, int log_size, int inverse, uint32_t flags, blz_ntt** out);
+/* out = {device bytes the handle holds (two transform buffers + scratch + twiddle / factor tables), 1 if pass 2 reads the
+ * per-element factor table / 0 if it steps its factors, 1 if pass 1 reads the column-independent boundary table, log_size} */
+int blz_ntt_info(blz_ntt* h, uint64_t out[4]);
 void blz_ntt_free(blz_ntt* h);
 /* NTTClient::initialize(NttInit{}) (ntt_api.rs:37-56) */
 int blz_ntt_initialize(blz_ntt* h);
@@ -277,6 +316,12 @@ int blz_ntt_wait_result(blz_ntt* h);
 /* NTTClient::result(Some(buf)) (ntt_api.rs:110-124) */
 int blz_ntt_result(blz_ntt* h, size_t buf, uint8_t* out, size_t out_cap);
 int blz_ntt_result_device(blz_ntt* h, size_t buf, void* d_out, size_t out_cap);
+/* NTTClient::result(Some(buf)) followed by NTTClient::set_data(NTTInput{buf_host: buf, data}) - what every cycle of the
+ * reference's double-buffered loop does while the kernel runs on the other buffer (tests/integration_ntt.rs:102-136) - as ONE
+ * call that drives the link in both directions at once: the buffer leaves for prev_out piece by piece and next_in lands in the
+ * places that have left.  Same preconditions as the two calls (the buffer must not be under transform); blocking; both host
+ * buffers may be dropped / read when it returns.  in_len = 2^log_size x 32, out_cap >= that. */
+int blz_ntt_exchange(blz_ntt* h, size_t buf, const uint8_t* next_in, size_t in_len, uint8_t* prev_out, size_t out_cap);
 /* DriverClient::reset (dclient.rs:88-93) without the 100 ms sleep */
 int blz_ntt_reset(blz_ntt* h);
 /* kernel time of the last transform in ms (what benches/ntt_bench.rs:34-39 times, minus reset()) */

@@ -47,8 +47,12 @@ extern "C" {
     pub fn blz_msm_nof_elements(h: *mut BlzMsm, out: *mut u32) -> c_int;
     pub fn blz_msm_is_engine_ready(h: *mut BlzMsm, out: *mut u32) -> c_int;
     pub fn blz_msm_reset(h: *mut BlzMsm) -> c_int;
+    pub fn blz_msm_memory_info(h: *mut BlzMsm, out: *mut u64) -> c_int;
     pub fn blz_msm_set_window_table(h: *mut BlzMsm, enable: c_int) -> c_int;
     pub fn blz_msm_prepare_window_table(h: *mut BlzMsm, nof_elements: u32, hbm_addr: u64, hbm_off: u64, wait_ms: c_int, ready: *mut c_int) -> c_int;
+    pub fn blz_msm_set_precompute_plan(h: *mut BlzMsm, enable: c_int) -> c_int;
+    pub fn blz_msm_prepare_precompute_plan(h: *mut BlzMsm, nof_elements: u32, hbm_addr: u64, hbm_off: u64, consistent: *mut c_int) -> c_int;
+    pub fn blz_msm_precompute_plan_info(h: *mut BlzMsm, out: *mut u64) -> c_int;
     pub fn blz_msm_set_scalar_range(h: *mut BlzMsm, bit_lo: u32, bit_hi: u32) -> c_int;
     pub fn blz_msm_shard_layout(curve: c_int, nof_elements: u32, nranks: c_int, rank: c_int, out: *mut u32) -> c_int;
     pub fn blz_msm_shard_layout_ex(curve: c_int, nof_elements: u32, nranks: c_int, rank: c_int, flags: u32, out: *mut u32) -> c_int;
@@ -74,6 +78,9 @@ extern "C" {
     pub fn blz_ntt_new(device_id: c_int, log_size: c_int, out: *mut *mut BlzNtt) -> c_int;
     pub fn blz_ntt_new_ex(device_id: c_int, log_size: c_int, inverse: c_int, out: *mut *mut BlzNtt) -> c_int;
     pub fn blz_ntt_new_field(device_id: c_int, field: c_int, log_size: c_int, inverse: c_int, out: *mut *mut BlzNtt) -> c_int;
+    pub fn blz_ntt_new_ex2(device_id: c_int, field: c_int, log_size: c_int, inverse: c_int, flags: u32, out: *mut *mut BlzNtt) -> c_int;
+    pub fn blz_ntt_info(h: *mut BlzNtt, out: *mut u64) -> c_int;
+    pub fn blz_ntt_exchange(h: *mut BlzNtt, buf: usize, next_in: *const u8, in_len: usize, prev_out: *mut u8, out_cap: usize) -> c_int;
     pub fn blz_ntt_free(h: *mut BlzNtt);
     pub fn blz_ntt_initialize(h: *mut BlzNtt) -> c_int;
     pub fn blz_ntt_set_data(h: *mut BlzNtt, buf_host: usize, data: *const u8, len: usize) -> c_int;

@@ -183,6 +183,23 @@ impl MSMClient {
         check(unsafe { blz_msm_prepare_window_table(self.h, nof_elements, hbm_addr.0, hbm_addr.1, wait_ms, &mut ready) })?;
         Ok(ready != 0)
     }
+    /// Opt a precompute client in to the checked-table plan (`include/blaze_hip.h`): resident x8 tables are checked once per
+    /// load against `precompute_base_*` and, if consistent, served as 4n even bases with 64-bit chunks; identical result bytes.
+    pub fn set_precompute_plan(&self, enable: bool) -> Result<()> {
+        check(unsafe { blz_msm_set_precompute_plan(self.h, enable as std::os::raw::c_int) })
+    }
+    /// Run the table check (and build the even-base copy) now; `true`: tasks over these bases take the plan.
+    pub fn prepare_precompute_plan(&self, nof_elements: u32, hbm_addr: (u64, u64)) -> Result<bool> {
+        let mut ok: std::os::raw::c_int = 0;
+        check(unsafe { blz_msm_prepare_precompute_plan(self.h, nof_elements, hbm_addr.0, hbm_addr.1, &mut ok) })?;
+        Ok(ok != 0)
+    }
+    /// `[took the plan, check state (0 unchecked, 1 consistent, 2 refuted), check microseconds, even-base copy bytes]`.
+    pub fn precompute_plan_info(&self) -> Result<[u64; 4]> {
+        let mut out = [0u64; 4];
+        check(unsafe { blz_msm_precompute_plan_info(self.h, out.as_mut_ptr()) })?;
+        Ok(out)
+    }
     /// One shard of a job split by scalar chunk: only bits `[bit_lo, bit_hi)` of every scalar, result weighted `2^bit_lo`.
     pub fn set_scalar_range(&self, bit_lo: u32, bit_hi: u32) -> Result<()> {
         check(unsafe { blz_msm_set_scalar_range(self.h, bit_lo, bit_hi) })
@@ -198,6 +215,13 @@ impl MSMClient {
     pub fn shard_layout_ex(curve: Curve, nof_elements: u32, nranks: i32, rank: i32, flags: u32) -> Result<[u32; 8]> {
         let mut out = [0u32; 8];
         check(unsafe { blz_msm_shard_layout_ex(curve.code(), nof_elements, nranks, rank, flags, out.as_mut_ptr()) })?;
+        Ok(out)
+    }
+    /// Device bytes behind this client: `[workspace, staging, arena raw, arena Montgomery copies, arena window tables, total]`
+    /// (the arena figures are per device).
+    pub fn memory_info(&self) -> Result<[u64; 6]> {
+        let mut out = [0u64; 6];
+        check(unsafe { blz_msm_memory_info(self.h, out.as_mut_ptr()) })?;
         Ok(out)
     }
     /// `[table bytes, window bits, windows, build time in microseconds]` of the table the last HBM task used.

@@ -88,6 +88,20 @@ impl NTTClient {
         Ok(v)
     }
 
+    /// `result(Some(buf))` and `set_data(NTTInput { buf_host: buf, data })` of the double-buffered loop
+    /// (tests/integration_ntt.rs:102-136) as one full-duplex call: the previous result leaves `buf` piece by piece into `out`
+    /// while `data` lands in the places that have left.
+    pub fn exchange(&self, buf: usize, data: &[u8], out: &mut [u8]) -> Result<()> {
+        check(unsafe { blz_ntt_exchange(self.h, buf, data.as_ptr(), data.len(), out.as_mut_ptr(), out.len()) })
+    }
+
+    /// `[device bytes held, pass 2 reads its factor table (1) or steps (0), pass 1 boundary table, log_size]`.
+    pub fn info(&self) -> Result<[u64; 4]> {
+        let mut v = [0u64; 4];
+        check(unsafe { blz_ntt_info(self.h, v.as_mut_ptr()) })?;
+        Ok(v)
+    }
+
     pub fn reset_engine(&self) -> Result<()> {
         check(unsafe { blz_ntt_reset(self.h) })
     }

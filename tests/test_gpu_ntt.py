@@ -116,6 +116,84 @@ def test_parallel_correctness_reference_sequence(gpu, orc):
     driver.close()
 
 
+@pytest.mark.parametrize("logn", [14, 20])
+def test_parallel_correctness_through_exchange(gpu, orc, logn):
+    """The same loop with result + set_data of a cycle fused into blz_ntt_exchange (both directions of the link at once): the
+    outputs are the reference loop's, byte for byte; the buffer under transform stays off limits."""
+    nof_vectors = 3
+    n = 1 << logn
+    rng = random.Random(78)
+    base = [b"".join(rng.randrange(R).to_bytes(32, "little") for _ in range(4096)) for _ in range(nof_vectors)]
+    in_vecs = []
+    for b in base:
+        v = bytearray((b * (n // 4096 + 1))[: 32 * n])
+        for i in range(0, n, 61):
+            v[32 * i: 32 * i + 8] = (i * 0x9E3779B97F4A7C15 % (1 << 64)).to_bytes(8, "little")
+        in_vecs.append(bytes(v))
+    ref_vecs = [bytes(orc.ntt("BLS381", v, logn, threads=8)) for v in in_vecs]
+    driver = NTTClient(NTT.Ntt, DriverClient(0), log_size=logn)
+    driver.initialize(NttInit())
+    outputs = []
+    res = bytearray(32 * n)
+    for i in range(nof_vectors + 2):
+        buf_host = i % 2
+        buf_kernel = 1 - buf_host
+        driver.start_process(buf_kernel)
+        with pytest.raises(DriverClientError):
+            driver.exchange(buf_kernel, in_vecs[0], res)
+        driver.exchange(buf_host, in_vecs[min(i, nof_vectors - 1)], res)
+        if i == 0:
+            assert bytes(res) == bytes(32 * n)
+        if i >= 2:
+            outputs.append(bytes(res))
+        driver.wait_result()
+    assert outputs == ref_vecs
+    with pytest.raises(DriverClientError):
+        driver.exchange(0, in_vecs[0][:-32], res)            # wrong input length
+    with pytest.raises(ValueError):
+        driver.exchange(0, in_vecs[0], bytearray(32 * n - 1))
+    driver.close()
+
+
+def test_exchange_full_size_2e27(gpu, orc):
+    """The reference shape through the fused cycle: 4 GiB out and 4 GiB in at once, three cycles; the bytes that come back are
+    the bytes result() returns (checked against a plain result of the same transform), and what went in is what set_data
+    would have written (read back with result after the closing transform's inverse property: X of a delta)."""
+    import numpy as np
+    logn = 27
+    n = 1 << logn
+    cl = NTTClient(NTT.Ntt, DriverClient(0), log_size=logn)
+    cl.initialize(NttInit())
+    d_in = DeviceBuffer(0, 32 * n)
+    blaze_amd._lib.check(blaze_amd.lib().blz_synth_field_elements(0, d_in.ptr, n, 777))
+    x = np.frombuffer(d_in.download(), dtype=np.uint8).copy()
+    d_in.free()
+    delta = np.zeros(32 * n, dtype=np.uint8)
+    delta[32] = 1
+    out = np.empty(32 * n, dtype=np.uint8)
+    out[:] = 7                                            # touched: no first-touch page faults inside the timed call
+    cl.set_data(NTTInput(0, x))
+    cl.start_process(0)
+    cl.wait_result()
+    y_plain = np.frombuffer(cl.result(0), dtype=np.uint8).copy()
+    # cycle: kernel on buffer 1 (zeros), exchange on buffer 0: the result leaves, the delta lands
+    import time
+    cl.start_process(1)
+    t0 = time.perf_counter()
+    cl.exchange(0, delta, out)
+    dt = time.perf_counter() - t0
+    cl.wait_result()
+    assert np.array_equal(out, y_plain), "exchange returned other bytes than result()"
+    cl.start_process(0)
+    cl.wait_result()
+    z = np.frombuffer(cl.result(0), dtype=np.uint8)
+    w = orc.omega("BLS381", logn)
+    for k in (0, 1, 2, 511, 512, 513, 1 << 18, 99999999, n - 1):
+        assert int.from_bytes(z[32 * k: 32 * k + 32].tobytes(), "little") == pow(w, k, R), k
+    print("exchange of 2 x 4 GiB: %.1f ms" % (dt * 1e3))
+    cl.close()
+
+
 def test_full_size_2e27_properties(gpu, orc):
     """The reference shape (2^27 x 32 B = 4 GiB, ntt_data.rs:65-66).  Checked by: delta -> all ones,
     X[0] = sum x, sum_k X[k] = n x[0], spot coefficients against the O(n) Horner oracle."""
@@ -163,14 +241,23 @@ def test_full_size_2e27_properties(gpu, orc):
     cl.close()
 
 
-def test_full_size_2e27_every_output(gpu, orc):
+@pytest.mark.parametrize("pass2", ["factor_table", "stepped"])
+def test_full_size_2e27_every_output(gpu, orc, pass2):
     """Every one of the 2^27 outputs of the reference shape, byte for byte against the oracle's threaded radix-2
     transform of the same 4 GiB input, and inverse(forward(x)) == x at 2^27 (the 512^3 kernel k_ntt512 only
-    ever runs at this size)."""
+    ever runs at this size).  Both pass-2 kernels: the one that reads its boundary factors from the 4 GiB per-element
+    table (what a handle gets when the table fits) and the one that steps them (what a memory-tight device gets, and what
+    BLZ_NTT_NO_FACTOR_TABLE asks for); blz_ntt_info says which one a handle runs and what it holds."""
     import numpy as np
     logn = 27
     n = 1 << logn
-    cl = NTTClient(NTT.Ntt, DriverClient(0), log_size=logn)
+    flags = NTTClient.NO_FACTOR_TABLE if pass2 == "stepped" else 0
+    cl = NTTClient(NTT.Ntt, DriverClient(0), log_size=logn, flags=flags)
+    info = cl.info()
+    assert info["log_size"] == 27 and info["pass1_boundary_table"]
+    assert info["pass2_factor_table"] == (pass2 == "factor_table")
+    want = (3 + (1 if pass2 == "factor_table" else 0)) * 32 * n      # two buffers + scratch (+ the factor table)
+    assert want <= info["device_bytes"] <= want * 1.05, info
     d_in = DeviceBuffer(0, 32 * n)
     blaze_amd._lib.check(blaze_amd.lib().blz_synth_field_elements(0, d_in.ptr, n, 4242))
     cl.set_data(NTTInput(0, d_in))
@@ -186,7 +273,8 @@ def test_full_size_2e27_every_output(gpu, orc):
         raise AssertionError(f"2^27 forward transform differs from the oracle, first at element {int(bad[0]) // 32}")
     del exp
     # round trip on the device: the forward result goes back through the inverse transform
-    inv = NTTClient(NTT.Ntt, DriverClient(0), log_size=logn, inverse=True)
+    inv = NTTClient(NTT.Ntt, DriverClient(0), log_size=logn, inverse=True, flags=flags)
+    assert inv.info()["pass2_factor_table"] == (pass2 == "factor_table")
     d_y = DeviceBuffer(0, 32 * n)
     cl.result_device(0, d_y)
     cl.close()
