@@ -8,9 +8,12 @@ A "step" is one complete MSM over the 2^26 synthetic (scalar, point) pairs, inpu
 in HBM, through the reference's call sequence (initialize -> start_process -> set_data ->
 wait_result -> result) on the C ABI.  Like the reference device's task queue, two tasks are kept in
 flight; every one of the K timed MSMs is submitted and collected inside the timed region.  With
-N > 1 the SAME 2^26 job is sharded by contiguous element chunk over the N GPUs of one node (strong
-scaling): each rank runs its shard, one all-gather of the 144-byte partials (RCCL), every rank adds
-them in rank order.  value = MSMs per second, whole job.
+N > 1 the SAME 2^26 job is sharded over the N GPUs of one node (strong scaling) as
+blz_msm_shard_layout_ex cuts it: element chunks x ranges of the scalars' bits (at 2^26 two and four
+ranks split the bits of all elements, eight take 64-bit ranges of half of the elements each;
+BLAZE_SHARD=elements forces contiguous element chunks, timed beside the headline as
+`alt_layout_elements`).  Each rank runs its shard, one all-gather of the 144-byte partials (RCCL),
+every rank adds them in rank order.  value = MSMs per second, whole job.
 
 N > 1 cannot hang: the timed loop exchanges the partials through torch.distributed (the process group
 the launcher's rendezvous already brought up); the exchange inside the library (blz_msm_comm_init /
@@ -210,7 +213,15 @@ def main():
         if os.environ.get("BLAZE_BENCH_ONE_GPU") == "1":
             local_rank = 0
         ndev = torch.cuda.device_count()
-        if ndev and local_rank >= ndev:   # a launcher that narrows every rank's visibility to its own GPU(s)
+        if ndev and local_rank >= ndev:
+            # A launcher that narrows every rank's visibility to its own GPU(s) (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES set per
+            # rank) leaves LOCAL_RANK pointing past the devices the rank can see; a plain mis-launch - more ranks than GPUs -
+            # looks the same and must not be folded onto shared GPUs (nccl: "duplicate GPU" or a hang; a scaling number from
+            # shared devices otherwise).
+            narrowed = any(os.environ.get(v) for v in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
+            if not narrowed:
+                raise SystemExit(f"bench: LOCAL_RANK {local_rank} but only {ndev} device(s) visible and no *_VISIBLE_DEVICES narrowing: "
+                                 f"{world} ranks need {world} GPUs (BLAZE_BENCH_ONE_GPU=1 BLAZE_BENCH_BACKEND=gloo runs them on one, for tests)")
             local_rank %= ndev
         torch.cuda.set_device(local_rank)
         t_pg = int(os.environ.get("BLAZE_BENCH_PG_TIMEOUT_S", "180"))
@@ -245,8 +256,8 @@ def main():
     # ---- synthetic inputs, generated on the device: P_i = (i+1) G, scalars uniform-ish in [0, r)
     d_pts = DeviceBuffer(dev, n_loc * 96)
     d_sc = DeviceBuffer(dev, n_loc * 32)
-    check(L.blz_synth_points(dev, cid, d_pts.ptr, n_loc, 1, lo))
-    check(L.blz_synth_scalars_at(dev, cid, d_sc.ptr, n_loc, 0xB1A2E, lo))  # same global set for every N
+    check(blaze_amd.aux().blz_synth_points(dev, cid, d_pts.ptr, n_loc, 1, lo))
+    check(blaze_amd.aux().blz_synth_scalars_at(dev, cid, d_sc.ptr, n_loc, 0xB1A2E, lo))  # same global set for every N
 
     # Points live in the device arena, as in the reference's HBM flow (tests/integration_msm_hbm.rs:
     # load_data_to_hbm once, then scalars-only set_data with hbm_point_addr): the bases of a prover are
@@ -341,7 +352,7 @@ def main():
     calib = None
     try:
         cal = (C.c_double * 4)()
-        check(L.blz_calib_mad_rate(dev, 50, cal))
+        check(blaze_amd.aux().blz_calib_mad_rate(dev, 50, cal))
         calib = {"mad_lane_ops_per_s": cal[0], "kernel_ms": round(cal[1], 3), "nominal_clock_mhz": cal[2]}
     except Exception as e:   # noqa: BLE001 - a measurement aid, never fatal
         print(f"[bench rank {rank}] mad-rate calibration failed: {e}", file=sys.stderr, flush=True)
@@ -359,7 +370,7 @@ def main():
                 sc_all = d_sc.download()
             else:   # the other ranks' scalars: same generator, same global indices
                 d_all = DeviceBuffer(dev, n * 32)
-                check(L.blz_synth_scalars_at(dev, cid, d_all.ptr, n, 0xB1A2E, 0))
+                check(blaze_amd.aux().blz_synth_scalars_at(dev, cid, d_all.ptr, n, 0xB1A2E, 0))
                 sc_all = d_all.download()
                 d_all.free()
             t1 = time.perf_counter()
@@ -488,6 +499,7 @@ def main():
     if hbm_mode and not args.no_extras and os.environ.get("BLAZE_BENCH_TABLE", "1") == "1":
         wd.arm(900, "window-table leg")
         terr, tdt, tinfo, first_ms, tkernel, n_before, until_ms, paced_ms, alloc_ms = None, -1.0, {"bytes": 0, "window_bits": 0, "windows": 0, "build_ms": 0.0}, 0.0, 0.0, 0, 0.0, 0.0, 0.0
+        first_plain, paced_plain = True, 0
         k_t = args.steps
         tcl = None
         try:
@@ -495,10 +507,13 @@ def main():
             if ranged:
                 tcl.set_scalar_range(lay["bit_lo"], lay["bit_hi"])
 
+            plain_flags = []
+
             def tsubmit():
                 tcl.initialize(params)
                 tcl.start_process()
                 tcl.set_data(MSMInput(None, d_sc, params))
+                plain_flags.append(tcl.window_table_info()["bytes"] == 0)   # (of the task just launched: did it take the plain path?)
 
             def tcollect():
                 tcl.wait_result()
@@ -530,14 +545,17 @@ def main():
             t1 = time.perf_counter()
             tcl.prepare_window_table(n_loc, (0, 0), 0)
             alloc_ms = (time.perf_counter() - t1) * 1e3
+            del plain_flags[:]
             t1 = time.perf_counter()
             tsubmit()
             first = tcollect()
             first_ms = (time.perf_counter() - t1) * 1e3
+            first_plain = plain_flags[0]
             t_sw = time.perf_counter()
             paced = trun(4)
             paced_ms = (time.perf_counter() - t_sw) / 4 * 1e3
-            n_before = 5
+            n_before = sum(1 for f_ in plain_flags if f_)     # measured: a small table is complete after a task or two
+            paced_plain = sum(1 for f_ in plain_flags[1:] if f_)
             if any(r_ != first[0] for r_, _ in paced):
                 raise RuntimeError("results differ while the table is being built")
             t_sw = time.perf_counter()
@@ -578,7 +596,8 @@ def main():
                              "used": tinfo["bytes"] > 0, "table_bytes_per_gpu": tinfo["bytes"], "window_bits": tinfo["window_bits"],
                              "windows": tinfo["windows"], "build_ms": round(tinfo["build_ms"], 1),
                              "prepare_no_wait_ms": round(alloc_ms, 1), "first_task_ms": round(first_ms, 1), "ms_per_task_while_building": round(paced_ms, 1),
-                             "tasks_on_the_plain_path": n_before, "prepare_wait_ms": round(until_ms, 1), "kernel_ms": round(tkernel, 3),
+                             "tasks_on_the_plain_path": n_before, "first_task_on_the_plain_path": bool(first_plain), "paced_tasks_on_the_plain_path": f"{paced_plain} of 4",
+                             "prepare_wait_ms": round(until_ms, 1), "kernel_ms": round(tkernel, 3),
                              "result_check": "this rank's result bytes equal its result in the headline loop (which the oracle checked"
                                              + (" after the exchange)" if multi else ")"),
                              "what": "opt-in blz_msm_set_window_table: the bases' window multiples 2^(c j) P tabulated once per load - paced by "
@@ -647,8 +666,8 @@ def main():
             if (lay_e["first"], lay_e["count"], lay_e["bit_lo"], lay_e["bit_hi"]) != (lay["first"], lay["count"], lay["bit_lo"], lay["bit_hi"]):
                 el_pts = DeviceBuffer(dev, max(lay_e["count"], 1) * 96)
                 el_sc = DeviceBuffer(dev, max(lay_e["count"], 1) * 32)
-                check(L.blz_synth_points(dev, cid, el_pts.ptr, lay_e["count"], 1, lay_e["first"]))
-                check(L.blz_synth_scalars_at(dev, cid, el_sc.ptr, lay_e["count"], 0xB1A2E, lay_e["first"]))
+                check(blaze_amd.aux().blz_synth_points(dev, cid, el_pts.ptr, lay_e["count"], 1, lay_e["first"]))
+                check(blaze_amd.aux().blz_synth_scalars_at(dev, cid, el_sc.ptr, lay_e["count"], 0xB1A2E, lay_e["first"]))
                 el_client = MSMClient(MSMInit(PointMemoryType.HBM, False, Curve[CURVE]), DriverClient(dev))
                 el_base = 1 << 40   # its own extent of the device arena, far from the headline's bases at 0
                 el_client.load_data_to_hbm(el_pts, el_base, 0)
@@ -790,8 +809,8 @@ def main():
             n3, c3 = 1 << 26, int(Curve["BN254"])
             p3 = DeviceBuffer(dev, n3 * 8 * 64)
             s3 = DeviceBuffer(dev, n3 * 32)
-            check(L.blz_synth_points(dev, c3, p3.ptr, n3, 8, 0))          # 2^(32 j) (i + 1) G, j < 8: the reference's precompute
-            check(L.blz_synth_scalars_at(dev, c3, s3.ptr, n3, 0xC0F3, 0))
+            check(blaze_amd.aux().blz_synth_points(dev, c3, p3.ptr, n3, 8, 0))          # 2^(32 j) (i + 1) G, j < 8: the reference's precompute
+            check(blaze_amd.aux().blz_synth_scalars_at(dev, c3, s3.ptr, n3, 0xC0F3, 0))
             cl3 = MSMClient(MSMInit(PointMemoryType.HBM, True, Curve["BN254"]), DriverClient(dev))
             cl3.load_data_to_hbm(p3, 0, 0)
             p3.free()
@@ -814,6 +833,35 @@ def main():
                                  "frac": round(bytes3 / (k3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)},
                     "what": "config 3: 2^26 BN254 elements, precompute factor 8: 2^29 bases (32 GiB) resident in the device arena, scalars-only "
                             "set_data (device-resident scalars), tests/integration_msm_hbm.rs flow", "result_check": chk3}
+            # the same tasks on the checked-table plan (opt-in, blz_msm_set_precompute_plan): the resident table is checked once
+            # against precompute_base_* on the device, then every task sums the 2^28 even bases with 64-bit chunks
+            try:
+                cl3.set_precompute_plan(True)
+                t_chk = time.perf_counter()
+                ok3 = cl3.prepare_precompute_plan(n3, (0, 0))
+                t_chk = (time.perf_counter() - t_chk) * 1e3
+                info3 = cl3.precompute_plan_info()
+                stream(cl3, prm3, None, s3, 2)
+                dt3p, outs3p, apis3p = stream(cl3, prm3, None, s3, 4)
+                used3 = cl3.precompute_plan_info()["used"]
+                k3p = statistics.mean(a_["accumulate_kernel_ms"] for a_ in apis3p)
+                if any(o != outs3[-1] for o in outs3p):
+                    raise SystemExit("bench: the config 3 result on the checked-table plan differs from the exact path's")
+                cfg3["checked_table_plan"] = {
+                    "ms_per_msm": round(dt3p / 4 * 1e3, 3), "msms": 4, "tasks_in_flight": queue, "kernel_ms": round(k3p, 3), "plan_taken": bool(used3 and ok3),
+                    "window_bits": int(apis3p[-1]["window_bits"]), "windows": int(apis3p[-1]["windows"]),
+                    "table_check_ms": round(info3["check_ms"], 1), "prepare_wall_ms": round(t_chk, 1), "even_base_copy_bytes": info3["even_copy_bytes"],
+                    "device_memory": apis3p[-1]["device_memory"],
+                    "roofline": {"bound": "hbm", "kernel": "k_accumulate", "algorithmic_bytes_per_launch": bytes3,
+                                 "achieved": round(bytes3 / (k3p * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": round(bytes3 / (k3p * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)},
+                    "what": "the same four tasks after blz_msm_set_precompute_plan(1): table checked once on the device (B_j == 2^32 B_(j-1), B_0 on the "
+                            "curve), then 2^28 even bases x 64-bit chunks: 3 windows of 22 / 22 / 21 bits, 12 bucket additions per element instead of 16",
+                    "result_check": {"ok": True, "method": "bytes equal the exact path's result" + (" (which the oracle checked)" if chk3 else "")}}
+            except SystemExit:
+                raise
+            except Exception as e:   # noqa: BLE001
+                cfg3["checked_table_plan"] = {"error": f"{type(e).__name__}: {e}"}
             cl3.close()
             s3.free()
             L.blz_arena_release(dev)
@@ -828,8 +876,8 @@ def main():
             n4 = lay4["count"]
             p4 = DeviceBuffer(dev, n4 * 96)
             s4 = DeviceBuffer(dev, n4 * 32)
-            check(L.blz_synth_points(dev, int(c4), p4.ptr, n4, 1, lay4["first"]))
-            check(L.blz_synth_scalars_at(dev, int(c4), s4.ptr, n4, 0x377, lay4["first"]))
+            check(blaze_amd.aux().blz_synth_points(dev, int(c4), p4.ptr, n4, 1, lay4["first"]))
+            check(blaze_amd.aux().blz_synth_scalars_at(dev, int(c4), s4.ptr, n4, 0x377, lay4["first"]))
             cl4 = MSMClient(MSMInit(PointMemoryType.HBM, False, c4), DriverClient(dev))
             cl4.load_data_to_hbm(p4, 0, 0)
             p4.free()
@@ -873,8 +921,8 @@ def main():
                 n5 = 1 << lg
                 p5 = DeviceBuffer(dev, n5 * 96)
                 s5 = DeviceBuffer(dev, n5 * 32)
-                check(L.blz_synth_points(dev, int(c5), p5.ptr, n5, 1, 0))
-                check(L.blz_synth_scalars_at(dev, int(c5), s5.ptr, n5, 0x5A11 + lg, 0))
+                check(blaze_amd.aux().blz_synth_points(dev, int(c5), p5.ptr, n5, 1, 0))
+                check(blaze_amd.aux().blz_synth_scalars_at(dev, int(c5), s5.ptr, n5, 0x5A11 + lg, 0))
                 cl5 = MSMClient(MSMInit(PointMemoryType.HBM, False, c5), DriverClient(dev))
                 cl5.load_data_to_hbm(p5, 0, 0)
                 p5.free()
@@ -912,7 +960,7 @@ def main():
             pass
         nn = 1 << NTT_LOG
         d_in = DeviceBuffer(dev, 32 * nn)
-        check(L.blz_synth_field_elements(dev, d_in.ptr, nn, 5))
+        check(blaze_amd.aux().blz_synth_field_elements(dev, d_in.ptr, nn, 5))
         nc = NTTClient(NTT.Ntt, DriverClient(dev), log_size=NTT_LOG)
         nc.set_data(NTTInput(0, d_in))
         d_in.free()
@@ -944,14 +992,57 @@ def main():
         # 9-multiply-add quotient reduction for each un-twiddled output: 5309 + 5389 + 4237 = 14 935 per lane
         # (tests/test_isa_counts.py counts them in the code object; round 3 and most of round 4: 16 242, pass 2 stepping its
         # factors), n / 8 lanes per pass.
+        ninfo = nc.info()
+        ntt["device_bytes"] = ninfo["device_bytes"]
+        ntt["pass2_reads_factor_table"] = ninfo["pass2_factor_table"]
         if NTT_LOG == 27:
-            ntt_mads = (37 * 143 + 2 * 9) + (29 * 143 + 8 * 153 + 2 * 9) + (29 * 143 + 10 * 9)
+            # (pass 2 reading its factor table: 29 Shoup + 8 Montgomery products; stepping its factors - what a handle without
+            # memory for the table runs, blz_ntt_info says which: 36 + 10)
+            pass2_table, pass2_stepped = 29 * 143 + 8 * 153 + 2 * 9, 36 * 143 + 10 * 153 + 2 * 9
+            ntt_mads = (37 * 143 + 2 * 9) + (pass2_table if ninfo["pass2_factor_table"] else pass2_stepped) + (29 * 143 + 10 * 9)
             mads_t = ntt_mads * (nn // 8)
             peak_i = calib["mad_lane_ops_per_s"] if calib else 3.1e13
             ntt["roofline"]["integer_issue"] = {"unit": "v_mad_u64_u32 lane-ops/s", "achieved": round(mads_t / (k * 1e-3), 0), "peak": round(peak_i, 0),
                                                 "frac": round(mads_t / (k * 1e-3) / peak_i, 4), "multiply_adds_per_transform": mads_t,
                                                 "multiply_adds_per_lane": ntt_mads,
                                                 "peak_source": "calibration kernel on this device, this run" if calib else "constant measured on another box"}
+        # The reference's double-buffered host loop (tests/integration_ntt.rs:102-136) with 4 GiB pageable host vectors: the kernel
+        # hides under the transfers; result + set_data of a cycle as two calls (one direction of the link at a time) and fused
+        # into blz_ntt_exchange (both at once).  PCIe-inclusive, never `ms`.
+        if rank == 0 and not args.no_extras and NTT_LOG >= 20:
+            try:
+                import numpy as np
+
+                hx = np.empty(32 * nn, dtype=np.uint8)
+                hy = np.empty(32 * nn, dtype=np.uint8)
+                nc.result_into(0, hx)        # canonical field elements (and every page of hx touched)
+                hy[:] = 0
+
+                def host_loop(fused, cycles=5):
+                    ts = []
+                    for i in range(cycles):
+                        t1 = time.perf_counter()
+                        bh, bk = i % 2, 1 - i % 2
+                        nc.start_process(bk)
+                        if fused:
+                            nc.exchange(bh, hx, hy)
+                        else:
+                            nc.result_into(bh, hy)
+                            nc.set_data(NTTInput(bh, hx))
+                        nc.wait_result()
+                        ts.append((time.perf_counter() - t1) * 1e3)
+                    return statistics.median(ts[1:])
+
+                two_calls = host_loop(False)
+                fused = host_loop(True)
+                ntt["host_loop_ms"] = round(fused, 2)
+                ntt["host_loop"] = {"exchange_ms_per_transform": round(fused, 2), "result_then_set_data_ms_per_transform": round(two_calls, 2),
+                                    "host_bytes_each_way": 32 * nn, "host_memory": "pageable (numpy)",
+                                    "what": "tests/integration_ntt.rs:102-136: start_process on one buffer, the previous result out of / the next input "
+                                            "into the other, wait_result; median of 4 cycles"}
+                del hx, hy
+            except Exception as e:   # noqa: BLE001 - an extra key, never fatal
+                ntt["host_loop"] = {"error": f"{type(e).__name__}: {e}"}
         try:   # PMC record of the three passes, quoted only while it matches the kernels being timed (see above)
             rec = json.load(open(tf)).get(f"ntt_2e{NTT_LOG}_BLS381")
             if rec and abs(k - rec.get("kernel_ms_at_measurement", k)) <= 0.10 * k:

@@ -7,6 +7,6 @@ C ABI in include/blaze_hip.h); the modules here mirror the reference's host-side
     ingo_ntt       <- src/ingo_ntt        (NTTClient, NTT, NttInit, NTTInput)
 """
 from . import driver_client, ingo_msm, ingo_ntt  # noqa: F401
-from ._lib import DeviceBuffer, DriverClientError, lib  # noqa: F401
+from ._lib import DeviceBuffer, DriverClientError, HostBuffer, aux, lib  # noqa: F401
 
-__all__ = ["driver_client", "ingo_msm", "ingo_ntt", "DeviceBuffer", "DriverClientError", "lib"]
+__all__ = ["driver_client", "ingo_msm", "ingo_ntt", "DeviceBuffer", "DriverClientError", "HostBuffer", "aux", "lib"]

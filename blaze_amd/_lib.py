@@ -32,6 +32,7 @@ class DriverClientError(Exception):
 
 
 _lib = None
+_aux = None
 
 # every exported symbol of include/blaze_hip.h: name -> (restype, argtypes)
 _u8p = C.c_void_p
@@ -55,6 +56,7 @@ _SIGS = {
     "blz_arena_release": (C.c_int, [C.c_int]),
     "blz_arena_export": (C.c_int, [C.c_int, C.c_char_p]),
     "blz_arena_attach": (C.c_int, [C.c_int, C.c_char_p]),
+    "blz_msm_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
     "blz_msm_task_label": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "blz_msm_nof_elements": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "blz_msm_is_engine_ready": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
@@ -95,14 +97,21 @@ _SIGS = {
     "blz_ntt_wait_result": (C.c_int, [C.c_void_p]),
     "blz_ntt_result": (C.c_int, [C.c_void_p, C.c_size_t, _u8p, C.c_size_t]),
     "blz_ntt_result_device": (C.c_int, [C.c_void_p, C.c_size_t, _u8p, C.c_size_t]),
+    "blz_ntt_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
     "blz_ntt_reset": (C.c_int, [C.c_void_p]),
     "blz_ntt_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "blz_ntt_banks_preprocess_device": (C.c_int, [C.c_void_p, _u8p, _u8p]),
     "blz_ntt_banks_postprocess_device": (C.c_int, [C.c_void_p, _u8p, _u8p]),
     "blz_device_malloc": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]),
     "blz_device_free": (C.c_int, [C.c_int, C.c_void_p]),
+    "blz_host_malloc": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "blz_host_free": (C.c_int, [C.c_void_p]),
     "blz_memcpy_h2d": (C.c_int, [C.c_int, C.c_void_p, _u8p, C.c_size_t]),
     "blz_memcpy_d2h": (C.c_int, [C.c_int, _u8p, C.c_void_p, C.c_size_t]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGS)
+# libblaze_hip_aux.so (include/blaze_hip_aux.h): test / bench scaffolding, not part of the product library
+_AUX_SIGS = {
     "blz_synth_scalars": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_uint64]),
     "blz_synth_scalars_at": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]),
     "blz_synth_points": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_int, C.c_uint64]),
@@ -114,7 +123,7 @@ _SIGS = {
     "blz_test_field_op": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _u8p, _u8p, _u8p, C.c_size_t]),
     "blz_test_ec_op": (C.c_int, [C.c_int, C.c_int, C.c_int, _u8p, _u8p, _u8p, _u8p, _u8p, C.c_size_t]),
 }
-EXPORTED_SYMBOLS = tuple(_SIGS)
+AUX_EXPORTED_SYMBOLS = tuple(_AUX_SIGS)
 
 
 def lib():
@@ -126,13 +135,31 @@ def lib():
                 f"{LIB_PATH} is missing: build it with `make -C blaze_amd/csrc` "
                 "(or __graft_entry__.build()); blaze_amd has no CPU fallback"
             )
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
         _lib = L
     return _lib
+
+
+def aux():
+    """Load libblaze_hip_aux.so - synthetic inputs, calibration, element-wise test hooks, stall kernels - next to the product
+    library.  Used by tests/, bench.py and tools/ only."""
+    global _aux
+    if _aux is None:
+        lib()   # the product library first: the aux library links against it (by soname)
+        path = LIB_PATH[:-3] + "_aux.so"
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: build it with `make -C blaze_amd/csrc`")
+        A = C.CDLL(path)
+        for name, (res, args) in _AUX_SIGS.items():
+            fn = getattr(A, name)
+            fn.restype = res
+            fn.argtypes = args
+        _aux = A
+    return _aux
 
 
 def check(rc: int):
@@ -185,6 +212,35 @@ class DeviceBuffer:
     def free(self):
         if self.ptr:
             lib().blz_device_free(self.device_id, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class HostBuffer:
+    """Page-locked host memory owned by the library (blz_host_malloc): a writable buffer (memoryview / numpy via
+    `array()`) that the runtime copies from and to without staging."""
+
+    def __init__(self, device_id: int, nbytes: int):
+        self.nbytes = nbytes
+        p = C.c_void_p()
+        check(lib().blz_host_malloc(device_id, nbytes, C.byref(p)))
+        self.ptr = p.value
+        self._arr = (C.c_uint8 * nbytes).from_address(self.ptr)
+
+    def array(self):
+        import numpy as np
+
+        return np.frombuffer(self._arr, dtype=np.uint8)
+
+    def free(self):
+        if self.ptr:
+            self._arr = None
+            lib().blz_host_free(self.ptr)
             self.ptr = None
 
     def __del__(self):

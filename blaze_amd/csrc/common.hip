@@ -173,36 +173,6 @@ int DevBuf::reserve(size_t bytes) {
     return BLZ_OK;
 }
 
-__global__ void k_stall(uint32_t* flag, uint64_t max_ticks) {
-    const uint64_t t0 = wall_clock64();
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u && wall_clock64() - t0 < max_ticks)
-        __builtin_amdgcn_s_sleep(127);
-}
-
-int launch_stall(hipStream_t st, uint32_t max_ms, void** token) {
-    if (!token) return fail(BLZ_ERR_INVALID_PARAM, "null token");
-    if (max_ms == 0 || max_ms > 30000) return fail(BLZ_ERR_INVALID_PARAM, "stall cap must be 1..30000 ms");
-    int dev = 0, khz = 0;
-    BLZ_HIP(hipGetDevice(&dev), BLZ_ERR_UNKNOWN);
-    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000;   // 100 MHz
-    // one pinned page per process, 64 flags handed out in turn (a flag cannot be freed - nobody knows when its kernel has read
-    // it for the last time - so none is allocated per call)
-    static std::mutex mu;
-    static uint32_t* pool = nullptr;
-    static unsigned next = 0;
-    uint32_t* flag = nullptr;
-    {
-        std::lock_guard<std::mutex> lk(mu);
-        if (!pool) BLZ_HIP(hipHostMalloc((void**)&pool, 64 * 64), BLZ_ERR_UNKNOWN);
-        flag = pool + 16 * (next++ % 64u);
-    }
-    *flag = 1u;
-    hipLaunchKernelGGL(k_stall, dim3(1), dim3(1), 0, st, flag, (uint64_t)max_ms * (uint64_t)khz);
-    BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
-    *token = flag;
-    return BLZ_OK;
-}
-
 int ensure_dynamic_lds(const void* kernel, int bytes) {
     static std::mutex mu;
     static std::map<std::pair<int, const void*>, int> done;   // (device, kernel) -> bytes granted
@@ -226,12 +196,6 @@ int blz_device_count(void) { return blz::device_count(); }
 size_t blz_point_size(int curve) { return curve == BLZ_BN254 ? 64 : (curve == BLZ_BLS377 || curve == BLZ_BLS381) ? 96 : 0; }
 size_t blz_result_size(int curve) { return curve == BLZ_BN254 ? 96 : (curve == BLZ_BLS377 || curve == BLZ_BLS381) ? 144 : 0; }
 
-int blz_test_stall_release(void* token) {
-    if (!token) return blz::fail(BLZ_ERR_INVALID_PARAM, "null token");
-    __atomic_store_n((uint32_t*)token, 0u, __ATOMIC_RELEASE);
-    return BLZ_OK;
-}
-
 int blz_device_malloc(int device_id, size_t bytes, void** out) {
     if (!out) return blz::fail(BLZ_ERR_INVALID_PARAM, "null out");
     BLZ_TRY(blz::use_device(device_id));
@@ -241,6 +205,18 @@ int blz_device_malloc(int device_id, size_t bytes, void** out) {
 int blz_device_free(int device_id, void* p) {
     BLZ_TRY(blz::use_device(device_id));
     BLZ_HIP(hipFree(p), BLZ_ERR_UNKNOWN);
+    return BLZ_OK;
+}
+int blz_host_malloc(int device_id, size_t bytes, void** out) {
+    if (!out) return blz::fail(BLZ_ERR_INVALID_PARAM, "null out");
+    *out = nullptr;
+    BLZ_TRY(blz::use_device(device_id));
+    BLZ_HIP(hipHostMalloc(out, bytes ? bytes : 16, hipHostMallocDefault), BLZ_ERR_UNKNOWN);
+    return BLZ_OK;
+}
+int blz_host_free(void* p) {
+    if (!p) return BLZ_OK;
+    BLZ_HIP(hipHostFree(p), BLZ_ERR_UNKNOWN);
     return BLZ_OK;
 }
 int blz_memcpy_h2d(int device_id, void* d_dst, const void* src, size_t bytes) {

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/blaze_hip.h"
+#include "../../include/blaze_hip_aux.h"
 
 namespace blz {
 
@@ -85,11 +86,6 @@ int sync_stream_bounded(hipStream_t st, const char* what);
 int sync_device_bounded(const char* what);   // every stream of the current device (before buffers other handles' tasks may read are freed)
 bool wait_timed_out();   // the last sync_*_bounded of this thread ended on its deadline
 void wait_clear();       // forget it (before a call that may fail without ever reaching a wait)
-
-// Test hook behind blz_test_*_stall: a one-lane kernel on `st` that spins until the host clears *token (a slot of one pinned
-// page the process keeps) or max_ms have passed on the device's wall clock - the cap keeps a failing test from wedging the GPU
-// for good.
-int launch_stall(hipStream_t st, uint32_t max_ms, void** token);
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (current device, kernel): the opt-in for more than
 // 64 KiB of dynamic LDS is per device, and a host may open clients on several devices of one process.

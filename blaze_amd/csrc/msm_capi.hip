@@ -1378,10 +1378,11 @@ int blz_msm_all_gather_combine_all(blz_msm* const* handles, int n, const uint8_t
     return BLZ_OK;
 }
 
-int blz_test_msm_stall(blz_msm* h, uint32_t max_ms, void** token) {
-    if (!h) return fail(BLZ_ERR_INVALID_PARAM, "null handle");
-    BLZ_TRY(use_device(h->device));
-    return launch_stall(h->eng.stream, max_ms, token);
+int blz_msm_stream(blz_msm* h, void** hip_stream, int* device_id) {
+    if (!h || !hip_stream) return fail(BLZ_ERR_INVALID_PARAM, "null argument");
+    if (device_id) *device_id = h->device;
+    *hip_stream = (void*)h->eng.stream;
+    return BLZ_OK;
 }
 
 int blz_msm_comm_free(blz_msm* h) {

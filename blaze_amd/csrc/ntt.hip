@@ -64,6 +64,7 @@ struct blz_ntt {
     hipStream_t copy_stream = nullptr;  // host<->buffer traffic, concurrent with the compute stream
     hipStream_t copy_stream2 = nullptr; // blz_ntt_exchange: the host -> device direction, while copy_stream carries device -> host
     uint32_t flags = 0;                 // blz_ntt_new_ex2
+    hipEvent_t xchg_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // blz_ntt_exchange with pinned host buffers: piece k has left
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     DevBuf buf[2], scratch, tables, tables_rr, table_b;
     NttTables T{};
@@ -209,6 +210,7 @@ int blz_ntt_new_ex2(int device_id, int field, int log_size, int inverse, uint32_
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->copy_stream2, hipStreamNonBlocking);
+    for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&h->xchg_ev[i], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreate(&h->ev0);
     if (e == hipSuccess) e = hipEventCreate(&h->ev1);
     int rc = e == hipSuccess ? ntt_setup(h) : fail(BLZ_ERR_UNKNOWN, "stream/event creation failed: %s", hipGetErrorString(e));
@@ -231,6 +233,8 @@ void blz_ntt_free(blz_ntt* h) {
         return;
     }
     h->buf[0].release(); h->buf[1].release(); h->scratch.release(); h->tables.release(); h->tables_rr.release(); h->table_b.release();
+    for (auto& e : h->xchg_ev)
+        if (e) (void)hipEventDestroy(e);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -324,10 +328,21 @@ int blz_ntt_result_device(blz_ntt* h, size_t buf, void* d_out, size_t out_cap) {
 // the link in both directions at once.  Called one after the other, the two copies are the whole cycle - 76 + 76.5 ms around a
 // hidden 14 ms kernel at 2^27 - and each leaves the opposite direction of the full-duplex link idle.  Here the buffer goes in
 // pieces: piece k leaves for prev_out on copy_stream, and as soon as it has, piece k of next_in lands in its place on
-// copy_stream2, while piece k + 1 is already leaving.  Pageable host memory makes hipMemcpyAsync return only when the runtime
-// has staged the copy, so the two directions are driven by two host threads (the caller's: device -> host; a helper: host ->
-// device, which waits for a piece's departure through a counter).
-constexpr size_t NTT_XCHG_PIECE = (size_t)32 << 20;
+// copy_stream2, while piece k + 1 is already leaving.
+//   * host buffers the runtime knows as pinned (blz_host_malloc, hipHostMalloc, hipHostRegister): every copy is a true
+//     asynchronous DMA; the pieces are chained with events and the caller waits once, at the end;
+//   * pageable host memory: hipMemcpyAsync returns only when the runtime has staged the copy, so the two directions are driven
+//     by two host threads (the caller's: device -> host; a helper: host -> device, which waits for a piece's departure
+//     through a counter).
+static bool host_ptr_is_pinned(const void* p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();   // an ordinary malloc'ed pointer: "invalid value"
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+
 int blz_ntt_exchange(blz_ntt* h, size_t buf, const uint8_t* next_in, size_t in_len, uint8_t* prev_out, size_t out_cap) {
     if (!h || !next_in || !prev_out) return fail(BLZ_ERR_INVALID_PARAM, "null argument");
     if (buf > 1) return fail(BLZ_ERR_INVALID_PARAM, "buffer index must be 0 or 1");
@@ -339,7 +354,21 @@ int blz_ntt_exchange(blz_ntt* h, size_t buf, const uint8_t* next_in, size_t in_l
         return fail(BLZ_ERR_INVALID_PARAM, "buffer %zu is being transformed; call wait_result first", buf);
     BLZ_TRY(use_device(h->device));
     char* dbuf = (char*)h->buf[buf].p;
-    const size_t npieces = (total + NTT_XCHG_PIECE - 1) / NTT_XCHG_PIECE;
+    const size_t piece = (size_t)exp_knob("BLAZE_NTT_XCHG_MB", 64) << 20;
+    const size_t npieces = (total + piece - 1) / piece;
+    if (exp_knob("BLAZE_NTT_XCHG_PINNED", 1) != 0 && host_ptr_is_pinned(next_in) && host_ptr_is_pinned(prev_out)) {
+        for (size_t k = 0; k < npieces; ++k) {
+            const size_t o = k * piece, len = total - o < piece ? total - o : piece;
+            hipEvent_t ev = h->xchg_ev[k % 4];
+            BLZ_HIP(hipMemcpyAsync(prev_out + o, dbuf + o, len, hipMemcpyDeviceToHost, h->copy_stream), BLZ_ERR_READ);
+            BLZ_HIP(hipEventRecord(ev, h->copy_stream), BLZ_ERR_READ);
+            BLZ_HIP(hipStreamWaitEvent(h->copy_stream2, ev, 0), BLZ_ERR_WRITE);   // (captures this record: the event is free to be re-recorded)
+            BLZ_HIP(hipMemcpyAsync(dbuf + o, next_in + o, len, hipMemcpyHostToDevice, h->copy_stream2), BLZ_ERR_WRITE);
+        }
+        BLZ_NTT_WAIT(h, sync_stream_bounded(h->copy_stream, "exchange: copy out of the NTT buffer"));
+        BLZ_NTT_WAIT(h, sync_stream_bounded(h->copy_stream2, "exchange: copy into the NTT buffer"));
+        return BLZ_OK;
+    }
     std::atomic<size_t> departed{0};     // pieces [0, departed) are in prev_out
     std::atomic<bool> abort_in{false};
     int rc_in = BLZ_OK;
@@ -354,7 +383,7 @@ int blz_ntt_exchange(blz_ntt* h, size_t buf, const uint8_t* next_in, size_t in_l
                 if (abort_in.load(std::memory_order_acquire)) return;
                 std::this_thread::yield();
             }
-            const size_t o = k * NTT_XCHG_PIECE, len = total - o < NTT_XCHG_PIECE ? total - o : NTT_XCHG_PIECE;
+            const size_t o = k * piece, len = total - o < piece ? total - o : piece;
             if (hipMemcpyAsync(dbuf + o, next_in + o, len, hipMemcpyHostToDevice, st_in) != hipSuccess) {
                 (void)hipGetLastError();
                 rc_in = BLZ_ERR_WRITE;
@@ -369,7 +398,7 @@ int blz_ntt_exchange(blz_ntt* h, size_t buf, const uint8_t* next_in, size_t in_l
     int rc_out = BLZ_OK;
     bool timed_out_out = false;
     for (size_t k = 0; k < npieces && rc_out == BLZ_OK; ++k) {
-        const size_t o = k * NTT_XCHG_PIECE, len = total - o < NTT_XCHG_PIECE ? total - o : NTT_XCHG_PIECE;
+        const size_t o = k * piece, len = total - o < piece ? total - o : piece;
         if (hipMemcpyAsync(prev_out + o, dbuf + o, len, hipMemcpyDeviceToHost, h->copy_stream) != hipSuccess) {
             (void)hipGetLastError();
             rc_out = fail(BLZ_ERR_READ, "exchange: device -> host copy failed");
@@ -412,10 +441,11 @@ int blz_ntt_reset(blz_ntt* h) {
     return BLZ_OK;
 }
 
-int blz_test_ntt_stall(blz_ntt* h, uint32_t max_ms, void** token) {
-    if (!h) return fail(BLZ_ERR_INVALID_PARAM, "null handle");
-    BLZ_TRY(use_device(h->device));
-    return launch_stall(h->stream, max_ms, token);
+int blz_ntt_stream(blz_ntt* h, void** hip_stream, int* device_id) {
+    if (!h || !hip_stream) return fail(BLZ_ERR_INVALID_PARAM, "null argument");
+    if (device_id) *device_id = h->device;
+    *hip_stream = (void*)h->stream;
+    return BLZ_OK;
 }
 
 int blz_ntt_last_kernel_ms(blz_ntt* h, float* out) {

@@ -133,6 +133,11 @@ int blz_arena_release(int device_id);
 int blz_arena_export(int device_id, const char* registry_path);
 int blz_arena_attach(int device_id, const char* registry_path);
 
+/* The HIP stream (hipStream_t, as void*) the handle's tasks are enqueued on, and its device ordinal (nullable): a host that
+ * produces scalars - or consumes results - with kernels of its own orders them against the handle's tasks with events on this
+ * stream instead of host-side waits.  The driver client of the reference holds file descriptors (dclient.rs:50-59); this is
+ * their GPU counterpart.  The stream stays the library's: do not destroy it. */
+int blz_msm_stream(blz_msm* h, void** hip_stream, int* device_id);
 /* MSMClient::task_label / nof_elements / is_msm_engine_ready (msm_api.rs:278-297) */
 int blz_msm_task_label(blz_msm* h, uint32_t* out);
 int blz_msm_nof_elements(blz_msm* h, uint32_t* out);
@@ -322,6 +327,8 @@ int blz_ntt_result_device(blz_ntt* h, size_t buf, void* d_out, size_t out_cap);
  * places that have left.  Same preconditions as the two calls (the buffer must not be under transform); blocking; both host
  * buffers may be dropped / read when it returns.  in_len = 2^log_size x 32, out_cap >= that. */
 int blz_ntt_exchange(blz_ntt* h, size_t buf, const uint8_t* next_in, size_t in_len, uint8_t* prev_out, size_t out_cap);
+/* the HIP stream (hipStream_t, as void*) the handle's transforms run on, and its device ordinal (nullable); see blz_msm_stream */
+int blz_ntt_stream(blz_ntt* h, void** hip_stream, int* device_id);
 /* DriverClient::reset (dclient.rs:88-93) without the 100 ms sleep */
 int blz_ntt_reset(blz_ntt* h);
 /* kernel time of the last transform in ms (what benches/ntt_bench.rs:34-39 times, minus reset()) */
@@ -333,50 +340,18 @@ int blz_ntt_last_kernel_ms(blz_ntt* h, float* out);
 int blz_ntt_banks_preprocess_device(blz_ntt* h, const void* d_in, void* d_banks);
 int blz_ntt_banks_postprocess_device(blz_ntt* h, const void* d_banks, void* d_out);
 
-/* ------------------------------------------------------------------ synthetic inputs (bench/tests) */
+/* ------------------------------------------------------------------ device / host memory helpers */
 
-/* Device memory owned by the library (bench/tests use these instead of a tensor library). */
+/* Device memory owned by the library (hosts without a tensor library of their own; bench.py and the tests use these). */
 int blz_device_malloc(int device_id, size_t bytes, void** out);
 int blz_device_free(int device_id, void* p);
+/* Host memory the runtime can DMA from / to without staging (page-locked, mapped for `device_id`): copies out of and into such
+ * buffers are truly asynchronous, which is what lets blz_ntt_exchange keep both directions of the link busy from one thread.
+ * Any pointer works everywhere (pageable memory is staged by the runtime); these are for hosts that own their I/O vectors. */
+int blz_host_malloc(int device_id, size_t bytes, void** out);
+int blz_host_free(void* p);
 int blz_memcpy_h2d(int device_id, void* d_dst, const void* src, size_t bytes);
 int blz_memcpy_d2h(int device_id, void* dst, const void* d_src, size_t bytes);
-/* scalars: n x 32 B, uniform-ish in [0, r) from a counter-based generator */
-int blz_synth_scalars(int device_id, int curve, void* d_out, uint64_t n, uint64_t seed);
-/* same stream of values, elements [start, start+n): a shard of a larger synthetic set */
-int blz_synth_scalars_at(int device_id, int curve, void* d_out, uint64_t n, uint64_t seed, uint64_t start);
-/* points: element i gets pf bases B_{i,j} = 2^(32 j) * (start+i+1) * G, wire format x||y canonical */
-int blz_synth_points(int device_id, int curve, void* d_out, uint64_t n, int pf, uint64_t start);
-/* NTT input: n x 32 B uniform-ish in [0, r) of BLS12-381 Fr */
-int blz_synth_field_elements(int device_id, void* d_out, uint64_t n, uint64_t seed);
-
-/* The issue rate of v_mad_u64_u32 - the instruction the MSM / NTT kernels are bound by - measured on this device at
- * its clocks of this moment: a ~target_ms kernel of independent multiply-add chains on every SIMD.  out[0] lane-ops
- * per second, [1] kernel ms, [2] the device's nominal clock in MHz (hipDeviceAttributeClockRate), [3] ops executed.
- * Measurement aid of bench.py (roofline.integer_issue.peak); no reference counterpart. */
-int blz_calib_mad_rate(int device_id, uint32_t target_ms, double out[4]);
-
-/* Test hooks for the bounded waits: enqueue, on the handle's main stream, a one-lane kernel that spins until
- * blz_test_stall_release(token) or until max_ms (1..30000) have passed on the device clock, whichever comes first. */
-int blz_test_msm_stall(blz_msm* h, uint32_t max_ms, void** token);
-int blz_test_ntt_stall(blz_ntt* h, uint32_t max_ms, void** token);
-int blz_test_stall_release(void* token);
-
-/* ------------------------------------------------------------------ test hooks (element-wise kernels)
- * Run the device field / group primitives on arrays so tests can compare them one by one with the
- * CPU oracle.  Host pointers; canonical little-endian encodings.
- *   fq ops (field = 0: Fq, 1: Fr): 0 mul, 1 add, 2 sub, 3 inverse(a), 4 sqr(a), 5/6 a b +- (a + b)(a - b);
- *     reduced-radix twin (every base field and every scalar field has one):
- *     10 mul, 11 sqr, 12 a b + (a + b)(a - b), 13 (a - 3b) b, 14 [a == b], 15 a (a - 3b) through the
- *     product-free reduction of a lazy value
- *   ec ops: 0 P+Q (mixed, P as accumulator), 1 2P, 2 P+Q (full XYZZ add), 3 P-Q (mixed, negated),
- *     4 / 5 P+Q / P-Q through the reduced-radix mixed add; 6 / 7 P+Q / Q-P with both operands affine (the first
- *     addition of a bucket run); 8 P+Q through the reduced-radix full add, 9 2P through its doubling (bucket reduce)
- *     points x||y; inf_flags[i] bit0: P is infinity, bit1: Q is infinity; out_inf[i]=1 if result inf */
-int blz_test_field_op(int device_id, int curve, int field, int op, const uint8_t* a, const uint8_t* b,
-                      uint8_t* out, size_t n);
-int blz_test_ec_op(int device_id, int curve, int op, const uint8_t* p, const uint8_t* q,
-                   const uint8_t* inf_flags, uint8_t* out, uint8_t* out_inf, size_t n);
-
 #ifdef __cplusplus
 }
 #endif

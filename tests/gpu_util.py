@@ -24,6 +24,6 @@ def synth(curve: str, n: int, pf: int = 1, start: int = 0, seed: int = 7, device
     ps = int(blaze_amd.lib().blz_point_size(cid))
     dp = DeviceBuffer(device, n * pf * ps)
     ds = DeviceBuffer(device, n * 32)
-    blaze_amd._lib.check(blaze_amd.lib().blz_synth_points(device, cid, dp.ptr, n, pf, start))
-    blaze_amd._lib.check(blaze_amd.lib().blz_synth_scalars(device, cid, ds.ptr, n, seed))
+    blaze_amd._lib.check(blaze_amd.aux().blz_synth_points(device, cid, dp.ptr, n, pf, start))
+    blaze_amd._lib.check(blaze_amd.aux().blz_synth_scalars(device, cid, ds.ptr, n, seed))
     return dp, ds

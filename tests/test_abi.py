@@ -3,20 +3,26 @@ declares, and fails loudly (FileError, no CPU fallback) when no device is presen
 import ctypes as C
 import os
 import re
+import subprocess
 
 import pytest
 
 import blaze_amd
 from blaze_amd import DriverClientError
-from blaze_amd._lib import EXPORTED_SYMBOLS
+from blaze_amd._lib import AUX_EXPORTED_SYMBOLS, EXPORTED_SYMBOLS, LIB_PATH
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_symbols():
-    src = open(os.path.join(ROOT, "include", "blaze_hip.h")).read()
+def _declared_symbols(header="blaze_hip.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(blz_[a-z0-9_]+)\s*\(", src)))
+
+
+def _dynamic_symbols(path):
+    out = subprocess.run(["nm", "-D", "--defined-only", path], check=True, capture_output=True, text=True).stdout
+    return {ln.split()[-1] for ln in out.splitlines() if ln.split()[-1].startswith("blz_")}
 
 
 def test_library_exports_every_declared_symbol():
@@ -26,6 +32,23 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), f"{name} declared in include/blaze_hip.h but not exported"
     assert sorted(EXPORTED_SYMBOLS) == declared, "python binding table out of sync with the header"
+
+
+def test_scaffolding_lives_in_the_aux_library_only():
+    """Synthetic inputs, the calibration kernel, element-wise test hooks and the stall kernels are test / bench scaffolding:
+    declared in include/blaze_hip_aux.h, exported by libblaze_hip_aux.so, and absent from the product library - a stall kernel
+    a host can enqueue on a production handle is not a product feature."""
+    A = blaze_amd.aux()
+    declared = _declared_symbols("blaze_hip_aux.h")
+    assert len(declared) >= 10
+    for name in declared:
+        assert hasattr(A, name), f"{name} declared in include/blaze_hip_aux.h but not exported by the aux library"
+    assert sorted(AUX_EXPORTED_SYMBOLS) == declared
+    assert not set(declared) & set(_declared_symbols())
+    product = _dynamic_symbols(LIB_PATH)
+    assert not [s for s in product if s.startswith(("blz_test_", "blz_synth_", "blz_calib_"))]
+    assert set(_declared_symbols()) <= product
+    assert set(declared) <= _dynamic_symbols(LIB_PATH[:-3] + "_aux.so")
 
 
 def test_sizes_match_reference_config():

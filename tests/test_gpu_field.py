@@ -5,6 +5,7 @@ import random
 
 import pytest
 
+import blaze_amd
 from oracle import pyref
 
 pytestmark = pytest.mark.gpu
@@ -50,7 +51,7 @@ def test_field_ops(gpu, curve, field):
     for op, fn in ops.items():
         cnt = n if op != 3 else 200  # inversion is slow on one lane; sample
         out = C.create_string_buffer(cnt * nb)
-        rc = gpu.blz_test_field_op(0, pyref.CURVES[curve]["id"], field, op, ab, bb, C.cast(out, C.c_void_p), cnt)
+        rc = blaze_amd.aux().blz_test_field_op(0, pyref.CURVES[curve]["id"], field, op, ab, bb, C.cast(out, C.c_void_p), cnt)
         assert rc == 0, gpu.blz_last_error_message()
         got = [int.from_bytes(out.raw[i * nb:(i + 1) * nb], "little") for i in range(cnt)]
         exp = [fn(a[i], b[i]) for i in range(cnt)]
@@ -79,7 +80,7 @@ def test_field_inversion_edge_representations(gpu, curve, field):
     xs = [a * Rinv % m for a in A]
     ab = b"".join(x.to_bytes(nb, "little") for x in xs)
     out = C.create_string_buffer(len(xs) * nb)
-    rc = gpu.blz_test_field_op(0, c["id"], field, 3, ab, ab, C.cast(out, C.c_void_p), len(xs))
+    rc = blaze_amd.aux().blz_test_field_op(0, c["id"], field, 3, ab, ab, C.cast(out, C.c_void_p), len(xs))
     assert rc == 0, gpu.blz_last_error_message()
     got = [int.from_bytes(out.raw[i * nb:(i + 1) * nb], "little") for i in range(len(xs))]
     bad = [i for i, x in enumerate(xs) if got[i] != pow(x, -1, m)]
@@ -126,7 +127,7 @@ def test_ec_ops(gpu, curve):
     for op in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9):
         out = C.create_string_buffer(n * sz)
         oinf = C.create_string_buffer(n)
-        rc = gpu.blz_test_ec_op(0, cid, op, pb, qb, flb, C.cast(out, C.c_void_p), C.cast(oinf, C.c_void_p), n)
+        rc = blaze_amd.aux().blz_test_ec_op(0, cid, op, pb, qb, flb, C.cast(out, C.c_void_p), C.cast(oinf, C.c_void_p), n)
         assert rc == 0, gpu.blz_last_error_message()
         for i in range(n):
             e = expect(op, P[i], Q[i], fl[i])

@@ -483,6 +483,47 @@ def test_bench_sharded_path_two_ranks_one_gpu(gpu, shard):
     assert flow["shard_rank0"]["ranges"] == 1 and flow["result_check"]["ok"] and flow["ms_per_msm_steady"] > 0
 
 
+@pytest.mark.parametrize("shard", ["auto", "elements"])
+def test_bench_eight_ranks_rehearsal_one_gpu(gpu, shard):
+    """The driver's first SCALE run, rehearsed: bench.py --gpus 8 through the real launcher path (torch.distributed.run, eight
+    ranks, gloo, all sharing this box's GPU), at 2^20 elements: the layout the library picks for 8 ranks (auto: scalar-bit ranges
+    x element chunks where the planner prices them cheaper) and the forced element split, `alt_layout_elements`, the per-rank
+    host-scalar flow, the watchdogs and the JSON line."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ, BLAZE_BENCH_LOGN="20", BLAZE_BENCH_EMIT_RESULT="1", BLAZE_BENCH_BACKEND="gloo",
+               BLAZE_BENCH_ONE_GPU="1", MASTER_ADDR="127.0.0.1")
+    if shard != "auto":
+        env["BLAZE_SHARD"] = shard
+    root = os.path.dirname(HERE)
+    common = ["--steps", "2", "--warmup", "1", "--no-ntt", "--no-cpu-baseline"]
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--no-extras"] + common, env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    eight = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+                            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                            os.path.join(root, "bench.py"), "--gpus", "8"] + common, env=env, capture_output=True, text=True, timeout=1500)
+    assert eight.returncode == 0, eight.stderr[-3000:]
+    j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    j8 = json.loads([l for l in eight.stdout.splitlines() if l.startswith("{")][-1])
+    assert j8["n_gpus"] == 8 and j8["scaling"] == "strong" and j8["result_check"]["ok"]
+    assert j8["result_hex"] == j1["result_hex"] and len(j8["result_hex"]) == 288
+    lay = j8["config"]["shard_rank0"]
+    R = lay["ranges"]
+    assert lay["count"] * (lay["bit_hi"] - lay["bit_lo"]) * 8 == (1 << 20) * 256 and R in (1, 2, 4, 8), lay
+    if shard == "elements":
+        assert R == 1 and lay["count"] == (1 << 17)
+    alt, flow = j8["alt_layout_elements"], j8["hbm_flow"]
+    assert "error" not in alt and "error" not in flow, (alt, flow)
+    if R == 1:
+        assert alt.get("same_as_headline")
+    else:
+        assert alt["shard_rank0"]["count"] == (1 << 17) and alt["ms_per_step"] > 0
+    assert flow["shard_rank0"]["ranges"] == 1 and flow["result_check"]["ok"] and flow["ms_per_msm_steady"] > 0
+    assert "error" not in (j8.get("window_table") or {})
+
+
 def test_bench_native_exchange_next_to_torch_process_group(gpu):
     """what the N > 1 bench does, as far as one GPU can do it - torch imported FIRST, torch's own
     NCCL (RCCL) process group alive, then the library brings up its second RCCL communicator (resolved next to the
@@ -659,7 +700,7 @@ def test_task_queue_overlap_large(gpu, orc):
     _, ds1 = synth(curve, 16, seed=4)
     ds1.free()
     ds1 = DeviceBuffer(0, n * 32)
-    blaze_amd._lib.check(blaze_amd.lib().blz_synth_scalars(0, 1, ds1.ptr, n, 4))
+    blaze_amd._lib.check(blaze_amd.aux().blz_synth_scalars(0, 1, ds1.ptr, n, 4))
     cl = msm_client(curve, 1)
     ref = [run_msm(cl, dp, d, n) for d in (ds0, ds1)]
     assert ref[0] != ref[1]
@@ -743,6 +784,133 @@ def test_two_clients_interleaved(gpu, orc):
     blaze_amd.lib().blz_arena_release(0)
 
 
+@pytest.mark.parametrize("hide", ["1", "2"])
+def test_two_host_threads_one_device(gpu, orc, hide, monkeypatch):
+    """"Distinct handles are independent" (include/blaze_hip.h) with two HOST THREADS at once on device 0 - the arena mutex, the
+    per-extent shadow event chain, the paced table builder and the bounded waits under real concurrency:
+      thread A  streams 2^20-element HBM-flow tasks (two in flight) over extent A;
+      thread B  loads and REWRITES extent B (two base sets in turn), has a window table built over it (forced: mode 2),
+                runs HBM tasks over it and DMA-mode tasks with host buffers in between.
+    200 tasks per thread, every result checked (linearity over the synthetic bases / the oracle's Pippenger)."""
+    import threading
+
+    monkeypatch.setenv("BLAZE_SORT_HIDE", hide)
+    monkeypatch.setenv("BLAZE_WAIT_TIMEOUT_MS", "20000")
+    curve = "BLS381"
+    L = blaze_amd.lib()
+    blaze_amd._lib.check(L.blz_arena_release(0))
+    tasks = 200
+    # ---- thread A's job
+    na = 1 << 20
+    dpa, dsa = synth(curve, na, 1, seed=11)
+    exp_a = _expected_synth(orc, curve, dsa, na)
+    a = msm_client(curve, 1, PointMemoryType.HBM)
+    ADDR_A, ADDR_B = 0, 1 << 34
+    a.load_data_to_hbm(dpa, ADDR_A, 0)
+    dpa.free()
+    # ---- thread B's job: two base sets for extent B, host inputs for DMA tasks
+    nb = 1 << 16
+    sets = []
+    for start in (0, 5000):
+        dpb, dsb = synth(curve, nb, 1, start=start, seed=13 + start)
+        sets.append((bytes(dpb.download()), bytes(dsb.download()), _expected_synth(orc, curve, dsb, nb, start)))
+        dpb.free(); dsb.free()
+    nd = 3000
+    pd, sd, exp_d = orc.input_generator(curve, nd, 1, 99)
+    errors = []
+
+    def run_a():
+        try:
+            p = MSMParams(na, (ADDR_A, 0))
+            done = 0
+            a.initialize(p); a.start_process(); a.set_data(MSMInput(None, dsa, p))
+            for i in range(tasks):
+                if i + 1 < tasks:
+                    a.initialize(p); a.start_process(); a.set_data(MSMInput(None, dsa, p))
+                a.wait_result()
+                if a.result().result != exp_a:
+                    raise AssertionError(f"thread A: task {i} differs")
+                done += 1
+            assert done == tasks
+        except BaseException as e:   # noqa: BLE001
+            errors.append(("A", e))
+
+    def run_b():
+        try:
+            b = msm_client(curve, 1, PointMemoryType.HBM)
+            b.set_window_table(2)
+            d = msm_client(curve, 1)
+            done = 0
+            rnd = 0
+            while done < tasks:
+                pts, sc, exp = sets[rnd % 2]
+                b.load_data_to_hbm(pts, ADDR_B, 0)             # rewrite: drops the table, dirties the shadow
+                if rnd % 3 == 1:
+                    b.prepare_window_table(nb, (ADDR_B, 0), -1)
+                for k in range(12):
+                    if run_msm(b, None, sc, nb, hbm=(ADDR_B, 0)) != exp:
+                        raise AssertionError(f"thread B: HBM task (round {rnd}, {k}) differs")
+                    done += 1
+                    if k % 4 == 3:
+                        if run_msm(d, pd, sd, nd) != exp_d:
+                            raise AssertionError(f"thread B: DMA task (round {rnd}, {k}) differs")
+                        done += 1
+                rnd += 1
+            b.close(); d.close()
+        except BaseException as e:   # noqa: BLE001
+            errors.append(("B", e))
+
+    ta, tb = threading.Thread(target=run_a), threading.Thread(target=run_b)
+    ta.start(); tb.start()
+    ta.join(600); tb.join(600)
+    assert not ta.is_alive() and not tb.is_alive(), "a host thread is stuck"
+    assert not errors, errors
+    a.close(); dsa.free()
+    blaze_amd._lib.check(L.blz_arena_release(0))
+
+
+def test_memory_info_accounts_for_the_arena_and_the_workspace(gpu, orc):
+    """blz_msm_memory_info (get_api()['device_memory']): what a loaded base costs in device memory - 96 raw + 128 Montgomery bytes
+    per BLS point - and what the engine's workspace has grown to."""
+    L = blaze_amd.lib()
+    blaze_amd._lib.check(L.blz_arena_release(0))
+    curve, n = "BLS381", 1 << 20
+    dp, ds = synth(curve, n, 1, seed=5)
+    cl = msm_client(curve, 1, PointMemoryType.HBM)
+    m0 = cl.memory_info()
+    assert m0["arena_raw"] == 0 and m0["arena_montgomery"] == 0 and m0["arena_window_tables"] == 0
+    cl.load_data_to_hbm(dp, 0, 0)
+    dp.free()
+    m1 = cl.memory_info()
+    assert m1["arena_raw"] == n * 96 and m1["arena_montgomery"] == 0          # the Montgomery copy is built by the first task
+    exp = _expected_synth(orc, curve, ds, n)
+    assert run_msm(cl, None, ds, n, hbm=(0, 0)) == exp
+    m2 = cl.get_api()["device_memory"]
+    assert n * 128 <= m2["arena_montgomery"] <= n * 128 * 1.05
+    assert (m2["arena_raw"] + m2["arena_montgomery"]) / n == pytest.approx(224, rel=0.05)
+    # workspace: at least the entries (4 B x n x windows) and one partial sum (224 B) per bucket
+    api = cl.get_api()
+    assert m2["workspace"] >= 4 * n * int(api["windows"]) and m2["staging"] == 0
+    assert m2["total"] == m2["workspace"] + m2["staging"] + m2["arena_raw"] + m2["arena_montgomery"] + m2["arena_window_tables"]
+    # a window table shows up where it belongs: W x the Montgomery copy
+    cl.set_window_table(2)
+    assert cl.prepare_window_table(n, (0, 0), -1)
+    assert run_msm(cl, None, ds, n, hbm=(0, 0)) == exp
+    tinfo = cl.window_table_info()
+    m3 = cl.memory_info()
+    assert tinfo["bytes"] > 0 and m3["arena_window_tables"] >= tinfo["bytes"]
+    assert tinfo["bytes"] == pytest.approx(n * 128 * tinfo["windows"], rel=0.05)
+    # host buffers (DMA mode) are staging, not arena
+    d = msm_client(curve, 1)
+    nd = 5000
+    pd, sd, exp_d = orc.input_generator(curve, nd, 1, 3)
+    assert run_msm(d, pd, sd, nd) == exp_d
+    md = d.memory_info()
+    assert md["staging"] >= nd * (32 + 96 + 128) and md["arena_raw"] == m3["arena_raw"]   # the arena figures are per device
+    d.close(); cl.close(); ds.free()
+    blaze_amd._lib.check(L.blz_arena_release(0))
+
+
 def test_shadow_conversions_are_ordered_across_handles(gpu, orc):
     """Two handles on one arena extent: handle A's task converts the whole extent on A's stream; handle
     B then rewrites a few points and launches - B converts only its span, on B's stream, and must still see every
@@ -788,7 +956,7 @@ def test_wait_result_is_bounded(gpu, orc, monkeypatch):
     assert run_msm(cl, pts, sc, n) == exp
     monkeypatch.setenv("BLAZE_WAIT_TIMEOUT_MS", "400")
     tok = C.c_void_p()
-    blaze_amd._lib.check(blaze_amd.lib().blz_test_msm_stall(cl._h, 20000, C.byref(tok)))   # capped at 20 s on the device
+    blaze_amd._lib.check(blaze_amd.aux().blz_test_msm_stall(cl._h, 20000, C.byref(tok)))   # capped at 20 s on the device
     params = MSMParams(n, None)
     cl.initialize(params); cl.start_process(); cl.set_data(MSMInput(pts, sc, params))   # queued behind the stall
     t0 = time.perf_counter()
@@ -804,7 +972,7 @@ def test_wait_result_is_bounded(gpu, orc, monkeypatch):
         assert ei.value.variant == "Unknown" and "wedged" in str(ei.value)
     with pytest.raises(DriverClientError):
         cl.reset()                                                       # still stalled: reset's own wait expires too
-    blaze_amd._lib.check(blaze_amd.lib().blz_test_stall_release(tok))
+    blaze_amd._lib.check(blaze_amd.aux().blz_test_stall_release(tok))
     monkeypatch.setenv("BLAZE_WAIT_TIMEOUT_MS", "60000")
     cl.reset()
     assert run_msm(cl, pts, sc, n) == exp                                # the handle is whole again
@@ -891,7 +1059,7 @@ def test_hidden_three_level_sort(gpu, orc, curve, logn, pf, monkeypatch):
     n = (1 << logn) - 12345            # ragged: the last level-1 block and the last slices are partial
     dp, ds0 = synth(curve, n, pf=pf, seed=11)
     ds1 = DeviceBuffer(0, n * 32)
-    blaze_amd._lib.check(blaze_amd.lib().blz_synth_scalars(0, int(Curve[curve]), ds1.ptr, n, 12))
+    blaze_amd._lib.check(blaze_amd.aux().blz_synth_scalars(0, int(Curve[curve]), ds1.ptr, n, 12))
     exp = []
     for d in (ds0, ds1):
         k = orc.index_weighted_sum(curve, d.download(), n, 0, threads=8)

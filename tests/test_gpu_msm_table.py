@@ -175,7 +175,7 @@ def test_tasks_in_flight_and_geometries(gpu, orc, curve, logn, c, monkeypatch):
         monkeypatch.setenv("BLAZE_MSM_PLAN", f"table_c={c}")
     dp, ds0 = synth(curve, n, seed=21)
     ds1 = DeviceBuffer(0, n * 32)
-    blaze_amd._lib.check(blaze_amd.lib().blz_synth_scalars(0, int(Curve[curve]), ds1.ptr, n, 22))
+    blaze_amd._lib.check(blaze_amd.aux().blz_synth_scalars(0, int(Curve[curve]), ds1.ptr, n, 22))
     exp = []
     for d in (ds0, ds1):
         k = orc.index_weighted_sum(curve, d.download(), n, 0, threads=8)

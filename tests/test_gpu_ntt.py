@@ -165,7 +165,7 @@ def test_exchange_full_size_2e27(gpu, orc):
     cl = NTTClient(NTT.Ntt, DriverClient(0), log_size=logn)
     cl.initialize(NttInit())
     d_in = DeviceBuffer(0, 32 * n)
-    blaze_amd._lib.check(blaze_amd.lib().blz_synth_field_elements(0, d_in.ptr, n, 777))
+    blaze_amd._lib.check(blaze_amd.aux().blz_synth_field_elements(0, d_in.ptr, n, 777))
     x = np.frombuffer(d_in.download(), dtype=np.uint8).copy()
     d_in.free()
     delta = np.zeros(32 * n, dtype=np.uint8)
@@ -201,7 +201,7 @@ def test_full_size_2e27_properties(gpu, orc):
     n = 1 << logn
     cl = NTTClient(NTT.Ntt, DriverClient(0), log_size=logn)
     d_in = DeviceBuffer(0, 32 * n)
-    blaze_amd._lib.check(blaze_amd.lib().blz_synth_field_elements(0, d_in.ptr, n, 99))
+    blaze_amd._lib.check(blaze_amd.aux().blz_synth_field_elements(0, d_in.ptr, n, 99))
     cl.set_data(NTTInput(0, d_in))
     cl.initialize(NttInit())
     cl.start_process(0)
@@ -259,7 +259,7 @@ def test_full_size_2e27_every_output(gpu, orc, pass2):
     want = (3 + (1 if pass2 == "factor_table" else 0)) * 32 * n      # two buffers + scratch (+ the factor table)
     assert want <= info["device_bytes"] <= want * 1.05, info
     d_in = DeviceBuffer(0, 32 * n)
-    blaze_amd._lib.check(blaze_amd.lib().blz_synth_field_elements(0, d_in.ptr, n, 4242))
+    blaze_amd._lib.check(blaze_amd.aux().blz_synth_field_elements(0, d_in.ptr, n, 4242))
     cl.set_data(NTTInput(0, d_in))
     cl.initialize(NttInit())
     cl.start_process(0)
@@ -485,7 +485,7 @@ def test_wait_result_is_bounded(gpu, orc, monkeypatch):
     nc.set_data(NTTInput(0, data))
     monkeypatch.setenv("BLAZE_WAIT_TIMEOUT_MS", "400")
     tok = C.c_void_p()
-    blaze_amd._lib.check(blaze_amd.lib().blz_test_ntt_stall(nc._h, 20000, C.byref(tok)))
+    blaze_amd._lib.check(blaze_amd.aux().blz_test_ntt_stall(nc._h, 20000, C.byref(tok)))
     nc.initialize(NttInit())
     nc.start_process(0)
     t0 = time.perf_counter()
@@ -498,7 +498,7 @@ def test_wait_result_is_bounded(gpu, orc, monkeypatch):
     assert "wedged" in str(ei.value)
     with pytest.raises(DriverClientError):
         nc.reset()
-    blaze_amd._lib.check(blaze_amd.lib().blz_test_stall_release(tok))
+    blaze_amd._lib.check(blaze_amd.aux().blz_test_stall_release(tok))
     monkeypatch.setenv("BLAZE_WAIT_TIMEOUT_MS", "60000")
     nc.reset()
     assert bytes(nc.result(0)) == bytes(orc.ntt("BLS381", data, logn))   # the queued transform ran once the stall ended

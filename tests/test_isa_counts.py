@@ -51,7 +51,7 @@ def test_ntt_pass_multiply_adds(disasm):
     count; passes 1 and 3 also carry the no-boundary-table chain and the inverse transform's closing products, so theirs bound
     it from above; pass 2 without the table (smaller transforms) steps its factors: 36 Shoup + 10 Montgomery products."""
     want = [37 * 143 + 2 * 9, 29 * 143 + 8 * 153 + 2 * 9, 29 * 143 + 10 * 9]
-    assert sum(want) == _bench_constant(r"multiply_adds_per_lane\D+(\d+)") or sum(want) == 14935
+    assert sum(want) == 14935
     got = []
     for p, tab in ((1, 0), (2, 1), (3, 0)):
         ins = function_instructions(disasm, f"_ZN3blz11k_ntt512_rrINS_9Fr_BLS381ELi{p}ELb{tab}EEEvPKjPjNS_7NttGeomENS_11NttTablesRRE")
@@ -62,4 +62,6 @@ def test_ntt_pass_multiply_adds(disasm):
     stepped = function_instructions(disasm, "_ZN3blz11k_ntt512_rrINS_9Fr_BLS381ELi2ELb0EEEvPKjPjNS_7NttGeomENS_11NttTablesRRE")
     assert abs(count(stepped, "v_mad_u64_u32") - (36 * 143 + 10 * 153 + 2 * 9)) <= 8
     src = open(os.path.join(ROOT, "bench.py")).read()
-    assert "(37 * 143 + 2 * 9) + (29 * 143 + 8 * 153 + 2 * 9) + (29 * 143 + 10 * 9)" in src
+    # bench.py prices the transform with these very counts, picking pass 2's by what blz_ntt_info reports for the handle it times
+    assert "pass2_table, pass2_stepped = 29 * 143 + 8 * 153 + 2 * 9, 36 * 143 + 10 * 153 + 2 * 9" in src
+    assert '(37 * 143 + 2 * 9) + (pass2_table if ninfo["pass2_factor_table"] else pass2_stepped) + (29 * 143 + 10 * 9)' in src

@@ -21,8 +21,8 @@ def main():
         n = 1 << logn
         dp = DeviceBuffer(0, n * ps * pf); ds = DeviceBuffer(0, n * 32)
         t = time.time()
-        blaze_amd.lib().blz_synth_points(0, cid, dp.ptr, n, pf, 0)
-        blaze_amd.lib().blz_synth_scalars(0, cid, ds.ptr, n, 7)
+        blaze_amd.aux().blz_synth_points(0, cid, dp.ptr, n, pf, 0)
+        blaze_amd.aux().blz_synth_scalars(0, cid, ds.ptr, n, 7)
         tg = time.time() - t
         for rep in range(reps):
             params = MSMParams(n, None)

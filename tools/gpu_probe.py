@@ -37,8 +37,8 @@ def main():
         n = 1 << logn
         dp = DeviceBuffer(0, n * 96); ds = DeviceBuffer(0, n * 32)
         t = time.time()
-        blaze_amd.lib().blz_synth_points(0, 1, dp.ptr, n, 1, 0)
-        blaze_amd.lib().blz_synth_scalars(0, 1, ds.ptr, n, 7)
+        blaze_amd.aux().blz_synth_points(0, 1, dp.ptr, n, 1, 0)
+        blaze_amd.aux().blz_synth_scalars(0, 1, ds.ptr, n, 7)
         tg = time.time() - t
         for rep in range(2):
             t = time.time()

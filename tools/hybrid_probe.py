@@ -18,7 +18,7 @@ N = 1 << 26
 ENTRIES = 12 * N
 assert HP.hp_setup(26, ENTRIES // 2) == 0
 dp = DeviceBuffer(0, N * 96); ds = DeviceBuffer(0, N * 32)
-check(L.blz_synth_points(0, 1, dp.ptr, N, 1, 0)); check(L.blz_synth_scalars(0, 1, ds.ptr, N, 7))
+check(blaze_amd.aux().blz_synth_points(0, 1, dp.ptr, N, 1, 0)); check(blaze_amd.aux().blz_synth_scalars(0, 1, ds.ptr, N, 7))
 L.blz_arena_release(0)
 cl = MSMClient(MSMInit(PointMemoryType.HBM, False, Curve.BLS381), DriverClient(0))
 cl.load_data_to_hbm(dp, 0, 0)

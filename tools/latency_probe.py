@@ -20,8 +20,8 @@ n = 1 << logn
 cid = int(Curve[curve])
 dp = DeviceBuffer(0, n * int(L.blz_point_size(cid)))
 ds = DeviceBuffer(0, n * 32)
-check(L.blz_synth_points(0, cid, dp.ptr, n, 1, 0))
-check(L.blz_synth_scalars(0, cid, ds.ptr, n, 7))
+check(blaze_amd.aux().blz_synth_points(0, cid, dp.ptr, n, 1, 0))
+check(blaze_amd.aux().blz_synth_scalars(0, cid, ds.ptr, n, 7))
 L.blz_arena_release(0)
 cl = MSMClient(MSMInit(PointMemoryType.HBM, False, Curve[curve]), DriverClient(0))
 cl.load_data_to_hbm(dp, 0, 0)

@@ -11,7 +11,7 @@ logn = int(sys.argv[1]) if len(sys.argv) > 1 else 27
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 n = 1 << logn
 d = DeviceBuffer(0, 32 * n)
-check(blaze_amd.lib().blz_synth_field_elements(0, d.ptr, n, 5))
+check(blaze_amd.aux().blz_synth_field_elements(0, d.ptr, n, 5))
 nc = NTTClient(NTT.Ntt, DriverClient(0), log_size=logn)
 nc.set_data(NTTInput(0, d))
 for i in range(reps):

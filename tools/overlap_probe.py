@@ -17,8 +17,8 @@ n = 1 << logn
 cid = int(Curve.BLS381)
 d_pts = DeviceBuffer(0, n * 96)
 d_sc = DeviceBuffer(0, n * 32)
-check(L.blz_synth_points(0, cid, d_pts.ptr, n, 1, 0))
-check(L.blz_synth_scalars_at(0, cid, d_sc.ptr, n, 0xB1A2E, 0))
+check(blaze_amd.aux().blz_synth_points(0, cid, d_pts.ptr, n, 1, 0))
+check(blaze_amd.aux().blz_synth_scalars_at(0, cid, d_sc.ptr, n, 0xB1A2E, 0))
 L.blz_arena_release(0)
 cur = Curve.BLS381
 clients = [MSMClient(MSMInit(PointMemoryType.HBM, False, cur), DriverClient(0)) for _ in range(2)]

@@ -40,6 +40,34 @@ for i in range(cycles + 2):
     nc.wait_result()
     per.append(time.perf_counter() - t)
 steady = sorted(per[2:])[len(per[2:]) // 2]
+
+
+# the same loop with result + set_data fused into blz_ntt_exchange (full duplex): pageable buffers, then page-locked ones
+def exchange_loop(xin, yout):
+    nc.initialize(NttInit())
+    ts = []
+    for i in range(cycles + 2):
+        t = time.perf_counter()
+        bh, bk = i % 2, 1 - i % 2
+        nc.start_process(bk)
+        nc.exchange(bh, xin, yout)
+        nc.wait_result()
+        ts.append(time.perf_counter() - t)
+    return ts
+
+
+per_x = exchange_loop(x, y)
+steady_x = sorted(per_x[2:])[len(per_x[2:]) // 2]
+import blaze_amd
+hx, hy = blaze_amd.HostBuffer(0, 32 * n), blaze_amd.HostBuffer(0, 32 * n)
+px, py = hx.array(), hy.array()
+px[:] = x
+py[:] = 1
+per_p = exchange_loop(px, py)
+steady_p = sorted(per_p[2:])[len(per_p[2:]) // 2]
+# (and the two plain calls with page-locked buffers, for reference)
+t = time.perf_counter(); nc.set_data(NTTInput(0, px)); sd_p = time.perf_counter() - t
+t = time.perf_counter(); nc.result_into(0, py); rs_p = time.perf_counter() - t
 out = {"config": f"2^{logn} NTT BLS12-381 Fr, host buffers (numpy, pageable)", "host_bytes_each_way": 32 * n,
        "set_data_ms": round(best[0] * 1e3, 1), "h2d_GBps": round(32 * n / best[0] / 1e9, 1),
        "start_to_wait_ms": round(best[1] * 1e3, 2), "kernel_ms": round(best[4], 2),
@@ -47,5 +75,8 @@ out = {"config": f"2^{logn} NTT BLS12-381 Fr, host buffers (numpy, pageable)", "
        "result_into_fresh_allocation_ms": round(fresh_ms, 1),
        "one_transform_full_ms": round(best[3] * 1e3, 1),
        "double_buffered_loop_ms_per_transform": round(steady * 1e3, 1),
-       "double_buffered_cycles_ms": [round(p * 1e3, 1) for p in per]}
+       "double_buffered_cycles_ms": [round(p * 1e3, 1) for p in per],
+       "exchange_loop_ms_per_transform_pageable": round(steady_x * 1e3, 1), "exchange_cycles_ms_pageable": [round(p * 1e3, 1) for p in per_x],
+       "exchange_loop_ms_per_transform_pinned": round(steady_p * 1e3, 1), "exchange_cycles_ms_pinned": [round(p * 1e3, 1) for p in per_p],
+       "set_data_ms_pinned": round(sd_p * 1e3, 1), "result_ms_pinned": round(rs_p * 1e3, 1)}
 print(json.dumps(out))

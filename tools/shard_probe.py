@@ -30,8 +30,8 @@ cnt = lay["count"]
 ps = int(L.blz_point_size(cid))
 dp = DeviceBuffer(0, cnt * ps)
 ds = DeviceBuffer(0, cnt * 32)
-check(L.blz_synth_points(0, cid, dp.ptr, cnt, 1, lay["first"]))
-check(L.blz_synth_scalars_at(0, cid, ds.ptr, cnt, 0xB1A2E, lay["first"]))
+check(blaze_amd.aux().blz_synth_points(0, cid, dp.ptr, cnt, 1, lay["first"]))
+check(blaze_amd.aux().blz_synth_scalars_at(0, cid, ds.ptr, cnt, 0xB1A2E, lay["first"]))
 L.blz_arena_release(0)
 cl = MSMClient(MSMInit(PointMemoryType.HBM, False, Curve[curve]), DriverClient(0))
 cl.set_scalar_range(lay["bit_lo"], lay["bit_hi"])

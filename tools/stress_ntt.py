@@ -43,7 +43,7 @@ for cl in clients.values():
 # 2^27: same input, many runs, one digest
 n = 1 << 27
 d = DeviceBuffer(0, 32 * n)
-check(blaze_amd.lib().blz_synth_field_elements(0, d.ptr, n, 77))
+check(blaze_amd.aux().blz_synth_field_elements(0, d.ptr, n, 77))
 nc = NTTClient(NTT.Ntt, DriverClient(0), log_size=27)
 digests = set()
 for i in range(reps27):

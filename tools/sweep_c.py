@@ -12,7 +12,7 @@ dc = DriverClient(0)
 for logn in [int(x) for x in sys.argv[1:]]:
     n = 1 << logn
     dp = DeviceBuffer(0, n * 96); ds = DeviceBuffer(0, n * 32)
-    blaze_amd.lib().blz_synth_points(0, 1, dp.ptr, n, 1, 0); blaze_amd.lib().blz_synth_scalars(0, 1, ds.ptr, n, 7)
+    blaze_amd.aux().blz_synth_points(0, 1, dp.ptr, n, 1, 0); blaze_amd.aux().blz_synth_scalars(0, 1, ds.ptr, n, 7)
     row = []
     for c in [0] + list(range(max(8, logn - 7), min(23, logn - 2) + 1)):
         if c:

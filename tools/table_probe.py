@@ -21,8 +21,8 @@ cid = int(Curve[curve])
 ps = int(L.blz_point_size(cid))
 dp = DeviceBuffer(0, n * ps)
 ds = DeviceBuffer(0, n * 32)
-check(L.blz_synth_points(0, cid, dp.ptr, n, 1, 0))
-check(L.blz_synth_scalars(0, cid, ds.ptr, n, 7))
+check(blaze_amd.aux().blz_synth_points(0, cid, dp.ptr, n, 1, 0))
+check(blaze_amd.aux().blz_synth_scalars(0, cid, ds.ptr, n, 7))
 L.blz_arena_release(0)
 cl = MSMClient(MSMInit(PointMemoryType.HBM, False, Curve[curve]), DriverClient(0))
 cl.set_window_table(bool(table))
