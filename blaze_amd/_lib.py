@@ -54,6 +54,7 @@ _SIGS = {
     "blz_msm_load_data_to_hbm_device": (C.c_int, [C.c_void_p, _u8p, C.c_size_t, C.c_uint64, C.c_uint64]),
     "blz_msm_get_data_from_hbm": (C.c_int, [C.c_void_p, _u8p, C.c_size_t, C.c_uint64, C.c_uint64]),
     "blz_arena_release": (C.c_int, [C.c_int]),
+    "blz_arena_set_policy": (C.c_int, [C.c_int, C.c_uint32]),
     "blz_arena_export": (C.c_int, [C.c_int, C.c_char_p]),
     "blz_arena_attach": (C.c_int, [C.c_int, C.c_char_p]),
     "blz_msm_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),

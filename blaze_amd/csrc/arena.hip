@@ -5,7 +5,7 @@
 // process, so "persistent" means: a holder process loads the bases and EXPORTS its arena (one
 // hipIpcMemHandle per extent, written to a registry file); any other process ATTACHES the registry and
 // addresses the same bytes through load_data_to_hbm / hbm_point_addr.  The bytes live as long as the holder.
-#include "common.hpp"
+#include "msm_engine.hpp"
 
 #include <atomic>
 #include <cstdlib>
@@ -48,12 +48,96 @@ void arena_free_extent(ArenaExtent& x) {
     if (x.mont) (void)hipFree(x.mont);
     arena_drop_table(x);
     if (x.shadow_ready) (void)hipEventDestroy(x.shadow_ready);
+    if (x.diet_ev) (void)hipEventDestroy(x.diet_ev);
     x = ArenaExtent();
 }
 
 uint64_t arena_next_epoch() {
     static std::atomic<uint64_t> next{1};
     return next.fetch_add(1);
+}
+
+static size_t format_point_bytes(int format_id) { return (format_id & 0xff) == BLZ_BN254 ? 64 : 96; }
+
+int arena_restore_raw(Arena& a, ArenaExtent& e, hipStream_t st) {
+    (void)a;
+    if (e.diet == 1) e.diet = 0;        // (a check in flight is simply forgotten: its event and flag slot are reused)
+    if (e.diet != 2) return BLZ_OK;
+    const size_t ps = format_point_bytes(e.mont_curve), mp = mont_point_bytes(e.mont_curve & 0xff);
+    void* raw = nullptr;
+    BLZ_HIP(hipMalloc(&raw, e.cap), BLZ_ERR_UNKNOWN);
+    int rc = msm_points_from_mont(e.mont_curve, e.mont, raw, e.len / ps, st);
+    if (rc == BLZ_OK) rc = sync_stream_bounded(st, "arena: raw bytes back from the Montgomery copy");
+    if (rc != BLZ_OK) {
+        if (!wait_timed_out()) (void)hipFree(raw);
+        return rc;
+    }
+    (void)mp;
+    e.raw = raw;
+    e.diet = 0;
+    BLZ_LOG(1, "arena diet: extent at %llu: %zu raw bytes restored from the Montgomery copy", (unsigned long long)e.start, e.len);
+    return BLZ_OK;
+}
+
+int arena_diet_step(Arena& a, ArenaExtent& e, size_t ps, hipStream_t st) {
+    if (!(a.policy & 1) || e.imported || e.exported || e.diet >= 2 || !e.raw || !e.mont) return BLZ_OK;
+    // the copy must BE the bytes: every point converted, the point grid flush with the extent, nothing tabulated from the raw
+    // bytes still to come, and a format that holds every base (not the even-base copy of a checked precompute table)
+    if (e.dirty_lo < e.dirty_hi || e.mont_phase != 0 || e.len % ps != 0 || (e.mont_curve >> 16) != 0 || e.build.tab) return BLZ_OK;
+    if (e.diet == 0) {
+        if (!a.build_flags && hipMalloc((void**)&a.build_flags, 256 * sizeof(uint32_t)) != hipSuccess) {
+            (void)hipGetLastError();
+            a.build_flags = nullptr;
+            return BLZ_OK;
+        }
+        if (!e.diet_ev) BLZ_HIP(hipEventCreateWithFlags(&e.diet_ev, hipEventDisableTiming), BLZ_ERR_UNKNOWN);
+        e.diet_flag = a.build_flags + (a.build_flag_next++ & 255u);
+        BLZ_HIP(hipMemsetAsync(e.diet_flag, 0, 4, st), BLZ_ERR_UNKNOWN);
+        BLZ_TRY(msm_points_all_canonical(e.mont_curve, e.raw, e.len / ps, e.diet_flag, st));
+        BLZ_HIP(hipEventRecord(e.diet_ev, st), BLZ_ERR_UNKNOWN);
+        e.diet = 1;
+        return BLZ_OK;
+    }
+    // diet == 1: the check (and, in front of it on the same stream, the last conversion) may be through
+    const hipError_t q = hipEventQuery(e.diet_ev);
+    if (q == hipErrorNotReady) return BLZ_OK;
+    if (q != hipSuccess) { (void)hipGetLastError(); e.diet = 0; return BLZ_OK; }
+    uint32_t flag_h = 1;
+    BLZ_HIP(hipMemcpy(&flag_h, e.diet_flag, 4, hipMemcpyDeviceToHost), BLZ_ERR_READ);
+    if (flag_h) {
+        BLZ_LOG(1, "arena diet: extent at %llu holds a coordinate >= q: its raw bytes stay", (unsigned long long)e.start);
+        e.diet = 3;
+        return BLZ_OK;
+    }
+    // conversions of OTHER handles read the raw bytes too (they are chained behind shadow_ready, which is complete here), and
+    // hipFree waits for the whole device: a bounded drain first
+    BLZ_TRY(sync_device_bounded("arena diet: dropping the raw bytes"));
+    (void)hipFree(e.raw);
+    e.raw = nullptr;
+    e.diet = 2;
+    BLZ_LOG(1, "arena diet: extent at %llu: %zu raw bytes dropped, the Montgomery copy (%zu bytes) is the only copy", (unsigned long long)e.start, e.cap,
+            e.mont_bytes);
+    return BLZ_OK;
+}
+
+int arena_read_bytes(Arena& a, ArenaExtent& e, uint64_t off, size_t len, void* out, hipStream_t st) {
+    (void)a;
+    if (len == 0) return BLZ_OK;
+    if (e.diet != 2) {
+        BLZ_HIP(hipMemcpy(out, (const char*)e.raw + off, len, hipMemcpyDeviceToHost), BLZ_ERR_READ);
+        return BLZ_OK;
+    }
+    // the points that cover [off, off + len), converted back into a bounce buffer
+    const size_t ps = format_point_bytes(e.mont_curve), mp = mont_point_bytes(e.mont_curve & 0xff);
+    const uint64_t p0 = off / ps, p1 = (off + len + ps - 1) / ps;
+    void* tmp = nullptr;
+    BLZ_HIP(hipMalloc(&tmp, (size_t)(p1 - p0) * ps), BLZ_ERR_READ);
+    int rc = msm_points_from_mont(e.mont_curve, (const char*)e.mont + p0 * mp, tmp, p1 - p0, st);
+    if (rc == BLZ_OK && hipMemcpyAsync(out, (const char*)tmp + (off - p0 * ps), len, hipMemcpyDeviceToHost, st) != hipSuccess)
+        rc = fail(BLZ_ERR_READ, "get_data_from_hbm: copy out of the bounce buffer failed");
+    if (rc == BLZ_OK) rc = sync_stream_bounded(st, "get_data_from_hbm: raw bytes from the Montgomery copy");
+    if (rc == BLZ_OK || !wait_timed_out()) (void)hipFree(tmp);
+    return rc;
 }
 
 static void mark_dirty(ArenaExtent& e, uint64_t lo, uint64_t hi) {
@@ -85,6 +169,8 @@ int arena_write(int device_id, uint64_t pos, const void* src, size_t len, bool s
         }
         if (pos <= x.start + x.len && x.start <= end) hit.push_back(i);
     }
+    // (a dieted extent gets its raw bytes back first: a write is byte-granular, the Montgomery copy is not)
+    for (size_t i : hit) BLZ_TRY(arena_restore_raw(A, A.ext[i], st));
     ArenaExtent* e = nullptr;
     if (hit.size() == 1) {
         ArenaExtent& x = A.ext[hit[0]];
@@ -140,6 +226,7 @@ int arena_write(int device_id, uint64_t pos, const void* src, size_t len, bool s
     }
     e->table_refused = false;
     e->pcheck = ArenaExtent::PrecompCheck();   // the table check was about the old bytes
+    e->diet = 0;                               // (so was a diet refusal / a canonical check in flight)
     e->epoch = arena_next_epoch();
     char* dst = (char*)e->raw + (pos - e->start);
     hipError_t he = hipMemcpyAsync(dst, src, len, src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st);
@@ -178,6 +265,15 @@ int blz_arena_release(int device_id) {
     return BLZ_OK;
 }
 
+int blz_arena_set_policy(int device_id, uint32_t policy) {
+    if (policy & ~(uint32_t)BLZ_ARENA_DROP_RAW) return fail(BLZ_ERR_INVALID_PARAM, "unknown arena policy bits 0x%x", policy);
+    BLZ_TRY(use_device(device_id));
+    Arena& A = arena_for(device_id);
+    std::lock_guard<std::mutex> lk(A.mu);
+    A.policy = (int)policy;
+    return BLZ_OK;
+}
+
 int blz_arena_export(int device_id, const char* path) {
     if (!path) return fail(BLZ_ERR_INVALID_PARAM, "null path");
     BLZ_TRY(use_device(device_id));
@@ -186,6 +282,7 @@ int blz_arena_export(int device_id, const char* path) {
     std::vector<RegistryRecord> recs;
     for (auto& x : A.ext) {
         if (x.imported) continue;   // only what this process owns
+        BLZ_TRY(arena_restore_raw(A, x, nullptr));   // (other processes map the RAW allocation)
         RegistryRecord r;
         memset(&r, 0, sizeof(r));
         r.start = x.start;

@@ -145,7 +145,7 @@ int sync_device_bounded(const char* what) {
     return BLZ_OK;
 }
 
-int DevBuf::reserve(size_t bytes) {
+int DevBuf::reserve(size_t bytes, bool exact) {
     if (bytes <= cap) return BLZ_OK;
     if (p) {
         // hipFree waits for the whole device: bounded here instead (a wedged kernel may still use the old buffer: leak it)
@@ -159,7 +159,7 @@ int DevBuf::reserve(size_t bytes) {
         p = nullptr;
         cap = 0;
     }
-    size_t want = bytes + bytes / 8;  // slack so slightly larger tasks do not reallocate
+    size_t want = exact ? bytes : bytes + bytes / 8;  // slack so slightly larger tasks do not reallocate (not for buffers of a fixed size)
     hipError_t e = hipMalloc(&p, want);
     if (e != hipSuccess) {
         e = hipMalloc(&p, bytes);

@@ -95,7 +95,8 @@ int ensure_dynamic_lds(const void* kernel, int bytes);
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
-    int reserve(size_t bytes);   // growth frees the old allocation behind a BOUNDED drain of the device (common.hip)
+    // growth frees the old allocation behind a BOUNDED drain of the device (common.hip); exact: no slack for later growth
+    int reserve(size_t bytes, bool exact = false);
     void release() {
         if (p) (void)hipFree(p);
         p = nullptr;
@@ -153,6 +154,12 @@ struct ArenaExtent {
         uint64_t first = 0, npts = 0;
         float ms = 0;                      // device time of the check
     } pcheck;
+    // Arena diet (blz_arena_set_policy, arena.hip): 0 raw bytes in place; 1 their canonical check is enqueued (diet_ev, diet_flag);
+    // 2 raw DROPPED - the complete Montgomery copy is the only copy, and get_data_from_hbm / writes / exports / table builds
+    // convert back from it; 3 refused until the next write (a coordinate >= q would not survive the round trip)
+    int diet = 0;
+    hipEvent_t diet_ev = nullptr;
+    uint32_t* diet_flag = nullptr;
     uint64_t epoch = 0;                    // changes with every write into the extent (a check that ran unlocked commits only to the bytes it read)
     // A table being built (msm_capi.hip arena_points_table): in chunks, paced by the tasks over these bases (each enqueues a
     // few chunks on its own stream ahead of itself and takes the plain path); the task that finds `done` complete behind the
@@ -178,6 +185,7 @@ struct Arena {
     bool scratch_recorded = false;
     uint32_t* build_flags = nullptr;       // 256 flag slots, one per build in turn
     uint32_t build_flag_next = 0;
+    int policy = 0;                        // blz_arena_set_policy: bit 0 = drop the raw bytes of an extent once its Montgomery copy is complete
 };
 Arena& arena_for(int device_id);
 // find extent containing [pos, pos+len); nullptr if none
@@ -186,6 +194,12 @@ ArenaExtent* arena_find(Arena& a, uint64_t pos, size_t len);
 int arena_write(int device_id, uint64_t pos, const void* src, size_t len, bool src_is_device, hipStream_t st);
 void arena_free_extent(ArenaExtent& x);
 uint64_t arena_next_epoch();
+// arena diet: give a dieted extent its raw bytes back (converted from the Montgomery copy, on st; blocking, bounded); no-op otherwise
+int arena_restore_raw(Arena& a, ArenaExtent& e, hipStream_t st);
+// ... and, after a conversion pass of arena_points_mont, move the extent one step along check -> drop (caller holds the lock)
+int arena_diet_step(Arena& a, ArenaExtent& e, size_t point_bytes, hipStream_t st);
+// bytes [off, off + len) of an extent (relative to its start) into host memory, whichever copy holds them
+int arena_read_bytes(Arena& a, ArenaExtent& e, uint64_t off, size_t len, void* out, hipStream_t st);
 void arena_drop_table(ArenaExtent& x);   // the table and a build in flight; the caller has drained the device
 
 }  // namespace blz

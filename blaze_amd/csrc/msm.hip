@@ -460,6 +460,17 @@ static const MsmCurveOps* ops_for(int curve, int repr = 0) {
     return nullptr;
 }
 
+int msm_points_from_mont(int format_id, const void* d_mont, void* d_raw, uint64_t npts, hipStream_t st) {
+    const MsmCurveOps* ops = (format_id >> 16) ? nullptr : ops_for(format_id & 0xff, (format_id >> 8) & 0xff);   // (an even-base copy is not the whole table)
+    if (!ops) return fail(BLZ_ERR_UNKNOWN, "no conversion back from Montgomery format 0x%x", format_id);
+    return ops->points_from_mont(d_mont, d_raw, npts, st);
+}
+int msm_points_all_canonical(int format_id, const void* d_raw, uint64_t npts, uint32_t* flag, hipStream_t st) {
+    const MsmCurveOps* ops = ops_for(format_id & 0xff, (format_id >> 8) & 0xff);
+    if (!ops) return fail(BLZ_ERR_UNKNOWN, "unknown Montgomery format 0x%x", format_id);
+    return ops->points_all_canonical(d_raw, npts, flag, st);
+}
+
 int launch_fill_units(MsmEngine& E, uint32_t U /* upper bound of the unit count */) {
     const uint64_t G = E.last_plan.G;
     const uint32_t L = E.last_plan.L;

@@ -86,6 +86,8 @@ size_t result_size(const blz_msm* h) { return blz_result_size(h->curve); }
 // Resolve the Montgomery-form view of `npts` points stored at arena offset `pos`: (re)builds the part of the
 // extent's shadow that is stale, on this handle's main stream, and orders this stream behind conversions other
 // handles may have enqueued.
+static bool wants_table_mode(const blz_msm* h) { return h->pf == 1 && h->window_table != 0; }
+
 int arena_points_mont(blz_msm* h, uint64_t pos, uint32_t npts, const void** out, bool even = false) {
     // even (checked-table plan of a precompute handle): the copy holds the even bases of every element only - B_0, B_2, B_4, B_6,
     // contiguous, 4 per element - and *out addresses the copy of the element at `pos`; npts counts the RAW points (8 per element)
@@ -105,6 +107,7 @@ int arena_points_mont(blz_msm* h, uint64_t pos, uint32_t npts, const void** out,
     const size_t want_bytes = (even ? (cap_pts / 8) * 4 : cap_pts) * mp;
     if (e->mont_curve != fmt || e->mont_phase != phase || e->mont_bytes < want_bytes) {
         // another curve / grid / layout (or the first use): a fresh shadow, everything stale
+        BLZ_TRY(arena_restore_raw(A, *e, h->eng.stream));   // (a dieted extent: the new copy is made from the bytes)
         if (e->mont) {
             BLZ_TRY(sync_device_bounded("replacing a Montgomery shadow"));   // a task of another handle may still read the old one
             (void)hipFree(e->mont);
@@ -143,6 +146,7 @@ int arena_points_mont(blz_msm* h, uint64_t pos, uint32_t npts, const void** out,
     }
     *out = (const char*)e->mont + (even ? first / 8 * 4 : first) * mp;
     if (even) h->pc_info[3] = e->mont_bytes;
+    else if (!wants_table_mode(h)) BLZ_TRY(arena_diet_step(A, *e, ps, h->eng.stream));   // (a table is tabulated from the raw bytes: no diet under such a handle)
     return BLZ_OK;
 }
 
@@ -184,6 +188,7 @@ int arena_precompute_check(blz_msm* h, uint64_t pos, uint32_t nelem, bool* ok) {
             BLZ_LOG(1, "precompute plan: no memory for the check's flag: exact path");
             return BLZ_OK;
         }
+        BLZ_TRY(arena_restore_raw(A, *e, h->eng.stream));   // (the check reads the raw bytes)
         flag = A.build_flags + (A.build_flag_next++ & 255u);
         epoch = e->epoch;
         hipStream_t st = h->eng.stream;
@@ -266,6 +271,7 @@ int arena_points_table(blz_msm* h, uint64_t pos, uint32_t npts, const void** out
         return fail(BLZ_ERR_INVALID_PARAM, "HBM bases: no loaded extent covers [%llu, +%zu) on device %d",
                     (unsigned long long)pos, len, h->device);
     if (npts == 0) return BLZ_OK;
+    BLZ_TRY(arena_restore_raw(A, *e, h->eng.stream));   // (tables are tabulated from the raw bytes)
     const uint32_t phase = (uint32_t)((pos - e->start) % ps);
     const uint64_t first = (pos - e->start - phase) / ps;
     const int fmt = h->eng.format_id();
@@ -1095,8 +1101,7 @@ int blz_msm_get_data_from_hbm(blz_msm* h, uint8_t* out, size_t len, uint64_t add
     std::lock_guard<std::mutex> lk(A.mu);
     ArenaExtent* e = arena_find(A, addr + off, len);
     if (!e) return fail(BLZ_ERR_READ, "no loaded extent covers [%llu, +%zu)", (unsigned long long)(addr + off), len);
-    BLZ_HIP(hipMemcpy(out, (const char*)e->raw + (addr + off - e->start), len, hipMemcpyDeviceToHost), BLZ_ERR_READ);
-    return BLZ_OK;
+    return arena_read_bytes(A, *e, addr + off - e->start, len, out, h->eng.aux_stream);
 }
 
 int blz_msm_task_label(blz_msm* h, uint32_t* out) {
@@ -1158,7 +1163,7 @@ int blz_msm_memory_info(blz_msm* h, uint64_t out[6]) {
         Arena& A = arena_for(h->device);
         std::lock_guard<std::mutex> lk(A.mu);
         for (const auto& e : A.ext) {
-            if (!e.imported) raw += e.cap;
+            if (!e.imported && e.raw) raw += e.cap;
             if (e.mont) mont += e.mont_bytes;
             for (const auto& t : e.tables) tables += t.bytes;
             if (e.build.tab) tables += e.build.bytes;

@@ -160,6 +160,10 @@ struct MsmEngine {
     int sync_all();
 };
 
+// arena diet: conversions keyed by the FORMAT of a Montgomery copy (MsmEngine::format_id(): curve | repr << 8), for callers
+// without an engine of that format at hand (arena.hip)
+int msm_points_from_mont(int format_id, const void* d_mont, void* d_raw, uint64_t npts, hipStream_t st);
+int msm_points_all_canonical(int format_id, const void* d_raw, uint64_t npts, uint32_t* flag, hipStream_t st);
 size_t fq_bytes(int curve);
 size_t mont_point_bytes(int curve);  // stride of the Montgomery point array the pipeline reads (msm_impl.hip.hpp MONT_STRIDE)
 // two-level LDS-privatised digit sort (msm_sort.hip): fills count[], then (after the scan) entries[]
@@ -205,6 +209,9 @@ struct MsmCurveOps {
     // *flag (device u32) is raised when the table of nelem elements is not B_j = 2^32 B_(j-1) over on-curve B_0
     int (*points_to_mont_even)(MsmEngine&, const void* d_raw, void* d_mont, uint32_t nq);
     int (*check_precompute)(MsmEngine&, const void* d_raw, uint64_t nelem, uint32_t* flag, hipStream_t st);
+    // arena diet (arena.hip): the Montgomery copy back to wire-format points; *flag raised when a raw coordinate is >= q
+    int (*points_from_mont)(const void* d_mont, void* d_raw, uint64_t npts, hipStream_t st);
+    int (*points_all_canonical)(const void* d_raw, uint64_t npts, uint32_t* flag, hipStream_t st);
 };
 const MsmCurveOps& msm_ops_bls377();
 const MsmCurveOps& msm_ops_bls381();

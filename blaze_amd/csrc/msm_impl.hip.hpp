@@ -96,6 +96,52 @@ __global__ __launch_bounds__(256) void k_points_to_mont_even(const uint32_t* __r
     store_mont_point<F>(mont, q, x, y);
 }
 
+// Arena diet (opt-in: blz_arena_set_policy, arena.hip): once an extent's Montgomery copy is complete the raw bytes are a second
+// copy of the same points (BLS: 96 + 128 bytes per base) that only get_data_from_hbm, a later write, an export or a table
+// build would ever read.  They can be dropped IF the copy gives them back exactly: canonical coordinates (x, y < q:
+// k_points_all_canonical checks the raw bytes before they go) convert to Montgomery form and back without loss.
+template <class F>
+__global__ __launch_bounds__(256) void k_points_from_mont(const uint32_t* __restrict__ mont, uint32_t* __restrict__ raw, uint64_t npts) {
+    const uint64_t p = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (p >= npts) return;
+    Fp<F> x, y;
+    if constexpr (USE_RR<F>) {
+        using Q = typename F::RR;
+        AffineRR<Q> a;
+        load_affine_rr<F>(a, mont, (uint32_t)p);
+        rr_to_mont32_words<Q>(x.v, a.x);
+        rr_to_mont32_words<Q>(y.v, a.y);
+    } else {
+        Affine<F> a;
+        load_affine<F>(a, mont, (uint32_t)p);
+        x = a.x;
+        y = a.y;
+    }
+    fp_from_mont(x, x);
+    fp_from_mont(y, y);
+    fp_store(raw + p * 2 * F::N, x);
+    fp_store(raw + p * 2 * F::N + F::N, y);
+}
+template <class F>
+__global__ __launch_bounds__(256) void k_points_all_canonical(const uint32_t* __restrict__ raw, uint64_t npts, uint32_t* __restrict__ flag) {
+    const uint64_t p = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (p >= npts) return;
+    bool bad = false;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        Fp<F> v;
+        fp_load(v, raw + p * 2 * F::N + c * F::N);
+        // v >= m ?  (compare from the top limb down)
+        bool ge = true;
+#pragma unroll
+        for (int i = F::N - 1; i >= 0; --i) {
+            if (v.v[i] != F::MOD[i]) { ge = v.v[i] > F::MOD[i]; break; }
+        }
+        bad |= ge;
+    }
+    if (bad) atomicOr(flag, 1u);
+}
+
 constexpr int TAG_CHECK = 77;
 template <class F>
 __global__ __launch_bounds__(64, 3) void k_check_precompute(const uint32_t* __restrict__ raw, uint64_t nelem, uint32_t* __restrict__ flag) {
@@ -1536,6 +1582,21 @@ int build_table_t(MsmEngine& E, const void* d_raw, void* d_table, uint32_t npts,
     return BLZ_OK;
 }
 
+template <class F>
+int points_from_mont_t(const void* d_mont, void* d_raw, uint64_t npts, hipStream_t st) {
+    if (npts == 0) return BLZ_OK;
+    hipLaunchKernelGGL(k_points_from_mont<F>, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, st, (const uint32_t*)d_mont, (uint32_t*)d_raw, npts);
+    BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
+    return BLZ_OK;
+}
+template <class F>
+int points_all_canonical_t(const void* d_raw, uint64_t npts, uint32_t* flag, hipStream_t st) {
+    if (npts == 0) return BLZ_OK;
+    hipLaunchKernelGGL(k_points_all_canonical<F>, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, st, (const uint32_t*)d_raw, npts, flag);
+    BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
+    return BLZ_OK;
+}
+
 constexpr uint32_t CHECK_BLOCKS = 256 * 4 * 3;   // 64-lane blocks: three waves on every SIMD
 template <class F>
 int points_to_mont_even_t(MsmEngine& E, const void* d_raw, void* d_mont, uint32_t nq) {
@@ -1580,6 +1641,8 @@ MsmCurveOps make_ops() {
     o.combine = &combine_t<F>;
     o.points_to_mont_even = &points_to_mont_even_t<F>;
     o.check_precompute = &check_precompute_t<F>;
+    o.points_from_mont = &points_from_mont_t<F>;
+    o.points_all_canonical = &points_all_canonical_t<F>;
     return o;
 }
 

@@ -150,7 +150,7 @@ int ntt_setup(blz_ntt* h) {
         h->TR.tB = nullptr;
         if (want_tb) {
             // (an optimisation, not a need: a device too full for it steps the factors as smaller transforms do)
-            if (h->table_b.reserve(ntt_bytes(h)) == BLZ_OK) h->TR.tB = h->table_b.as<uint32_t>();
+            if (h->table_b.reserve(ntt_bytes(h), true) == BLZ_OK) h->TR.tB = h->table_b.as<uint32_t>();
             else BLZ_LOG(1, "NTT: no memory for the boundary-factor table (%zu bytes): pass 2 steps its factors", ntt_bytes(h));
         }
         // pass 1 tile order (ntt_rr.hip.hpp): 0 plain, 1 + s: 2^s adjacent column groups back to back (s = 3), + 16 b: b bits of
@@ -163,10 +163,10 @@ int ntt_setup(blz_ntt* h) {
     // double-buffer loop opens with start_process on a buffer nobody wrote and result on the other
     // (tests/integration_ntt.rs:102-136, cycle 0)
     for (int b = 0; b < 2; ++b) {
-        BLZ_TRY(h->buf[b].reserve(ntt_bytes(h)));
+        BLZ_TRY(h->buf[b].reserve(ntt_bytes(h), true));   // (a transform's size is fixed: no growth slack - it was 1.5 GiB at 2^27)
         BLZ_HIP(hipMemsetAsync(h->buf[b].p, 0, ntt_bytes(h), h->stream), BLZ_ERR_UNKNOWN);
     }
-    BLZ_TRY(h->scratch.reserve(ntt_bytes(h)));
+    BLZ_TRY(h->scratch.reserve(ntt_bytes(h), true));
     BLZ_TRY(sync_stream_bounded(h->stream, "NTT set-up: tables and zero-filled buffers"));
     return BLZ_OK;
 }

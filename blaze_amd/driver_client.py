@@ -59,6 +59,10 @@ class DriverClient:
     def arena_attach(self, registry_path: str) -> None:
         check(lib().blz_arena_attach(self.id, registry_path.encode()))
 
+    def arena_set_policy(self, drop_raw: bool) -> None:
+        """include/blaze_hip.h blz_arena_set_policy: free an extent's raw bytes once its Montgomery copy is complete."""
+        check(lib().blz_arena_set_policy(self.id, 1 if drop_raw else 0))
+
     # FPGA-shell management (dclient.rs:88-279): accepted, nothing to do on a GPU
     def reset(self) -> None:
         return None

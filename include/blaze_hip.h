@@ -122,6 +122,17 @@ int blz_msm_load_data_to_hbm_device(blz_msm* h, const void* d_points, size_t len
 int blz_msm_get_data_from_hbm(blz_msm* h, uint8_t* out, size_t len, uint64_t addr, uint64_t off);
 /* drop every arena extent of a device (no reference counterpart; the card keeps HBM until reset) */
 int blz_arena_release(int device_id);
+/* Arena policy (per device, process-wide; default 0).  BLZ_ARENA_DROP_RAW: an extent keeps its bytes as loaded AND a Montgomery
+ * copy of the points the tasks gather from (BLS: 96 + 128 bytes per base; 48 + 64 GiB for the reference's largest precompute
+ * shape) although only get_data_from_hbm, a later write, an export or a table build ever read the former.  With the bit set,
+ * once an extent's copy is complete and every coordinate has been seen to be canonical (< q: such points convert to Montgomery
+ * form and back without loss; an extent that holds one that is not keeps its bytes), the raw bytes are freed; whoever needs them
+ * again gets them converted back - get_data_from_hbm returns the same bytes as before, a write / blz_arena_export /
+ * window-table build / precompute-table check first restores the whole extent (one pass).  Not applied to extents shared with
+ * other processes, to extents whose point grid does not start at their first byte, under handles that asked for a window table,
+ * or to the even-base copy of a checked precompute table (which is not the whole table).  blz_msm_memory_info shows the effect. */
+#define BLZ_ARENA_DROP_RAW 1u
+int blz_arena_set_policy(int device_id, uint32_t policy);
 /* Cross-process arena (the card's HBM outlives the process that loaded it; GPU memory does not, so a holder
  * process keeps it): blz_arena_export writes one IPC handle per extent of this process to `registry_path`;
  * blz_arena_attach, in ANOTHER process, maps those extents at the same arena offsets (all of them or, on any

@@ -78,6 +78,7 @@ extern "C" {
     pub fn blz_ntt_new(device_id: c_int, log_size: c_int, out: *mut *mut BlzNtt) -> c_int;
     pub fn blz_ntt_new_ex(device_id: c_int, log_size: c_int, inverse: c_int, out: *mut *mut BlzNtt) -> c_int;
     pub fn blz_ntt_new_field(device_id: c_int, field: c_int, log_size: c_int, inverse: c_int, out: *mut *mut BlzNtt) -> c_int;
+    pub fn blz_arena_set_policy(device_id: c_int, policy: u32) -> c_int;
     pub fn blz_host_malloc(device_id: c_int, bytes: usize, out: *mut *mut std::os::raw::c_void) -> c_int;
     pub fn blz_host_free(p: *mut std::os::raw::c_void) -> c_int;
     pub fn blz_ntt_new_ex2(device_id: c_int, field: c_int, log_size: c_int, inverse: c_int, flags: u32, out: *mut *mut BlzNtt) -> c_int;

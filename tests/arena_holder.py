@@ -15,6 +15,17 @@ addr = int(sys.argv[2])
 dc = DriverClient(0)
 cl = MSMClient(MSMInit(PointMemoryType.HBM, False, Curve.BLS381), dc)
 cl.load_data_to_hbm(pts, addr, 0)
+if os.environ.get("BLAZE_TEST_ARENA_POLICY", "0") == "1":
+    # the holder runs on the arena diet: two tasks leave it without the raw bytes, and the export has to bring them back
+    import blaze_amd
+    from blaze_amd.ingo_msm import MSMInput, MSMParams
+
+    blaze_amd._lib.check(blaze_amd.lib().blz_arena_set_policy(0, 1))
+    n = len(pts) // 96
+    for _ in range(2):
+        p = MSMParams(n, (addr, 0))
+        cl.initialize(p); cl.start_process(); cl.set_data(MSMInput(None, bytes(32 * n), p)); cl.wait_result(); cl.result()
+    assert cl.memory_info()["arena_raw"] == 0
 dc.arena_export(sys.argv[3])
 print("READY", flush=True)
 sys.stdin.read()

@@ -103,7 +103,16 @@ def test_empty_and_zero(gpu, orc):
     cl.close()
 
 
-def test_hbm_modes(gpu, orc):
+@pytest.fixture(params=[0, 1], ids=["keep_raw", "drop_raw"])
+def arena_policy(request, gpu):
+    """Both arena policies (include/blaze_hip.h blz_arena_set_policy): the default, and the diet that frees an extent's raw
+    bytes once its Montgomery copy is complete (reads, writes and exports then go through the conversion back)."""
+    blaze_amd._lib.check(gpu.blz_arena_set_policy(0, request.param))
+    yield request.param
+    blaze_amd._lib.check(gpu.blz_arena_set_policy(0, 0))
+
+
+def test_hbm_modes(gpu, orc, arena_policy):
     """tests/integration_msm_hbm.rs: points resident in device memory, scalars-only set_data; plus
     mode (iii) load-then-stream and the raw read-back of msm_api.rs:315-322."""
     curve, n = "BLS381", 2048
@@ -115,6 +124,10 @@ def test_hbm_modes(gpu, orc):
     assert cl.get_data_from_hbm(len(pts), addr, off) == bytes(pts)
     assert cl.get_data_from_hbm(96, addr, off + 96 * 7) == bytes(pts[96 * 7: 96 * 8])
     assert run_msm(cl, None, sc, n, hbm=(addr, off)) == exp           # mode (i): scalars only
+    assert run_msm(cl, None, sc, n, hbm=(addr, off)) == exp           # (drop_raw: the second task finds the check done and drops the bytes)
+    assert cl.memory_info()["arena_raw"] == (0 if arena_policy else n * 96)
+    assert cl.get_data_from_hbm(len(pts), addr, off) == bytes(pts)    # ... which read back all the same
+    assert cl.get_data_from_hbm(100, addr, off + 96 * 7 + 50) == bytes(pts[96 * 7 + 50: 96 * 7 + 150])
     cl.close()
     # points persist across client instances (integration_msm_hbm.rs:51-56 relies on it),
     # and a DMA-typed client may still select HBM bases through hbm_point_addr (:41)
@@ -135,7 +148,7 @@ def test_hbm_modes(gpu, orc):
     blaze_amd.lib().blz_arena_release(0)
 
 
-def test_arena_is_flat_memory(gpu, orc):
+def test_arena_is_flat_memory(gpu, orc, arena_policy):
     """load_data_to_hbm is a raw write into the card's memory (msm_api.rs:299-313): overlapping and adjacent loads
     keep every byte they do not cover, a table loaded in pieces is one address range, and only the rewritten
     points change in the next MSM (the Montgomery copy is refreshed for the written span alone)."""
@@ -151,6 +164,8 @@ def test_arena_is_flat_memory(gpu, orc):
     mem = bytes(ptsA[: 96 * 500]) + bytes(ptsB[96 * 500: 96 * 1500])
     assert cl.get_data_from_hbm(96 * 1500, base, 0) == mem              # the first 500 points survived
     assert run_msm(cl, None, sc, n, hbm=(base, 0)) == orc.msm_pippenger(curve, mem, sc, n, 1, threads=4)
+    assert run_msm(cl, None, sc, n, hbm=(base, 0)) == orc.msm_pippenger(curve, mem, sc, n, 1, threads=4)
+    assert (cl.memory_info()["arena_raw"] == 0) == bool(arena_policy)   # drop_raw: the writes below restore the bytes first
     # rewrite 10 points in the middle: only they change
     cl.load_data_to_hbm(ptsA[96 * 700: 96 * 710], base, 96 * 700)
     mem = mem[: 96 * 700] + bytes(ptsA[96 * 700: 96 * 710]) + mem[96 * 710:]
@@ -171,7 +186,7 @@ def test_arena_is_flat_memory(gpu, orc):
     blaze_amd.lib().blz_arena_release(0)
 
 
-def test_arena_across_processes(gpu, orc, tmp_path):
+def test_arena_across_processes(gpu, orc, tmp_path, arena_policy):
     """tests/integration_msm_hbm.rs:51-56: the bases were loaded by an earlier process.  Here a holder process
     loads and exports them (blz_arena_export); this process attaches (blz_arena_attach) and runs the scalars-only
     flow against bases it never loaded."""
@@ -183,7 +198,7 @@ def test_arena_across_processes(gpu, orc, tmp_path):
     pts, sc, exp = orc.input_generator(curve, n, 1, 21)
     (tmp_path / "pts.bin").write_bytes(bytes(pts))
     reg = str(tmp_path / "arena.reg")
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), BLAZE_TEST_ARENA_POLICY=str(arena_policy))
     holder = subprocess.Popen([_sys.executable, os.path.join(HERE, "arena_holder.py"), str(tmp_path / "pts.bin"), str(0x2000), reg],
                               stdin=subprocess.PIPE, stdout=subprocess.PIPE, env=env)
     try:
@@ -199,6 +214,65 @@ def test_arena_across_processes(gpu, orc, tmp_path):
         blaze_amd.lib().blz_arena_release(0)       # unmap before the holder frees
         holder.stdin.close()
         holder.wait(timeout=60)
+
+
+@pytest.mark.parametrize("curve,pf", [("BLS381", 1), ("BLS377", 1), ("BN254", 1), ("BN254", 8)])
+def test_arena_diet(gpu, orc, curve, pf):
+    """BLZ_ARENA_DROP_RAW: device bytes per loaded BLS point 224 -> 128 (BN254: 128 -> 64); the bytes read back identically,
+    a write restores them, a coordinate >= q keeps them, a window-table handle keeps them."""
+    L = blaze_amd.lib()
+    blaze_amd._lib.check(L.blz_arena_release(0))
+    blaze_amd._lib.check(L.blz_arena_set_policy(0, 1))
+    try:
+        ps = orc.point_bytes(curve)
+        mp = 64 if curve == "BN254" else 128
+        n = 6000
+        pts, sc, exp = orc.input_generator(curve, n, pf, 88)
+        npts = n * pf
+        cl = msm_client(curve, pf, PointMemoryType.HBM)
+        cl.load_data_to_hbm(pts, 0, 0)
+        assert cl.memory_info()["arena_raw"] == npts * ps
+        assert run_msm(cl, None, sc, n, hbm=(0, 0)) == exp
+        assert run_msm(cl, None, sc, n, hbm=(0, 0)) == exp
+        m = cl.memory_info()
+        assert m["arena_raw"] == 0 and npts * mp <= m["arena_montgomery"] <= npts * mp + 64
+        assert cl.get_data_from_hbm(len(pts), 0, 0) == bytes(pts)
+        assert cl.get_data_from_hbm(3 * ps + 11, 0, 17 * ps + 5) == bytes(pts[17 * ps + 5: 20 * ps + 16])
+        assert cl.memory_info()["arena_raw"] == 0                      # reads do not bring the bytes back
+        # a write does (it is byte-granular): the extent is whole again, the next tasks slim it down again
+        other, _, _ = orc.input_generator(curve, 16, pf, 89)
+        cl.load_data_to_hbm(other[: 5 * ps], 0, 100 * pf * ps)
+        mem = bytes(pts[: 100 * pf * ps]) + bytes(other[: 5 * ps]) + bytes(pts[100 * pf * ps + 5 * ps:])
+        assert cl.memory_info()["arena_raw"] == npts * ps
+        assert cl.get_data_from_hbm(len(mem), 0, 0) == mem
+        exp2 = orc.msm_pippenger(curve, mem, sc, n, pf, threads=8)
+        assert run_msm(cl, None, sc, n, hbm=(0, 0)) == exp2
+        assert run_msm(cl, None, sc, n, hbm=(0, 0)) == exp2
+        assert cl.memory_info()["arena_raw"] == 0
+        # a coordinate that is not canonical (x + q, same residue: the task computes the same sum) would come back as x: the
+        # extent keeps its bytes
+        q = pyref.CURVES[curve]["q"]
+        fb = ps // 2
+        x = int.from_bytes(mem[:fb], "little")
+        if x + q < (1 << (8 * fb)):
+            cl.load_data_to_hbm((x + q).to_bytes(fb, "little"), 0, 0)
+            mem3 = (x + q).to_bytes(fb, "little") + mem[fb:]
+            assert run_msm(cl, None, sc, n, hbm=(0, 0)) == exp2
+            assert run_msm(cl, None, sc, n, hbm=(0, 0)) == exp2
+            assert cl.memory_info()["arena_raw"] == npts * ps
+            assert cl.get_data_from_hbm(len(mem3), 0, 0) == mem3
+        if pf == 1:
+            # under a handle that wants a window table the raw bytes stay (tables are tabulated from them)
+            blaze_amd._lib.check(L.blz_arena_release(0))
+            cl.load_data_to_hbm(pts, 0, 0)
+            cl.set_window_table(2)
+            for _ in range(3):
+                assert run_msm(cl, None, sc, n, hbm=(0, 0)) == exp
+            assert cl.memory_info()["arena_raw"] == npts * ps
+        cl.close()
+    finally:
+        blaze_amd._lib.check(L.blz_arena_set_policy(0, 0))
+        blaze_amd._lib.check(L.blz_arena_release(0))
 
 
 def test_bn254_hbm_precompute_small(gpu, orc):
