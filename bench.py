@@ -243,6 +243,14 @@ def main():
     from blaze_amd.multi_gpu import SHARD_SCALARS_FROM_HOST, shard_layout_ex, sharded_msm
 
     L = blaze_amd.lib()
+    # The interpreter's cyclic garbage collector: with torch imported the process holds millions of long-lived objects, and a
+    # full collection - triggered by an allocation count, i.e. at some arbitrary get_api() of some timed loop - takes 0.6 - 0.7 s
+    # (it showed up as ONE 700 ms interval among the 17 ms ones of the config 4 leg).  Everything alive now is moved out of the
+    # collector's sight, and the timed loops run with it switched off.
+    import gc
+
+    gc.collect()
+    gc.freeze()
     n = 1 << LOG_N
     # rank's shard: an element chunk x a range of the scalars' bits (blz_msm_shard_layout: the library picks the mix by the
     # window planner's cost - 2 and 4 ranks split the bits of all 2^26 elements, 8 ranks take 64-bit ranges of half of the
@@ -334,10 +342,12 @@ def main():
     fence()
     sclk = SclkSampler(torch, dev)
     sclk.start()
+    gc.disable()
     t0 = time.perf_counter()
     done = run_steps(args.steps)
     fence()
     dt = time.perf_counter() - t0
+    gc.enable()
     sclk_rec = sclk.stop()
     res, api = done[-1]
     accum_ms = [a["accumulate_kernel_ms"] for _, a in done]
@@ -609,6 +619,7 @@ def main():
     def stream(cl, prm, pts_in, sc_in, k, on_set=None, on_done=None):
         """k tasks through `cl`, `queue` in flight (the headline's submission pattern); returns (seconds, results, apis)."""
         outs, apis, pending = [], [], 0
+        gc.disable()
         t_0 = time.perf_counter()
         for _ in range(k):
             cl.initialize(prm)
@@ -619,9 +630,14 @@ def main():
                 on_set((time.perf_counter() - t_s) * 1e3)
             pending += 1
             if pending >= queue:
+                t_w = time.perf_counter()
                 cl.wait_result()
+                t_w1 = time.perf_counter()
                 outs.append(cl.result().result)
+                t_w2 = time.perf_counter()
                 apis.append(cl.get_api())
+                if os.environ.get("BENCH_DEBUG") and time.perf_counter() - t_w > 0.2:
+                    print(f"[bench debug] slow collect: wait_result {(t_w1 - t_w) * 1e3:.1f} ms, result {(t_w2 - t_w1) * 1e3:.1f} ms, get_api {(time.perf_counter() - t_w2) * 1e3:.1f} ms", file=sys.stderr, flush=True)
                 if on_done is not None:
                     on_done(time.perf_counter())
                 pending -= 1
@@ -633,7 +649,9 @@ def main():
                 on_done(time.perf_counter())
             pending -= 1
         torch.cuda.synchronize(tdev)
-        return time.perf_counter() - t_0, outs, apis
+        dt_ = time.perf_counter() - t_0
+        gc.enable()
+        return dt_, outs, apis
 
     def all_ranks(dt_local, err_local):
         """(max over ranks of a leg's time, error of any rank): every rank calls it once per leg, whatever happened to it"""
@@ -885,7 +903,11 @@ def main():
                 cl4.set_scalar_range(lay4["bit_lo"], lay4["bit_hi"])
             prm4 = MSMParams(n4, (0, 0))
             stream(cl4, prm4, None, s4, 3)
-            dt4, outs4, apis4 = stream(cl4, prm4, None, s4, 10)
+            done4, set4 = [], []
+            dt4, outs4, apis4 = stream(cl4, prm4, None, s4, 10, on_set=set4.append, on_done=done4.append)
+            gaps4 = [round((b_ - a_) * 1e3, 2) for a_, b_ in zip(done4, done4[1:])]
+            if os.environ.get("BENCH_DEBUG"):
+                print("[bench debug] config 4 result intervals (ms):", gaps4, "set_data (ms):", [round(x_, 2) for x_ in set4], file=sys.stderr, flush=True)
             chk4 = None
             if not args.no_check:
                 import numpy as np
@@ -897,7 +919,7 @@ def main():
                     raise SystemExit("bench: the config 4 rank-task result is WRONG")
                 chk4 = {"ok": True, "method": "partial == (sum_i (s_i masked to the rank's bit range) (i+1) mod r) G over the rank's elements, CPU oracle"}
                 del sc4
-            cfg4 = {"ms_per_task": round(dt4 / 10 * 1e3, 3), "tasks": 10, "tasks_in_flight": queue, "shard_rank0_of_8": lay4,
+            cfg4 = {"ms_per_task": round(dt4 / 10 * 1e3, 3), "ms_per_task_steady": round(statistics.median(gaps4), 3), "tasks": 10, "tasks_in_flight": queue, "shard_rank0_of_8": lay4,
                     "kernel_ms": round(statistics.mean(a_["accumulate_kernel_ms"] for a_ in apis4), 3),
                     "window_bits": int(apis4[-1]["window_bits"]), "windows": int(apis4[-1]["windows"]),
                     "what": "config 4, one rank's share: rank 0 of 8 of a 2^26 BLS12-377 job as blz_msm_shard_layout_ex cuts it (resident "

@@ -207,6 +207,17 @@ __global__ __launch_bounds__(256) void k_extract_range(const uint32_t* __restric
     }
 }
 
+__global__ __launch_bounds__(64) void k_words_to_pinned(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, uint32_t n) {
+    __builtin_amdgcn_s_setprio(3);
+    if (threadIdx.x < n) __hip_atomic_store(dst + threadIdx.x, src[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+int copy_words_to_pinned(void* host_pinned, const void* d_src, uint32_t dwords, hipStream_t st) {
+    if (dwords > 64) return fail(BLZ_ERR_UNKNOWN, "copy_words_to_pinned: %u dwords", dwords);
+    hipLaunchKernelGGL(k_words_to_pinned, dim3(1), dim3(64), 0, st, (uint32_t*)host_pinned, (const uint32_t*)d_src, dwords);
+    BLZ_HIP(hipGetLastError(), BLZ_ERR_READ);
+    return BLZ_OK;
+}
+
 // p[i] = i: the "every bucket has exactly one sum, at its own index" unit_off of piecewise tasks (begin() / end())
 __global__ __launch_bounds__(256) void k_iota(uint32_t* __restrict__ p, uint64_t n) {
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) p[i] = (uint32_t)i;
@@ -841,7 +852,7 @@ int MsmEngine::sort_slice(int slot, int sl, const void* d_scalars, uint32_t np) 
     // No host round trip: the unit count stays on the device.  Buffers and grids are sized by the bound
     // (every bucket at most one short unit, plus entries / L full ones) and the kernels read the real count
     // from `stats`; the host copy below is for the log line, the sanity check of finish() and the hot-bucket guard.
-    BLZ_HIP(hipMemcpyAsync(S.stats_h, B.stats.p, 16, hipMemcpyDeviceToHost, ss), BLZ_ERR_READ);
+    BLZ_TRY(copy_words_to_pinned(S.stats_h, B.stats.p, 4, ss));
     if (!tiny) BLZ_TRY(launch_fill_units(E, (uint32_t)S.max_units));
     hipEvent_t sorted = S.pingpong ? S.ev_sorted_pp[sl & 1] : S.ev_sorted;
     BLZ_HIP(hipEventRecord(sorted, ss), BLZ_ERR_UNKNOWN);
@@ -932,7 +943,7 @@ int MsmEngine::run(const void* d_pts, const void* d_scalars, uint32_t npts, int 
         BLZ_HIP(hipEventRecord(S.ev[0], st), BLZ_ERR_UNKNOWN);
         BLZ_TRY(ops->emit_infinity(*this));
         for (int i = 1; i <= 4; ++i) BLZ_HIP(hipEventRecord(S.ev[i], st), BLZ_ERR_UNKNOWN);
-        BLZ_HIP(hipMemcpyAsync(S.result_h, slot_result(slot), 3 * fq_bytes(curve), hipMemcpyDeviceToHost, st), BLZ_ERR_READ);
+        BLZ_TRY(copy_words_to_pinned(S.result_h, slot_result(slot), (uint32_t)(3 * fq_bytes(curve) / 4), st));
         BLZ_HIP(hipEventRecord(S.ev_done, st), BLZ_ERR_UNKNOWN);
         last_plan = S.plan = MsmPlan();
         S.accum_timed = false;

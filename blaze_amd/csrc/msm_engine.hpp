@@ -164,6 +164,12 @@ struct MsmEngine {
 // without an engine of that format at hand (arena.hip)
 int msm_points_from_mont(int format_id, const void* d_mont, void* d_raw, uint64_t npts, hipStream_t st);
 int msm_points_all_canonical(int format_id, const void* d_raw, uint64_t npts, uint32_t* flag, hipStream_t st);
+// A few result / statistics words from device memory into PINNED host memory, stored by a one-wave kernel instead of a
+// device -> host hipMemcpyAsync: the copy engines (SDMA) are shared with every large transfer on the device - the next task's
+// 2 GiB upload, another process's traffic, the driver's own wipes of freed memory - and a 144-byte read-back queued behind
+// one of those holds a finished task's result for as long as the transfer takes (seen: 0.7 s in bench.py's config 4 leg behind
+// the release of 75 GiB).  dwords <= 64.
+int copy_words_to_pinned(void* host_pinned, const void* d_src, uint32_t dwords, hipStream_t st);
 size_t fq_bytes(int curve);
 size_t mont_point_bytes(int curve);  // stride of the Montgomery point array the pipeline reads (msm_impl.hip.hpp MONT_STRIDE)
 // two-level LDS-privatised digit sort (msm_sort.hip): fills count[], then (after the scan) entries[]

@@ -1533,7 +1533,7 @@ int run_reduce_t(MsmEngine& E, const void* sums, const void* unit_off_v) {
     }
     BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
     BLZ_HIP(hipEventRecord(S.ev[4], st), BLZ_ERR_UNKNOWN);
-    BLZ_HIP(hipMemcpyAsync(S.result_h, E.slot_result(E.cur), 12 * F::N, hipMemcpyDeviceToHost, st), BLZ_ERR_READ);
+    BLZ_TRY(copy_words_to_pinned(S.result_h, E.slot_result(E.cur), 3 * F::N, st));   // (not a copy-engine transfer: msm_engine.hpp)
     BLZ_HIP(hipEventRecord(S.ev_done, st), BLZ_ERR_UNKNOWN);
     return BLZ_OK;
 }
@@ -1557,7 +1557,7 @@ int combine_t(MsmEngine& E, const uint8_t* partials, size_t count, uint8_t* out,
     }
     hipLaunchKernelGGL(k_combine_partials<F>, dim3(1), dim3(64), 0, st, d_in, (uint32_t)count, d_out);
     BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);
-    BLZ_HIP(hipMemcpyAsync(E.combine_h, d_out, rs, hipMemcpyDeviceToHost, st), BLZ_ERR_READ);
+    BLZ_TRY(copy_words_to_pinned(E.combine_h, d_out, (uint32_t)(rs / 4), st));
     const int rc = sync_stream_bounded(st, on_device ? "all_gather_combine: exchange + combine" : "combine_partials");
     if (rc == BLZ_OK) memcpy(out, E.combine_h, rs);
     if (rc == BLZ_OK || !wait_timed_out()) tmp.release();   // (a wedged stream may still read it: leak rather than block)

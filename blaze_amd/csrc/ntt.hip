@@ -14,6 +14,7 @@
 #include <atomic>
 #include <string>
 #include <thread>
+#include <vector>
 
 #include "common.hpp"
 #include "ntt_engine.hpp"
@@ -354,11 +355,30 @@ int blz_ntt_exchange(blz_ntt* h, size_t buf, const uint8_t* next_in, size_t in_l
         return fail(BLZ_ERR_INVALID_PARAM, "buffer %zu is being transformed; call wait_result first", buf);
     BLZ_TRY(use_device(h->device));
     char* dbuf = (char*)h->buf[buf].p;
+    // Pieces of 64 MiB (1.2 ms of link; smaller ones pay more per-copy overhead than they hide: 16 MiB 93.3 ms per cycle, 64 MiB
+    // 91.3, 256 MiB 93.6, 1 GiB 105.6), except at the ends: the host -> device direction can only start once the first piece has
+    // left and runs alone behind the last one, so the first and the last pieces ramp 8 / 16 / 32 MiB.
     const size_t piece = (size_t)exp_knob("BLAZE_NTT_XCHG_MB", 64) << 20;
-    const size_t npieces = (total + piece - 1) / piece;
+    std::vector<size_t> cut;   // piece k = bytes [cut[k], cut[k + 1])
+    {
+        const size_t ramp0 = exp_knob("BLAZE_NTT_XCHG_RAMP", 1) != 0 ? (size_t)8 << 20 : piece;
+        std::vector<size_t> head, tail;
+        size_t lo = 0, hi = total;
+        for (size_t r = ramp0; r < piece && hi - lo > 4 * piece; r <<= 1) {
+            head.push_back(lo);
+            lo += r;
+            hi -= r;
+            tail.push_back(hi);
+        }
+        cut = head;
+        for (size_t o = lo; o < hi; o += piece) cut.push_back(o);
+        for (size_t i = tail.size(); i-- > 0;) cut.push_back(tail[i]);
+        cut.push_back(total);
+    }
+    const size_t npieces = cut.size() - 1;
     if (exp_knob("BLAZE_NTT_XCHG_PINNED", 1) != 0 && host_ptr_is_pinned(next_in) && host_ptr_is_pinned(prev_out)) {
         for (size_t k = 0; k < npieces; ++k) {
-            const size_t o = k * piece, len = total - o < piece ? total - o : piece;
+            const size_t o = cut[k], len = cut[k + 1] - cut[k];
             hipEvent_t ev = h->xchg_ev[k % 4];
             BLZ_HIP(hipMemcpyAsync(prev_out + o, dbuf + o, len, hipMemcpyDeviceToHost, h->copy_stream), BLZ_ERR_READ);
             BLZ_HIP(hipEventRecord(ev, h->copy_stream), BLZ_ERR_READ);
@@ -383,7 +403,7 @@ int blz_ntt_exchange(blz_ntt* h, size_t buf, const uint8_t* next_in, size_t in_l
                 if (abort_in.load(std::memory_order_acquire)) return;
                 std::this_thread::yield();
             }
-            const size_t o = k * piece, len = total - o < piece ? total - o : piece;
+            const size_t o = cut[k], len = cut[k + 1] - cut[k];
             if (hipMemcpyAsync(dbuf + o, next_in + o, len, hipMemcpyHostToDevice, st_in) != hipSuccess) {
                 (void)hipGetLastError();
                 rc_in = BLZ_ERR_WRITE;
@@ -398,7 +418,7 @@ int blz_ntt_exchange(blz_ntt* h, size_t buf, const uint8_t* next_in, size_t in_l
     int rc_out = BLZ_OK;
     bool timed_out_out = false;
     for (size_t k = 0; k < npieces && rc_out == BLZ_OK; ++k) {
-        const size_t o = k * piece, len = total - o < piece ? total - o : piece;
+        const size_t o = cut[k], len = cut[k + 1] - cut[k];
         if (hipMemcpyAsync(prev_out + o, dbuf + o, len, hipMemcpyDeviceToHost, h->copy_stream) != hipSuccess) {
             (void)hipGetLastError();
             rc_out = fail(BLZ_ERR_READ, "exchange: device -> host copy failed");
