@@ -81,9 +81,9 @@ int arena_restore_raw(Arena& a, ArenaExtent& e, hipStream_t st) {
 
 int arena_diet_step(Arena& a, ArenaExtent& e, size_t ps, hipStream_t st) {
     if (!(a.policy & 1) || e.imported || e.exported || e.diet >= 2 || !e.raw || !e.mont) return BLZ_OK;
-    // the copy must BE the bytes: every point converted, the point grid flush with the extent, nothing tabulated from the raw
-    // bytes still to come, and a format that holds every base (not the even-base copy of a checked precompute table)
-    if (e.dirty_lo < e.dirty_hi || e.mont_phase != 0 || e.len % ps != 0 || (e.mont_curve >> 16) != 0 || e.build.tab) return BLZ_OK;
+    // the copy must BE the bytes: every point converted, the point grid flush with the extent, no window table on the extent (its
+    // handle would restore the bytes at every launch) or being tabulated from them, and a format that holds every base (not the even-base copy of a checked precompute table)
+    if (e.dirty_lo < e.dirty_hi || e.mont_phase != 0 || e.len % ps != 0 || (e.mont_curve >> 16) != 0 || e.build.tab || !e.tables.empty()) return BLZ_OK;
     if (e.diet == 0) {
         if (!a.build_flags && hipMalloc((void**)&a.build_flags, 256 * sizeof(uint32_t)) != hipSuccess) {
             (void)hipGetLastError();

@@ -41,3 +41,25 @@ fn hbm_msm_bls12_381_scalars_only() {
     second.wait_result().unwrap();
     assert_eq!(second.result(None).unwrap().unwrap().result, v.result);
 }
+
+/// A precompute client (`PRECOMPUTE_FACTOR` = 8) over a resident table on the checked-table plan: same bytes as the exact path.
+#[test]
+fn hbm_msm_precompute_checked_table_plan() {
+    let id = env::var("ID").unwrap_or_else(|_| 0.to_string());
+    for v in common::msm_vectors().into_iter().filter(|v| v.pf == 8) {
+        let driver = MSMClient::new(
+            MSMInit { mem_type: PointMemoryType::HBM, is_precompute: true, curve: v.curve },
+            DriverClient::new(&id, DriverConfig::driver_client_cfg(CardType::C1100)),
+        );
+        driver.set_precompute_plan(true).unwrap();
+        driver.load_data_to_hbm(&v.points, 0, 0).unwrap();
+        assert!(driver.prepare_precompute_plan(v.n, (0, 0)).unwrap());
+        let msm_params = MSMParams { nof_elements: v.n, hbm_point_addr: Some((0, 0)) };
+        driver.initialize(msm_params).unwrap();
+        driver.start_process(None).unwrap();
+        driver.set_data(MSMInput { points: None, scalars: v.scalars.clone(), params: msm_params }).unwrap();
+        driver.wait_result().unwrap();
+        assert_eq!(driver.result(None).unwrap().unwrap().result, v.result);
+        assert_eq!(driver.precompute_plan_info().unwrap()[0], 1);
+    }
+}

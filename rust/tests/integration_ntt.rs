@@ -33,3 +33,25 @@ fn ntt_parallel_test_correctness() {
         }
     }
 }
+
+/// The same loop with `result` + `set_data` of a cycle fused into `exchange` (both directions of the link at once).
+#[test]
+fn ntt_parallel_test_correctness_with_exchange() {
+    let id = env::var("ID").unwrap_or_else(|_| 0.to_string());
+    for (logn, input, output) in common::ntt_vectors() {
+        let nof_vectors: usize = 3;
+        let dclient = DriverClient::new(&id, DriverConfig::driver_client_cfg(CardType::C1100));
+        let driver = NTTClient::with_log_size(dclient, logn);
+        driver.initialize(NttInit {}).unwrap();
+        let mut res = vec![0u8; input.len()];
+        for i in 0..(nof_vectors + 2) {
+            let buf_host = i % 2;
+            driver.start_process(Some(1 - buf_host)).unwrap();
+            driver.exchange(buf_host, &input, &mut res).unwrap();
+            if i >= 2 {
+                assert_eq!(res, output, "log size {}", logn);
+            }
+            driver.wait_result().unwrap();
+        }
+    }
+}

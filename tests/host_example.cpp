@@ -9,12 +9,53 @@ static std::vector<uint8_t> slurp(const char* p) {
     std::ifstream f(p, std::ios::binary);
     return std::vector<uint8_t>(std::istreambuf_iterator<char>(f), {});
 }
+// mode "plan": a precompute client (PRECOMPUTE_FACTOR = 8) over a RESIDENT table on the checked-table plan
+// (tests/integration_msm_hbm.rs flow; points.bin holds 8 n bases), then the device-memory figures
+static int run_plan(const std::vector<uint8_t>& points, const std::vector<uint8_t>& scalars, uint32_t n, const char* out_path) {
+    DriverClient dclient(0, DriverConfig::driver_client_cfg(CardType::MI355X));
+    MSMClient driver(MSMInit{PointMemoryType::HBM, true, Curve::BN254}, dclient);
+    driver.set_precompute_plan(true);
+    driver.load_data_to_hbm(points, 0, 0);
+    const bool ok = driver.prepare_precompute_plan(n, {0, 0});
+    MSMParams params{n, std::make_pair<uint64_t, uint64_t>(0, 0)};
+    driver.initialize(params);
+    driver.start_process();
+    driver.set_data(MSMInput{std::nullopt, scalars, params});
+    driver.wait_result();
+    MSMResult r = *driver.result();
+    const auto info = driver.precompute_plan_info();
+    const auto mem = driver.memory_info();
+    std::ofstream(out_path, std::ios::binary).write((const char*)r.result.data(), r.result.size());
+    std::printf("plan consistent %d used %llu check_state %llu raw %llu montgomery %llu\n", ok ? 1 : 0, (unsigned long long)info[0],
+                (unsigned long long)info[1], (unsigned long long)mem[2], (unsigned long long)mem[3]);
+    return 0;
+}
+// mode "ntt": two cycles of the reference's double-buffered loop (tests/integration_ntt.rs:102-136) with result + set_data
+// fused into exchange(); points.bin = the input vector, n = log_size; the transform of the input comes back in cycle 2
+static int run_ntt(const std::vector<uint8_t>& input, int logn, const char* out_path) {
+    DriverClient dclient(0, DriverConfig::driver_client_cfg(CardType::MI355X));
+    NTTClient driver(NTT::Ntt, dclient, logn);
+    driver.initialize(NttInit{});
+    std::vector<uint8_t> res;
+    for (int i = 0; i < 3; ++i) {
+        const size_t buf_host = i % 2, buf_kernel = 1 - buf_host;
+        driver.start_process(buf_kernel);
+        driver.exchange(buf_host, input, res);
+        driver.wait_result();
+    }
+    const auto info = driver.info();
+    std::ofstream(out_path, std::ios::binary).write((const char*)res.data(), res.size());
+    std::printf("ntt log_size %llu device_bytes %llu\n", (unsigned long long)info[3], (unsigned long long)info[0]);
+    return 0;
+}
 int main(int argc, char** argv) {
-    if (argc < 5) { std::fprintf(stderr, "usage: %s points.bin scalars.bin n out.bin\n", argv[0]); return 2; }
+    if (argc < 5) { std::fprintf(stderr, "usage: %s points.bin scalars.bin n out.bin [plan|ntt]\n", argv[0]); return 2; }
     try {
         auto points = slurp(argv[1]);
         auto scalars = slurp(argv[2]);
         uint32_t msm_size = (uint32_t)std::stoul(argv[3]);
+        if (argc > 5 && std::string(argv[5]) == "plan") return run_plan(points, scalars, msm_size, argv[4]);
+        if (argc > 5 && std::string(argv[5]) == "ntt") return run_ntt(points, (int)msm_size, argv[4]);
         DriverClient dclient(0, DriverConfig::driver_client_cfg(CardType::MI355X));
         MSMClient driver(MSMInit{PointMemoryType::DMA, false, Curve::BLS381}, dclient);
         MSMParams params{msm_size, std::nullopt};

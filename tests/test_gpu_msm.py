@@ -510,6 +510,24 @@ def test_cpp_host_mirror(gpu, orc, tmp_path):
     out = tmp_path / "r.bin"
     subprocess.check_call([exe, str(tmp_path / "p.bin"), str(tmp_path / "s.bin"), str(n), str(out)])
     assert out.read_bytes() == exp
+    # the round-5 additions through the same mirror: a precompute client on the checked-table plan with its memory figures ...
+    n8 = 900
+    pts8, sc8, exp8 = orc.input_generator("BN254", n8, 8, 33)
+    (tmp_path / "p8.bin").write_bytes(bytes(pts8))
+    (tmp_path / "s8.bin").write_bytes(bytes(sc8))
+    blaze_amd._lib.check(blaze_amd.lib().blz_arena_release(0))
+    said = subprocess.check_output([exe, str(tmp_path / "p8.bin"), str(tmp_path / "s8.bin"), str(n8), str(out), "plan"], text=True)
+    assert out.read_bytes() == exp8
+    assert said.startswith("plan consistent 1 used 1 check_state 1 raw %d montgomery" % (n8 * 8 * 64)), said
+    # ... and the NTT's double-buffered loop through exchange()
+    logn = 12
+    rng = __import__("random").Random(5)
+    r = pyref.CURVES["BLS381"]["r"]
+    data = b"".join(rng.randrange(r).to_bytes(32, "little") for _ in range(1 << logn))
+    (tmp_path / "x.bin").write_bytes(data)
+    said = subprocess.check_output([exe, str(tmp_path / "x.bin"), str(tmp_path / "s.bin"), str(logn), str(out), "ntt"], text=True)
+    assert out.read_bytes() == bytes(orc.ntt("BLS381", data, logn))
+    assert said.startswith("ntt log_size 12 device_bytes"), said
 
 
 @pytest.mark.parametrize("shard", ["auto", "bits", "elements"])

@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Dev tool: long-lived clients fed a random mix of task kinds - plain, resident-base window table (arena bases, sub-ranges,
 rewrites that drop the table), scalar ranges, host buffers (DMA mode and the HBM flow with host scalars: tasks enqueued piece by
-piece, BLAZE_MSM_PIECES drawn per task) - at random sizes, two in flight, every result checked through linearity
-(P_i = (i + 1) G).  python3 tools/stress_modes.py [iterations] [seed]"""
+piece, BLAZE_MSM_PIECES drawn per task), precompute clients over a resident x8 table on the checked-table plan and on the exact
+path (sub-ranges on the element grid, rewrites that re-arm the check, host scalars) - at random sizes, two in flight, every result
+checked through linearity (P_i = (i + 1) G).  STRESS_DIET=1: the arena drops raw bytes (blz_arena_set_policy).
+    python3 tools/stress_modes.py [iterations] [seed]"""
 import os
 import random
 import sys
@@ -49,6 +51,19 @@ def expected(c, first, n, lo, hi):
     return oracle.result_from_affine(c, oracle.generator_mul(c, k))
 
 
+if os.environ.get("STRESS_DIET") == "1":
+    check(L.blz_arena_set_policy(0, 1))
+# precompute tables: N8 elements x 8 bases per curve, resident at their own arena address; one client on the plan, one exact
+N8 = NMAX // 8
+ARENA8 = {c: (i + 9) << 32 for i, c in enumerate(curves)}
+pc_plan = {c: msm_client(c, 8, PointMemoryType.HBM) for c in curves}
+pc_exact = {c: msm_client(c, 8, PointMemoryType.HBM) for c in curves}
+dev8 = {}
+for c in curves:
+    dp8, _ = synth(c, N8, pf=8, seed=13)
+    dev8[c] = dp8
+    pc_plan[c].set_precompute_plan(True)
+    pc_plan[c].load_data_to_hbm(dp8, ARENA8[c], 0)
 plain = {c: msm_client(c, 1) for c in curves}
 table = {c: msm_client(c, 1, PointMemoryType.HBM) for c in curves}
 hbm = {c: msm_client(c, 1, PointMemoryType.HBM) for c in curves}
@@ -75,7 +90,7 @@ def collect(cl, key):
 for it in range(iters):
     c = rng.choice(curves)
     kind = rng.choice(("plain", "table", "table", "range", "range", "rewrite", "table+range", "dma_host", "dma_host", "hbm_host", "hbm_host",
-                       "dma_host+range", "pieces"))
+                       "dma_host+range", "pieces", "pc_plan", "pc_plan", "pc_plan_host", "pc_exact", "pc_rewrite"))
     pc = rng.choice(("", "", "1", "2", "3", "8", "16"))
     if pc:
         os.environ["BLAZE_MSM_PIECES"] = pc
@@ -94,8 +109,24 @@ for it in range(iters):
         at = rng.randrange(0, NMAX - m)
         cl.load_data_to_hbm(View(dp, at * ps[c], m * ps[c]), ARENA[c], at * ps[c])
         continue
+    if kind == "pc_rewrite":
+        # rewrite a span of a precompute table with the bytes it already holds: the check's answer goes, the results must not change
+        for cl, key in ((pc_plan[c], ("pp", c)), (pc_exact[c], ("pe", c))):
+            while pending.get(key):
+                collect(cl, key)
+        m = rng.choice([1, 9, 1 << 13])
+        at = rng.randrange(0, N8 * 8 - m)
+        pc_plan[c].load_data_to_hbm(View(dev8[c], at * ps[c], m * ps[c]), ARENA8[c], at * ps[c])
+        continue
     lo, hi = 0, 256
-    if kind == "hbm_host":
+    if kind in ("pc_plan", "pc_plan_host", "pc_exact"):
+        n = min(n, N8)
+        first = 0 if n == N8 else rng.randrange(0, N8 - n)
+        cl, key = (pc_exact[c], ("pe", c)) if kind == "pc_exact" else (pc_plan[c], ("pp", c))
+        params = MSMParams(n, (ARENA8[c], first * 8 * ps[c]))
+        sc_in = host_sc[c][first:first + n].tobytes() if kind == "pc_plan_host" else View(ds, first * 32, n * 32)
+        inp = MSMInput(None, sc_in, params)
+    elif kind == "hbm_host":
         # the reference's HBM flow: bases in the arena, the scalars a host buffer (an idle handle enqueues it piece by piece)
         cl, key = hbm[c], ("h", c)
         params = MSMParams(n, (ARENA[c], first * ps[c]))
@@ -132,8 +163,10 @@ for it in range(iters):
     if it % 20 == 19:
         print(f"iter {it + 1}: {time.time() - t0:.1f} s, mismatches so far {bad}", flush=True)
 for (k, c), lst in pending.items():
-    cl = table[c] if k == "t" else hbm[c] if k == "h" else plain[c]
+    cl = table[c] if k == "t" else hbm[c] if k == "h" else pc_plan[c] if k == "pp" else pc_exact[c] if k == "pe" else plain[c]
     while lst:
         collect(cl, (k, c))
+used = {c: pc_plan[c].precompute_plan_info() for c in curves}
+print("precompute plan, last task per curve:", used)
 print("mismatches:", bad)
 sys.exit(1 if bad else 0)
