@@ -844,11 +844,21 @@ def main():
                 if outs3[-1] != weighted_expect("BN254", s3.download(), n3, 0) or any(o != outs3[-1] for o in outs3):
                     raise SystemExit("bench: the config 3 result is WRONG")
                 chk3 = {"ok": True, "method": "result == (sum_i s_i (i+1) mod r) G over all 2^26 scalars (the bases are 2^(32 j) (i+1) G), CPU oracle"}
+            def traffic3(key, kernel_ms):
+                """counter traffic of config 3's accumulation (profiles/pmc_traffic.json), quoted while the kernel still matches the record"""
+                try:
+                    rec3 = json.load(open(tf)).get(key)
+                    if rec3 and abs(kernel_ms - rec3["kernel_ms_at_measurement"]) <= 0.10 * kernel_ms:
+                        return rec3["hbm_bytes_per_launch"]
+                except Exception:   # noqa: BLE001
+                    pass
+                return None
+
             cfg3 = {"ms_per_msm": round(dt3 / 4 * 1e3, 3), "msms": 4, "tasks_in_flight": queue, "kernel_ms": round(k3, 3),
                     "window_bits": int(apis3[-1]["window_bits"]), "windows": int(apis3[-1]["windows"]),
                     "roofline": {"bound": "hbm", "kernel": "k_accumulate", "algorithmic_bytes_per_launch": bytes3,
                                  "achieved": round(bytes3 / (k3 * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": round(bytes3 / (k3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)},
+                                 "frac": round(bytes3 / (k3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": traffic3("k_accumulate_config3_exact", k3)},
                     "what": "config 3: 2^26 BN254 elements, precompute factor 8: 2^29 bases (32 GiB) resident in the device arena, scalars-only "
                             "set_data (device-resident scalars), tests/integration_msm_hbm.rs flow", "result_check": chk3}
             # the same tasks on the checked-table plan (opt-in, blz_msm_set_precompute_plan): the resident table is checked once
@@ -872,7 +882,7 @@ def main():
                     "device_memory": apis3p[-1]["device_memory"],
                     "roofline": {"bound": "hbm", "kernel": "k_accumulate", "algorithmic_bytes_per_launch": bytes3,
                                  "achieved": round(bytes3 / (k3p * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": round(bytes3 / (k3p * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)},
+                                 "frac": round(bytes3 / (k3p * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": traffic3("k_accumulate_config3_plan", k3p)},
                     "what": "the same four tasks after blz_msm_set_precompute_plan(1): table checked once on the device (B_j == 2^32 B_(j-1), B_0 on the "
                             "curve), then 2^28 even bases x 64-bit chunks: 3 windows of 22 / 22 / 21 bits, 12 bucket additions per element instead of 16",
                     "result_check": {"ok": True, "method": "bytes equal the exact path's result" + (" (which the oracle checked)" if chk3 else "")}}
