@@ -29,6 +29,11 @@ python3 tools/rocpd_summary.py gpurun_out/prof_c2/*/*_results.db > gpurun_out/${
 CURVE=BLS377 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_c4 -- python3 tools/shard_probe.py 26 8 0 10 > gpurun_out/${R}_config4_probe.txt 2> gpurun_out/prof_c4.err
 python3 tools/rocpd_summary.py gpurun_out/prof_c4/*/*_results.db > gpurun_out/${R}_config4_kernel_stats.txt
 rm -rf gpurun_out/prof_c2 gpurun_out/prof_c4
+# PCIe-inclusive flows (never the bench value): the NTT's host loop (two calls / blz_ntt_exchange, pageable and pinned), config 2 and
+# the 2^26 DMA flow
+python3 tools/pcie_inclusive_ntt.py 27 > gpurun_out/${R}_pcie_inclusive_ntt_2e27.json 2>> gpurun_out/prof_$T.err
+python3 tools/pcie_inclusive.py 22 > gpurun_out/${R}_pcie_inclusive_cfg2_2e22.json 2>> gpurun_out/prof_$T.err
+python3 tools/pcie_inclusive.py 26 > gpurun_out/${R}_pcie_inclusive_2e26.json 2>> gpurun_out/prof_$T.err
 rm -rf gpurun_out/prof_$T gpurun_out/pmc_fetch_$T gpurun_out/pmc_write_$T
 cut -c1-600 gpurun_out/${T}_bench_line.json
 head -24 gpurun_out/${T}_bench_kernel_stats.txt | cut -c1-160
