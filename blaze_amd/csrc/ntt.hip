@@ -48,6 +48,12 @@ __global__ __launch_bounds__(256) void k_ntt_banks_post(const uint4* __restrict_
     out[2 * a + 1] = banks[2 * src + 1];
 }
 
+#ifdef BLZ_EXPERIMENT_KNOBS
+__global__ __launch_bounds__(256) void k_copy16(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+#endif
+
 }  // namespace blz
 
 using namespace blz;
@@ -376,6 +382,26 @@ int blz_ntt_exchange(blz_ntt* h, size_t buf, const uint8_t* next_in, size_t in_l
         cut.push_back(total);
     }
     const size_t npieces = cut.size() - 1;
+#ifdef BLZ_EXPERIMENT_KNOBS
+    // (experiments, profiles/r05_ntt_exchange_variants.txt: a copy KERNEL for one direction instead of the copy engine)
+    if (exp_knob("BLAZE_NTT_XCHG_KERNEL", 0) != 0 && host_ptr_is_pinned(next_in) && host_ptr_is_pinned(prev_out)) {
+        const int mode = exp_knob("BLAZE_NTT_XCHG_KERNEL", 0);   // 1: host -> device by kernel, 2: device -> host by kernel, 3: both
+        const int blocks = exp_knob("BLAZE_NTT_XCHG_BLOCKS", 64);
+        for (size_t k = 0; k < npieces; ++k) {
+            const size_t o = cut[k], len = cut[k + 1] - cut[k];
+            hipEvent_t ev = h->xchg_ev[k % 4];
+            if (mode & 2) hipLaunchKernelGGL(k_copy16, dim3(blocks), dim3(256), 0, h->copy_stream, (uint4*)(prev_out + o), (const uint4*)(dbuf + o), len / 16);
+            else BLZ_HIP(hipMemcpyAsync(prev_out + o, dbuf + o, len, hipMemcpyDeviceToHost, h->copy_stream), BLZ_ERR_READ);
+            BLZ_HIP(hipEventRecord(ev, h->copy_stream), BLZ_ERR_READ);
+            BLZ_HIP(hipStreamWaitEvent(h->copy_stream2, ev, 0), BLZ_ERR_WRITE);
+            if (mode & 1) hipLaunchKernelGGL(k_copy16, dim3(blocks), dim3(256), 0, h->copy_stream2, (uint4*)(dbuf + o), (const uint4*)(next_in + o), len / 16);
+            else BLZ_HIP(hipMemcpyAsync(dbuf + o, next_in + o, len, hipMemcpyHostToDevice, h->copy_stream2), BLZ_ERR_WRITE);
+        }
+        BLZ_NTT_WAIT(h, sync_stream_bounded(h->copy_stream, "exchange: copy out of the NTT buffer"));
+        BLZ_NTT_WAIT(h, sync_stream_bounded(h->copy_stream2, "exchange: copy into the NTT buffer"));
+        return BLZ_OK;
+    }
+#endif
     if (exp_knob("BLAZE_NTT_XCHG_PINNED", 1) != 0 && host_ptr_is_pinned(next_in) && host_ptr_is_pinned(prev_out)) {
         for (size_t k = 0; k < npieces; ++k) {
             const size_t o = cut[k], len = cut[k + 1] - cut[k];

@@ -262,6 +262,19 @@ def test_arena_diet(gpu, orc, curve, pf):
             assert cl.memory_info()["arena_raw"] == npts * ps
             assert cl.get_data_from_hbm(len(mem3), 0, 0) == mem3
         if pf == 1:
+            # coordinates at the edges of the canonical range survive the round trip too: 0, 1, q - 1, q - 2, 2^k (elements with
+            # zero scalars: no task ever gathers them, the Montgomery copy still has to hold them exactly)
+            blaze_amd._lib.check(L.blz_arena_release(0))
+            edge = [0, 1, 2, q - 1, q - 2, (q - 1) // 2, 1 << (q.bit_length() - 1), (1 << (q.bit_length() - 1)) - 1]
+            extra = b"".join(a.to_bytes(fb, "little") + b_.to_bytes(fb, "little") for a in edge for b_ in edge)
+            ne = len(edge) ** 2
+            mem4 = bytes(pts) + extra
+            sc4 = bytes(sc) + bytes(32 * ne)
+            cl.load_data_to_hbm(mem4, 0, 0)
+            assert run_msm(cl, None, sc4, n + ne, hbm=(0, 0)) == exp
+            assert run_msm(cl, None, sc4, n + ne, hbm=(0, 0)) == exp
+            assert cl.memory_info()["arena_raw"] == 0
+            assert cl.get_data_from_hbm(len(mem4), 0, 0) == mem4
             # under a handle that wants a window table the raw bytes stay (tables are tabulated from them)
             blaze_amd._lib.check(L.blz_arena_release(0))
             cl.load_data_to_hbm(pts, 0, 0)

@@ -15,6 +15,22 @@ n = 1 << logn
 x = np.random.default_rng(1).integers(0, 256, size=32 * n, dtype=np.uint8)
 x[31::32] &= 0x3F
 nc = NTTClient(NTT.Ntt, DriverClient(0), log_size=logn)
+if os.environ.get("ONLY_PINNED") == "1":   # (experiment runs: just the exchange loop over page-locked buffers)
+    import blaze_amd
+    hx, hy = blaze_amd.HostBuffer(0, 32 * n), blaze_amd.HostBuffer(0, 32 * n)
+    px, py = hx.array(), hy.array()
+    px[:] = x
+    py[:] = 1
+    nc.initialize(NttInit())
+    ts = []
+    for i in range(8):
+        t = time.perf_counter()
+        nc.start_process(1 - i % 2)
+        nc.exchange(i % 2, px, py)
+        nc.wait_result()
+        ts.append(round((time.perf_counter() - t) * 1e3, 1))
+    print(json.dumps({"exchange_cycles_ms_pinned": ts}))
+    sys.exit(0)
 y = np.zeros(32 * n, dtype=np.uint8)   # the host's output vector, kept between transforms (pages touched once)
 y[:] = 1
 t = time.perf_counter(); fresh = nc.result(0); fresh_ms = (time.perf_counter() - t) * 1e3   # a fresh 4 GiB allocation per call
