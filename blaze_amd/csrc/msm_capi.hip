@@ -42,6 +42,7 @@ struct blz_msm {
     const void* d_points_mont = nullptr;
     uint32_t staged_n = 0;
     bool staged_from_arena = false;
+    bool staged_loaded_now = false;   // this set_data also loaded the bases (mode iii: points + hbm address)
     uint64_t staged_arena_pos = 0;
     MsmEngine eng;
     // a wait ran into its deadline (BLAZE_WAIT_TIMEOUT_MS): device work of this handle may never complete, so nothing
@@ -83,14 +84,17 @@ namespace {
 size_t point_size(const blz_msm* h) { return blz_point_size(h->curve); }
 size_t result_size(const blz_msm* h) { return blz_result_size(h->curve); }
 
+static bool wants_table_mode(const blz_msm* h) { return h->pf == 1 && h->window_table != 0; }
+
 // Resolve the Montgomery-form view of `npts` points stored at arena offset `pos`: (re)builds the part of the
 // extent's shadow that is stale, on this handle's main stream, and orders this stream behind conversions other
 // handles may have enqueued.
-static bool wants_table_mode(const blz_msm* h) { return h->pf == 1 && h->window_table != 0; }
-
+// even (checked-table plan of a precompute handle): the copy holds the even bases of every element only - B_0, B_2, B_4, B_6,
+// contiguous, 4 per element - and *out addresses the copy of the element at `pos`; npts counts the RAW points (8 per element).
+// Granted only while the extent's table check still stands for these points (looked up under the same lock that resolves the
+// copy: a write by another thread between the check and this call leaves *out null, and the caller takes the exact path).
 int arena_points_mont(blz_msm* h, uint64_t pos, uint32_t npts, const void** out, bool even = false) {
-    // even (checked-table plan of a precompute handle): the copy holds the even bases of every element only - B_0, B_2, B_4, B_6,
-    // contiguous, 4 per element - and *out addresses the copy of the element at `pos`; npts counts the RAW points (8 per element)
+    *out = nullptr;
     const size_t ps = point_size(h), mp = mont_point_bytes(h->curve);
     const size_t len = (size_t)npts * ps;
     Arena& A = arena_for(h->device);
@@ -102,7 +106,10 @@ int arena_points_mont(blz_msm* h, uint64_t pos, uint32_t npts, const void** out,
     const uint32_t phase = (uint32_t)((pos - e->start) % ps);   // where the point grid sits inside the extent
     const size_t cap_pts = (e->cap - phase) / ps, ext_pts = (e->len - phase) / ps;
     const uint64_t first = (pos - e->start - phase) / ps;
-    if (even && (first & 7u)) return fail(BLZ_ERR_UNKNOWN, "even-base copy asked for a task that does not start on the extent's element grid");
+    if (even) {
+        const ArenaExtent::PrecompCheck& C = e->pcheck;
+        if ((first & 7u) || C.state != 1 || C.curve != h->curve || C.phase != phase || first < C.first || first + npts > C.first + C.npts) return BLZ_OK;
+    }
     const int fmt = h->eng.format_id() | (even ? 1 << 16 : 0);
     const size_t want_bytes = (even ? (cap_pts / 8) * 4 : cap_pts) * mp;
     if (e->mont_curve != fmt || e->mont_phase != phase || e->mont_bytes < want_bytes) {
@@ -155,8 +162,9 @@ int arena_points_mont(blz_msm* h, uint64_t pos, uint32_t npts, const void** out,
 // 3059 multiply-adds per doubling, 224 doublings per element: 0.80 s for 2^26 BN254 elements, 1.7 s for BLS - 76 % of the bare
 // multiply-add rate) and the caller waits
 // for it - with the arena unlocked; the answer is committed only if no write reached the extent in the meantime (epoch).
-int arena_precompute_check(blz_msm* h, uint64_t pos, uint32_t nelem, bool* ok) {
+int arena_precompute_check(blz_msm* h, uint64_t pos, uint32_t nelem, bool* ok, uint64_t* checked_elems = nullptr) {
     *ok = false;
+    if (checked_elems) *checked_elems = nelem;
     const size_t ps = point_size(h);
     const size_t len = (size_t)nelem * 8 * ps;
     Arena& A = arena_for(h->device);
@@ -179,6 +187,7 @@ int arena_precompute_check(blz_msm* h, uint64_t pos, uint32_t nelem, bool* ok) {
         const ArenaExtent::PrecompCheck& C = e->pcheck;
         if (C.state != 0 && C.curve == h->curve && C.phase == phase && first >= C.first && first + (uint64_t)nelem * 8 <= C.first + C.npts) {
             *ok = C.state == 1;
+            if (checked_elems) *checked_elems = C.npts / 8;
             h->pc_info[1] = (uint64_t)C.state;
             h->pc_info[2] = (uint64_t)(C.ms * 1000.0f);
             return BLZ_OK;
@@ -469,12 +478,13 @@ bool wants_table(const blz_msm* h) {
 // handle always runs on 32-bit limbs (2^29 bases, 32 GiB); the plan's even-base copy is a quarter of that per element, so it
 // takes the reduced radix up to 2^25 elements (8 GiB of even bases) and 32-bit limbs above - measured, same box, ms per MSM in a
 // stream of tasks, reduced radix / 32-bit limbs: 2^20 1.85 / 2.20, 2^22 6.60 / 7.49, 2^24 18.2 / 19.2, 2^26 74.8 / 70.0
-// (exact path: 2.2, 7.2, 24.6, 92.5).  BLAZE_MSM_PLAN pc_repr=0|1 forces one (tests).  Switched only while nothing of the
-// handle is in flight.
-int plan_repr_bn254(uint32_t nelem) {
+// (exact path: 2.2, 7.2, 24.6, 92.5).  Decided by the size of the CHECKED table, not of the task (tasks over sub-ranges of one table
+// would otherwise flip the arithmetic - and with it the format of the extent's copy - from task to task).  BLAZE_MSM_PLAN
+// pc_repr=0|1 forces one (tests).  Switched only while nothing of the handle is in flight.
+int plan_repr_bn254(uint64_t nelem) {
     const int forced = plan_override("pc_repr", -1);
     if (forced == 0 || forced == 1) return forced;
-    return nelem > (1u << 25) ? 1 : 0;
+    return nelem > (1ull << 25) ? 1 : 0;
 }
 
 // Which task serves `n` elements whose bases sit in the arena at `pos`: a precompute handle on the checked-table plan whose
@@ -482,22 +492,30 @@ int plan_repr_bn254(uint32_t nelem) {
 // everything else is the plain task over the Montgomery copy.  Resolves h->d_points_mont (shadow pointers are resolved when
 // the task is launched, not when its data was staged: a load by another handle in between may have moved or re-converted
 // the extent).
-int resolve_arena_task(blz_msm* h, uint64_t pos, uint32_t n, bool allow_table, uint32_t* npts, int* sbits, int* table_c) {
+int resolve_arena_task(blz_msm* h, uint64_t pos, uint32_t n, bool allow_table, bool allow_plan, uint32_t* npts, int* sbits, int* table_c) {
     *npts = n * h->pf;
     *sbits = h->pf == 1 ? 256 : 32;
     *table_c = 0;
     memset(h->table_info, 0, sizeof(h->table_info));
     memset(h->pc_info, 0, sizeof(h->pc_info));
-    if (h->pf == BLZ_PRECOMPUTE_FACTOR && h->precompute_plan && n > 0) {
+    if (h->pf == BLZ_PRECOMPUTE_FACTOR && h->precompute_plan && allow_plan && n > 0) {
         bool ok = false;
-        BLZ_TRY(arena_precompute_check(h, pos, n, &ok));
-        if (h->curve == BLZ_BN254 && h->in_flight.empty()) h->eng.repr = exp_knob("BLAZE_BN254_REPR", ok ? plan_repr_bn254(n) : 1) ? 1 : 0;
+        uint64_t checked = n;
+        BLZ_TRY(arena_precompute_check(h, pos, n, &ok, &checked));
+        if (h->curve == BLZ_BN254 && h->in_flight.empty()) h->eng.repr = exp_knob("BLAZE_BN254_REPR", ok ? plan_repr_bn254(checked) : 1) ? 1 : 0;
         if (ok && h->eng.plan_for(n * 4, 64).c != 0) {
-            BLZ_TRY(arena_points_mont(h, pos, n * 8, &h->d_points_mont, true));
-            *npts = n * 4;
-            *sbits = 64;
-            h->pc_info[0] = 1;
-            return BLZ_OK;
+            const void* even = nullptr;
+            BLZ_TRY(arena_points_mont(h, pos, n * 8, &even, true));
+            if (even) {
+                h->d_points_mont = even;
+                *npts = n * 4;
+                *sbits = 64;
+                h->pc_info[0] = 1;
+                return BLZ_OK;
+            }
+            // (the extent was written between the check and now: this task takes the exact path, the next one checks again)
+            h->pc_info[1] = 0;
+            if (h->curve == BLZ_BN254 && h->in_flight.empty()) h->eng.repr = exp_knob("BLAZE_BN254_REPR", 1) ? 1 : 0;
         }
     }
     if (allow_table && wants_table(h)) {
@@ -520,7 +538,9 @@ int launch_if_ready(blz_msm* h) {
     int table_c = 0;
     memset(h->table_info, 0, sizeof(h->table_info));
     memset(h->pc_info, 0, sizeof(h->pc_info));
-    if (h->staged_from_arena) BLZ_TRY(resolve_arena_task(h, h->staged_arena_pos, h->staged_n, true, &npts, &sbits, &table_c));
+    // (a task that has just loaded its own table - set_data mode iii, msm_api.rs:203-216 - is a DMA-mode task as far as the plan is
+    // concerned: a check per task would cost more than it saves)
+    if (h->staged_from_arena) BLZ_TRY(resolve_arena_task(h, h->staged_arena_pos, h->staged_n, true, !h->staged_loaded_now, &npts, &sbits, &table_c));
     h->eng.inputs_event = h->staged_set >= 0 ? h->set_free[h->staged_set] : nullptr;
     BLZ_TRY(h->eng.run(h->d_points_mont, h->d_scalars, npts, sbits, &slot, table_c, h->range_lo, h->range_hi));
     if (h->staged_set >= 0) h->set_used[h->staged_set] = true;
@@ -569,6 +589,7 @@ int stage_common(blz_msm* h, bool have_points, const void* points, size_t points
         h->staged_set = -1;
     }
 
+    h->staged_loaded_now = have_points && has_hbm;
     if (have_points && has_hbm) {
         // msm_api.rs:203-206: load_data_to_hbm(points, addr, offset) first
         BLZ_WAIT(h, arena_write(h->device, hbm_addr + hbm_off, points, points_len, on_device, st));
@@ -620,7 +641,7 @@ int stage_common(blz_msm* h, bool have_points, const void* points, size_t points
         } else {
             // (stale spans are converted on the main stream; a precompute handle on the checked-table plan: 4n even bases, 64-bit chunks)
             int tc = 0;
-            BLZ_TRY(resolve_arena_task(h, h->staged_arena_pos, n, false, &npts, &sbits, &tc));
+            BLZ_TRY(resolve_arena_task(h, h->staged_arena_pos, n, false, !h->staged_loaded_now, &npts, &sbits, &tc));
             arena_mont = h->d_points_mont;
         }
         const size_t sb = (size_t)sbits / 8;
@@ -867,12 +888,14 @@ int blz_msm_prepare_precompute_plan(blz_msm* h, uint32_t nof_elements, uint64_t 
     if (!h->precompute_plan || nof_elements == 0) return BLZ_OK;
     if ((uint64_t)nof_elements * h->pf >= (1ull << 31)) return fail(BLZ_ERR_INVALID_PARAM, "too many points");
     bool ok = false;
-    BLZ_TRY(arena_precompute_check(h, hbm_addr + hbm_off, nof_elements, &ok));
+    uint64_t checked = nof_elements;
+    BLZ_TRY(arena_precompute_check(h, hbm_addr + hbm_off, nof_elements, &ok, &checked));
     if (ok && h->in_flight.empty()) {
         // the even-base copy too, so that the first task finds it in place
-        if (h->curve == BLZ_BN254) h->eng.repr = exp_knob("BLAZE_BN254_REPR", plan_repr_bn254(nof_elements)) ? 1 : 0;
+        if (h->curve == BLZ_BN254) h->eng.repr = exp_knob("BLAZE_BN254_REPR", plan_repr_bn254(checked)) ? 1 : 0;
         const void* p = nullptr;
         BLZ_TRY(arena_points_mont(h, hbm_addr + hbm_off, nof_elements * 8, &p, true));
+        if (!p) ok = false;   // (written in between)
         BLZ_WAIT(h, sync_stream_bounded(h->eng.stream, "precompute plan: even-base copy"));
     }
     if (consistent) *consistent = ok ? 1 : 0;

@@ -224,8 +224,9 @@ int blz_msm_window_table_info(blz_msm* h, uint64_t out[4]);
  * off the curve, any multiple that is not 2^32 times its predecessor, a multiple at infinity) keeps the exact path - silently;
  * BLAZE_LOG=1 says so, blz_msm_precompute_plan_info reports it.  Any write into the extent forgets the answer and the next task
  * checks again.  The check runs inside the first set_data / start_process that launches a task over the bases (the call blocks
- * for it), or in blz_msm_prepare_precompute_plan for a host that wants to pay with the load.  DMA-mode tasks (points with every
- * task) always take the exact path: they are link-bound, and a check per task would cost more than it saves.
+ * for it), or in blz_msm_prepare_precompute_plan for a host that wants to pay with the load.  Tasks that bring their own points
+ * (DMA mode, and set_data with points AND an hbm address) always take the exact path: they are link-bound, and a check per task
+ * would cost more than it saves.
  * New handles start with 0.  InvalidPrimitiveParam for a handle without is_precompute. */
 int blz_msm_set_precompute_plan(blz_msm* h, int enable);
 /* run the check (and build the even-base copy) now for the nof_elements elements at hbm_addr + hbm_off; *consistent = 1 when

@@ -192,8 +192,9 @@ def test_plan_through_every_task_shape(gpu, orc, curve, mode, monkeypatch):
 
 
 def test_plan_survives_a_table_loaded_in_pieces_and_mode_iii(gpu, orc):
-    """The table arrives in ragged pieces (load_data_to_hbm, msm_api.rs:299-313) - some of them cutting elements in two - and
-    set_data mode iii (points + hbm address: load, then scalars; msm_api.rs:203-216) re-arms the check like any other write."""
+    """The table arrives in ragged pieces (load_data_to_hbm, msm_api.rs:299-313) - some of them cutting elements in two; a task
+    of set_data mode iii (points + hbm address: load, then scalars; msm_api.rs:203-216) brings its own table and takes the exact
+    path like a DMA-mode task, and its write re-arms the check for the tasks that follow."""
     _release()
     curve, n = "BN254", 5000
     ps = orc.point_bytes(curve)
@@ -205,7 +206,10 @@ def test_plan_survives_a_table_loaded_in_pieces_and_mode_iii(gpu, orc):
     assert run_msm(cl, None, sc, n, hbm=(0, 0)) == exp
     assert cl.precompute_plan_info()["used"]
     pts2, sc2, exp2 = orc.input_generator(curve, n, 8, 61)
-    assert run_msm(cl, pts2, sc2, n, hbm=(0, 0)) == exp2          # mode iii
+    assert run_msm(cl, pts2, sc2, n, hbm=(0, 0)) == exp2          # mode iii: the task brings its own table - exact path, no check
+    info = cl.precompute_plan_info()
+    assert not info["used"] and info["check"] == "unchecked"
+    assert run_msm(cl, None, sc2, n, hbm=(0, 0)) == exp2          # ... which the next scalars-only task over it pays, once
     info = cl.precompute_plan_info()
     assert info["used"] and info["check"] == "consistent"
     cl.close()
