@@ -29,6 +29,24 @@ def _plan_client(curve):
     return cl
 
 
+def test_golden_precompute_vectors_on_the_plan(gpu):
+    """The committed pf = 8 golden vectors (tests/golden/msm_vectors.json, minted by the pure-Python implementation) through the
+    HBM flow of a client on the checked-table plan: n = 1, 2, 5 - the plan's smallest tasks."""
+    import json
+
+    _release()
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "msm_vectors.json")) as f:
+        vecs = [v for v in json.load(f) if v["pf"] == 8]
+    assert len(vecs) >= 9
+    for v in vecs:
+        cl = _plan_client(v["curve"])
+        cl.load_data_to_hbm(bytes.fromhex(v["points"]), 0, 0)
+        assert run_msm(cl, None, bytes.fromhex(v["scalars"]), v["n"], hbm=(0, 0)) == bytes.fromhex(v["result"]), (v["curve"], v["name"])
+        assert cl.precompute_plan_info()["used"]
+        cl.close()
+        _release()
+
+
 @pytest.mark.parametrize("curve", CURVES)
 def test_plan_matches_the_exact_path_on_the_harness_sizes(gpu, orc, curve):
     """tests/integration_msm.rs sizes through the HBM flow of a precompute client: plan on == plan off == oracle."""
