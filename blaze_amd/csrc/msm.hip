@@ -44,7 +44,7 @@ size_t mont_point_bytes(int curve) { return curve == BLZ_BN254 ? 64 : 128; }
 // window of max(cmin, what is left of sbits+1) bits (its upper bits are zero for canonical scalars, so
 // its signed digits never go negative; only 2^(real bits) of its buckets are occupied).  k = 0 with a
 // top window of cmin bits is the uniform plan; BLAZE_MSM_PLAN c= forces that one.
-static MsmPlan search_plan(uint32_t npts, int sbits, int ebits, int force_c, int split_ns) {
+static MsmPlan search_plan(uint32_t npts, int sbits, int ebits, int force_c, int split_ns, int max_w) {
     MsmPlan best;
     double best_cost = 1e300;
     const double t_entry = 0.163, t_bucket = 0.62, t_empty = 0.03, t_hot = 0.01;
@@ -52,7 +52,7 @@ static MsmPlan search_plan(uint32_t npts, int sbits, int ebits, int force_c, int
     const double t_split = (double)split_ns;
     for (int cmin = 3; cmin <= 23; ++cmin) {
         if (force_c > 0 && cmin != force_c) continue;
-        for (int W = 1; W <= MSM_MAX_W; ++W) {
+        for (int W = 1; W <= max_w; ++W) {
             if ((uint64_t)npts * W >= (1ull << 32)) break;     // entries are indexed with u32
             const int lower = W - 1;
             for (int k = 0; k <= lower; ++k) {
@@ -143,7 +143,12 @@ MsmPlan make_plan(uint32_t npts, int sbits, int ebits, int force_c) {
         for (const Memo& m : memo)
             if (m.sbits == sbits && m.npts == npts && m.ebits == ebits && m.force_c == force_c && m.split_ns == split_ns) return m.plan;
     }
-    const MsmPlan P = search_plan(npts, sbits, ebits, force_c, split_ns);
+    // The 64-bit chunks of a checked precompute table (msm_capi.hip resolve_arena_task): the cost model, fitted to 256-bit scalars,
+    // moves from four windows of 16 / 17 bits to three of 22 / 22 / 21 at 2^24.5 points; measured (BN254, same box), the three-window
+    // plan already wins at 2^24 points (5.60 against 6.53 ms per MSM) and loses at 2^22 (2.67 against 1.81): four windows leave
+    // 163 K buckets of hundreds of entries - a few units per lane - and the accumulation's last wave of units idles the chip.
+    const int max_w = (sbits == 64 && force_c == 0 && npts >= (3u << 22)) ? 3 : MSM_MAX_W;
+    const MsmPlan P = search_plan(npts, sbits, ebits, force_c, split_ns, max_w);
     std::lock_guard<std::mutex> lk(mu);
     Memo& m = memo[next++ % 16];
     m.npts = npts; m.sbits = sbits; m.ebits = ebits; m.force_c = force_c; m.split_ns = split_ns;
