@@ -96,6 +96,11 @@ __global__ __launch_bounds__(256) void k_points_to_mont_even(const uint32_t* __r
     store_mont_point<F>(mont, q, x, y);
 }
 
+template <class F>
+BLZ_DEV void load_affine_rr(AffineRR<typename F::RR>& a, const uint32_t* pts, uint32_t idx);   // (below, with the accumulation's loaders)
+template <class F>
+BLZ_DEV void load_affine(Affine<F>& a, const uint32_t* pts, uint32_t idx);
+
 // Arena diet (opt-in: blz_arena_set_policy, arena.hip): once an extent's Montgomery copy is complete the raw bytes are a second
 // copy of the same points (BLS: 96 + 128 bytes per base) that only get_data_from_hbm, a later write, an export or a table
 // build would ever read.  They can be dropped IF the copy gives them back exactly: canonical coordinates (x, y < q:
@@ -1416,7 +1421,6 @@ int run_reduce_t(MsmEngine& E, const void* sums, const void* unit_off_v) {
     hipStream_t st = E.stream;
     MsmSlot& S = E.slots[E.cur];
     const MsmPlan& P = E.last_plan;
-    const uint64_t G = P.G;
     const uint32_t* unit_off = (const uint32_t*)unit_off_v;
     BLZ_HIP(hipEventRecord(S.ev[2], st), BLZ_ERR_UNKNOWN);
 

@@ -201,7 +201,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_coarse_scatter(const uint32_t*
 #endif
 constexpr int CS_THREADS = BLZ_CS_THREADS;
 constexpr int CS_T = BLZ_CS_T;
-constexpr int CS_PTS = CS_THREADS * CS_T;  // 8192 points per block: 64 KiB of staging
+// (CS_THREADS * CS_T = 8192 points per block: 64 KiB of staging)
 constexpr int CS_T_SMALL = 2;             // inputs of up to CS_SMALL_PTS points: 1024 per block
 constexpr uint32_t CS_SMALL_PTS = 1u << 19;
 
