@@ -225,7 +225,21 @@ int arena_write(int device_id, uint64_t pos, const void* src, size_t len, bool s
         arena_drop_table(*e);
     }
     e->table_refused = false;
-    e->pcheck = ArenaExtent::PrecompCheck();   // the table check was about the old bytes
+    // the table check was about the old bytes: a table that was consistent needs another look at the elements this write
+    // touches (an element's eight bases are checked against each other only); anything else is checked from scratch
+    if (e->pcheck.state == 1 || e->pcheck.state == 3) {
+        const uint64_t lo = pos - e->start, hi = end - e->start;
+        if (e->pcheck.state == 3) {
+            e->pcheck.redo_lo = lo < e->pcheck.redo_lo ? lo : e->pcheck.redo_lo;
+            e->pcheck.redo_hi = hi > e->pcheck.redo_hi ? hi : e->pcheck.redo_hi;
+        } else {
+            e->pcheck.redo_lo = lo;
+            e->pcheck.redo_hi = hi;
+            e->pcheck.state = 3;
+        }
+    } else {
+        e->pcheck = ArenaExtent::PrecompCheck();
+    }
     e->diet = 0;                               // (so was a diet refusal / a canonical check in flight)
     e->epoch = arena_next_epoch();
     char* dst = (char*)e->raw + (pos - e->start);

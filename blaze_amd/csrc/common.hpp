@@ -148,11 +148,13 @@ struct ArenaExtent {
     // been compared, element by element, with what precompute_base_* produces (tests/msm/mod.rs:360-380: B_j = 2^32 B_(j-1), B_0
     // on the curve)?  For the points [first, +npts) of the grid at `phase`; any write into the extent forgets the answer.
     struct PrecompCheck {
-        int state = 0;                     // 0 not checked, 1 consistent, 2 refuted
+        int state = 0;                     // 0 not checked, 1 consistent, 2 refuted, 3 consistent but for the elements a later write
+                                           // touched (bytes [redo_lo, redo_hi) of the extent): only those are checked again
         int curve = -1;
         uint32_t phase = 0;
         uint64_t first = 0, npts = 0;
-        float ms = 0;                      // device time of the check
+        uint64_t redo_lo = 0, redo_hi = 0;
+        float ms = 0;                      // device time of the (last) check
     } pcheck;
     // Arena diet (blz_arena_set_policy, arena.hip): 0 raw bytes in place; 1 their canonical check is enqueued (diet_ev, diet_flag);
     // 2 raw DROPPED - the complete Montgomery copy is the only copy, and get_data_from_hbm / writes / exports / table builds

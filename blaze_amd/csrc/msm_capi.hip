@@ -172,6 +172,8 @@ int arena_precompute_check(blz_msm* h, uint64_t pos, uint32_t nelem, bool* ok, u
     uint32_t phase = 0;
     uint32_t* flag = nullptr;
     hipEvent_t t0 = nullptr, t1 = nullptr;
+    bool partial = false;          // only the elements a write touched since the table was found consistent
+    uint64_t chk_elems = nelem;
     {
         std::lock_guard<std::mutex> lk(A.mu);
         ArenaExtent* e = arena_find(A, pos, len);
@@ -185,12 +187,24 @@ int arena_precompute_check(blz_msm* h, uint64_t pos, uint32_t nelem, bool* ok, u
             return BLZ_OK;
         }
         const ArenaExtent::PrecompCheck& C = e->pcheck;
-        if (C.state != 0 && C.curve == h->curve && C.phase == phase && first >= C.first && first + (uint64_t)nelem * 8 <= C.first + C.npts) {
+        const bool covered = C.state != 0 && C.curve == h->curve && C.phase == phase && first >= C.first && first + (uint64_t)nelem * 8 <= C.first + C.npts;
+        if (covered && C.state != 3) {
             *ok = C.state == 1;
             if (checked_elems) *checked_elems = C.npts / 8;
             h->pc_info[1] = (uint64_t)C.state;
             h->pc_info[2] = (uint64_t)(C.ms * 1000.0f);
             return BLZ_OK;
+        }
+        uint64_t chk_pos = pos;
+        if (covered) {
+            // state 3: the elements of the checked range that the writes since then touched
+            uint64_t plo = C.redo_lo > phase ? (C.redo_lo - phase) / ps : 0, phi = C.redo_hi > phase ? (C.redo_hi - phase + ps - 1) / ps : 0;
+            uint64_t elo = plo / 8, ehi = (phi + 7) / 8;
+            if (elo < C.first / 8) elo = C.first / 8;
+            if (ehi > (C.first + C.npts) / 8) ehi = (C.first + C.npts) / 8;
+            partial = true;
+            chk_elems = ehi > elo ? ehi - elo : 0;
+            chk_pos = e->start + phase + elo * 8 * ps;
         }
         if (!A.build_flags && hipMalloc((void**)&A.build_flags, 256 * sizeof(uint32_t)) != hipSuccess) {
             (void)hipGetLastError();
@@ -208,7 +222,7 @@ int arena_precompute_check(blz_msm* h, uint64_t pos, uint32_t nelem, bool* ok, u
         }
         int rc = BLZ_OK;
         if (hipMemsetAsync(flag, 0, 4, st) != hipSuccess || hipEventRecord(t0, st) != hipSuccess) rc = fail(BLZ_ERR_UNKNOWN, "precompute check: enqueue failed");
-        if (rc == BLZ_OK) rc = h->eng.check_precompute((const char*)e->raw + (pos - e->start), nelem, flag, st);
+        if (rc == BLZ_OK) rc = h->eng.check_precompute((const char*)e->raw + (chk_pos - e->start), chk_elems, flag, st);
         if (rc == BLZ_OK && hipEventRecord(t1, st) != hipSuccess) rc = fail(BLZ_ERR_UNKNOWN, "precompute check: enqueue failed");
         if (rc != BLZ_OK) {
             (void)hipEventDestroy(t0);
@@ -241,13 +255,17 @@ int arena_precompute_check(blz_msm* h, uint64_t pos, uint32_t nelem, bool* ok, u
     C.state = flag_h ? 2 : 1;
     C.curve = h->curve;
     C.phase = phase;
-    C.first = first;
-    C.npts = (uint64_t)nelem * 8;
+    if (!partial) {   // (a partial check confirms - or refutes - the range that had been checked before)
+        C.first = first;
+        C.npts = (uint64_t)nelem * 8;
+    }
+    C.redo_lo = C.redo_hi = 0;
     C.ms = ms;
     *ok = flag_h == 0;
+    if (checked_elems) *checked_elems = C.npts / 8;
     h->pc_info[1] = (uint64_t)C.state;
     h->pc_info[2] = (uint64_t)(ms * 1000.0f);
-    BLZ_LOG(1, "precompute plan: table of %u elements %s (%.1f ms)", nelem,
+    BLZ_LOG(1, "precompute plan: %s%llu elements checked: the table %s (%.1f ms)", partial ? "rewritten span, " : "", (unsigned long long)chk_elems,
             flag_h ? "is NOT B_j = 2^32 B_(j-1) over on-curve bases: exact path (8n points, 32-bit chunks)" : "is consistent: 4n even bases, 64-bit chunks", ms);
     return BLZ_OK;
 }

@@ -222,8 +222,8 @@ int blz_msm_window_table_info(blz_msm* h, uint64_t out[4]);
  * the even bases only (half the copy's memory).  The two sums are the same group element exactly when the check holds, and the
  * result is emitted normalised (Z = 1), so the bytes are identical to the exact path's.  A table that fails the check (any base
  * off the curve, any multiple that is not 2^32 times its predecessor, a multiple at infinity) keeps the exact path - silently;
- * BLAZE_LOG=1 says so, blz_msm_precompute_plan_info reports it.  Any write into the extent forgets the answer and the next task
- * checks again.  The check runs inside the first set_data / start_process that launches a task over the bases (the call blocks
+ * BLAZE_LOG=1 says so, blz_msm_precompute_plan_info reports it.  A write into a consistent table has the next task check the elements
+ * it touched (only those); a write into a refuted one, the whole range again.  The check runs inside the first set_data / start_process that launches a task over the bases (the call blocks
  * for it), or in blz_msm_prepare_precompute_plan for a host that wants to pay with the load.  Tasks that bring their own points
  * (DMA mode, and set_data with points AND an hbm address) always take the exact path: they are link-bound, and a check per task
  * would cost more than it saves.

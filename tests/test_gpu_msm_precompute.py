@@ -123,6 +123,44 @@ def test_a_corrupted_multiple_keeps_the_exact_path(gpu, orc, curve):
     _release()
 
 
+def test_rewrites_recheck_only_what_they_touch(gpu, orc):
+    """A write into a table that was found consistent re-arms the check for the elements it touches only (an element's eight
+    bases are checked against each other and nothing else): rewriting a few points of a 2^18-element table costs a check of a few
+    elements, not of the table; a wrong point among them is still caught; a repair brings the plan back."""
+    _release()
+    curve, n = "BLS381", 1 << 18
+    ps = orc.point_bytes(curve)
+    dp, ds = synth(curve, n, pf=8)
+    exp = _expected_synth(orc, curve, ds, n)
+    cl = _plan_client(curve)
+    cl.load_data_to_hbm(dp, 0, 0)
+    assert run_msm(cl, None, ds, n, hbm=(0, 0)) == exp
+    full = cl.precompute_plan_info()
+    assert full["used"] and full["check_ms"] > 5.0                      # 2^18 elements x 224 doublings
+    raw = bytes(dp.download(40 * 8 * ps, 1000 * 8 * ps))                # elements 1000 .. 1039 as loaded
+    cl.load_data_to_hbm(raw[: 3 * ps], 0, 1000 * 8 * ps)                # the same bytes again: three points of element 1000
+    cl.load_data_to_hbm(raw[20 * 8 * ps:], 0, 1020 * 8 * ps)            # ... and elements 1020 .. 1039
+    assert run_msm(cl, None, ds, n, hbm=(0, 0)) == exp
+    part = cl.precompute_plan_info()
+    assert part["used"] and part["check"] == "consistent" and part["check_ms"] < full["check_ms"] / 4
+    # a wrong multiple inside a rewritten span: caught by the partial check; the exact path's result is the literal sum
+    wrong = raw[5 * ps: 6 * ps]                                         # B_(1000,5) where B_(1000,6) belongs
+    cl.load_data_to_hbm(wrong, 0, (1000 * 8 + 6) * ps)
+    pts = bytearray(dp.download())
+    pts[(1000 * 8 + 6) * ps: (1000 * 8 + 7) * ps] = wrong
+    sc = bytes(ds.download())
+    got = run_msm(cl, None, ds, n, hbm=(0, 0))
+    info = cl.precompute_plan_info()
+    assert not info["used"] and info["check"] == "refuted"
+    assert got == orc.msm_pippenger(curve, bytes(pts), sc, n, 8, threads=os.cpu_count() or 8)
+    cl.load_data_to_hbm(raw[6 * ps: 7 * ps], 0, (1000 * 8 + 6) * ps)    # repaired: checked from scratch (what else was wrong is not known)
+    assert run_msm(cl, None, ds, n, hbm=(0, 0)) == exp
+    again = cl.precompute_plan_info()
+    assert again["used"] and again["check_ms"] > full["check_ms"] / 2
+    cl.close(); dp.free(); ds.free()
+    _release()
+
+
 def test_plan_needs_the_element_grid_and_a_precompute_client(gpu, orc):
     _release()
     curve, n = "BLS381", 600
