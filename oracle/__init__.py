@@ -49,6 +49,7 @@ def lib():
         L.orc_omega.argtypes = [C.c_int, C.c_int, u8p]
         L.orc_ntt.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.orc_ntt_eval_at.argtypes = [C.c_int, C.c_void_p, C.c_int, u64, u8p]
+        L.orc_ntt_eval_at_mt.argtypes = [C.c_int, C.c_void_p, C.c_int, u64, C.c_int, u8p]
         L.orc_dft_naive.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_ntt_preprocess.argtypes = [C.c_void_p, C.c_void_p, u64]
         L.orc_ntt_postprocess.argtypes = [C.c_void_p, C.c_void_p, u64, u64]
@@ -185,9 +186,12 @@ def ntt(curve, data, logn: int, inverse: bool = False, threads: int = 1) -> byte
     return out
 
 
-def ntt_eval_at(curve, data, logn: int, k: int) -> int:
+def ntt_eval_at(curve, data, logn: int, k: int, threads: int = 1) -> int:
     out = C.create_string_buffer(32)
-    rc = lib().orc_ntt_eval_at(_cid(curve), _ptr(data), logn, k, out)
+    if threads > 1:
+        rc = lib().orc_ntt_eval_at_mt(_cid(curve), _ptr(data), logn, k, threads, out)
+    else:
+        rc = lib().orc_ntt_eval_at(_cid(curve), _ptr(data), logn, k, out)
     assert rc == 0
     return int.from_bytes(out.raw, "little")
 

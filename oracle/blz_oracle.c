@@ -938,6 +938,51 @@ int orc_ntt_eval_at(int curve, const uint8_t* in, int logn, u64 k, uint8_t* out3
     return 0;
 }
 
+/* the same coefficient with the sum cut into `threads` chunks: X[k] = sum_t (w^k)^(lo_t) * Horner(chunk t) */
+typedef struct { const curve_t* c; const uint8_t* in; u64 lo, hi; const u64* wk; u64 part[MAXL]; } eval_job;
+static void* eval_worker(void* arg) {
+    eval_job* J = (eval_job*)arg;
+    const fctx* f = &J->c->fr;
+    u64 acc[MAXL] = {0};
+    for (u64 i = J->hi; i-- > J->lo;) {
+        u64 t[MAXL];
+        f_mul(f, acc, acc, J->wk);
+        f_from_bytes(f, t, J->in + 32 * i);
+        f_add(f, acc, acc, t);
+    }
+    /* times (w^k)^lo */
+    u64 sh[MAXL], e[1] = {J->lo};
+    f_pow(f, sh, J->wk, e, 1);
+    f_mul(f, acc, acc, sh);
+    memcpy(J->part, acc, sizeof(acc));
+    return NULL;
+}
+int orc_ntt_eval_at_mt(int curve, const uint8_t* in, int logn, u64 k, int threads, uint8_t* out32) {
+    const curve_t* c = get_curve(curve);
+    if (!c || logn > c->two_adicity) return -1;
+    const fctx* f = &c->fr;
+    u64 n = (u64)1 << logn;
+    if (threads < 1) threads = 1;
+    if ((u64)threads > n) threads = (int)n;
+    u64 w[MAXL], wk[MAXL], e[1] = {k};
+    memcpy(w, c->root, sizeof(w));
+    for (int i = 0; i < c->two_adicity - logn; ++i) f_sqr(f, w, w);
+    f_pow(f, wk, w, e, 1);
+    pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * threads);
+    eval_job* jobs = (eval_job*)malloc(sizeof(eval_job) * threads);
+    for (int t = 0; t < threads; ++t) {
+        jobs[t] = (eval_job){c, in, n * t / threads, n * (t + 1) / threads, wk, {0}};
+        pthread_create(&th[t], NULL, eval_worker, &jobs[t]);
+    }
+    u64 acc[MAXL] = {0};
+    for (int t = 0; t < threads; ++t) {
+        pthread_join(th[t], NULL);
+        f_add(f, acc, acc, jobs[t].part);
+    }
+    f_to_bytes(f, out32, acc);
+    free(th); free(jobs);
+    return 0;
+}
 /* O(n^2) DFT for tiny n (independent structure from orc_ntt) */
 int orc_dft_naive(int curve, const uint8_t* in, uint8_t* out, int logn) {
     const curve_t* c = get_curve(curve);

@@ -23,6 +23,7 @@ int orc_msm_pippenger(int, const uint8_t*, const uint8_t*, uint64_t, int, int, i
 int orc_omega(int, int, uint8_t*);
 int orc_ntt(int, const uint8_t*, uint8_t*, int, int, int);
 int orc_ntt_eval_at(int, const uint8_t*, int, uint64_t, uint8_t*);
+int orc_ntt_eval_at_mt(int, const uint8_t*, int, uint64_t, int, uint8_t*);
 int orc_dft_naive(int, const uint8_t*, uint8_t*, int);
 int orc_ntt_preprocess(const uint8_t*, uint8_t*, uint64_t);
 int orc_ntt_postprocess(const uint8_t*, uint8_t*, uint64_t, uint64_t);
@@ -72,6 +73,7 @@ int main(void) {
         CHECK(orc_ntt(1, out, back, LOGN, 1, 1) == 0);
         CHECK(memcmp(back, in, sizeof(in)) == 0);
         CHECK(orc_ntt_eval_at(1, in, LOGN, 5, e) == 0);
+        { uint8_t e2[32]; CHECK(orc_ntt_eval_at_mt(1, in, LOGN, 5, 3, e2) == 0); CHECK(memcmp(e, e2, 32) == 0); }
         CHECK(memcmp(e, out + 32 * 5, 32) == 0);
         CHECK(orc_omega(1, 27, w) == 0);
     }

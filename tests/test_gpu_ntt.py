@@ -227,7 +227,7 @@ def test_full_size_2e27_properties(gpu, orc):
     assert elem(y, 0) == field_sum(x)
     assert field_sum(y) == (n * elem(x, 0)) % R
     for k in (1, 12345678, n - 1):
-        assert elem(y, k) == orc.ntt_eval_at("BLS381", x, logn, k), k
+        assert elem(y, k) == orc.ntt_eval_at("BLS381", x, logn, k, threads=16), k
     # delta at index 1 -> X[k] = w^k
     delta = np.zeros(32 * n, dtype=np.uint8)
     delta[32] = 1
@@ -239,6 +239,9 @@ def test_full_size_2e27_properties(gpu, orc):
     for k in (0, 1, 2, 511, 512, 513, 1 << 18, (1 << 18) + 1, 99999999, n - 1):
         assert elem(z, k) == pow(w, k, R), k
     cl.close()
+
+
+_ORACLE_2E27 = {}
 
 
 @pytest.mark.parametrize("pass2", ["factor_table", "stepped"])
@@ -267,7 +270,13 @@ def test_full_size_2e27_every_output(gpu, orc, pass2):
     x = np.frombuffer(d_in.download(), dtype=np.uint8)
     y = np.frombuffer(cl.result(0), dtype=np.uint8)
     threads = max(1, min(64, (os.cpu_count() or 8)))
-    exp = np.frombuffer(orc.ntt("BLS381", x, logn, threads=threads), dtype=np.uint8)
+    # (the oracle's transform of this input - 20 s of host time - is computed by the first of the two variants and kept for
+    # the second: same seed, same input)
+    exp = _ORACLE_2E27.pop("exp", None)
+    if exp is None:
+        exp = np.frombuffer(orc.ntt("BLS381", x, logn, threads=threads), dtype=np.uint8)
+        if pass2 == "factor_table":
+            _ORACLE_2E27["exp"] = exp
     if not np.array_equal(y, exp):
         bad = np.flatnonzero(y.reshape(-1, 32) != exp.reshape(-1, 32))
         raise AssertionError(f"2^27 forward transform differs from the oracle, first at element {int(bad[0]) // 32}")
@@ -321,7 +330,11 @@ def test_full_size_2e27_other_fields(gpu, orc, field):
     n = 1 << logn
     r = pyref.CURVES[field]["r"]
     rng = np.random.default_rng(27 + len(field))
-    x = rng.integers(0, 256, size=32 * n, dtype=np.uint8)
+    # (a 2^20-element random block tiled 128 times, every element's low word then mixed with its index: no period, and
+    # a tenth of the time 4 GiB of generator output takes)
+    blk = rng.integers(0, 256, size=32 << 20, dtype=np.uint8)
+    x = np.tile(blk, 128)
+    x.view(np.uint64)[0::4] ^= np.arange(n, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
     x[31::32] &= 0x0F          # < 2^252 < r: canonical in both fields
     cl = NTTClient(NTT.Ntt, DriverClient(0), log_size=logn, field=field)
     cl.set_data(NTTInput(0, x))
@@ -347,7 +360,7 @@ def test_full_size_2e27_other_fields(gpu, orc, field):
     for k in (1, 87654321, n - 1):
         got = elem(y, k)
         assert got < r
-        assert got == orc.ntt_eval_at(field, x, logn, k), k
+        assert got == orc.ntt_eval_at(field, x, logn, k, threads=16), k
     inv = NTTClient(NTT.Ntt, DriverClient(0), log_size=logn, inverse=True, field=field)
     d_y = DeviceBuffer(0, 32 * n)
     cl.result_device(0, d_y)
@@ -463,7 +476,7 @@ def test_other_fields_large_and_limits(gpu, orc):
     y = np.frombuffer(_ntt(cl, x.tobytes()), dtype=np.uint8)
     for k in (0, 1, 54321, n - 1):
         got = int.from_bytes(y[32 * k: 32 * k + 32].tobytes(), "little")
-        assert got == orc.ntt_eval_at(field, x, logn, k), k
+        assert got == orc.ntt_eval_at(field, x, logn, k, threads=16), k
         assert got < r
     cl.close()
     with pytest.raises(DriverClientError) as ei:
