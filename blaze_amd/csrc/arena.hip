@@ -29,15 +29,20 @@ ArenaExtent* arena_find(Arena& a, uint64_t pos, size_t len) {
     return nullptr;
 }
 
-// the table and a build in flight (the caller has drained the device)
-void arena_drop_table(ArenaExtent& x) {
-    for (auto& t : x.tables)
-        if (t.p) (void)hipFree(t.p);
-    x.tables.clear();
+// a build in flight (the caller has drained the device)
+void arena_drop_build(ArenaExtent& x) {
     if (x.build.tab) (void)hipFree(x.build.tab);
     if (x.build.done) (void)hipEventDestroy(x.build.done);
     if (x.build.t0) (void)hipEventDestroy(x.build.t0);
     x.build = ArenaExtent::TableBuild();
+}
+// the tables and a build in flight (the caller has drained the device)
+void arena_drop_table(ArenaExtent& x) {
+    for (auto& t : x.tables)
+        if (t.p) (void)hipFree(t.p);
+    x.tables.clear();
+    x.tab_dirty_lo = x.tab_dirty_hi = 0;
+    arena_drop_build(x);
 }
 
 void arena_free_extent(ArenaExtent& x) {
@@ -218,11 +223,25 @@ int arena_write(int device_id, uint64_t pos, const void* src, size_t len, bool s
         e->mont_curve = -1;   // no shadow yet
     }
     mark_dirty(*e, pos - e->start, end - e->start);
-    if (!e->tables.empty() || e->build.tab) {
-        // the window table is a function of the bytes: gone with any write (a task in flight may still gather from it, a
-        // build in flight still writes it)
-        if (sync_device_bounded("load_data_to_hbm: drain before the window table goes") != BLZ_OK) return BLZ_ERR_WRITE;
-        arena_drop_table(*e);
+    if (e->build.tab) {
+        // a build in flight tabulates the old bytes: gone (it still writes its table: drain first)
+        if (sync_device_bounded("load_data_to_hbm: drain before the window-table build goes") != BLZ_OK) return BLZ_ERR_WRITE;
+        arena_drop_build(*e);
+    }
+    if (!e->tables.empty()) {
+        // The window tables are a function of the bytes.  A small rewrite keeps them: the span is remembered and the next task
+        // that asks for a table re-tabulates the rows of the rewritten bases first (arena_points_table); a large one drops them
+        // (a task in flight may still gather from them: drain first) and the tasks that follow rebuild, paced as ever.
+        const uint64_t lo = pos - e->start, hi = end - e->start;
+        const uint64_t nlo = e->tab_dirty_lo < e->tab_dirty_hi && e->tab_dirty_lo < lo ? e->tab_dirty_lo : lo;
+        const uint64_t nhi = e->tab_dirty_lo < e->tab_dirty_hi && e->tab_dirty_hi > hi ? e->tab_dirty_hi : hi;
+        if (nhi - nlo > ArenaExtent::TABLE_PATCH_MAX_POINTS * 64) {   // (64 = the smaller point size: BN254)
+            if (sync_device_bounded("load_data_to_hbm: drain before the window tables go") != BLZ_OK) return BLZ_ERR_WRITE;
+            arena_drop_table(*e);
+        } else {
+            e->tab_dirty_lo = nlo;
+            e->tab_dirty_hi = nhi;
+        }
     }
     e->table_refused = false;
     // the table check was about the old bytes: a table that was consistent needs another look at the elements this write

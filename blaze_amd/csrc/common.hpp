@@ -131,7 +131,8 @@ struct ArenaExtent {
     // window tables (msm_impl.hip.hpp k_build_window_table; opt-in per handle): for the points [first, +npts) of the grid at `phase`
     // the W multiples 2^(lo + c j) P, j < W, in the shadow's point format, point-major.  One per (bases, scalar range) that
     // a handle asked for - the ranks of a job sharded by scalar chunk each tabulate their own range - at most
-    // MAX_TABLES per extent.  Any write into the extent drops them all.
+    // MAX_TABLES per extent.  A write of up to TABLE_PATCH_MAX_POINTS bases has their rows re-tabulated by the next task; a
+    // larger one (or one that moves the extent) drops the tables.
     struct WindowTable {
         void* p = nullptr;
         size_t bytes = 0;
@@ -142,7 +143,10 @@ struct ArenaExtent {
         float build_ms = 0;
     };
     static constexpr size_t MAX_TABLES = 32;
+    static constexpr uint64_t TABLE_PATCH_MAX_POINTS = 1u << 18;
     std::vector<WindowTable> tables;
+    uint64_t tab_dirty_lo = 0, tab_dirty_hi = 0;   // bytes (relative to start) rewritten since the tables were built: their rows are
+                                           // re-tabulated by the next task that asks for a table (msm_capi.hip arena_points_table)
     bool table_refused = false;            // a build failed (a base of even order, or no memory): no NEW build until the next write
     // Checked-table plan of precompute handles (msm_capi.hip arena_precompute_check; opt-in per handle): has the caller's x8 table
     // been compared, element by element, with what precompute_base_* produces (tests/msm/mod.rs:360-380: B_j = 2^32 B_(j-1), B_0
@@ -202,6 +206,7 @@ int arena_restore_raw(Arena& a, ArenaExtent& e, hipStream_t st);
 int arena_diet_step(Arena& a, ArenaExtent& e, size_t point_bytes, hipStream_t st);
 // bytes [off, off + len) of an extent (relative to its start) into host memory, whichever copy holds them
 int arena_read_bytes(Arena& a, ArenaExtent& e, uint64_t off, size_t len, void* out, hipStream_t st);
-void arena_drop_table(ArenaExtent& x);   // the table and a build in flight; the caller has drained the device
+void arena_drop_table(ArenaExtent& x);   // the tables and a build in flight; the caller has drained the device
+void arena_drop_build(ArenaExtent& x);   // a build in flight only
 
 }  // namespace blz

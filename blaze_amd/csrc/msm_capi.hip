@@ -373,6 +373,47 @@ int arena_points_table(blz_msm* h, uint64_t pos, uint32_t npts, const void** out
         BLZ_LOG(1, "window table: %llu bases x %d windows of %d bits, %.1f MiB, complete %.1f ms after its first chunk", (unsigned long long)t.npts,
                 t.W, t.c, t.bytes / 1048576.0, ms);
     }
+    // rows of bases that were rewritten since the tables were built (arena_write: small rewrites keep the tables): re-tabulated
+    // here, on this handle's main stream, behind a drain (another handle's task may be gathering from the very rows).  A table
+    // of another format than this handle's (its curve's other arithmetic), or one whose scratch rows are gone, is dropped instead.
+    if (e->tab_dirty_lo < e->tab_dirty_hi && !e->tables.empty()) {
+        BLZ_TRY(sync_device_bounded("window table: drain before the rewritten bases are re-tabulated"));
+        uint32_t* pflag = nullptr;
+        if (A.build_flags) {
+            pflag = A.build_flags + (A.build_flag_next++ & 255u);
+            BLZ_HIP(hipMemsetAsync(pflag, 0, 4, h->eng.stream), BLZ_ERR_UNKNOWN);
+        }
+        bool patched = false;
+        for (size_t k = e->tables.size(); k-- > 0;) {
+            ArenaExtent::WindowTable& t = e->tables[k];
+            const uint64_t plo = e->tab_dirty_lo > t.phase ? (e->tab_dirty_lo - t.phase) / ps : 0;
+            const uint64_t phi = e->tab_dirty_hi > t.phase ? (e->tab_dirty_hi - t.phase + ps - 1) / ps : 0;
+            const uint64_t lo_p = plo > t.first ? plo : t.first, hi_p = phi < t.first + t.npts ? phi : t.first + t.npts;
+            if (lo_p >= hi_p) continue;
+            if (t.format != fmt || !pflag || A.build_scratch_bytes < h->eng.table_scratch_bytes(t.W) + 16) {
+                (void)hipFree(t.p);
+                e->tables.erase(e->tables.begin() + (long)k);
+                continue;
+            }
+            BLZ_TRY(h->eng.build_table((const char*)e->raw + t.phase + lo_p * ps, (char*)t.p + (lo_p - t.first) * (size_t)t.W * mp, (uint32_t)(hi_p - lo_p), t.c,
+                                       t.W, t.lo, A.build_scratch, pflag, h->eng.stream));
+            patched = true;
+        }
+        if (patched) {
+            uint32_t flag_h = 0;
+            BLZ_WAIT(h, sync_stream_bounded(h->eng.stream, "window table: rewritten bases re-tabulated"));
+            BLZ_HIP(hipMemcpy(&flag_h, pflag, 4, hipMemcpyDeviceToHost), BLZ_ERR_READ);
+            if (flag_h) {
+                BLZ_LOG(1, "window table: a rewritten base has a multiple at infinity (a point of even order): plain path for this extent");
+                arena_drop_table(*e);   // (the stream was drained just now, the device before)
+                e->table_refused = true;
+                return BLZ_OK;
+            }
+            BLZ_LOG(1, "window table: rows of the rewritten bases re-tabulated (bytes [%llu, %llu) of the extent)", (unsigned long long)e->tab_dirty_lo,
+                    (unsigned long long)e->tab_dirty_hi);
+        }
+        e->tab_dirty_lo = e->tab_dirty_hi = 0;
+    }
     // one table per (bases, scalar range) that was asked for: the handles of a curve share it, a sub-range of its bases is
     // served from it, a handle with another scalar range gets its own (two handles evicting each other's table on every
     // launch would rebuild for ever: ADVICE r03)

@@ -189,7 +189,8 @@ int blz_msm_plan(int curve, uint32_t nof_elements, int is_precompute, uint32_t o
  * gathered at the memory system's rate and lose 4 % with a table, so 1 leaves BN254 on the plain path), 2 always.
  * With it, a pf = 1 handle whose bases live in the arena (hbm_point_addr) builds the table of their window multiples
  * 2^(c j) P, j < W = ceil(257 / c) - 3.1 s of the chip for 2^26 BLS12-381 bases, paced by the tasks (below), W x the memory
- * of the Montgomery copy (2^26: 10 x 8 GiB) - and keeps it with the arena extent until the next write into it.  Tasks over
+ * of the Montgomery copy (2^26: 10 x 8 GiB) - and keeps it with the arena extent: a later write of up to 2^18 bases has their rows
+ * re-tabulated ahead of the next task, a larger one drops the table (the tasks that follow rebuild it).  Tasks over
  * those bases then add every window's digit into ONE bucket set:
  * 10 windows of 26 bits at 2^26 (671 M bucket additions, 2^25 buckets) instead of 12 windows of 21-23 bits (805 M).
  * Results are bit-identical to the plain path's.  Falls back to the plain path (silently; BLAZE_LOG=1 says why) when
