@@ -358,6 +358,27 @@ def test_call_order_and_errors(gpu, orc):
     cl.close(); clh.close()
 
 
+def test_stream_accessors(gpu):
+    """blz_msm_stream / blz_ntt_stream: the handle's main stream and device ordinal (what the bounded-wait test hooks in the aux
+    library enqueue their stall kernels on; a host's own kernels can be ordered against the tasks the same way)."""
+    from blaze_amd.driver_client import DriverClient
+    from blaze_amd.ingo_ntt import NTT, NTTClient
+
+    cl = msm_client("BLS381", 1)
+    st, dev = C.c_void_p(), C.c_int(-1)
+    blaze_amd._lib.check(gpu.blz_msm_stream(cl._h, C.byref(st), C.byref(dev)))
+    assert st.value and dev.value == 0
+    st2 = C.c_void_p()
+    blaze_amd._lib.check(gpu.blz_msm_stream(cl._h, C.byref(st2), None))
+    assert st2.value == st.value
+    assert gpu.blz_msm_stream(None, C.byref(st), None) == 4
+    nc = NTTClient(NTT.Ntt, DriverClient(0), log_size=8)
+    sn = C.c_void_p()
+    blaze_amd._lib.check(gpu.blz_ntt_stream(nc._h, C.byref(sn), C.byref(dev)))
+    assert sn.value and sn.value != st.value and dev.value == 0
+    nc.close(); cl.close()
+
+
 def test_labels_and_result_queue(gpu, orc):
     cl = msm_client("BN254", 1)
     exps = []
