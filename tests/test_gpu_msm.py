@@ -995,6 +995,81 @@ def test_two_host_threads_one_device(gpu, orc, hide, monkeypatch):
     blaze_amd._lib.check(L.blz_arena_release(0))
 
 
+def test_two_host_threads_plan_and_diet(gpu, orc, monkeypatch):
+    """Two host threads again, on round 5's machinery: the arena runs on the diet (raw bytes dropped once a copy is complete);
+    thread A streams HBM-flow tasks over extent A - whose raw bytes are gone after its second task - while thread B, a precompute
+    client on the checked-table plan over extent B, keeps rewriting spans of its table (partial re-checks), runs its tasks, and
+    READS BACK pieces of extent A (converted from A's Montgomery copy while A's tasks gather from it)."""
+    import threading
+
+    monkeypatch.setenv("BLAZE_WAIT_TIMEOUT_MS", "20000")
+    curve = "BLS381"
+    L = blaze_amd.lib()
+    blaze_amd._lib.check(L.blz_arena_release(0))
+    blaze_amd._lib.check(L.blz_arena_set_policy(0, 1))
+    try:
+        na = 1 << 19
+        dpa, dsa = synth(curve, na, 1, seed=21)
+        raw_a = bytes(dpa.download())
+        exp_a = _expected_synth(orc, curve, dsa, na)
+        a = msm_client(curve, 1, PointMemoryType.HBM)
+        ADDR_A, ADDR_B = 0, 1 << 34
+        a.load_data_to_hbm(dpa, ADDR_A, 0)
+        dpa.free()
+        nb = 1 << 14
+        dpb, dsb = synth(curve, nb, 8, seed=23)
+        raw_b = bytes(dpb.download())
+        exp_b = _expected_synth(orc, curve, dsb, nb)
+        errors, tasks = [], 150
+
+        def run_a():
+            try:
+                p = MSMParams(na, (ADDR_A, 0))
+                a.initialize(p); a.start_process(); a.set_data(MSMInput(None, dsa, p))
+                for i in range(tasks):
+                    if i + 1 < tasks:
+                        a.initialize(p); a.start_process(); a.set_data(MSMInput(None, dsa, p))
+                    a.wait_result()
+                    if a.result().result != exp_a:
+                        raise AssertionError(f"thread A: task {i} differs")
+                if a.memory_info()["arena_raw"] > len(raw_b) * 2:
+                    raise AssertionError("thread A: its extent still holds raw bytes")
+            except BaseException as e:   # noqa: BLE001
+                errors.append(("A", e))
+
+        def run_b():
+            try:
+                b = msm_client(curve, 8, PointMemoryType.HBM)
+                b.set_precompute_plan(True)
+                b.load_data_to_hbm(dpb, ADDR_B, 0)
+                rng = __import__("random").Random(5)
+                for i in range(tasks):
+                    if i % 5 == 1:
+                        at = rng.randrange(0, nb * 8 - 40)
+                        b.load_data_to_hbm(raw_b[96 * at: 96 * (at + 40)], ADDR_B, 96 * at)      # same bytes: a partial re-check
+                    if run_msm(b, None, dsb, nb, hbm=(ADDR_B, 0)) != exp_b:
+                        raise AssertionError(f"thread B: task {i} differs")
+                    if not b.precompute_plan_info()["used"]:
+                        raise AssertionError(f"thread B: task {i} left the plan")
+                    if i % 7 == 3:
+                        at = rng.randrange(0, na - 64) * 96 + rng.randrange(0, 96)
+                        if b.get_data_from_hbm(500, ADDR_A, at) != raw_a[at: at + 500]:
+                            raise AssertionError("thread B: extent A read back differently")
+                b.close()
+            except BaseException as e:   # noqa: BLE001
+                errors.append(("B", e))
+
+        ta, tb = threading.Thread(target=run_a), threading.Thread(target=run_b)
+        ta.start(); tb.start()
+        ta.join(600); tb.join(600)
+        assert not ta.is_alive() and not tb.is_alive(), "a host thread is stuck"
+        assert not errors, errors
+        a.close(); dsa.free(); dpb.free(); dsb.free()
+    finally:
+        blaze_amd._lib.check(L.blz_arena_set_policy(0, 0))
+        blaze_amd._lib.check(L.blz_arena_release(0))
+
+
 def test_memory_info_accounts_for_the_arena_and_the_workspace(gpu, orc):
     """blz_msm_memory_info (get_api()['device_memory']): what a loaded base costs in device memory - 96 raw + 128 Montgomery bytes
     per BLS point - and what the engine's workspace has grown to."""
