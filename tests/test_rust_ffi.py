@@ -116,3 +116,29 @@ def test_image_parameter_word_layout():
                     m.hif2_cpu_c_buckets_mem_addr_width, m.hif2_cpu_c_number_of_segments, m.hif2_cpu_c_place_holder) == \
                    (0, curve_code << 2, adders, width, segs, 0)
             assert m.curve_name() == ["BLS12_377", "BN254", "BLS12_381"][curve_code]
+
+
+def test_rust_sources_only_use_what_is_declared():
+    """More of what a compiler would have said: every blz_* function a Rust source CALLS is declared in hip_ffi.rs, and every
+    method the ported integration tests / benches call on a client is defined in msm_api.rs / ntt_api.rs / dclient.rs."""
+    import glob
+
+    rust = os.path.join(ROOT, "rust")
+    declared = set(_rust_decls())
+    used = set()
+    for f in glob.glob(os.path.join(rust, "src", "**", "*.rs"), recursive=True):
+        if f.endswith("hip_ffi.rs"):
+            continue
+        used |= set(re.findall(r"\b(blz_\w+)\s*\(", open(f).read()))
+    assert used and not used - declared, sorted(used - declared)
+    methods = set()
+    for rel in ("src/ingo_msm/msm_api.rs", "src/ingo_ntt/ntt_api.rs", "src/driver_client/dclient.rs"):
+        methods |= set(re.findall(r"fn (\w+)\s*[<(]", open(os.path.join(rust, rel)).read()))
+    calls = set()
+    for f in glob.glob(os.path.join(rust, "tests", "*.rs")) + glob.glob(os.path.join(rust, "benches", "*.rs")):
+        calls |= set(re.findall(r"\b(?:driver|second|dclient|client)\.(\w+)\(", open(f).read()))
+    assert calls and not calls - methods, sorted(calls - methods)
+    # the round-5 entry points are bound
+    for need in ("blz_msm_set_precompute_plan", "blz_msm_prepare_precompute_plan", "blz_msm_precompute_plan_info", "blz_msm_memory_info",
+                 "blz_ntt_exchange", "blz_ntt_info", "blz_ntt_new_ex2", "blz_arena_set_policy", "blz_host_malloc"):
+        assert need in declared, need
