@@ -533,7 +533,8 @@ bool wants_table(const blz_msm* h) {
 }
 
 // BN254 has two arithmetics (msm_engine.hpp `repr`): the 9 x 29-bit reduced radix wins while the accumulation is bound by its
-// multiplier, 32-bit limbs win once it is bound by the reach of the TLB over the gathered copy.  The exact path of a precompute
+// multiplier, 32-bit limbs win once it is bound by the memory system's rate of random line gathers out of a copy far larger than
+// the caches (profiles/r05_tlb_probe.txt).  The exact path of a precompute
 // handle always runs on 32-bit limbs (2^29 bases, 32 GiB); the plan's even-base copy is a quarter of that per element, so it
 // takes the reduced radix up to 2^25 elements (8 GiB of even bases) and 32-bit limbs above - measured, same box, ms per MSM in a
 // stream of tasks, reduced radix / 32-bit limbs: 2^20 1.85 / 2.20, 2^22 6.60 / 7.49, 2^24 18.2 / 19.2, 2^26 74.8 / 70.0
