@@ -155,6 +155,41 @@ def test_parallel_correctness_through_exchange(gpu, orc, logn):
     driver.close()
 
 
+def test_exchange_with_page_locked_buffers(gpu, orc):
+    """blz_host_malloc buffers take the exchange's other path (true asynchronous copies chained by events on the caller's
+    thread, no helper thread): same bytes.  2^22 elements = 128 MiB: several pieces, the ramped ones included."""
+    import numpy as np
+
+    logn = 22
+    n = 1 << logn
+    rng = np.random.default_rng(9)
+    x = rng.integers(0, 256, size=32 * n, dtype=np.uint8)
+    x[31::32] &= 0x3F
+    ref = bytes(orc.ntt("BLS381", x, logn, threads=16))
+    hin, hout = blaze_amd.HostBuffer(0, 32 * n), blaze_amd.HostBuffer(0, 32 * n)
+    a_in, a_out = hin.array(), hout.array()
+    a_in[:] = x
+    a_out[:] = 0xEE
+    cl = NTTClient(NTT.Ntt, DriverClient(0), log_size=logn)
+    cl.initialize(NttInit())
+    for i in range(3):
+        bh = i % 2
+        cl.start_process(1 - bh)
+        cl.exchange(bh, a_in, a_out)
+        if i == 0:
+            assert not a_out.any()                     # the buffer nobody wrote
+        if i == 2:
+            assert a_out.tobytes() == ref              # cycle 0's input, transformed in cycle 1
+        cl.wait_result()
+    # a pinned input with a pageable output takes the threaded path: still the same bytes
+    out2 = bytearray(32 * n)
+    cl.start_process(0)
+    cl.exchange(1, a_in, out2)
+    cl.wait_result()
+    assert bytes(out2) == ref
+    cl.close(); hin.free(); hout.free()
+
+
 def test_exchange_full_size_2e27(gpu, orc):
     """The reference shape through the fused cycle: 4 GiB out and 4 GiB in at once, three cycles; the bytes that come back are
     the bytes result() returns (checked against a plain result of the same transform), and what went in is what set_data
