@@ -150,7 +150,7 @@ struct ArenaExtent {
     bool table_refused = false;            // a build failed (a base of even order, or no memory): no NEW build until the next write
     // Checked-table plan of precompute handles (msm_capi.hip arena_precompute_check; opt-in per handle): has the caller's x8 table
     // been compared, element by element, with what precompute_base_* produces (tests/msm/mod.rs:360-380: B_j = 2^32 B_(j-1), B_0
-    // on the curve)?  For the points [first, +npts) of the grid at `phase`; any write into the extent forgets the answer.
+    // on the curve)?  For the points [first, +npts) of the grid at `phase`; a write re-arms the check (state 3: for the elements it touched).
     struct PrecompCheck {
         int state = 0;                     // 0 not checked, 1 consistent, 2 refuted, 3 consistent but for the elements a later write
                                            // touched (bytes [redo_lo, redo_hi) of the extent): only those are checked again

@@ -271,7 +271,7 @@ int arena_precompute_check(blz_msm* h, uint64_t pos, uint32_t nelem, bool* ok, u
 }
 
 // Window table of the `npts` bases at arena offset `pos` (msm_impl.hip.hpp k_build_window_table, MsmPlan::table), kept with the
-// extent, dropped by any write into it.  *out stays null - and the task takes the plain path - while the table is not to be
+// extent (a small rewrite has its rows re-tabulated below, a large one drops it: arena.hip arena_write).  *out stays null - and the task takes the plain path - while the table is not to be
 // had: it is still being built, there is no memory for it, a base has even order, or the task is over a sub-range whose
 // best window width is not the table's.
 //
