@@ -2,7 +2,7 @@
 # The kernel-trace run shows the pipeline as shipped (the next task's sort hidden underneath the accumulation); the two PMC passes
 # run with BLAZE_SORT_HIDE=0 so that a dispatch's counters are its own (concurrent kernels share the counters).
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-T=${1:-r03_final}
+T=${1:-r05a_final}
 python3 bench.py > gpurun_out/${T}_bench_line.json 2> gpurun_out/${T}_bench.err
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$T -- python3 bench.py --no-cpu-baseline --no-extras > gpurun_out/${T}_bench_line_under_rocprof.json 2> gpurun_out/prof_$T.err
 python3 tools/rocpd_summary.py gpurun_out/prof_$T/*/*_results.db > gpurun_out/${T}_bench_kernel_stats.txt
