@@ -176,23 +176,39 @@ BLZ_DEV void ptrr_aadd(XYZZRR<Q>& acc, const AffineRR<Q>& p, bool negp, const Af
     acc.zzz = PPP;
 }
 
-// p = 2 p for an accumulator that is not the point at infinity (dbl-2008-s-1), inlined: the doubling chains of the table check
-// (msm_impl.hip.hpp k_check_precompute: 32 in a row per lane).  Independent products in pairs, like ptrr_madd.
+// Jacobian coordinates (x = X / Z^2, y = Y / Z^3) for chains of doublings only - the table check's 32 in a row
+// (msm_impl.hip.hpp k_check_precompute).  On a = 0 a doubling is 3 squarings + 2 products + one fused sum of two products
+// (dbl-2009-l with D = 4 X Y^2 as a product and 8 Y^4 = (8 Y^2) Y^2 folded into Y3's reduction): 2275 multiply-adds on 14 x 28
+// bits against the XYZZ doubling's 3059 (963 against 1278 on 9 x 29) - XYZZ earns its two Z powers only in mixed ADDITIONS.
 template <class Q>
-BLZ_DEV void ptrr_dbl_inl(XYZZRR<Q>& p) {
-    const auto U = rr_tn(rr_add(p.y, p.y));            // (2, 8) | (1, 4)
-    Frr<Q, 1, 2> V, W, S, t, Msq, y3;
-    rr_sqr_pair(V, U, t, p.x);
-    rr_mul_pair(W, U, V, S, p.x, V);
-    const auto M = rr_tn(rr_add(rr_add(t, t), t));     // (3, 6) | (1, 6)
-    rr_sqr(Msq, M);
-    const auto X3 = rr_xfix(rr_sub_twice<2>(Msq, S));  // (1, 10) | (1, 2)
-    const auto D = rr_tn(rr_sub<RR_JX<Q>>(S, X3));     // (3, 34) | (1, 6)
-    const auto nW = rr_neg<2>(W);                      // (2, 4)
-    rr_mul2(y3, M, D, nW, p.y);                        // M (S - X3) - W Y1
-    p.x = rr_as<1, XYZZRR<Q>::VX>(X3);
-    p.y = rr_as<1, XYZZRR<Q>::VY>(y3);
-    rr_mul_pair(p.zz, V, p.zz, p.zzz, W, p.zzz);
+struct JacRR {
+    static constexpr int VX = RR_TIGHT<Q> ? 2 : 34;   // loose: X3 = E^2 - 8S stays the lazy difference it is (+ 32m)
+    static constexpr int JX = RR_TIGHT<Q> ? 2 : 7;    // 2^JX m dominates it
+    Frr<Q, 1, VX> x;
+    Frr<Q, 1, 2> y;
+    Frr<Q, 2, 4> z;                                   // 2 (Y Z): the doubled product as it is
+};
+// p = 2 p.  No infinity branch: a point of order two (Y = 0) gives Z3 = 0, and Z stays 0 mod m from there on.
+// Bounds (limb factor, value factor), loose budget first, tight budget after the bar; in the tight budget (sum of limb-factor
+// products <= 6, values <= 128) 4S and X3 go through the one-digit quotient reduction, the rest are carry propagations.
+template <class Q>
+BLZ_DEV void ptrr_jdbl(JacRR<Q>& p) {
+    Frr<Q, 1, 2> A, B, S, E2, y3, yz;
+    rr_sqr_pair(A, p.x, B, p.y);
+    rr_mul_pair(S, p.x, B, yz, p.y, p.z);              // S = X Y^2, Y Z
+    const auto E = rr_tn(rr_add(rr_add(A, A), A));     // 3 X^2: (3, 6) | (1, 6)
+    rr_sqr(E2, E);
+    const auto s2 = rr_add(S, S);
+    const auto S4 = rr_xfix(rr_add(s2, s2));           // 4S: (1, 8) | (1, 2)
+    const auto X3 = rr_xfix(rr_sub_twice<RR_TIGHT<Q> ? 2 : 4>(E2, S4));   // E^2 - 8S + 32m: (1, 34) | + 8m: (1, 2)
+    const auto D = rr_tn(rr_sub<JacRR<Q>::JX>(S4, X3));   // 4S - X3 + 128m: (3, 136) | + 4m: (1, 6)
+    const auto b2 = rr_add(B, B);                      // (2, 4)
+    const auto nB4 = rr_neg<4>(rr_norm(rr_add(b2, b2)));   // 16m - 4 Y^2: (2, 16)
+    // E (4S - X3) - 8 Y^4 = E D + (16m - 4 Y^2)(2 Y^2), one reduction: columns 9 + 4, values 816 + 64 | 1 + 4, 36 + 64
+    rr_mul2(y3, E, D, nB4, b2);
+    p.x = X3;
+    p.y = y3;
+    p.z = rr_add(yz, yz);
 }
 
 // 2 p for an accumulator (dbl-2008-s-1).  By value and out of line, like ptrr_mdbl_val.

@@ -158,9 +158,9 @@ int arena_points_mont(blz_msm* h, uint64_t pos, uint32_t npts, const void** out,
 }
 
 // Checked-table plan (msm_impl.hip.hpp k_check_precompute): is the x8 table of the `nelem` elements at arena offset `pos` what
-// precompute_base_* produces?  Answered once per (extent contents, range): the check runs on this handle's main stream (1278 /
-// 3059 multiply-adds per doubling, 224 doublings per element: 0.80 s for 2^26 BN254 elements, 1.7 s for BLS - 76 % of the bare
-// multiply-add rate) and the caller waits
+// precompute_base_* produces?  Answered once per (extent contents, range): the check runs on this handle's main stream (969 /
+// 2275 multiply-adds per Jacobian doubling, 224 doublings per element: 0.68 s for 2^26 BN254 elements, 1.33 s for BLS - 68 / 83 %
+// of the bare multiply-add rate; XYZZ doublings, same box: 0.84 / 1.71 s) and the caller waits
 // for it - with the arena unlocked; the answer is committed only if no write reached the extent in the meantime (epoch).
 int arena_precompute_check(blz_msm* h, uint64_t pos, uint32_t nelem, bool* ok, uint64_t* checked_elems = nullptr) {
     *ok = false;

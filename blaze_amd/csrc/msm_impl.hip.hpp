@@ -78,8 +78,8 @@ __global__ __launch_bounds__(256) void k_points_to_mont(const uint32_t* __restri
 // 4n points with 64-bit scalars - three windows of 22 / 22 / 21 bits, 12 additions per element into 3 bucket sets of 2^21 +
 // 2^21 + 2^20 slots.  The library cannot take the caller's word for it (a table that is NOT consistent has a defined result
 // too: the exact sum over all 8 bases), so the resident table is checked once per load, base by base:
-//   k_check_precompute      one lane per (element, j in 1..7): 32 doublings of B_(j-1), compared with B_j projectively
-//                           (X3 == x_j ZZ3, Y3 == y_j ZZZ3, ZZ3 != 0: no inversion); the j = 1 lane also checks that B_0 is
+//   k_check_precompute      one lane per (element, j in 1..7): 32 doublings of B_(j-1) in Jacobian coordinates, compared with
+//                           B_j projectively (X == x_j Z^2, Y == y_j Z^3, Z != 0: no inversion); the j = 1 lane also checks that B_0 is
 //                           on the curve (then every B_j is, and every evaluation order of the sum gives the same point).
 //                           Any miss raises *flag and the extent stays on the exact path.
 //   k_points_to_mont_even   the Montgomery copy of the even bases only (B_0, B_2, B_4, B_6 of every element, contiguous):
@@ -147,7 +147,6 @@ __global__ __launch_bounds__(256) void k_points_all_canonical(const uint32_t* __
     if (bad) atomicOr(flag, 1u);
 }
 
-constexpr int TAG_CHECK = 77;
 template <class F>
 __global__ __launch_bounds__(64, 3) void k_check_precompute(const uint32_t* __restrict__ raw, uint64_t nelem, uint32_t* __restrict__ flag) {
     const uint64_t items = nelem * 7u;
@@ -182,15 +181,22 @@ __global__ __launch_bounds__(64, 3) void k_check_precompute(const uint32_t* __re
             rr_to_mont_from_words<Q>(ay, y0.v);
             rr_to_mont_from_words<Q>(bj.x, x1.v);
             rr_to_mont_from_words<Q>(bj.y, y1.v);
-            XYZZRR<Q> p = ptrr_mdbl_val<Q, TAG_CHECK>(ax, rr_cneg<2>(ay, false));
-            // (a doubling that reaches infinity - ZZ == 0 mod m - stays there: every later ZZ is a multiple of it)
+            // a chain of doublings and nothing else: Jacobian coordinates (ec_rr.hip.hpp JacRR: 2275 multiply-adds per doubling
+            // against XYZZ's 3059)
+            JacRR<Q> p;
+            p.x = rr_as<1, JacRR<Q>::VX>(ax);
+            p.y = ay;
+            rr_one(p.z);
+            // (a doubling that reaches infinity - Z == 0 mod m - stays there: every later Z is a multiple of it)
 #pragma unroll 1
-            for (int d = 1; d < 32; ++d) ptrr_dbl_inl(p);
-            if (rr_is_zero(p.zz)) ok = false;   // 2^32 B_(j-1) is the point at infinity: no affine B_j equals it
-            Frr<Q, 1, 2> U2, S2;
-            rr_mul_pair(U2, bj.x, p.zz, S2, bj.y, p.zzz);
-            const auto P0 = rr_sub<RR_JX<Q>>(U2, p.x);
-            const auto R0 = rr_sub<RR_JY<Q>>(S2, p.y);
+            for (int d = 0; d < 32; ++d) ptrr_jdbl(p);
+            if (rr_is_zero(p.z)) ok = false;   // 2^32 B_(j-1) is the point at infinity: no affine B_j equals it
+            Frr<Q, 1, 2> ZZ, ZZZ, U2, S2;
+            rr_sqr(ZZ, p.z);
+            rr_mul(ZZZ, ZZ, p.z);
+            rr_mul_pair(U2, bj.x, ZZ, S2, bj.y, ZZZ);
+            const auto P0 = rr_sub<JacRR<Q>::JX>(U2, p.x);
+            const auto R0 = rr_sub<2>(S2, p.y);
             if (!rr_is_zero(P0) || !rr_is_zero(R0)) ok = false;
         } else {
             Affine<F> a, bj;

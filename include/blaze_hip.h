@@ -217,8 +217,8 @@ int blz_msm_window_table_info(blz_msm* h, uint64_t out[4]);
  * task as sum_i sum_j s_(i,j) B_(i,j) over the 32-bit chunks of the scalars.  Served literally - the default - that is an 8n-point
  * MSM of 32-bit scalars: 16 bucket additions per element where the same elements without a table need 12.  With enable = 1 a
  * handle whose bases live in the arena (hbm_point_addr) CHECKS the table once per load - on the device, base by base: B_(i,0) on the
- * curve and B_(i,j) == 2^32 B_(i,j-1) for j = 1..7 (32 doublings each, compared projectively; 0.8 s for 2^26 BN254 elements,
- * 1.7 s on the BLS curves) - and, if it holds, sums sum_i sum_k (s_(i,2k) + 2^32 s_(i,2k+1)) B_(i,2k) instead: 4n points with 64-bit
+ * curve and B_(i,j) == 2^32 B_(i,j-1) for j = 1..7 (32 doublings each, compared projectively; 0.7 s for 2^26 BN254 elements,
+ * 1.3 s on the BLS curves) - and, if it holds, sums sum_i sum_k (s_(i,2k) + 2^32 s_(i,2k+1)) B_(i,2k) instead: 4n points with 64-bit
  * scalars, three windows of 22 / 22 / 21 bits, 12 additions per element into 3 shared bucket sets, over a Montgomery copy of
  * the even bases only (half the copy's memory).  The two sums are the same group element exactly when the check holds, and the
  * result is emitted normalised (Z = 1), so the bytes are identical to the exact path's.  A table that fails the check (any base

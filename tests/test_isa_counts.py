@@ -65,3 +65,15 @@ def test_ntt_pass_multiply_adds(disasm):
     # bench.py prices the transform with these very counts, picking pass 2's by what blz_ntt_info reports for the handle it times
     assert "pass2_table, pass2_stepped = 29 * 143 + 8 * 153 + 2 * 9, 36 * 143 + 10 * 153 + 2 * 9" in src
     assert '(37 * 143 + 2 * 9) + (pass2_table if ninfo["pass2_factor_table"] else pass2_stepped) + (29 * 143 + 10 * 9)' in src
+
+
+def test_table_check_doubling_multiply_adds(disasm):
+    """The checked-table plan's device check walks chains of 32 Jacobian doublings (ec_rr.hip.hpp ptrr_jdbl): 3 squarings x 301 +
+    2 products x 392 + one fused sum of two products x 588 = 2275 multiply-adds on 14 x 28 bits; 969 on 9 x 29
+    (945 in the six products, the rest in the two one-digit quotient reductions): the doubling loop of the shipped kernels holds
+    that many."""
+    assert 3 * 301 + 2 * 392 + 588 == 2275
+    for curve, want in (("9Fq_BLS381", 2275), ("9Fq_BLS377", 2275 - 6 * 14), ("8Fq_BN254", 969)):
+        ins = function_instructions(disasm, f"_ZN3blz18k_check_precomputeINS_{curve}EEEvPKjmPj")
+        per_loop = [count(body, "v_mad_u64_u32") for _, _, body in loops(ins)]
+        assert want in per_loop, (curve, per_loop)
