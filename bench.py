@@ -541,9 +541,9 @@ def main():
                         pending += 1
                 return out
 
-            # The build is paced by the tasks (msm_capi.hip arena_points_table): every task over the bases first enqueues two
-            # ~9 ms chunks of it and takes the plain path until the table is complete.  first_task_ms is the first task's
-            # latency (plain path + its two chunks); a few more tasks show the surcharge in a stream; then the host says it
+            # The build is paced by the tasks (msm_capi.hip arena_points_table): every task over the bases first enqueues four
+            # ~5.5 ms chunks of it and takes the plain path until the table is complete.  first_task_ms is the first task's
+            # latency (plain path + its four chunks); a few more tasks show the surcharge in a stream; then the host says it
             # would rather have the table now (prepare_window_table with a wait: all the remaining chunks at once) and the
             # steady state is timed.
             tsubmit()                       # (a fresh handle's first task pays its workspace allocations: not the table's doing)
@@ -611,7 +611,7 @@ def main():
                              "result_check": "this rank's result bytes equal its result in the headline loop (which the oracle checked"
                                              + (" after the exchange)" if multi else ")"),
                              "what": "opt-in blz_msm_set_window_table: the bases' window multiples 2^(c j) P tabulated once per load - paced by "
-                                     "the tasks (two ~9 ms chunks ahead of each task, which takes the plain path meanwhile: first_task_ms, "
+                                     "the tasks (four ~5.5 ms chunks ahead of each task, which takes the plain path meanwhile: first_task_ms, "
                                      "ms_per_task_while_building), the rest at once when the host asks for it (prepare_wait_ms) - then every "
                                      "window's digit added into one bucket set; same steps / queue as the headline" + (", the slowest rank's time, without the 144-byte exchange" if multi else "")}
         wd.disarm()

@@ -280,13 +280,13 @@ int arena_precompute_check(blz_msm* h, uint64_t pos, uint32_t nelem, bool* ok, u
 // (profiles/r04_window_table_async.txt): on a lowest-priority stream its long-lived waves hold their registers and halve the
 // tasks' speed for as long as it takes; confined to a quarter of the CUs it is worse (the accumulation's blocks on the shared CUs
 // issue behind the build's older waves and become the kernel's tail).  So the build is PACED by the tasks: it is cut into chunks
-// of TABLE_BUILD_CHUNK bases (~9 ms of the chip), every task launched over the bases first enqueues `chunk_budget` of them on
+// of TABLE_BUILD_CHUNK bases (~5.5 ms of the chip), every task launched over the bases first enqueues `chunk_budget` of them on
 // its own main stream - a fixed, small surcharge per task while the table is being built - and keeps taking the plain path;
 // the first task launched after the last chunk has completed adopts the table.  blz_msm_prepare_window_table enqueues ALL the
 // remaining chunks at once for a host that would rather pay the build now.  Results are bit-identical either way
 // (tests/test_gpu_msm_table.py).
 constexpr uint32_t TABLE_BUILD_CHUNK = 3u << 16;   // bases per launch = the build kernel's lanes (msm_impl.hip.hpp TABLE_BUILD_BLOCKS x 64)
-constexpr int TABLE_CHUNKS_PER_TASK = 2;           // ~18 ms on top of a 2^26 task's 117: 171 tasks until a 2^26 table is there
+constexpr int TABLE_CHUNKS_PER_TASK = 4;           // ~22 ms on top of a 2^26 task's 117: 86 tasks until a 2^26 table is there
 int arena_points_table(blz_msm* h, uint64_t pos, uint32_t npts, const void** out, int* c_out, int chunk_budget) {
     *out = nullptr;
     *c_out = 0;

@@ -232,6 +232,9 @@ __global__ __launch_bounds__(64, 3) void k_check_precompute(const uint32_t* __re
 // A base whose multiple comes out as infinity (only a point of even order can: none in the r-torsion) cannot be
 // tabulated: *flag is raised and the host falls back to the plain path.
 // ------------------------------------------------------------------------------------------------
+#ifndef BLZ_TABLE_BUILD_JACOBIAN
+#define BLZ_TABLE_BUILD_JACOBIAN 1
+#endif
 template <class F>
 constexpr size_t TABLE_SCRATCH_ROW = 5 * F::N;   // dwords per parked multiple: X, Y, ZZ, ZZZ, running product
 template <class F>
@@ -250,16 +253,47 @@ __global__ __launch_bounds__(64, 3) void k_build_window_table(const uint32_t* __
         Affine<F> a;
         fp_to_mont(a.x, x);
         fp_to_mont(a.y, y);
-        if (j0 == 1) store_mont_point<F>(table, (size_t)i * W, x, y);   // the base itself (x, y are consumed)
         XYZZ<F> p;
         Fp<F> prod;
         bool bad = false;
+#if BLZ_TABLE_BUILD_JACOBIAN
+        // the chain of doublings - 95 % of the kernel - runs in Jacobian coordinates on the reduced radix where the field has one
+        // (ec_rr.hip.hpp ptrr_jdbl: ~3200 instructions per doubling against ~5600 for the 32-bit XYZZ doubling); every c-th
+        // point leaves it as (X, Y, Z^2, Z^3) in the 32-bit form the parking and normalising code below works on
+        typename std::conditional<USE_RR<F>, JacRR<typename F::RR>, int>::type jp;
+        if constexpr (USE_RR<F>) {
+            using Q = typename F::RR;
+            Frr<Q, 1, 2> ax;
+            rr_to_mont_from_words<Q>(ax, x.v);
+            rr_to_mont_from_words<Q>(jp.y, y.v);
+            jp.x = rr_as<1, JacRR<Q>::VX>(ax);
+            rr_one(jp.z);
+        }
+#endif
+        if (j0 == 1) store_mont_point<F>(table, (size_t)i * W, x, y);   // the base itself (x, y are consumed)
         for (int j = j0; j < W; ++j) {
-            XYZZ<F> t;
             int nd = j == 0 ? base_shift : c;   // doublings from the previous entry (or from the base)
-            if (j == j0) { pt_mdbl(p, a); --nd; }
-            for (int d = 0; d < nd; ++d) { pt_dbl(t, p); p = t; }
-            if (pt_is_inf(p)) { bad = true; break; }
+#if BLZ_TABLE_BUILD_JACOBIAN
+            if constexpr (USE_RR<F>) {
+                using Q = typename F::RR;
+#pragma unroll 1
+                for (int d = 0; d < nd; ++d) ptrr_jdbl(jp);
+                if (rr_is_zero(jp.z)) { bad = true; break; }
+                Frr<Q, 1, 2> zz, zzz;
+                rr_sqr(zz, jp.z);
+                rr_mul(zzz, zz, jp.z);
+                rr_to_mont32_words<Q>(p.x.v, jp.x);
+                rr_to_mont32_words<Q>(p.y.v, jp.y);
+                rr_to_mont32_words<Q>(p.zz.v, zz);
+                rr_to_mont32_words<Q>(p.zzz.v, zzz);
+            } else
+#endif
+            {
+                XYZZ<F> t;
+                if (j == j0) { pt_mdbl(p, a); --nd; }
+                for (int d = 0; d < nd; ++d) { pt_dbl(t, p); p = t; }
+                if (pt_is_inf(p)) { bad = true; break; }
+            }
             if (j == j0) prod = p.zzz;
             else fp_mul(prod, prod, p.zzz);
             uint32_t* q = row + (size_t)(j - j0) * TABLE_SCRATCH_ROW<F>;

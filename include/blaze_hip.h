@@ -188,7 +188,7 @@ int blz_msm_plan(int curve, uint32_t nof_elements, int is_precompute, uint32_t o
  * enable: 0 off, 1 on where it was measured to pay (BLS12-377 / BLS12-381; BN254's 64-byte points are already
  * gathered at the memory system's rate and lose 4 % with a table, so 1 leaves BN254 on the plain path), 2 always.
  * With it, a pf = 1 handle whose bases live in the arena (hbm_point_addr) builds the table of their window multiples
- * 2^(c j) P, j < W = ceil(257 / c) - 3.1 s of the chip for 2^26 BLS12-381 bases, paced by the tasks (below), W x the memory
+ * 2^(c j) P, j < W = ceil(257 / c) - 1.9 s of the chip for 2^26 BLS12-381 bases, paced by the tasks (below), W x the memory
  * of the Montgomery copy (2^26: 10 x 8 GiB) - and keeps it with the arena extent: a later write of up to 2^18 bases has their rows
  * re-tabulated ahead of the next task, a larger one drops the table (the tasks that follow rebuild it).  Tasks over
  * those bases then add every window's digit into ONE bucket set:
@@ -199,8 +199,8 @@ int blz_msm_plan(int curve, uint32_t nof_elements, int is_precompute, uint32_t o
  * A handle with a scalar range (blz_msm_set_scalar_range) tabulates 2^(bit_lo + c j) P for the windows of its range.
  * New handles start with 0 (off).  No other value of `enable` is accepted (InvalidPrimitiveParam). */
 int blz_msm_set_window_table(blz_msm* h, int enable);
-/* The table's build is never one lump inside a task: it is cut into chunks of 196 608 bases (~9 ms of the chip), every task
- * launched over the bases first enqueues two of them on its own stream and takes the plain path, like every task until the
+/* The table's build is never one lump inside a task: it is cut into chunks of 196 608 bases (~5.5 ms of the chip), every task
+ * launched over the bases first enqueues four of them on its own stream and takes the plain path, like every task until the
  * last chunk has completed; the next task adopts the table.  Results are bit-identical either way.  A host that wants the
  * table in place before its first task calls this after load_data_to_hbm: it allocates the table (do this with the load: an
  * 80 GiB hipMalloc takes 0.3 ms on a clean device and seconds on one that has memory to scrub), enqueues the first chunks
