@@ -123,6 +123,34 @@ def test_a_corrupted_multiple_keeps_the_exact_path(gpu, orc, curve):
     _release()
 
 
+def test_a_base_of_order_two_refutes_the_table(gpu, orc):
+    """(-1, 0) lies on BLS12-377's curve y^2 = x^3 + 1 and has order 2: 2^32 times it is the point at infinity, which no affine
+    B_1 equals - the check's chain of doublings runs into Z = 0 and stays there (ec_rr.hip.hpp ptrr_jdbl has no infinity
+    branch).  Whatever stands in the element's other slots, the table is refuted and the result is the literal sum."""
+    _release()
+    curve, n = "BLS377", 700
+    ps = orc.point_bytes(curve)
+    q = pyref.CURVES[curve]["q"]
+    pts, sc, _ = orc.input_generator(curve, n, 8, 77)
+    bad = bytearray(pts)
+    bad[(333 * 8) * ps: (333 * 8 + 1) * ps] = (q - 1).to_bytes(48, "little") + bytes(48)
+    exp = orc.msm_pippenger(curve, bytes(bad), sc, n, 8, threads=8)
+    cl = _plan_client(curve)
+    cl.load_data_to_hbm(bytes(bad), 0, 0)
+    assert not cl.prepare_precompute_plan(n, (0, 0))
+    assert run_msm(cl, None, sc, n, hbm=(0, 0)) == exp
+    info = cl.precompute_plan_info()
+    assert not info["used"] and info["check"] == "refuted", info
+    # ... and as the LAST base of an element (the chain that starts from it is never walked; the one that should end in it is)
+    bad2 = bytearray(pts)
+    bad2[(334 * 8 + 7) * ps: (334 * 8 + 8) * ps] = (q - 1).to_bytes(48, "little") + bytes(48)
+    cl.load_data_to_hbm(bytes(bad2), 0, 0)
+    assert run_msm(cl, None, sc, n, hbm=(0, 0)) == orc.msm_pippenger(curve, bytes(bad2), sc, n, 8, threads=8)
+    assert cl.precompute_plan_info()["check"] == "refuted"
+    cl.close()
+    _release()
+
+
 def test_rewrites_recheck_only_what_they_touch(gpu, orc):
     """A write into a table that was found consistent re-arms the check for the elements it touches only (an element's eight
     bases are checked against each other and nothing else): rewriting a few points of a 2^18-element table costs a check of a few
