@@ -551,3 +551,17 @@ def test_wait_result_is_bounded(gpu, orc, monkeypatch):
     nc.reset()
     assert bytes(nc.result(0)) == bytes(orc.ntt("BLS381", data, logn))   # the queued transform ran once the stall ended
     nc.close()
+
+
+def test_random_call_sequences_never_break_a_client(gpu):
+    """tools/ntt_monkey.py: the reference's double-buffer cycle cut up at random - wrong buffer numbers and lengths, results read
+    from the buffer under transform, start_process twice, exchange on either buffer - on clients of several sizes, fields and
+    directions (both pass-2 kernels at 2^19 / 2^20).  Every call succeeds or fails with one of src/error.rs's variants; after every
+    burst each client is reset and transforms a known vector into the oracle's bytes."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "ntt_monkey.py"), "40", "23"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "mismatches: 0" in r.stdout and "'ok':" in r.stdout and "InvalidPrimitiveParam" in r.stdout
