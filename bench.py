@@ -20,7 +20,9 @@ the launcher's rendezvous already brought up); the exchange inside the library (
 blz_msm_all_gather_combine: a second RCCL communicator on the handle's own stream) is tried AFTER the
 headline is measured and reported as the extra key `exchange_native`; every bring-up and every phase
 runs under a deadline, and a rank whose deadline expires prints what it was waiting for and exits
-non-zero (an exit, never a re-exec).
+non-zero (an exit, never a re-exec) - unless the headline is already measured and checked: a deadline
+that expires in one of the EXTRA legs prints the line without the remaining extras (`extras_aborted`
+names the leg) and exits 0.
 
 With --gpus N > 1 and no WORLD_SIZE in the environment the script starts the N ranks itself (a child
 `torch.distributed.run`, before this process touches the GPU) and relays their output.
@@ -85,10 +87,15 @@ def host_threads() -> int:
 class Watchdog:
     """A deadline around phases that can block for ever on a peer that died (rendezvous, collectives, a wedged
     kernel).  On expiry the rank says what it was waiting for and exits with status 3: the launcher then tears the
-    other ranks down.  os._exit, never an exec: this process has initialised the GPU."""
+    other ranks down - unless the headline is already in hand (`fallback`).  os._exit, never an exec: this process has
+    initialised the GPU."""
 
     def __init__(self, rank):
         self.rank, self.timer = rank, None
+        # once the headline has been measured and checked: a callable that returns the line as far as it has got (rank 0) or
+        # None (other ranks).  A deadline that expires in one of the EXTRA legs then costs the extras, not the headline: the
+        # rank prints what it has - with `extras_aborted` saying which leg hung - and exits 0
+        self.fallback = None
 
     def arm(self, seconds, what):
         import threading
@@ -96,6 +103,15 @@ class Watchdog:
         self.disarm()
 
         def fire():
+            if self.fallback is not None:
+                print(f"[bench rank {self.rank}] DEADLINE: {what} did not complete within {seconds} s; the headline is printed without the "
+                      f"remaining extras", file=sys.stderr, flush=True)
+                try:
+                    line = self.fallback(f"{what}: not complete within {seconds} s")
+                    if line is not None:
+                        print(json.dumps(line), flush=True)
+                finally:
+                    os._exit(0)
             print(f"[bench rank {self.rank}] DEADLINE: {what} did not complete within {seconds} s; exiting 3", file=sys.stderr, flush=True)
             os._exit(3)
 
@@ -396,55 +412,7 @@ def main():
             dist.barrier()
             wd.disarm()
 
-    # ---- the library's own exchange, after the fact (VERDICT r2 item 1): RCCL resolved at run time inside
-    # libblaze_hip, a communicator per handle, ncclAllGather on the handle's stream + k_combine_partials.  Nothing
-    # here can hang the job: "is RCCL loadable" is agreed on first, rank 0 ALWAYS broadcasts (an id or None), the
-    # bring-up has its own deadline inside the library (BLAZE_COMM_TIMEOUT_MS), the exchange is a bounded wait, and
-    # the watchdog stands behind all of it.
-    native = None
-    if multi and os.environ.get("BLAZE_BENCH_EXCHANGE", "native") == "native":
-        wd.arm(240, "native RCCL exchange (bring-up + 5 exchanges)")
-        fdev = gather_dev if gather_dev is not None else "cpu"
-        err = None
-        try:
-            my_id = MSMClient.comm_unique_id()          # loads librccl through the library; every rank tries
-            ok = 1
-        except Exception as e:   # noqa: BLE001
-            my_id, ok, err = None, 0, f"RCCL not loadable: {e}"
-        flag = torch.tensor([ok if dist.get_backend() == "nccl" else 0], dtype=torch.int32, device=fdev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 1:
-            ids = [my_id if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)      # unconditional on every rank
-            try:
-                client.comm_init(rank, world, ids[0])
-                ok = 1
-            except Exception as e:   # noqa: BLE001
-                ok, err = 0, f"comm_init: {e}"
-            flag = torch.tensor([ok], dtype=torch.int32, device=fdev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 1:
-                try:
-                    my_part = last_partial[0]
-                    outs, tms = [], []
-                    for _ in range(5):
-                        t1 = time.perf_counter()
-                        outs.append(client.all_gather_combine(my_part))
-                        tms.append((time.perf_counter() - t1) * 1e3)
-                    same = all(o == res for o in outs)
-                    native = {"ok": bool(same), "ms": round(statistics.median(tms), 3), "error": None if same else "result differs from the torch.distributed exchange",
-                              "what": "blz_msm_all_gather_combine: ncclAllGather on the handle's stream + k_combine_partials, median of 5"}
-                except Exception as e:   # noqa: BLE001
-                    native = {"ok": False, "ms": None, "error": f"all_gather_combine: {e}"}
-            else:
-                native = {"ok": False, "ms": None, "error": err or "comm_init failed on another rank"}
-        else:
-            native = {"ok": False, "ms": None, "error": err or ("process group backend is not nccl" if dist.get_backend() != "nccl" else "RCCL not loadable on another rank")}
-        agree = torch.tensor([1 if native["ok"] else 0], dtype=torch.int32, device=fdev)
-        dist.all_reduce(agree, op=dist.ReduceOp.MIN)
-        if native["ok"] and int(agree.item()) == 0:
-            native = {"ok": False, "ms": native["ms"], "error": "the exchange failed on another rank"}
-        wd.disarm()
+    native = None   # (the library's own exchange is measured below, once the headline line is in hand)
 
     # ---- roofline of the dominant kernel (k_accumulate: one launch covers this rank's whole shard)
     acc_avg_ms = statistics.mean(accum_ms)
@@ -498,6 +466,88 @@ def main():
                                                              "element and occupied window"}
     clock = {"nominal_mhz": calib["nominal_clock_mhz"] if calib else None, "sclk_mhz_timed_steps": sclk_rec,
              "mad_calibration": calib}
+
+    # every extra key exists from here on (None until its leg has run): the line can be printed at any point after this
+    table_rec = alt_rec = hbm_flow = cfg2 = cfg3 = cfg4 = lone_small = ntt = cpu = cpu_ref = None
+
+    def make_line(extras_aborted=None):
+        if rank != 0:
+            return None
+        line = {
+            "metric": f"BLS12-381 MSM/s at 2^{LOG_N}", "value": round(value, 4), "unit": "MSM/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "u32 registers holding 28-bit limbs (381-bit Fq, Montgomery)", "data": "synthetic",
+            "config": {"workload": f"2^{LOG_N} BLS12-381 G1 MSM, pf=1, scalars+points resident in HBM"
+                                   + (" (points in the device arena, scalars-only set_data)" if hbm_mode else " (DMA-mode set_data with device pointers)"),
+                       "elements": n, "elements_per_gpu": n_loc, "parallelism": f"shard{world}" if world > 1 else "single",
+                       "shard_rank0": lay, "exchange": exchange, "tasks_in_flight": queue,
+                       "window_bits": int(api["window_bits"]), "windows": int(api["windows"]),
+                       "sort_hidden_under_previous_accumulation": bool(api.get("sort_hidden", 0))},
+            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_ref_semantics": cpu_ref, "result_check": check_rec,
+            "ntt_2e27": ntt, "clock": clock, "exchange_native": native, "window_table": table_rec, "alt_layout_elements": alt_rec, "hbm_flow": hbm_flow, "config2_dma": cfg2,
+            "config3_bn254_pf8": cfg3, "config4_rank_task": cfg4, "lone_small_msm": lone_small,
+            "phases_ms": {k: round(v, 3) for k, v in api.items() if k.endswith("_ms")},
+        }
+        if os.environ.get("BLAZE_BENCH_EMIT_RESULT") == "1":
+            line["result_hex"] = res.hex()
+        if extras_aborted is not None:
+            line["extras_aborted"] = extras_aborted
+        return line
+
+    wd.fallback = make_line   # (from here on a hung extra leg costs the extras only)
+    if os.environ.get("BLAZE_BENCH_TEST_STALL_EXTRAS") == "1":   # (tests: an extra leg that never comes back)
+        wd.arm(2, "test stall in the extras")
+        time.sleep(3600)
+
+    # ---- the library's own exchange, after the fact (VERDICT r2 item 1): RCCL resolved at run time inside
+    # libblaze_hip, a communicator per handle, ncclAllGather on the handle's stream + k_combine_partials.  Nothing
+    # here can hang the job: "is RCCL loadable" is agreed on first, rank 0 ALWAYS broadcasts (an id or None), the
+    # bring-up has its own deadline inside the library (BLAZE_COMM_TIMEOUT_MS), the exchange is a bounded wait, and
+    # the watchdog stands behind all of it.
+    if multi and os.environ.get("BLAZE_BENCH_EXCHANGE", "native") == "native":
+        wd.arm(240, "native RCCL exchange (bring-up + 5 exchanges)")
+        fdev = gather_dev if gather_dev is not None else "cpu"
+        err = None
+        try:
+            my_id = MSMClient.comm_unique_id()          # loads librccl through the library; every rank tries
+            ok = 1
+        except Exception as e:   # noqa: BLE001
+            my_id, ok, err = None, 0, f"RCCL not loadable: {e}"
+        flag = torch.tensor([ok if dist.get_backend() == "nccl" else 0], dtype=torch.int32, device=fdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            ids = [my_id if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)      # unconditional on every rank
+            try:
+                client.comm_init(rank, world, ids[0])
+                ok = 1
+            except Exception as e:   # noqa: BLE001
+                ok, err = 0, f"comm_init: {e}"
+            flag = torch.tensor([ok], dtype=torch.int32, device=fdev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                try:
+                    my_part = last_partial[0]
+                    outs, tms = [], []
+                    for _ in range(5):
+                        t1 = time.perf_counter()
+                        outs.append(client.all_gather_combine(my_part))
+                        tms.append((time.perf_counter() - t1) * 1e3)
+                    same = all(o == res for o in outs)
+                    native = {"ok": bool(same), "ms": round(statistics.median(tms), 3), "error": None if same else "result differs from the torch.distributed exchange",
+                              "what": "blz_msm_all_gather_combine: ncclAllGather on the handle's stream + k_combine_partials, median of 5"}
+                except Exception as e:   # noqa: BLE001
+                    native = {"ok": False, "ms": None, "error": f"all_gather_combine: {e}"}
+            else:
+                native = {"ok": False, "ms": None, "error": err or "comm_init failed on another rank"}
+        else:
+            native = {"ok": False, "ms": None, "error": err or ("process group backend is not nccl" if dist.get_backend() != "nccl" else "RCCL not loadable on another rank")}
+        agree = torch.tensor([1 if native["ok"] else 0], dtype=torch.int32, device=fdev)
+        dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+        if native["ok"] and int(agree.item()) == 0:
+            native = {"ok": False, "ms": native["ms"], "error": "the exchange failed on another rank"}
+        wd.disarm()
+
 
     # ---- the same workload with the resident-base window table (extra key, never the headline value): an opted-in
     # handle tabulates the window multiples of the bases once (blz_msm_set_window_table) and then runs fewer, wider
@@ -1139,23 +1189,7 @@ def main():
             del xin
 
     if rank == 0:
-        line = {
-            "metric": f"BLS12-381 MSM/s at 2^{LOG_N}", "value": round(value, 4), "unit": "MSM/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "u32 registers holding 28-bit limbs (381-bit Fq, Montgomery)", "data": "synthetic",
-            "config": {"workload": f"2^{LOG_N} BLS12-381 G1 MSM, pf=1, scalars+points resident in HBM"
-                                   + (" (points in the device arena, scalars-only set_data)" if hbm_mode else " (DMA-mode set_data with device pointers)"),
-                       "elements": n, "elements_per_gpu": n_loc, "parallelism": f"shard{world}" if world > 1 else "single",
-                       "shard_rank0": lay, "exchange": exchange, "tasks_in_flight": queue,
-                       "window_bits": int(api["window_bits"]), "windows": int(api["windows"]),
-                       "sort_hidden_under_previous_accumulation": bool(api.get("sort_hidden", 0))},
-            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_ref_semantics": cpu_ref, "result_check": check_rec,
-            "ntt_2e27": ntt, "clock": clock, "exchange_native": native, "window_table": table_rec, "alt_layout_elements": alt_rec, "hbm_flow": hbm_flow, "config2_dma": cfg2,
-            "config3_bn254_pf8": cfg3, "config4_rank_task": cfg4, "lone_small_msm": lone_small,
-            "phases_ms": {k: round(v, 3) for k, v in api.items() if k.endswith("_ms")},
-        }
-        if os.environ.get("BLAZE_BENCH_EMIT_RESULT") == "1":
-            line["result_hex"] = res.hex()
+        line = make_line()
         print(json.dumps(line), flush=True)
     if multi:
         wd.arm(120, "process-group teardown")

@@ -1415,3 +1415,22 @@ def test_random_call_sequences_never_break_a_client(gpu):
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "api_monkey.py"), "40", "17"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "mismatches: 0" in r.stdout and "'ok':" in r.stdout and "InvalidPrimitiveParam" in r.stdout
+
+
+def test_bench_a_hung_extra_leg_costs_the_extras_only(gpu):
+    """bench.py's watchdog exits 3 when a phase of the HEADLINE hangs; once the headline is measured and checked, a deadline that
+    expires in one of the extra legs (window table, configs 2 - 4, NTT, the library's own exchange for N > 1 ...) prints the line as
+    far as it has got - `extras_aborted` names the leg - and exits 0."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ, BLAZE_BENCH_LOGN="16", BLAZE_BENCH_TEST_STALL_EXTRAS="1")
+    root = os.path.dirname(HERE)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["value"] > 0 and j["result_check"]["ok"] and j["roofline"]["kernel_ms"] > 0
+    assert "test stall" in j["extras_aborted"] and j["window_table"] is None and j["ntt_2e27"] is None
+    assert "DEADLINE" in r.stderr
