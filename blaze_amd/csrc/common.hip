@@ -18,6 +18,10 @@ void set_last_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
     BLZ_LOG(1, "error: %s", g_err);
+    // A failed runtime call (an allocation on a full device, say) also leaves its code behind as this thread's sticky "last error",
+    // where the next launch check - BLZ_HIP(hipGetLastError()) behind some kernel of some later, healthy call - would find it and
+    // fail for no reason.  Whatever went wrong is reported HERE: the slate is wiped with the report.
+    (void)hipGetLastError();
 }
 
 int log_level() {

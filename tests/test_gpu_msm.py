@@ -1434,3 +1434,16 @@ def test_bench_a_hung_extra_leg_costs_the_extras_only(gpu):
     assert j["value"] > 0 and j["result_check"]["ok"] and j["roofline"]["kernel_ms"] > 0
     assert "test stall" in j["extras_aborted"] and j["window_table"] is None and j["ntt_2e27"] is None
     assert "DEADLINE" in r.stderr
+
+
+def test_a_full_device_is_an_error_not_a_crash(gpu):
+    """tools/oom_probe.py: all but 600 MiB of the device taken - a DMA-mode task (twice), an arena load and an NTT client each fail with
+    an error that names the allocation (a failed hipMalloc leaves a sticky error in the HIP runtime: it is cleared where it is
+    reported, so that the next launch check does not report it again), and every client works once the memory is back."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(HERE)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "oom_probe.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "PROBLEM" not in r.stdout and "[True, True, True]" in r.stdout
