@@ -1447,3 +1447,18 @@ def test_a_full_device_is_an_error_not_a_crash(gpu):
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "oom_probe.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "PROBLEM" not in r.stdout and "[True, True, True]" in r.stdout
+
+
+def test_teardown_with_work_in_flight(gpu):
+    """tools/teardown_probe.py: close() with two tasks queued (device inputs, host inputs, arena bases, window table, host scalars),
+    blz_arena_release and a rewrite of the bases under tasks in flight (the tasks that were accepted return the right bytes; a task
+    over the released range is refused), NTT close() / reset() under a transform."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(HERE)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "teardown_probe.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    out = r.stdout
+    assert out.rstrip().endswith("done") and "PROBLEM" not in out and "False" not in out
+    assert out.count("closed with two tasks in flight") == 5 and "task over the released arena: InvalidPrimitiveParam" in out
