@@ -626,9 +626,10 @@ int stage_common(blz_msm* h, bool have_points, const void* points, size_t points
                     n, h->pf, point_size(h));
     if ((uint64_t)n * h->pf >= (1ull << 31)) return fail(BLZ_ERR_INVALID_PARAM, "too many points");
     // refuse sizes the window planner cannot serve BEFORE anything is copied or converted (u32 entry indexing:
-    // 256-bit scalars stop below 2^29 points, 32-bit chunks of pf = 8 below 2^31)
+    // points x windows <= 2^32 - 2^26 (msm_engine.hpp MSM_MAX_ENTRIES) with windows of at most 23 bits - 256-bit scalars need 12,
+    // so pf = 1 stops at 352 321 536 points (2^28.39; checked there: tests/test_gpu_msm.py), the 32-bit chunks of pf = 8 at 2^31 - 2^25)
     if (n && h->eng.plan_for(n * h->pf, h->pf == 1 ? 256 : 32).c == 0)
-        return fail(BLZ_ERR_INVALID_PARAM, "no window plan for %llu points of %d-bit scalars (maximum: 2^29 - 1 points at pf = 1)",
+        return fail(BLZ_ERR_INVALID_PARAM, "no window plan for %llu points of %d-bit scalars (u32 entry indexing: at most 352321536 points at pf = 1, 2113929216 at pf = 8)",
                     (unsigned long long)n * h->pf, h->pf == 1 ? 256 : 32);
     if (!h->eng.can_accept())
         return fail(BLZ_ERR_INVALID_PARAM, "task queue full (%d in flight); call wait_result first", MSM_QUEUE_DEPTH);

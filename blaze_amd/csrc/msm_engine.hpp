@@ -11,6 +11,8 @@ namespace blz {
 // flat; the bucket reduce walks it as Wv "virtual windows" of V = 2^(cmin-1) buckets each (every
 // window's bucket count is a multiple of V) and k_finish stitches them (msm_impl.hip.hpp).
 constexpr int MSM_MAX_W = 96;
+// entries (points x windows) of one task: u32 indices, and room for the kernels' strided walks to step past the end without wrapping
+constexpr uint64_t MSM_MAX_ENTRIES = (1ull << 32) - (1ull << 26);
 struct MsmPlan {
     uint32_t npts = 0;   // points in the sum (n * precompute_factor)
     int sbits = 256;     // scalar width per point: 256 (pf=1), 32 (pf=8 chunk) or 64 (pf=8, checked-table plan: two chunks per even base)

@@ -1462,3 +1462,37 @@ def test_teardown_with_work_in_flight(gpu):
     out = r.stdout
     assert out.rstrip().endswith("done") and "PROBLEM" not in out and "False" not in out
     assert out.count("closed with two tasks in flight") == 5 and "task over the released arena: InvalidPrimitiveParam" in out
+
+
+def test_largest_task_the_planner_serves(gpu, orc):
+    """Maximum size: a task's entries (points x windows) are indexed with u32 and walked in strides, so the planner stops at
+    2^32 - 2^26 of them (msm_engine.hpp MSM_MAX_ENTRIES) - 256-bit scalars need 12 windows of at most 23 bits, so pf = 1 ends at
+    352 321 536 points, 5 x the reference's largest shape.  That task is served and right (linearity over all its scalars); one
+    point more is refused before anything is copied.  (At 2^32 - 4 entries the strided walks wrapped: wrong sums - found by
+    tools/big_probe.py, which also holds 2^27 and 2^28.)"""
+    curve, n = "BN254", 352321536
+    _free_arena = blaze_amd.lib().blz_arena_release
+    blaze_amd._lib.check(_free_arena(0))
+    dp, ds = synth(curve, n + 1, seed=29)
+
+    class View(DeviceBuffer):
+        def __init__(self, base, nbytes):
+            self.device_id, self.nbytes, self.ptr = base.device_id, nbytes, base.ptr
+
+        def free(self):
+            pass
+
+    cl = msm_client(curve, 1, PointMemoryType.HBM)
+    cl.load_data_to_hbm(dp, 0, 0)
+    dp.free()
+    with pytest.raises(DriverClientError) as ei:
+        run_msm(cl, None, ds, n + 1, hbm=(0, 0))
+    assert ei.value.variant == "InvalidPrimitiveParam" and "no window plan" in str(ei.value)
+    cl.reset()
+    got = run_msm(cl, None, View(ds, n * 32), n, hbm=(0, 0))
+    api = cl.get_api()
+    assert int(api["windows"]) * n <= (1 << 32) - (1 << 26) < (int(api["windows"]) + 1) * n
+    k = orc.index_weighted_sum(curve, ds.download(n * 32), n, 0, threads=16)
+    assert got == orc.result_from_affine(curve, orc.generator_mul(curve, k))
+    cl.close(); ds.free()
+    blaze_amd._lib.check(_free_arena(0))
