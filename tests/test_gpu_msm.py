@@ -1496,3 +1496,16 @@ def test_largest_task_the_planner_serves(gpu, orc):
     assert got == orc.result_from_affine(curve, orc.generator_mul(curve, k))
     cl.close(); ds.free()
     blaze_amd._lib.check(_free_arena(0))
+
+
+def test_dense_walk_over_task_sizes(gpu):
+    """tools/msm_sizes_probe.py: 2^k - 1, 2^k, 2^k + 1, 3 2^(k-1) for every k up to 2^22 (pf = 1: device buffers and arena bases in
+    turn) and 2^19 (pf = 8: exact path and checked-table plan), three curves, two tasks in flight, every result checked through
+    linearity - the sizes where the planner changes structure all lie on the way (2^24 / 2^21 ran clean the same way)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(HERE)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "msm_sizes_probe.py"), "22", "19"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "mismatches: 0" in r.stdout and "MISMATCH" not in r.stdout and r.stdout.count("sizes up to") == 6
