@@ -1509,3 +1509,18 @@ def test_dense_walk_over_task_sizes(gpu):
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "msm_sizes_probe.py"), "22", "19"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "mismatches: 0" in r.stdout and "MISMATCH" not in r.stdout and r.stdout.count("sizes up to") == 6
+
+
+def test_scalar_distributions_a_bucket_method_likes_least(gpu):
+    """tools/msm_skew_probe.py: all scalars equal (one bucket per window holds every entry), all r - 1, all 2^256 - 1, all zero, one
+    non-zero among zeros, low / top words only, byte patterns on the edges of the signed-digit recoding (0x80.., 0x7f.., 0xff.., 0x55..,
+    0xaa.., 0x01..), half equal / half random, seven distinct values - 2^20 points (pf = 1) and 2^17 elements (pf = 8: exact path and
+    checked-table plan) on the three curves, device and host scalars, every result checked through linearity (2^24 / 2^21 ran clean
+    the same way: the worst case, all equal, costs 2 - 3 x a random task)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(HERE)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "msm_skew_probe.py"), "20", "17"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "mismatches: 0" in r.stdout and "MISMATCH" not in r.stdout and r.stdout.count(": ok") == 135
