@@ -1411,6 +1411,9 @@ def test_random_call_sequences_never_break_a_client(gpu):
     lengths, arena ranges nobody loaded, queue overflow, options flipped in mid-stream - against DMA, HBM and precompute clients of the
     three curves.  Every call succeeds or fails with one of src/error.rs's variants; after every burst each client is reset and
     returns the right bytes for a known task.  (Campaigns of 3 x 120 000 calls ran clean; the suite runs 40 bursts.)"""
+    import subprocess
+    import sys
+
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "api_monkey.py"), "40", "17"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
