@@ -24,6 +24,7 @@ Arena& arena_for(int device_id) {
 }
 
 ArenaExtent* arena_find(Arena& a, uint64_t pos, size_t len) {
+    if (pos + len < pos) return nullptr;   // (a range that wraps around 2^64 lies in no extent)
     for (auto& e : a.ext)
         if (pos >= e.start && pos + len <= e.start + e.len) return &e;
     return nullptr;
@@ -153,6 +154,7 @@ static void mark_dirty(ArenaExtent& e, uint64_t lo, uint64_t hi) {
 int arena_write(int device_id, uint64_t pos, const void* src, size_t len, bool src_is_device, hipStream_t st) {
     BLZ_TRY(use_device(device_id));
     if (len == 0) return BLZ_OK;
+    if (pos + len < pos) return fail(BLZ_ERR_INVALID_PARAM, "arena: [%llu, +%zu) wraps around 2^64", (unsigned long long)pos, len);
     Arena& A = arena_for(device_id);
     std::lock_guard<std::mutex> lk(A.mu);
     const uint64_t end = pos + len;

@@ -81,6 +81,14 @@ namespace {
         }                                          \
     } while (0)
 
+// hbm_point_addr = (addr, offset): the byte address addr + offset of the flat arena; a sum that wraps is nobody's address
+#define BLZ_ARENA_ADDR(addr, off)                                                                                          \
+    do {                                                                                                                   \
+        if ((uint64_t)(addr) + (uint64_t)(off) < (uint64_t)(addr))                                                         \
+            return fail(BLZ_ERR_INVALID_PARAM, "HBM address %llu + offset %llu wraps around 2^64", (unsigned long long)(addr), \
+                        (unsigned long long)(off));                                                                        \
+    } while (0)
+
 size_t point_size(const blz_msm* h) { return blz_point_size(h->curve); }
 size_t result_size(const blz_msm* h) { return blz_result_size(h->curve); }
 
@@ -617,6 +625,7 @@ int stage_common(blz_msm* h, bool have_points, const void* points, size_t points
     BLZ_LIVE(h);
     BLZ_TRY(use_device(h->device));
     if (!have_points && !has_hbm) return BLZ_OK;  // reference: falls through every branch (msm_api.rs:163-216)
+    if (has_hbm) BLZ_ARENA_ADDR(hbm_addr, hbm_off);
     if (!scalars && n) return fail(BLZ_ERR_INVALID_PARAM, "null scalars");
     if (scalars_len != (size_t)n * BLZ_SCALAR_SIZE)
         return fail(BLZ_ERR_INVALID_PARAM, "scalars length %zu != nof_elements %u * 32", scalars_len, n);
@@ -898,6 +907,7 @@ int blz_msm_prepare_window_table(blz_msm* h, uint32_t nof_elements, uint64_t hbm
     if (ready) *ready = 0;
     BLZ_TRY(use_device(h->device));
     if (!wants_table(h) || nof_elements == 0) return BLZ_OK;
+    BLZ_ARENA_ADDR(hbm_addr, hbm_off);
     const auto t0 = std::chrono::steady_clock::now();
     const int limit = wait_ms < 0 ? wait_timeout_ms() : wait_ms;
     for (;;) {
@@ -948,6 +958,7 @@ int blz_msm_prepare_precompute_plan(blz_msm* h, uint32_t nof_elements, uint64_t 
     BLZ_TRY(use_device(h->device));
     if (!h->precompute_plan || nof_elements == 0) return BLZ_OK;
     if ((uint64_t)nof_elements * h->pf >= (1ull << 31)) return fail(BLZ_ERR_INVALID_PARAM, "too many points");
+    BLZ_ARENA_ADDR(hbm_addr, hbm_off);
     bool ok = false;
     uint64_t checked = nof_elements;
     BLZ_TRY(arena_precompute_check(h, hbm_addr + hbm_off, nof_elements, &ok, &checked));
@@ -1164,6 +1175,7 @@ int blz_msm_result(blz_msm* h, uint8_t* out, size_t out_cap, size_t* out_len, ui
 int blz_msm_load_data_to_hbm(blz_msm* h, const uint8_t* points, size_t len, uint64_t addr, uint64_t off) {
     if (!h || (!points && len)) return fail(BLZ_ERR_INVALID_PARAM, "null argument");
     BLZ_LIVE(h);
+    BLZ_ARENA_ADDR(addr, off);
     BLZ_WAIT(h, arena_write(h->device, addr + off, points, len, false, h->eng.stream));
     h->bases_from_hbm = true;  // msm_api.rs:301-311 flips BASES_SOURCE and programs the address
     h->hbm_addr = addr;
@@ -1173,6 +1185,7 @@ int blz_msm_load_data_to_hbm(blz_msm* h, const uint8_t* points, size_t len, uint
 int blz_msm_load_data_to_hbm_device(blz_msm* h, const void* d_points, size_t len, uint64_t addr, uint64_t off) {
     if (!h || (!d_points && len)) return fail(BLZ_ERR_INVALID_PARAM, "null argument");
     BLZ_LIVE(h);
+    BLZ_ARENA_ADDR(addr, off);
     BLZ_WAIT(h, arena_write(h->device, addr + off, d_points, len, true, h->eng.stream));
     h->bases_from_hbm = true;
     h->hbm_addr = addr;
@@ -1181,6 +1194,7 @@ int blz_msm_load_data_to_hbm_device(blz_msm* h, const void* d_points, size_t len
 
 int blz_msm_get_data_from_hbm(blz_msm* h, uint8_t* out, size_t len, uint64_t addr, uint64_t off) {
     if (!h || (!out && len)) return fail(BLZ_ERR_INVALID_PARAM, "null argument");
+    BLZ_ARENA_ADDR(addr, off);
     BLZ_TRY(use_device(h->device));
     Arena& A = arena_for(h->device);
     std::lock_guard<std::mutex> lk(A.mu);

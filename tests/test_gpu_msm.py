@@ -334,6 +334,18 @@ def test_call_order_and_errors(gpu, orc):
     with pytest.raises(DriverClientError) as ei:
         clh.initialize(MSMParams(n, None))
     assert ei.value.variant == "InvalidPrimitiveParam"
+    # hbm_point_addr = (addr, offset) whose sum wraps around 2^64 - or a range that does - is nobody's address: load, read-back and
+    # task are refused, none of them lands at the wrapped position
+    top = (1 << 64) - 96
+    for f in (lambda: clh.load_data_to_hbm(pts, top, 96), lambda: clh.load_data_to_hbm(pts, top, 0), lambda: clh.get_data_from_hbm(96, top, 200),
+              lambda: run_msm(clh, None, sc, n, hbm=(top, 4096)), lambda: run_msm(clh, pts, sc, n, hbm=((1 << 64) - 1, 1))):
+        with pytest.raises(DriverClientError) as ei:
+            f()
+        assert ei.value.variant in ("InvalidPrimitiveParam", "ReadError"), ei.value
+        clh.reset()
+    clh.load_data_to_hbm(pts[:96], top - 1, 0)             # ... while a range that ENDS below 2^64 is an address like any other
+    assert clh.get_data_from_hbm(96, top - 1, 0) == pts[:96]
+    blaze_amd._lib.check(blaze_amd.lib().blz_arena_release(0))
     # (None, None): silent no-op like the reference (msm_api.rs:163-216 falls through)
     cl.initialize(params)
     cl.set_data(MSMInput(None, sc, params))
