@@ -179,6 +179,9 @@ def buf_ptr(buf):
         arr = (C.c_char * len(buf)).from_buffer(buf)
         return C.cast(arr, C.c_void_p), len(buf), arr
     if hasattr(buf, "ctypes") and hasattr(buf, "nbytes"):  # numpy
+        if not buf.flags["C_CONTIGUOUS"]:
+            # (data, nbytes) of a strided view would name bytes that are not the view's: the caller decides whether to copy
+            raise ValueError("numpy array is not C-contiguous: pass np.ascontiguousarray(a) (inputs) or a contiguous buffer (outputs)")
         return C.c_void_p(buf.ctypes.data), int(buf.nbytes), buf
     mv = memoryview(buf)
     if mv.readonly:

@@ -106,3 +106,24 @@ def test_readme_switch_table_is_what_the_sources_read():
     hpp = open(os.path.join(root, "blaze_amd", "csrc", "common.hpp")).read()
     assert "#ifdef BLZ_EXPERIMENT_KNOBS" in hpp and "inline int exp_knob(const char*, int dflt) { return dflt; }" in hpp
     assert "BLZ_EXPERIMENT_KNOBS" not in open(os.path.join(root, "blaze_amd", "csrc", "Makefile")).read().replace("EXTRA=-DBLZ_EXPERIMENT_KNOBS", "")
+
+
+def test_buffers_handed_to_the_c_abi():
+    """blaze_amd._lib.buf_ptr turns host buffers into (pointer, length) without copying: bytes, bytearray, memoryview, contiguous numpy
+    arrays - and refuses a strided numpy view, whose (data, nbytes) would name bytes that are not the view's."""
+    import numpy as np
+    import pytest
+
+    from blaze_amd._lib import buf_ptr
+
+    assert buf_ptr(None)[:2] == (None, 0)
+    for b in (b"abcd", bytearray(b"abcd"), memoryview(bytearray(b"abcd")), np.frombuffer(b"abcd", dtype=np.uint8), memoryview(b"abcd")):
+        p, n, _keep = buf_ptr(b)
+        assert n == 4 and p
+    assert buf_ptr(bytearray())[1] == 0 and buf_ptr(b"")[1] == 0
+    a = np.arange(64, dtype=np.uint8).reshape(8, 8)
+    assert buf_ptr(a)[1] == 64 and buf_ptr(a[2:4])[1] == 16          # row slices stay contiguous
+    with pytest.raises(ValueError):
+        buf_ptr(a[:, :4])                                             # a strided view is refused
+    with pytest.raises(ValueError):
+        buf_ptr(a[::2])
