@@ -84,6 +84,9 @@ int blz_msm_start_process(blz_msm* h);
  *   points != NULL, has_hbm      : load_data_to_hbm(points) then scalars (:203-216)
  *   points == NULL, !has_hbm     : silent no-op in the reference (falls through) -> no-op here
  * points_len must be nof_elements * precompute_factor * point_size, scalars_len nof_elements*32.
+ * Largest task: points x windows <= 2^32 - 2^26 - 352 321 536 points at precompute_factor 1 (5 x the reference's largest shape;
+ * 134 GiB of device memory on BN254), 2^31 - 2^25 points at precompute_factor 8 (2^30 run: 172 GiB); beyond: InvalidPrimitiveParam
+ * before anything is copied.  hbm_addr + hbm_off must not wrap around 2^64.
  * Blocking: host buffers may be dropped when it returns (pwrite with O_SYNC, utils.rs:71). */
 int blz_msm_set_data(blz_msm* h, const uint8_t* points, size_t points_len, const uint8_t* scalars,
                      size_t scalars_len, uint32_t nof_elements, int has_hbm, uint64_t hbm_addr,

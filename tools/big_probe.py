@@ -13,7 +13,9 @@ from blaze_amd import DriverClientError  # noqa: E402
 from blaze_amd.ingo_msm import MSMInput, MSMParams, PointMemoryType  # noqa: E402
 from gpu_util import msm_client, synth  # noqa: E402
 
-curve = sys.argv[1]
+curve, _, opt = sys.argv[1].partition(":")          # CURVE, CURVE:8 (precompute handle, exact path), CURVE:8:plan (checked-table plan)
+pf = 8 if opt.startswith("8") else 1
+use_plan = opt.endswith("plan")
 import math  # noqa: E402
 
 for a in sys.argv[2:]:
@@ -21,8 +23,10 @@ for a in sys.argv[2:]:
     lg = round(math.log2(n), 3)
     blaze_amd._lib.check(blaze_amd.lib().blz_arena_release(0))
     try:
-        dp, ds = synth(curve, n)
-        cl = msm_client(curve, 1, PointMemoryType.HBM)
+        dp, ds = synth(curve, n, pf=pf)
+        cl = msm_client(curve, pf, PointMemoryType.HBM)
+        if use_plan:
+            cl.set_precompute_plan(True)
         cl.load_data_to_hbm(dp, 0, 0)
         dp.free()
         prm = MSMParams(n, (0, 0))
@@ -43,7 +47,8 @@ for a in sys.argv[2:]:
         continue
     k = oracle.index_weighted_sum(curve, ds.download(), n, 0, threads=16)
     exp = oracle.result_from_affine(curve, oracle.generator_mul(curve, k))
-    print(f"{curve} n = {n} (2^{lg}): {dt:.1f} ms per MSM (three, two in flight), windows {api['windows']:.0f} x {api['window_bits']:.0f} bits, accumulate "
+    tag = " plan" if use_plan else ""
+    print(f"{curve} pf={pf}{tag} n = {n} (2^{lg}): {dt:.1f} ms per MSM (three, two in flight), windows {api['windows']:.0f} x {api['window_bits']:.0f} bits, accumulate "
           f"{api['accumulate_kernel_ms']:.1f} ms, results right: {[o == exp for o in outs]}, device memory {api['device_memory']['total'] / 2**30:.1f} GiB; phases "
           f"{ {k: round(v, 1) for k, v in api.items() if k.endswith('_ms')} }", flush=True)
     cl.close(); ds.free()
