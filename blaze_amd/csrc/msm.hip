@@ -54,7 +54,7 @@ static MsmPlan search_plan(uint32_t npts, int sbits, int ebits, int force_c, int
         if (force_c > 0 && cmin != force_c) continue;
         for (int W = 1; W <= max_w; ++W) {
             // entries are indexed with u32, and the kernels' strided walks over them (i += stride, up to 2^24 lanes) must not wrap:
-            // at 2^32 - 4 entries they did - wrong sums after seconds of re-walking the bins (tools/big_probe.py)
+            // at 2^32 - 4 entries they did - wrong sums after seconds of re-walking the bins (tests/probes/big_probe.py)
             if ((uint64_t)npts * W > MSM_MAX_ENTRIES) break;
             const int lower = W - 1;
             for (int k = 0; k <= lower; ++k) {

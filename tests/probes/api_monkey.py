@@ -3,13 +3,13 @@
 ranges, queue overflow, option flips in mid-stream) - on long-lived clients of every kind.  Every call either succeeds or fails with
 one of the reference's error variants; nothing may crash, hang or leave a client in a state reset() does not clear: after every
 burst each client is reset and must return the right bytes for a known task (P_i = (i + 1) G: linearity).
-    python3 tools/api_monkey.py [bursts] [seed]"""
+    python3 tests/probes/api_monkey.py [bursts] [seed]"""
 import os
 import random
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import numpy as np  # noqa: E402
 
 import blaze_amd  # noqa: E402

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Dev tool: pf = 1 MSMs beyond the reference's largest shape (2^27, 2^28 points: the window planner's u32 entry indexing stops
-below 2^29), checked through linearity (P_i = (i + 1) G).   python3 tools/big_probe.py CURVE logn|n [...]"""
+below 2^29), checked through linearity (P_i = (i + 1) G).   python3 tests/probes/big_probe.py CURVE logn|n [...]"""
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import blaze_amd  # noqa: E402
 import oracle  # noqa: E402
 from blaze_amd import DriverClientError  # noqa: E402

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Dev tool: time synthetic MSMs at large sizes and check them through the linearity oracle."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import oracle
 import blaze_amd
 from blaze_amd import DeviceBuffer

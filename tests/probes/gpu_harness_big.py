@@ -2,7 +2,7 @@
 """Dev tool: the reference harness's repeated 256-tile at large n (tests/integration_msm.rs:385-467
 uses 2^26): every bucket that is hit at all holds n/256 equal points."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import oracle
 from blaze_amd.driver_client import DriverClient
 from blaze_amd.ingo_msm import *

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Quick GPU-side probe: small MSMs against the oracle + timing of synthetic sizes.  Dev tool."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import oracle
 from oracle import pyref
 import blaze_amd

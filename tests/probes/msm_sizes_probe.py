@@ -2,13 +2,13 @@
 """Dev tool: a dense walk over task SIZES - 2^k - 1, 2^k, 2^k + 1, 3 2^(k-1) for k = 1 .. max_log - on the three curves, pf = 1 (device
 buffers and arena bases in turn, two tasks in flight) and pf = 8 (exact path and checked-table plan), every result checked through
 linearity (P_i = (i + 1) G).  The sizes where the planner changes structure (tiny sort / big sort, row-law levels, hot top windows,
-window widths) all lie on the way.   python3 tools/msm_sizes_probe.py [max_log] [max_log_pf8]"""
+window widths) all lie on the way.   python3 tests/probes/msm_sizes_probe.py [max_log] [max_log_pf8]"""
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import numpy as np  # noqa: E402
 
 import blaze_amd  # noqa: E402

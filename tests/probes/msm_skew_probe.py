@@ -3,13 +3,13 @@
 2^256 - 1 (non-canonical), one non-zero among zeros, low words only (upper windows empty), byte patterns that sit on the edges of the
 signed-digit recoding (0x80.., 0x7f.., 0xff.., 0x55.., 0xaa..), half equal / half random - at 2^logn points on the three curves, pf = 1
 (arena bases, two in flight) and pf = 8 (exact path and checked-table plan), every result checked through linearity.
-    python3 tools/msm_skew_probe.py [logn] [logn_pf8]"""
+    python3 tests/probes/msm_skew_probe.py [logn] [logn_pf8]"""
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import numpy as np  # noqa: E402
 
 import blaze_amd  # noqa: E402

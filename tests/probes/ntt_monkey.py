@@ -3,13 +3,13 @@
 buffer numbers, wrong lengths, results read from the buffer under transform, start_process twice, exchange on either buffer - on
 clients of several sizes, fields and directions.  Every call succeeds or fails with one of the reference's error variants; after every
 burst each client is reset and must transform a known vector into the oracle's bytes.
-    python3 tools/ntt_monkey.py [bursts] [seed]"""
+    python3 tests/probes/ntt_monkey.py [bursts] [seed]"""
 import ctypes as C
 import os
 import random
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import blaze_amd  # noqa: E402
 import oracle  # noqa: E402
 from blaze_amd import DeviceBuffer  # noqa: E402

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Dev tool: every transform size 2^1 .. 2^26 (forward and inverse, BLS12-381 Fr; the other two fields at the sizes where the
-pass geometry changes) against the threaded CPU oracle, every output compared.   python3 tools/ntt_sizes_probe.py [max_log]"""
+pass geometry changes) against the threaded CPU oracle, every output compared.   python3 tests/probes/ntt_sizes_probe.py [max_log]"""
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np  # noqa: E402
 
 import oracle  # noqa: E402

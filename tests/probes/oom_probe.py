@@ -2,12 +2,12 @@
 """Dev tool / test body: the device nearly full (all but 600 MiB taken by a hog) - a DMA-mode task, an arena load and an NTT client
 must each fail with an error of the reference's enum that names the allocation (never a crash, never a stale error of an earlier
 failure), and every client must work again once the memory is back.
-    python3 tools/oom_probe.py"""
+    python3 tests/probes/oom_probe.py"""
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import blaze_amd  # noqa: E402
 import oracle  # noqa: E402
 from blaze_amd import DeviceBuffer, DriverClientError  # noqa: E402

@@ -2,8 +2,8 @@
 """Dev tool: bring up a one-rank RCCL communicator through the library (blz_msm_comm_init) with NCCL_DEBUG=INFO."""
 import os, sys
 os.environ.setdefault("NCCL_DEBUG", "INFO")
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 if len(sys.argv) > 1 and sys.argv[1] == "torch":
     import torch  # loads torch's own librccl first
 import oracle

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Dev tool: long streams of identical tasks, two in flight, every result compared with the first one (which the oracle
 checks by linearity): device-resident 2^24 and 2^26 (hidden sort), DMA-mode 2^22 (pieces), host-scalar HBM flow 2^24.
-    python tools/soak.py [scale]   (scale 1 = about a minute)"""
+    python tests/probes/soak.py [scale]   (scale 1 = about a minute)"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import blaze_amd
 import oracle
 from blaze_amd.ingo_msm import MSMInput, MSMParams, PointMemoryType

@@ -2,8 +2,8 @@
 """Dev tool: many MSMs of varying size / curve on long-lived clients (two in flight), results checked
 through linearity; prints device memory in use at intervals to spot leaks."""
 import sys, os, random, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import ctypes as C
 import oracle
 import blaze_amd

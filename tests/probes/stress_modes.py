@@ -4,14 +4,14 @@ rewrites that drop the table), scalar ranges, host buffers (DMA mode and the HBM
 piece, BLAZE_MSM_PIECES drawn per task), precompute clients over a resident x8 table on the checked-table plan and on the exact
 path (sub-ranges on the element grid, rewrites that re-arm the check, host scalars) - at random sizes, two in flight, every result
 checked through linearity (P_i = (i + 1) G).  STRESS_DIET=1: the arena drops raw bytes (blz_arena_set_policy).
-    python3 tools/stress_modes.py [iterations] [seed]"""
+    python3 tests/probes/stress_modes.py [iterations] [seed]"""
 import os
 import random
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import numpy as np  # noqa: E402
 
 import blaze_amd  # noqa: E402

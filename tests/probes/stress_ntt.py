@@ -3,7 +3,7 @@
 repeated 2^27 transforms of the same input (every repetition must give the same bytes: a race in the tile exchange
 would show up as a run-to-run difference)."""
 import hashlib, os, random, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import oracle
 import blaze_amd

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Dev tool / test body: clients torn down with work in flight - close() with two tasks queued (device inputs, host inputs, arena
 bases, window table, host scalars), blz_arena_release and a rewrite of the bases under tasks in flight, NTT close() / reset() under a
-transform.  Nothing may crash or hang, tasks that were accepted return the right bytes.   python3 tools/teardown_probe.py"""
+transform.  Nothing may crash or hang, tasks that were accepted return the right bytes.   python3 tests/probes/teardown_probe.py"""
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import blaze_amd, oracle
 from blaze_amd import DeviceBuffer, DriverClientError
 from blaze_amd.driver_client import DriverClient

@@ -1419,7 +1419,7 @@ def test_switches_hip_lib_and_log(gpu, orc, tmp_path):
 
 
 def test_random_call_sequences_never_break_a_client(gpu):
-    """tools/api_monkey.py: random call sequences - valid ones and the reference's error cases mixed: wrong call order, wrong
+    """tests/probes/api_monkey.py: random call sequences - valid ones and the reference's error cases mixed: wrong call order, wrong
     lengths, arena ranges nobody loaded, queue overflow, options flipped in mid-stream - against DMA, HBM and precompute clients of the
     three curves.  Every call succeeds or fails with one of src/error.rs's variants; after every burst each client is reset and
     returns the right bytes for a known task.  (Campaigns of 3 x 120 000 calls ran clean; the suite runs 40 bursts.)"""
@@ -1427,7 +1427,7 @@ def test_random_call_sequences_never_break_a_client(gpu):
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "api_monkey.py"), "40", "17"], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "probes", "api_monkey.py"), "40", "17"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "mismatches: 0" in r.stdout and "'ok':" in r.stdout and "InvalidPrimitiveParam" in r.stdout
 
@@ -1452,27 +1452,27 @@ def test_bench_a_hung_extra_leg_costs_the_extras_only(gpu):
 
 
 def test_a_full_device_is_an_error_not_a_crash(gpu):
-    """tools/oom_probe.py: all but 600 MiB of the device taken - a DMA-mode task (twice), an arena load and an NTT client each fail with
+    """tests/probes/oom_probe.py: all but 600 MiB of the device taken - a DMA-mode task (twice), an arena load and an NTT client each fail with
     an error that names the allocation (a failed hipMalloc leaves a sticky error in the HIP runtime: it is cleared where it is
     reported, so that the next launch check does not report it again), and every client works once the memory is back."""
     import subprocess
     import sys
 
     root = os.path.dirname(HERE)
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "oom_probe.py")], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "probes", "oom_probe.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "PROBLEM" not in r.stdout and "[True, True, True]" in r.stdout
 
 
 def test_teardown_with_work_in_flight(gpu):
-    """tools/teardown_probe.py: close() with two tasks queued (device inputs, host inputs, arena bases, window table, host scalars),
+    """tests/probes/teardown_probe.py: close() with two tasks queued (device inputs, host inputs, arena bases, window table, host scalars),
     blz_arena_release and a rewrite of the bases under tasks in flight (the tasks that were accepted return the right bytes; a task
     over the released range is refused), NTT close() / reset() under a transform."""
     import subprocess
     import sys
 
     root = os.path.dirname(HERE)
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "teardown_probe.py")], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "probes", "teardown_probe.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     out = r.stdout
     assert out.rstrip().endswith("done") and "PROBLEM" not in out and "False" not in out
@@ -1484,7 +1484,7 @@ def test_largest_task_the_planner_serves(gpu, orc):
     2^32 - 2^26 of them (msm_engine.hpp MSM_MAX_ENTRIES) - 256-bit scalars need 12 windows of at most 23 bits, so pf = 1 ends at
     352 321 536 points, 5 x the reference's largest shape.  That task is served and right (linearity over all its scalars); one
     point more is refused before anything is copied.  (At 2^32 - 4 entries the strided walks wrapped: wrong sums - found by
-    tools/big_probe.py, which also holds 2^27 and 2^28.)"""
+    tests/probes/big_probe.py, which also holds 2^27 and 2^28.)"""
     curve, n = "BN254", 352321536
     _free_arena = blaze_amd.lib().blz_arena_release
     blaze_amd._lib.check(_free_arena(0))
@@ -1514,20 +1514,20 @@ def test_largest_task_the_planner_serves(gpu, orc):
 
 
 def test_dense_walk_over_task_sizes(gpu):
-    """tools/msm_sizes_probe.py: 2^k - 1, 2^k, 2^k + 1, 3 2^(k-1) for every k up to 2^22 (pf = 1: device buffers and arena bases in
+    """tests/probes/msm_sizes_probe.py: 2^k - 1, 2^k, 2^k + 1, 3 2^(k-1) for every k up to 2^22 (pf = 1: device buffers and arena bases in
     turn) and 2^19 (pf = 8: exact path and checked-table plan), three curves, two tasks in flight, every result checked through
     linearity - the sizes where the planner changes structure all lie on the way (2^24 / 2^21 ran clean the same way)."""
     import subprocess
     import sys
 
     root = os.path.dirname(HERE)
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "msm_sizes_probe.py"), "22", "19"], capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "probes", "msm_sizes_probe.py"), "22", "19"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "mismatches: 0" in r.stdout and "MISMATCH" not in r.stdout and r.stdout.count("sizes up to") == 6
 
 
 def test_scalar_distributions_a_bucket_method_likes_least(gpu):
-    """tools/msm_skew_probe.py: all scalars equal (one bucket per window holds every entry), all r - 1, all 2^256 - 1, all zero, one
+    """tests/probes/msm_skew_probe.py: all scalars equal (one bucket per window holds every entry), all r - 1, all 2^256 - 1, all zero, one
     non-zero among zeros, low / top words only, byte patterns on the edges of the signed-digit recoding (0x80.., 0x7f.., 0xff.., 0x55..,
     0xaa.., 0x01..), half equal / half random, seven distinct values - 2^20 points (pf = 1) and 2^17 elements (pf = 8: exact path and
     checked-table plan) on the three curves, device and host scalars, every result checked through linearity (2^24 / 2^21 ran clean
@@ -1536,6 +1536,6 @@ def test_scalar_distributions_a_bucket_method_likes_least(gpu):
     import sys
 
     root = os.path.dirname(HERE)
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "msm_skew_probe.py"), "20", "17"], capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "probes", "msm_skew_probe.py"), "20", "17"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "mismatches: 0" in r.stdout and "MISMATCH" not in r.stdout and r.stdout.count(": ok") == 135

@@ -554,7 +554,7 @@ def test_wait_result_is_bounded(gpu, orc, monkeypatch):
 
 
 def test_random_call_sequences_never_break_a_client(gpu):
-    """tools/ntt_monkey.py: the reference's double-buffer cycle cut up at random - wrong buffer numbers and lengths, results read
+    """tests/probes/ntt_monkey.py: the reference's double-buffer cycle cut up at random - wrong buffer numbers and lengths, results read
     from the buffer under transform, start_process twice, exchange on either buffer - on clients of several sizes, fields and
     directions (both pass-2 kernels at 2^19 / 2^20).  Every call succeeds or fails with one of src/error.rs's variants; after every
     burst each client is reset and transforms a known vector into the oracle's bytes."""
@@ -562,19 +562,19 @@ def test_random_call_sequences_never_break_a_client(gpu):
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "ntt_monkey.py"), "40", "23"], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "probes", "ntt_monkey.py"), "40", "23"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "mismatches: 0" in r.stdout and "'ok':" in r.stdout and "InvalidPrimitiveParam" in r.stdout
 
 
 def test_every_size_against_the_oracle(gpu):
-    """tools/ntt_sizes_probe.py: EVERY transform size 2^1 .. 2^24, forward and inverse over BLS12-381 Fr - and BLS12-377 / BN254 Fr at
+    """tests/probes/ntt_sizes_probe.py: EVERY transform size 2^1 .. 2^24, forward and inverse over BLS12-381 Fr - and BLS12-377 / BN254 Fr at
     the sizes where the pass geometry changes - with every output compared to the CPU oracle (2^25 and 2^26 ran clean the same way;
     2^27 has its own tests)."""
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "ntt_sizes_probe.py"), "24"], capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "probes", "ntt_sizes_probe.py"), "24"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "mismatches: 0" in r.stdout and "MISMATCH" not in r.stdout and r.stdout.count(": ok") >= 2 * 24 + 2 * 7

@@ -127,3 +127,30 @@ def test_buffers_handed_to_the_c_abi():
         buf_ptr(a[:, :4])                                             # a strided view is refused
     with pytest.raises(ValueError):
         buf_ptr(a[::2])
+
+
+def test_only_the_checkers_touch_the_oracle():
+    """The oracle is test infrastructure: only tests/ (its probes included), __graft_entry__.smoke() and bench.py (result checks and
+    the cpu_baseline legs) may import it; nothing under blaze_amd/, include/, rust/ or tools/ does, and the product library links
+    nothing of it."""
+    import os
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    allowed = {"bench.py", "__graft_entry__.py"}
+    pat = re.compile(r"^\s*(import|from)\s+([\w., ]*\boracle\b)", re.M)
+    offenders = []
+    for base, dirs, files in os.walk(root):
+        rel = os.path.relpath(base, root)
+        dirs[:] = [d for d in dirs if d not in (".git", "gpurun_out", "build", "__pycache__") and not (rel == "." and d in ("tests", "oracle"))]
+        for f in files:
+            p = os.path.relpath(os.path.join(base, f), root)
+            if f.endswith((".py", ".sh")) and p not in allowed and pat.search(open(os.path.join(base, f), errors="replace").read()):
+                offenders.append(p)
+    assert offenders == [], offenders
+    mk = open(os.path.join(root, "blaze_amd", "csrc", "Makefile")).read()
+    assert "oracle" not in mk
+    for base, _dirs, files in os.walk(os.path.join(root, "blaze_amd", "csrc")):
+        for f in files:
+            if f.endswith((".hip", ".hpp", ".h", ".inc")):
+                assert "blz_oracle" not in open(os.path.join(base, f), errors="replace").read(), f
