@@ -250,31 +250,32 @@ __global__ __launch_bounds__(64, 3) void k_build_window_table(const uint32_t* __
         Fp<F> x, y;
         fp_load(x, raw + (size_t)i * 2 * F::N);
         fp_load(y, raw + (size_t)i * 2 * F::N + F::N);
-        Affine<F> a;
-        fp_to_mont(a.x, x);
-        fp_to_mont(a.y, y);
         XYZZ<F> p;
         Fp<F> prod;
         bool bad = false;
-#if BLZ_TABLE_BUILD_JACOBIAN
-        // the chain of doublings - 95 % of the kernel - runs in Jacobian coordinates on the reduced radix where the field has one
+        // The chain of doublings - 95 % of the kernel - runs in Jacobian coordinates on the reduced radix where the field has one
         // (ec_rr.hip.hpp ptrr_jdbl: ~3200 instructions per doubling against ~5600 for the 32-bit XYZZ doubling); every c-th
-        // point leaves it as (X, Y, Z^2, Z^3) in the 32-bit form the parking and normalising code below works on
-        typename std::conditional<USE_RR<F>, JacRR<typename F::RR>, int>::type jp;
-        if constexpr (USE_RR<F>) {
+        // point leaves it as (X, Y, Z^2, Z^3) in the 32-bit form the parking and normalising code below works on.
+        // (-DBLZ_TABLE_BUILD_JACOBIAN=0: the 32-bit chain everywhere, for A/B runs - profiles/r05_table_build_ab.txt)
+        constexpr bool JAC = BLZ_TABLE_BUILD_JACOBIAN != 0 && USE_RR<F>;
+        typename std::conditional<JAC, JacRR<typename F::RR>, int>::type jp;
+        Affine<F> a;
+        if constexpr (JAC) {
             using Q = typename F::RR;
             Frr<Q, 1, 2> ax;
             rr_to_mont_from_words<Q>(ax, x.v);
             rr_to_mont_from_words<Q>(jp.y, y.v);
             jp.x = rr_as<1, JacRR<Q>::VX>(ax);
             rr_one(jp.z);
+        } else {
+            (void)jp;
+            fp_to_mont(a.x, x);
+            fp_to_mont(a.y, y);
         }
-#endif
         if (j0 == 1) store_mont_point<F>(table, (size_t)i * W, x, y);   // the base itself (x, y are consumed)
         for (int j = j0; j < W; ++j) {
             int nd = j == 0 ? base_shift : c;   // doublings from the previous entry (or from the base)
-#if BLZ_TABLE_BUILD_JACOBIAN
-            if constexpr (USE_RR<F>) {
+            if constexpr (JAC) {
                 using Q = typename F::RR;
 #pragma unroll 1
                 for (int d = 0; d < nd; ++d) ptrr_jdbl(jp);
@@ -286,9 +287,7 @@ __global__ __launch_bounds__(64, 3) void k_build_window_table(const uint32_t* __
                 rr_to_mont32_words<Q>(p.y.v, jp.y);
                 rr_to_mont32_words<Q>(p.zz.v, zz);
                 rr_to_mont32_words<Q>(p.zzz.v, zzz);
-            } else
-#endif
-            {
+            } else {
                 XYZZ<F> t;
                 if (j == j0) { pt_mdbl(p, a); --nd; }
                 for (int d = 0; d < nd; ++d) { pt_dbl(t, p); p = t; }
