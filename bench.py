@@ -591,7 +591,7 @@ def main():
                         pending += 1
                 return out
 
-            # The build is paced by the tasks (msm_capi.hip arena_points_table): every task over the bases first enqueues four
+            # The build is paced by the tasks (arena_tables.hip arena_points_table): every task over the bases first enqueues four
             # ~5.5 ms chunks of it and takes the plain path until the table is complete.  first_task_ms is the first task's
             # latency (plain path + its four chunks); a few more tasks show the surcharge in a stream; then the host says it
             # would rather have the table now (prepare_window_table with a wait: all the remaining chunks at once) and the

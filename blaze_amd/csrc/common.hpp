@@ -146,9 +146,9 @@ struct ArenaExtent {
     static constexpr uint64_t TABLE_PATCH_MAX_POINTS = 1u << 18;
     std::vector<WindowTable> tables;
     uint64_t tab_dirty_lo = 0, tab_dirty_hi = 0;   // bytes (relative to start) rewritten since the tables were built: their rows are
-                                           // re-tabulated by the next task that asks for a table (msm_capi.hip arena_points_table)
+                                           // re-tabulated by the next task that asks for a table (arena_tables.hip arena_points_table)
     bool table_refused = false;            // a build failed (a base of even order, or no memory): no NEW build until the next write
-    // Checked-table plan of precompute handles (msm_capi.hip arena_precompute_check; opt-in per handle): has the caller's x8 table
+    // Checked-table plan of precompute handles (arena_tables.hip arena_precompute_check; opt-in per handle): has the caller's x8 table
     // been compared, element by element, with what precompute_base_* produces (tests/msm/mod.rs:360-380: B_j = 2^32 B_(j-1), B_0
     // on the curve)?  For the points [first, +npts) of the grid at `phase`; a write re-arms the check (state 3: for the elements it touched).
     struct PrecompCheck {
@@ -167,7 +167,7 @@ struct ArenaExtent {
     hipEvent_t diet_ev = nullptr;
     uint32_t* diet_flag = nullptr;
     uint64_t epoch = 0;                    // changes with every write into the extent (a check that ran unlocked commits only to the bytes it read)
-    // A table being built (msm_capi.hip arena_points_table): in chunks, paced by the tasks over these bases (each enqueues a
+    // A table being built (arena_tables.hip arena_points_table): in chunks, paced by the tasks over these bases (each enqueues a
     // few chunks on its own stream ahead of itself and takes the plain path); the task that finds `done` complete behind the
     // last chunk adopts the table.
     struct TableBuild {

@@ -145,7 +145,7 @@ MsmPlan make_plan(uint32_t npts, int sbits, int ebits, int force_c) {
         for (const Memo& m : memo)
             if (m.sbits == sbits && m.npts == npts && m.ebits == ebits && m.force_c == force_c && m.split_ns == split_ns) return m.plan;
     }
-    // The 64-bit chunks of a checked precompute table (msm_capi.hip resolve_arena_task): the cost model, fitted to 256-bit scalars,
+    // The 64-bit chunks of a checked precompute table (arena_tables.hip resolve_arena_task): the cost model, fitted to 256-bit scalars,
     // moves from four windows of 16 / 17 bits to three of 22 / 22 / 21 at 2^24.5 points; measured (BN254, same box), the three-window
     // plan already wins at 2^24 points (5.60 against 6.53 ms per MSM) and loses at 2^22 (2.67 against 1.81): four windows leave
     // 163 K buckets of hundreds of entries - a few units per lane - and the accumulation's last wave of units idles the chip.
@@ -667,7 +667,7 @@ MsmPlan MsmEngine::plan_for_range(uint32_t npts, int bit_lo, int bit_hi) const {
 }
 
 // A task is enqueued in four steps - begin(), then per piece sort_slice() and accumulate_slice(), then end() - so that a
-// caller whose inputs arrive over time (msm_capi.hip: host buffers crossing the PCIe link piece by piece, the reference's
+// caller whose inputs arrive over time (msm_stage.hip: host buffers crossing the PCIe link piece by piece, the reference's
 // own flow: msm_api.rs:175-202 streams interleaved chunks of scalars and points into the card while it computes) can hand
 // each piece to the device when it has landed.  run() is the four steps back to back for inputs that are all there.
 //
@@ -866,9 +866,9 @@ int MsmEngine::sort_slice(int slot, int sl, const void* d_scalars, uint32_t np) 
     last_sort_done = sorted;
     BLZ_HIP(hipEventRecord(S.ev_s1, ss), BLZ_ERR_UNKNOWN);
     // run() (inputs all there before the task began): the staged inputs have been consumed once the LAST sort has read
-    // the scalars - and, in DMA mode, once the to-Montgomery pass, which msm_capi.hip enqueued on the MAIN stream ahead of
+    // the scalars - and, in DMA mode, once the to-Montgomery pass, which msm_stage.hip enqueued on the MAIN stream ahead of
     // run(), has read the raw points (ev[0] sits behind it): only then may a later task's host -> device copies overwrite
-    // this staging set (msm_capi.hip's copy stream waits for the event).  On the sort stream the wait comes last, behind
+    // this staging set (msm_stage.hip's copy stream waits for the event).  On the sort stream the wait comes last, behind
     // ev_sorted, so it delays nothing but the event.  (Phased tasks: end() records it.)
     if (!S.phased && S.task_inputs_event && sl + 1 == S.slices) {
         if (hide) BLZ_HIP(hipStreamWaitEvent(ss, S.ev[0], 0), BLZ_ERR_UNKNOWN);

@@ -14,7 +14,7 @@ struct ScalarWords {
             uint4 a = q[0], b = q[1];
             s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
         } else if constexpr (SW == 2) {
-            // the 64-bit chunks of a precompute handle on the checked-table plan (msm_capi.hip resolve_precompute_plan)
+            // the 64-bit chunks of a precompute handle on the checked-table plan (arena_tables.hip resolve_arena_task)
             const uint2 a = reinterpret_cast<const uint2*>(scalars)[p];
             s[0] = a.x; s[1] = a.y;
         } else {

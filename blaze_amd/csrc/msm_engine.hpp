@@ -114,7 +114,7 @@ struct MsmEngine {
     DevBuf coarse, inter, inter2, slice_map, partial, blocksums, result, sort3_tabs;
     DevBuf bucket_sums, bucket_ident;   // piecewise tasks: the bucket sums carried across pieces; identity unit_off for the reduce
     // A task in four steps (msm.hip): begin() plans it and takes a slot; per piece sort_slice() (needs the piece's scalars)
-    // and accumulate_slice() (needs its points); end() enqueues the bucket reduce and the tail.  msm_capi.hip uses the steps
+    // and accumulate_slice() (needs its points); end() enqueues the bucket reduce and the tail.  msm_stage.hip uses the steps
     // for host buffers (DMA mode): a piece is handed to the device as soon as it has crossed the PCIe link.  `pieces` > 1:
     // the pieces share one bucket space, the sums are carried from piece to piece (k_accumulate_cont).
     int begin(uint32_t npts, int sbits, int* slot, int table_c, int bit_lo, int bit_hi, int pieces, bool phased);

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void k_points_to_mont(const uint32_t* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
-// Checked-table plan of precompute handles (opt-in: blz_msm_set_precompute_plan; msm_capi.hip arena_precompute_check).
+// Checked-table plan of precompute handles (opt-in: blz_msm_set_precompute_plan; arena_tables.hip arena_precompute_check).
 // The reference's precompute mode (MSMInit.is_precompute, msm_api.rs:39-50) has the CALLER supply, per element, the 8 bases
 // B_j = 2^(32 j) P (precompute_base_*: tests/msm/mod.rs:360-380) and the device sums s_j B_j over the 32-bit chunks s_j of the
 // scalar.  Served as the 8n-point MSM it is, that is 16 bucket additions per element (two 17-bit windows per chunk) against 12

@@ -77,7 +77,7 @@ __device__ __forceinline__ uint32_t s3_block_excl_scan(uint32_t v, uint32_t* wav
 
 // ---------------------------------------------------------------------------------------------- level 1
 // NW: 32-bit words per scalar - 8 (256-bit scalars), 1 (the 32-bit chunks of a precompute handle: pf = 8) or 2 (its 64-bit
-// chunks on the checked-table plan: msm_capi.hip)
+// chunks on the checked-table plan: arena_tables.hip)
 template <int NW>
 __global__ __launch_bounds__(S3_THREADS, 4) void k3_l1_count(const uint32_t* __restrict__ scalars, uint32_t npts, S3Geom g,
                                                             uint32_t* __restrict__ cnt1) {

@@ -1,0 +1,229 @@
+// set_data of the MSM primitive (src/ingo_msm/msm_api.rs:155-220): where a task's bytes go - staged whole, handed to the device
+// piece by piece while they cross the link, or taken from the arena - and the launch of a task whose data is complete.
+#include "msm_handle.hpp"
+
+namespace blz {
+
+int launch_if_ready(blz_msm* h) {
+    if (!(h->armed && h->data_ready)) return BLZ_OK;
+    if (!h->eng.can_accept())
+        return fail(BLZ_ERR_INVALID_PARAM, "task queue full (%d in flight); call wait_result first", MSM_QUEUE_DEPTH);
+    uint32_t npts = h->staged_n * h->pf;
+    int sbits = h->pf == 1 ? 256 : 32;
+    int slot = 0;
+    int table_c = 0;
+    memset(h->table_info, 0, sizeof(h->table_info));
+    memset(h->pc_info, 0, sizeof(h->pc_info));
+    // (a task that has just loaded its own table - set_data mode iii, msm_api.rs:203-216 - is a DMA-mode task as far as the plan is
+    // concerned: a check per task would cost more than it saves)
+    if (h->staged_from_arena) BLZ_TRY(resolve_arena_task(h, h->staged_arena_pos, h->staged_n, true, !h->staged_loaded_now, &npts, &sbits, &table_c));
+    h->eng.inputs_event = h->staged_set >= 0 ? h->set_free[h->staged_set] : nullptr;
+    BLZ_TRY(h->eng.run(h->d_points_mont, h->d_scalars, npts, sbits, &slot, table_c, h->range_lo, h->range_hi));
+    if (h->staged_set >= 0) h->set_used[h->staged_set] = true;
+    h->staged_set = -1;
+    h->armed = false;
+    h->data_ready = false;
+    h->in_flight.push_back({slot, h->task_label});
+    return BLZ_OK;
+}
+
+int stage_common(blz_msm* h, bool have_points, const void* points, size_t points_len, const void* scalars,
+                 size_t scalars_len, uint32_t n, int has_hbm, uint64_t hbm_addr, uint64_t hbm_off, bool on_device) {
+    if (!h) return fail(BLZ_ERR_INVALID_PARAM, "null handle");
+    BLZ_LIVE(h);
+    BLZ_TRY(use_device(h->device));
+    if (!have_points && !has_hbm) return BLZ_OK;  // reference: falls through every branch (msm_api.rs:163-216)
+    if (has_hbm) BLZ_ARENA_ADDR(hbm_addr, hbm_off);
+    if (!scalars && n) return fail(BLZ_ERR_INVALID_PARAM, "null scalars");
+    if (scalars_len != (size_t)n * BLZ_SCALAR_SIZE)
+        return fail(BLZ_ERR_INVALID_PARAM, "scalars length %zu != nof_elements %u * 32", scalars_len, n);
+    size_t want_pts = (size_t)n * h->pf * point_size(h);
+    if (have_points && points_len != want_pts)
+        return fail(BLZ_ERR_INVALID_PARAM, "points length %zu != nof_elements %u * precompute_factor %u * %zu", points_len,
+                    n, h->pf, point_size(h));
+    if ((uint64_t)n * h->pf >= (1ull << 31)) return fail(BLZ_ERR_INVALID_PARAM, "too many points");
+    // refuse sizes the window planner cannot serve BEFORE anything is copied or converted (u32 entry indexing:
+    // points x windows <= 2^32 - 2^26 (msm_engine.hpp MSM_MAX_ENTRIES) with windows of at most 23 bits - 256-bit scalars need 12,
+    // so pf = 1 stops at 352 321 536 points (2^28.39; checked there: tests/test_gpu_msm.py), the 32-bit chunks of pf = 8 at 2^31 - 2^25)
+    if (n && h->eng.plan_for(n * h->pf, h->pf == 1 ? 256 : 32).c == 0)
+        return fail(BLZ_ERR_INVALID_PARAM, "no window plan for %llu points of %d-bit scalars (u32 entry indexing: at most 352321536 points at pf = 1, 2113929216 at pf = 8)",
+                    (unsigned long long)n * h->pf, h->pf == 1 ? 256 : 32);
+    if (!h->eng.can_accept())
+        return fail(BLZ_ERR_INVALID_PARAM, "task queue full (%d in flight); call wait_result first", MSM_QUEUE_DEPTH);
+    hipStream_t st = h->eng.stream;
+    // Host buffers are staged on their own stream, so the PCIe transfer of this task overlaps the
+    // accumulation of the task in flight (the reference's DMA writes overlap device compute the same
+    // way).
+    hipStream_t cst = h->copy_stream;
+    uint32_t npts = n * h->pf;
+    // this task's staging set was last used two tasks ago: its to-Montgomery pass and digit sort must have read
+    // it before the new copies land (an event on the main stream, not a host wait; normally long past)
+    const int set = h->stage_idx;
+    if (!on_device) {
+        if (h->set_used[set]) BLZ_HIP(hipStreamWaitEvent(cst, h->set_free[set], 0), BLZ_ERR_UNKNOWN);
+        h->stage_idx ^= 1;
+        h->staged_set = set;
+    } else {
+        h->staged_set = -1;
+    }
+
+    h->staged_loaded_now = have_points && has_hbm;
+    if (have_points && has_hbm) {
+        // msm_api.rs:203-206: load_data_to_hbm(points, addr, offset) first
+        BLZ_WAIT(h, arena_write(h->device, hbm_addr + hbm_off, points, points_len, on_device, st));
+        h->bases_from_hbm = true;
+        h->hbm_addr = hbm_addr;
+    }
+    if (has_hbm) {
+        // bases come from the arena.  The reference's initialize() programs only hbm_point_addr.0
+        // as the start address (msm_api.rs:84-95) while load_data_to_hbm writes at addr+offset
+        // (msm_api.rs:312); both tests use offset 0.  Here the task reads where the load wrote.
+        {
+            Arena& A = arena_for(h->device);
+            std::lock_guard<std::mutex> lk(A.mu);
+            if (!arena_find(A, hbm_addr + hbm_off, (size_t)npts * point_size(h)))
+                return fail(BLZ_ERR_INVALID_PARAM, "HBM bases: no loaded extent covers [%llu, +%zu) on device %d",
+                            (unsigned long long)(hbm_addr + hbm_off), (size_t)npts * point_size(h), h->device);
+        }
+        h->staged_from_arena = true;
+        h->staged_arena_pos = hbm_addr + hbm_off;
+    } else {
+        h->staged_from_arena = false;
+    }
+    // Host buffers with a task already armed (DMA mode, the reference's primary flow: tests/integration_msm.rs:149-207):
+    // the task is enqueued PIECE BY PIECE while its data crosses the link, the way the reference streams interleaved chunks
+    // of scalars and points into the card's FIFOs while the card computes (msm_api.rs:175-202).  Per piece: its scalars,
+    // then its sort stage goes to the device; its points, then their to-Montgomery pass and the piece's accumulation
+    // (MsmEngine::begin / sort_slice / accumulate_slice / end: the pieces share one bucket space and the bucket sums are
+    // carried from piece to piece).  Link and multiplier work at the same time; what is left on the critical path behind the
+    // last byte is the last piece's accumulation, the bucket reduce and the tail.
+    // The reference's HBM flow (bases resident in the arena, the scalars a host Vec<u8> with every task:
+    // tests/integration_msm_hbm.rs:57-100) goes the same way when the handle is idle: a lone task's 2 GiB of scalars would
+    // otherwise cross the link with the chip doing nothing (38 of 163 ms at 2^26); in a stream of tasks the whole upload
+    // already hides under the previous task's accumulation, and the task keeps its one-piece form (hidden sort, no
+    // carried sums).
+    int sbits = h->pf == 1 ? 256 : 32;
+    const bool dma_pieces = !on_device && !has_hbm && h->armed && npts > 0 && exp_knob("BLAZE_DMA_OVERLAP", 1) != 0;
+    const bool hbm_pieces = !on_device && has_hbm && h->armed && npts > 0 && (npts >= (1u << 22) || env_int("BLAZE_MSM_PIECES", 0) > 1) &&
+                            h->in_flight.empty() && !wants_table(h) &&
+                            exp_knob("BLAZE_DMA_OVERLAP", 1) != 0;
+    if (dma_pieces || hbm_pieces) {
+        const size_t mp = mont_point_bytes(h->curve), ps = point_size(h);
+        BLZ_TRY(h->scalars_buf[set].reserve(scalars_len));
+        const void* arena_mont = nullptr;
+        memset(h->table_info, 0, sizeof(h->table_info));
+        memset(h->pc_info, 0, sizeof(h->pc_info));
+        if (dma_pieces) {
+            BLZ_TRY(h->points_raw[set].reserve(want_pts));
+            BLZ_TRY(h->points_mont.reserve((size_t)npts * mp));
+        } else {
+            // (stale spans are converted on the main stream; a precompute handle on the checked-table plan: 4n even bases, 64-bit chunks)
+            int tc = 0;
+            BLZ_TRY(resolve_arena_task(h, h->staged_arena_pos, n, false, !h->staged_loaded_now, &npts, &sbits, &tc));
+            arena_mont = h->d_points_mont;
+        }
+        const size_t sb = (size_t)sbits / 8;
+        // pieces of >= 2^19 points with their scalars (64 MiB of host bytes: 1.2 ms of link), at most 16.
+        // Measured (profiles/r04_dma_pieces.txt): 2^22 elements 22.6 ms in one piece, 16.2 / 15.35 / 17.1 in 4 / 8 / 16; 2^26
+        // 270.8, 191.8 / 178.3 / 171.5
+        int pieces = env_int("BLAZE_MSM_PIECES", 0);   // (the same switch forces the piece count of device-resident tasks, msm.hip run())
+        if (pieces <= 0) {
+            if (dma_pieces) {
+                pieces = (int)(npts >> 19);
+                if (npts >= (1u << 20) && npts <= (1u << 21)) pieces = (int)(npts >> 18);   // 2^20: 5.49 ms in 2 pieces, 5.23 in 4; 2^21: 8.47 in 4, 8.25 in 8
+                if (pieces > 16) pieces = 16;
+                // with another task in flight the link is the bound whatever the pieces do, and every piece costs it the
+                // ~150 us of launches between two copies: fewer, larger pieces (2^22: 10.4 against 10.8 ms per MSM)
+                if (!h->in_flight.empty() && pieces > 4) pieces = 4;
+            } else {
+                // scalars alone: the link is a quarter of the task, and every piece pays the sort stage's passes over the
+                // bucket space again (not hidden here) - 2^26: 163.7 ms whole, 158.5 / 145.4 / 181.8 in 16 / 8 / 32 pieces
+                // (2^22 .. 2^24 lone tasks: 14.25 / 25.6 / 46.2 ms whole, 13.3 / 23.6 / 42.5 in two pieces, 12.7 / 22.5 / 40.6 in four)
+                pieces = (int)(npts >> 23);
+                if (pieces > 8) pieces = 8;
+                if (pieces < 4) pieces = 4;
+            }
+        }
+        if (pieces < 1) pieces = 1;
+        int slot = -1;
+        h->eng.inputs_event = h->set_free[set];
+        BLZ_TRY(h->eng.begin(npts, sbits, &slot, 0, h->range_lo, h->range_hi, pieces, true));
+        const uint32_t per = h->eng.slots[slot].pts_per_slice;
+        pieces = h->eng.slots[slot].slices;
+        int rc = BLZ_OK;
+        auto copy_in = [&](void* dst, const void* src, size_t len, const char* what) -> int {
+            if (hipMemcpyAsync(dst, src, len, hipMemcpyHostToDevice, cst) != hipSuccess) return fail(BLZ_ERR_WRITE, "%s failed", what);
+            // the caller may drop its buffers as soon as we return (set_data is synchronous: utils.rs:71), and the piece's
+            // device work is enqueued when its bytes are there.  The first copy waits for the staging set's previous user
+            // (set_free, two tasks back): bounded like every wait
+            wait_clear();
+            const int r = sync_stream_bounded(cst, what);
+            if (r != BLZ_OK && wait_timed_out()) h->wedged = true;
+            return r;
+        };
+        for (int k = 0; k < pieces && rc == BLZ_OK; ++k) {
+            const uint32_t p0 = (uint32_t)k * per;
+            const uint32_t np = npts - p0 < per ? npts - p0 : per;
+            char* d_sc = (char*)h->scalars_buf[set].p + (size_t)p0 * sb;
+            rc = copy_in(d_sc, (const char*)scalars + (size_t)p0 * sb, (size_t)np * sb, "set_data: host -> device copy of the scalars");
+            if (rc == BLZ_OK) rc = h->eng.sort_slice(slot, k, d_sc, np);
+            if (dma_pieces) {
+                char* d_raw = (char*)h->points_raw[set].p + (size_t)p0 * ps;
+                char* d_mont = (char*)h->points_mont.p + (size_t)p0 * mp;
+                if (rc == BLZ_OK) rc = copy_in(d_raw, (const char*)points + (size_t)p0 * ps, (size_t)np * ps, "set_data: host -> device copy of the points");
+                if (rc == BLZ_OK) rc = h->eng.points_to_mont(d_raw, d_mont, np);
+                if (rc == BLZ_OK) rc = h->eng.accumulate_slice(slot, k, d_mont);
+            } else if (rc == BLZ_OK) {
+                rc = h->eng.accumulate_slice(slot, k, (const char*)arena_mont + (size_t)p0 * mp);
+            }
+        }
+        if (rc == BLZ_OK) rc = h->eng.end(slot);
+        if (rc != BLZ_OK) {
+            h->eng.abandon(slot);
+            return rc;
+        }
+        h->d_scalars = h->scalars_buf[set].p;
+        h->d_points_mont = dma_pieces ? h->points_mont.p : arena_mont;
+        h->staged_n = n;
+        h->set_used[set] = true;
+        h->staged_set = -1;
+        h->armed = false;
+        h->data_ready = false;
+        h->in_flight.push_back({slot, h->task_label});
+        return BLZ_OK;
+    }
+    // Everything else is staged whole: the scalars first ...
+    if (on_device) {
+        if (((uintptr_t)scalars) % 16) return fail(BLZ_ERR_INVALID_PARAM, "device scalars must be 16-byte aligned");
+        h->d_scalars = scalars;
+    } else {
+        BLZ_TRY(h->scalars_buf[set].reserve(scalars_len ? scalars_len : 16));
+        if (scalars_len) BLZ_HIP(hipMemcpyAsync(h->scalars_buf[set].p, scalars, scalars_len, hipMemcpyHostToDevice, cst), BLZ_ERR_WRITE);
+        h->d_scalars = h->scalars_buf[set].p;
+        // the caller may drop its buffers as soon as we return (set_data is synchronous: utils.rs:71).  The copy waits
+        // for the staging set's previous user (set_free, two tasks back): bounded like every wait
+        BLZ_WAIT(h, sync_stream_bounded(cst, "set_data: host -> device copy of the scalars"));
+    }
+    h->staged_n = n;
+    if (!has_hbm) {
+        // ... then the points, converted to Montgomery form on the main stream
+        const size_t mp = mont_point_bytes(h->curve);
+        const size_t want_mont = (size_t)npts * mp;
+        BLZ_TRY(h->points_mont.reserve(want_mont ? want_mont : 16));
+        if (on_device) {
+            if (((uintptr_t)points) % 16) return fail(BLZ_ERR_INVALID_PARAM, "device points must be 16-byte aligned");
+            BLZ_TRY(h->eng.points_to_mont(points, h->points_mont.p, npts));
+        } else {
+            BLZ_TRY(h->points_raw[set].reserve(want_pts ? want_pts : 16));
+            if (want_pts) BLZ_HIP(hipMemcpyAsync(h->points_raw[set].p, points, want_pts, hipMemcpyHostToDevice, cst), BLZ_ERR_WRITE);
+            BLZ_WAIT(h, sync_stream_bounded(cst, "set_data: host -> device copy of the points"));
+            BLZ_TRY(h->eng.points_to_mont(h->points_raw[set].p, h->points_mont.p, npts));
+        }
+        h->d_points_mont = h->points_mont.p;
+    }
+    h->staged_n = n;
+    h->data_ready = true;
+    return launch_if_ready(h);
+}
+
+}  // namespace blz

@@ -1228,7 +1228,7 @@ def test_piecewise_accumulation(gpu, orc, curve, pf, monkeypatch):
 @pytest.mark.parametrize("curve,pf,n", [("BLS381", 1, 70001), ("BLS377", 8, 9000), ("BN254", 1, 33333), ("BN254", 8, 4100)])
 def test_dma_pieces_host_buffers(gpu, orc, curve, pf, n, monkeypatch):
     """DMA mode with host buffers and a task already armed: the task is enqueued piece by piece while its bytes cross the
-    link (msm_capi.hip stage_common; the reference streams interleaved chunks of scalars and points while the card computes,
+    link (msm_stage.hip stage_common; the reference streams interleaved chunks of scalars and points while the card computes,
     msm_api.rs:175-202).  Forced to 1 / 4 / 5 / 16 pieces at oracle-checkable sizes (ragged last piece, pieces of whole
     16-point groups), uniform scalars; then two tasks in flight, and the whole-staging path of an unarmed set_data."""
     pts, sc, _ = orc.input_generator(curve, n, pf, 777 + pf)
