@@ -30,31 +30,53 @@ ArenaExtent* arena_find(Arena& a, uint64_t pos, size_t len) {
     return nullptr;
 }
 
+uint32_t* arena_flag_acquire(Arena& a) {
+    if (!a.build_flags) {
+        if (hipMalloc((void**)&a.build_flags, 256 * sizeof(uint32_t)) != hipSuccess) {
+            (void)hipGetLastError();
+            a.build_flags = nullptr;
+            return nullptr;
+        }
+        a.flag_free.clear();
+        for (int i = 255; i >= 0; --i) a.flag_free.push_back((uint16_t)i);
+    }
+    if (a.flag_free.empty()) return nullptr;
+    uint32_t* f = a.build_flags + a.flag_free.back();
+    a.flag_free.pop_back();
+    return f;
+}
+void arena_flag_release(Arena& a, uint32_t*& f) {
+    if (f && a.build_flags && f >= a.build_flags && f < a.build_flags + 256) a.flag_free.push_back((uint16_t)(f - a.build_flags));
+    f = nullptr;
+}
+
 // a build in flight (the caller has drained the device)
-void arena_drop_build(ArenaExtent& x) {
+void arena_drop_build(Arena& a, ArenaExtent& x) {
     if (x.build.tab) (void)hipFree(x.build.tab);
     if (x.build.done) (void)hipEventDestroy(x.build.done);
     if (x.build.t0) (void)hipEventDestroy(x.build.t0);
+    arena_flag_release(a, x.build.flag);
     x.build = ArenaExtent::TableBuild();
 }
 // the tables and a build in flight (the caller has drained the device)
-void arena_drop_table(ArenaExtent& x) {
+void arena_drop_table(Arena& a, ArenaExtent& x) {
     for (auto& t : x.tables)
         if (t.p) (void)hipFree(t.p);
     x.tables.clear();
     x.tab_dirty_lo = x.tab_dirty_hi = 0;
-    arena_drop_build(x);
+    arena_drop_build(a, x);
 }
 
-void arena_free_extent(ArenaExtent& x) {
+void arena_free_extent(Arena& a, ArenaExtent& x) {
     if (x.raw) {
         if (x.imported) (void)hipIpcCloseMemHandle(x.raw);
         else (void)hipFree(x.raw);
     }
     if (x.mont) (void)hipFree(x.mont);
-    arena_drop_table(x);
+    arena_drop_table(a, x);
     if (x.shadow_ready) (void)hipEventDestroy(x.shadow_ready);
     if (x.diet_ev) (void)hipEventDestroy(x.diet_ev);
+    arena_flag_release(a, x.diet_flag);
     x = ArenaExtent();
 }
 
@@ -67,7 +89,7 @@ static size_t format_point_bytes(int format_id) { return (format_id & 0xff) == B
 
 int arena_restore_raw(Arena& a, ArenaExtent& e, hipStream_t st) {
     (void)a;
-    if (e.diet == 1) e.diet = 0;        // (a check in flight is simply forgotten: its event and flag slot are reused)
+    if (e.diet == 1) e.diet = 0;        // (a check in flight is simply forgotten: its event and the extent's flag word are reused)
     if (e.diet != 2) return BLZ_OK;
     const size_t ps = format_point_bytes(e.mont_curve), mp = mont_point_bytes(e.mont_curve & 0xff);
     void* raw = nullptr;
@@ -91,13 +113,9 @@ int arena_diet_step(Arena& a, ArenaExtent& e, size_t ps, hipStream_t st) {
     // handle would restore the bytes at every launch) or being tabulated from them, and a format that holds every base (not the even-base copy of a checked precompute table)
     if (e.dirty_lo < e.dirty_hi || e.mont_phase != 0 || e.len % ps != 0 || (e.mont_curve >> 16) != 0 || e.build.tab || !e.tables.empty()) return BLZ_OK;
     if (e.diet == 0) {
-        if (!a.build_flags && hipMalloc((void**)&a.build_flags, 256 * sizeof(uint32_t)) != hipSuccess) {
-            (void)hipGetLastError();
-            a.build_flags = nullptr;
-            return BLZ_OK;
-        }
+        // (the extent keeps its flag word for as long as it lives: the check may sit in state 1 until a task next touches the extent)
+        if (!e.diet_flag && !(e.diet_flag = arena_flag_acquire(a))) return BLZ_OK;
         if (!e.diet_ev) BLZ_HIP(hipEventCreateWithFlags(&e.diet_ev, hipEventDisableTiming), BLZ_ERR_UNKNOWN);
-        e.diet_flag = a.build_flags + (a.build_flag_next++ & 255u);
         BLZ_HIP(hipMemsetAsync(e.diet_flag, 0, 4, st), BLZ_ERR_UNKNOWN);
         BLZ_TRY(msm_points_all_canonical(e.mont_curve, e.raw, e.len / ps, e.diet_flag, st));
         BLZ_HIP(hipEventRecord(e.diet_ev, st), BLZ_ERR_UNKNOWN);
@@ -140,7 +158,7 @@ int arena_read_bytes(Arena& a, ArenaExtent& e, uint64_t off, size_t len, void* o
     BLZ_HIP(hipMalloc(&tmp, (size_t)(p1 - p0) * ps), BLZ_ERR_READ);
     int rc = msm_points_from_mont(e.mont_curve, (const char*)e.mont + p0 * mp, tmp, p1 - p0, st);
     if (rc == BLZ_OK && hipMemcpyAsync(out, (const char*)tmp + (off - p0 * ps), len, hipMemcpyDeviceToHost, st) != hipSuccess)
-        rc = fail(BLZ_ERR_READ, "get_data_from_hbm: copy out of the bounce buffer failed");
+        rc = fail_hip(BLZ_ERR_READ, "get_data_from_hbm: copy out of the bounce buffer failed");
     if (rc == BLZ_OK) rc = sync_stream_bounded(st, "get_data_from_hbm: raw bytes from the Montgomery copy");
     if (rc == BLZ_OK || !wait_timed_out()) (void)hipFree(tmp);
     return rc;
@@ -202,7 +220,7 @@ int arena_write(int device_id, uint64_t pos, const void* src, size_t len, bool s
         hipError_t he = hipMalloc(&n.raw, n.cap);
         if (he != hipSuccess && n.cap != nlen) { n.cap = nlen; he = hipMalloc(&n.raw, n.cap); }
         if (he != hipSuccess)
-            return fail(BLZ_ERR_WRITE, "arena: hipMalloc(%zu) at offset %llu failed: %s", n.cap, (unsigned long long)nstart,
+            return fail_hip(BLZ_ERR_WRITE, "arena: hipMalloc(%zu) at offset %llu failed: %s", n.cap, (unsigned long long)nstart,
                         hipGetErrorString(he));
         if (!hit.empty()) {
             // tasks in flight may still read the old extents or their shadows: drain (bounded) before they go
@@ -216,7 +234,7 @@ int arena_write(int device_id, uint64_t pos, const void* src, size_t len, bool s
             }
             if (sync_stream_bounded(st, "load_data_to_hbm: carrying the old extents over") != BLZ_OK) return BLZ_ERR_WRITE;   // (the new allocation is leaked: the copy may still run)
             for (size_t k = hit.size(); k-- > 0;) {
-                arena_free_extent(A.ext[hit[k]]);
+                arena_free_extent(A, A.ext[hit[k]]);
                 A.ext.erase(A.ext.begin() + hit[k]);
             }
         }
@@ -228,7 +246,7 @@ int arena_write(int device_id, uint64_t pos, const void* src, size_t len, bool s
     if (e->build.tab) {
         // a build in flight tabulates the old bytes: gone (it still writes its table: drain first)
         if (sync_device_bounded("load_data_to_hbm: drain before the window-table build goes") != BLZ_OK) return BLZ_ERR_WRITE;
-        arena_drop_build(*e);
+        arena_drop_build(A, *e);
     }
     if (!e->tables.empty()) {
         // The window tables are a function of the bytes.  A small rewrite keeps them: the span is remembered and the next task
@@ -239,7 +257,7 @@ int arena_write(int device_id, uint64_t pos, const void* src, size_t len, bool s
         const uint64_t nhi = e->tab_dirty_lo < e->tab_dirty_hi && e->tab_dirty_hi > hi ? e->tab_dirty_hi : hi;
         if (nhi - nlo > ArenaExtent::TABLE_PATCH_MAX_POINTS * 64) {   // (64 = the smaller point size: BN254)
             if (sync_device_bounded("load_data_to_hbm: drain before the window tables go") != BLZ_OK) return BLZ_ERR_WRITE;
-            arena_drop_table(*e);
+            arena_drop_table(A, *e);
         } else {
             e->tab_dirty_lo = nlo;
             e->tab_dirty_hi = nhi;
@@ -266,7 +284,7 @@ int arena_write(int device_id, uint64_t pos, const void* src, size_t len, bool s
     char* dst = (char*)e->raw + (pos - e->start);
     hipError_t he = hipMemcpyAsync(dst, src, len, src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st);
     if (he != hipSuccess)
-        return fail(BLZ_ERR_WRITE, "arena write of %zu bytes at offset %llu failed: %s", len, (unsigned long long)pos,
+        return fail_hip(BLZ_ERR_WRITE, "arena write of %zu bytes at offset %llu failed: %s", len, (unsigned long long)pos,
                     hipGetErrorString(he));
     // the copy is ordered on the caller's main stream, behind its tasks in flight: a bounded wait (common.hpp)
     return sync_stream_bounded(st, "load_data_to_hbm: copy into the arena");
@@ -290,13 +308,14 @@ int blz_arena_release(int device_id) {
     Arena& A = arena_for(device_id);
     std::lock_guard<std::mutex> lk(A.mu);
     BLZ_TRY(sync_device_bounded("arena release"));   // (on expiry nothing is freed: wedged work may still read the extents)
-    for (auto& x : A.ext) arena_free_extent(x);
+    for (auto& x : A.ext) arena_free_extent(A, x);
     A.ext.clear();
     if (A.build_scratch) (void)hipFree(A.build_scratch);
     A.build_scratch = nullptr;
     A.build_scratch_bytes = 0;
     if (A.build_flags) (void)hipFree(A.build_flags);
     A.build_flags = nullptr;
+    A.flag_free.clear();
     return BLZ_OK;
 }
 
@@ -368,10 +387,10 @@ int blz_arena_attach(int device_id, const char* path) {
         hipError_t he = hipIpcOpenMemHandle(&n.raw, r.handle, hipIpcMemLazyEnablePeerAccess);
         if (he != hipSuccess) {
             while (A.ext.size() > before) {
-                arena_free_extent(A.ext.back());
+                arena_free_extent(A, A.ext.back());
                 A.ext.pop_back();
             }
-            return fail(BLZ_ERR_UNKNOWN, "arena attach: hipIpcOpenMemHandle of [%llu, +%llu) failed: %s (nothing was attached)",
+            return fail_hip(BLZ_ERR_UNKNOWN, "arena attach: hipIpcOpenMemHandle of [%llu, +%llu) failed: %s (nothing was attached)",
                         (unsigned long long)r.start, (unsigned long long)r.len, hipGetErrorString(he));
         }
         n.dirty_lo = 0;

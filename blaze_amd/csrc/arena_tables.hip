@@ -84,14 +84,15 @@ int arena_points_mont(blz_msm* h, uint64_t pos, uint32_t npts, const void** out,
 // precompute_base_* produces?  Answered once per (extent contents, range): the check runs on this handle's main stream (969 /
 // 2275 multiply-adds per Jacobian doubling, 224 doublings per element: 0.68 s for 2^26 BN254 elements, 1.33 s for BLS - 68 / 83 %
 // of the bare multiply-add rate; XYZZ doublings, same box: 0.84 / 1.71 s) and the caller waits
-// for it - with the arena unlocked; the answer is committed only if no write reached the extent in the meantime (epoch).
+// for it - with the arena unlocked; the answer is committed only if no write reached the extent (epoch) and no other check of it
+// committed (PrecompCheck::gen) in the meantime.
 int arena_precompute_check(blz_msm* h, uint64_t pos, uint32_t nelem, bool* ok, uint64_t* checked_elems) {
     *ok = false;
     if (checked_elems) *checked_elems = nelem;
     const size_t ps = point_size(h);
     const size_t len = (size_t)nelem * 8 * ps;
     Arena& A = arena_for(h->device);
-    uint64_t epoch = 0, first = 0;
+    uint64_t epoch = 0, first = 0, gen = 0;
     uint32_t phase = 0;
     uint32_t* flag = nullptr;
     hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -129,27 +130,27 @@ int arena_precompute_check(blz_msm* h, uint64_t pos, uint32_t nelem, bool* ok, u
             chk_elems = ehi > elo ? ehi - elo : 0;
             chk_pos = e->start + phase + elo * 8 * ps;
         }
-        if (!A.build_flags && hipMalloc((void**)&A.build_flags, 256 * sizeof(uint32_t)) != hipSuccess) {
-            (void)hipGetLastError();
-            A.build_flags = nullptr;
-            BLZ_LOG(1, "precompute plan: no memory for the check's flag: exact path");
+        BLZ_TRY(arena_restore_raw(A, *e, h->eng.stream));   // (the check reads the raw bytes)
+        if (!(flag = arena_flag_acquire(A))) {
+            BLZ_LOG(1, "precompute plan: no flag word for the check: exact path");
             return BLZ_OK;
         }
-        BLZ_TRY(arena_restore_raw(A, *e, h->eng.stream));   // (the check reads the raw bytes)
-        flag = A.build_flags + (A.build_flag_next++ & 255u);
         epoch = e->epoch;
+        gen = C.gen;   // (the verdict below is about the record as it stands NOW: state, range and redo span)
         hipStream_t st = h->eng.stream;
         if (hipEventCreate(&t0) != hipSuccess || hipEventCreate(&t1) != hipSuccess) {
             if (t0) (void)hipEventDestroy(t0);
-            return fail(BLZ_ERR_UNKNOWN, "event creation failed");
+            arena_flag_release(A, flag);
+            return fail_hip(BLZ_ERR_UNKNOWN, "event creation failed");
         }
         int rc = BLZ_OK;
-        if (hipMemsetAsync(flag, 0, 4, st) != hipSuccess || hipEventRecord(t0, st) != hipSuccess) rc = fail(BLZ_ERR_UNKNOWN, "precompute check: enqueue failed");
+        if (hipMemsetAsync(flag, 0, 4, st) != hipSuccess || hipEventRecord(t0, st) != hipSuccess) rc = fail_hip(BLZ_ERR_UNKNOWN, "precompute check: enqueue failed");
         if (rc == BLZ_OK) rc = h->eng.check_precompute((const char*)e->raw + (chk_pos - e->start), chk_elems, flag, st);
-        if (rc == BLZ_OK && hipEventRecord(t1, st) != hipSuccess) rc = fail(BLZ_ERR_UNKNOWN, "precompute check: enqueue failed");
+        if (rc == BLZ_OK && hipEventRecord(t1, st) != hipSuccess) rc = fail_hip(BLZ_ERR_UNKNOWN, "precompute check: enqueue failed");
         if (rc != BLZ_OK) {
             (void)hipEventDestroy(t0);
             (void)hipEventDestroy(t1);
+            // (a check kernel that did get enqueued may still raise the word: it stays owned - 4 bytes - rather than be handed to someone else)
             return rc;
         }
     }
@@ -161,20 +162,30 @@ int arena_precompute_check(blz_msm* h, uint64_t pos, uint32_t nelem, bool* ok, u
     float ms = 0;
     if (rc == BLZ_OK) {
         (void)hipEventElapsedTime(&ms, t0, t1);
-        if (hipMemcpy(&flag_h, flag, 4, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(BLZ_ERR_READ, "precompute check: flag read failed");
+        if (hipMemcpy(&flag_h, flag, 4, hipMemcpyDeviceToHost) != hipSuccess) rc = fail_hip(BLZ_ERR_READ, "precompute check: flag read failed");
     }
-    if (rc == BLZ_OK || !wait_timed_out()) {
+    const bool kernel_done = rc == BLZ_OK || !wait_timed_out();
+    if (kernel_done) {
         (void)hipEventDestroy(t0);
         (void)hipEventDestroy(t1);
     }
-    BLZ_TRY(rc);
     std::lock_guard<std::mutex> lk(A.mu);
+    if (kernel_done) arena_flag_release(A, flag);   // (a wedged check keeps its word: the kernel may still write it)
+    BLZ_TRY(rc);
     ArenaExtent* e = arena_find(A, pos, len);
     if (!e || e->epoch != epoch) {
         BLZ_LOG(1, "precompute plan: the extent was written while its table was being checked: exact path for this task");
         return BLZ_OK;
     }
     ArenaExtent::PrecompCheck& C = e->pcheck;
+    if (C.gen != gen) {
+        // another handle's check of this extent committed while this one ran unlocked: its record (state, range) is not the one
+        // this verdict was formed against - a partial re-check must not turn a range the other check refuted into a consistent
+        // one, a full check must not shrink or move the other's range.  This task takes the exact path; the next one looks again.
+        BLZ_LOG(1, "precompute plan: another check of the extent committed while this one ran: exact path for this task");
+        return BLZ_OK;
+    }
+    ++C.gen;
     C.state = flag_h ? 2 : 1;
     C.curve = h->curve;
     C.phase = phase;
@@ -271,6 +282,7 @@ int arena_points_table(blz_msm* h, uint64_t pos, uint32_t npts, const void** out
             (void)hipFree(B.tab);
             (void)hipEventDestroy(B.done);
             (void)hipEventDestroy(B.t0);
+            arena_flag_release(A, B.flag);
             B = ArenaExtent::TableBuild();
             e->table_refused = true;
             return BLZ_OK;
@@ -291,6 +303,7 @@ int arena_points_table(blz_msm* h, uint64_t pos, uint32_t npts, const void** out
         B.tab = nullptr;
         (void)hipEventDestroy(B.done);
         (void)hipEventDestroy(B.t0);
+        arena_flag_release(A, B.flag);
         B = ArenaExtent::TableBuild();
         BLZ_LOG(1, "window table: %llu bases x %d windows of %d bits, %.1f MiB, complete %.1f ms after its first chunk", (unsigned long long)t.npts,
                 t.W, t.c, t.bytes / 1048576.0, ms);
@@ -300,10 +313,10 @@ int arena_points_table(blz_msm* h, uint64_t pos, uint32_t npts, const void** out
     // of another format than this handle's (its curve's other arithmetic), or one whose scratch rows are gone, is dropped instead.
     if (e->tab_dirty_lo < e->tab_dirty_hi && !e->tables.empty()) {
         BLZ_TRY(sync_device_bounded("window table: drain before the rewritten bases are re-tabulated"));
-        uint32_t* pflag = nullptr;
-        if (A.build_flags) {
-            pflag = A.build_flags + (A.build_flag_next++ & 255u);
-            BLZ_HIP(hipMemsetAsync(pflag, 0, 4, h->eng.stream), BLZ_ERR_UNKNOWN);
+        uint32_t* pflag = arena_flag_acquire(A);   // owned for this call (every exit below is behind a drained stream, or leaks the word)
+        if (pflag && hipMemsetAsync(pflag, 0, 4, h->eng.stream) != hipSuccess) {
+            (void)hipGetLastError();
+            arena_flag_release(A, pflag);
         }
         bool patched = false;
         for (size_t k = e->tables.size(); k-- > 0;) {
@@ -321,13 +334,16 @@ int arena_points_table(blz_msm* h, uint64_t pos, uint32_t npts, const void** out
                                        t.W, t.lo, A.build_scratch, pflag, h->eng.stream));
             patched = true;
         }
+        if (!patched) arena_flag_release(A, pflag);
         if (patched) {
             uint32_t flag_h = 0;
             BLZ_WAIT(h, sync_stream_bounded(h->eng.stream, "window table: rewritten bases re-tabulated"));
-            BLZ_HIP(hipMemcpy(&flag_h, pflag, 4, hipMemcpyDeviceToHost), BLZ_ERR_READ);
+            const hipError_t he_flag = hipMemcpy(&flag_h, pflag, 4, hipMemcpyDeviceToHost);
+            arena_flag_release(A, pflag);
+            BLZ_HIP(he_flag, BLZ_ERR_READ);
             if (flag_h) {
                 BLZ_LOG(1, "window table: a rewritten base has a multiple at infinity (a point of even order): plain path for this extent");
-                arena_drop_table(*e);   // (the stream was drained just now, the device before)
+                arena_drop_table(A, *e);   // (the stream was drained just now, the device before)
                 e->table_refused = true;
                 return BLZ_OK;
             }
@@ -400,24 +416,23 @@ int arena_points_table(blz_msm* h, uint64_t pos, uint32_t npts, const void** out
         }
         hipEvent_t done = nullptr, t0 = nullptr;
         int rc = BLZ_OK;
-        if (hipEventCreate(&t0) != hipSuccess || hipEventCreate(&done) != hipSuccess) rc = fail(BLZ_ERR_UNKNOWN, "event creation failed");
-        // the build's "a multiple came out as infinity" flag: its own slot (builds share the scratch rows in stream order, but a
-        // flag is read by the host when its build is ADOPTED, possibly after a later build has started)
-        if (!A.build_flags && hipMalloc((void**)&A.build_flags, 256 * sizeof(uint32_t)) != hipSuccess) {
-            (void)hipGetLastError();
-            A.build_flags = nullptr;
+        if (hipEventCreate(&t0) != hipSuccess || hipEventCreate(&done) != hipSuccess) rc = fail_hip(BLZ_ERR_UNKNOWN, "event creation failed");
+        // the build's "a multiple came out as infinity" flag: a word of its own until the build is adopted or dropped (builds share
+        // the scratch rows in stream order, but a flag is read by the host when its build is ADOPTED, many tasks later)
+        uint32_t* flag = arena_flag_acquire(A);
+        if (!flag) {
             (void)hipFree(tab);
             if (t0) (void)hipEventDestroy(t0);
             if (done) (void)hipEventDestroy(done);
             e->table_refused = true;
             return BLZ_OK;
         }
-        uint32_t* flag = A.build_flags + (A.build_flag_next++ & 255u);
-        if (rc == BLZ_OK && hipMemsetAsync(flag, 0, 4, h->eng.stream) != hipSuccess) rc = fail(BLZ_ERR_UNKNOWN, "memset failed");
+        if (rc == BLZ_OK && hipMemsetAsync(flag, 0, 4, h->eng.stream) != hipSuccess) rc = fail_hip(BLZ_ERR_UNKNOWN, "memset failed");
         if (rc != BLZ_OK) {
             if (t0) (void)hipEventDestroy(t0);
             if (done) (void)hipEventDestroy(done);
             (void)hipFree(tab);
+            arena_flag_release(A, flag);
             return rc;
         }
         B.tab = tab;
@@ -456,17 +471,28 @@ bool wants_table(const blz_msm* h) {
 
 // BN254 has two arithmetics (msm_engine.hpp `repr`): the 9 x 29-bit reduced radix wins while the accumulation is bound by its
 // multiplier, 32-bit limbs win once it is bound by the memory system's rate of random line gathers out of a copy far larger than
-// the caches (profiles/r05_tlb_probe.txt).  The exact path of a precompute
-// handle always runs on 32-bit limbs (2^29 bases, 32 GiB); the plan's even-base copy is a quarter of that per element, so it
-// takes the reduced radix up to 2^25 elements (8 GiB of even bases) and 32-bit limbs above - measured, same box, ms per MSM in a
-// stream of tasks, reduced radix / 32-bit limbs: 2^20 1.85 / 2.20, 2^22 6.60 / 7.49, 2^24 18.2 / 19.2, 2^26 74.8 / 70.0
+// the caches (profiles/r05_tlb_probe.txt).  A precompute handle's tasks off the plan - the exact path (2^29 bases, 32 GiB at
+// config 3), DMA-mode tasks, tasks that bring their own table - run on 32-bit limbs; the plan's even-base copy is a quarter of that
+// per element, so it takes the reduced radix up to 2^25 elements (8 GiB of even bases) and 32-bit limbs above - measured, same box,
+// ms per MSM in a stream of tasks, reduced radix / 32-bit limbs: 2^20 1.85 / 2.20, 2^22 6.60 / 7.49, 2^24 18.2 / 19.2, 2^26 74.8 / 70.0
 // (exact path: 2.2, 7.2, 24.6, 92.5).  Decided by the size of the CHECKED table, not of the task (tasks over sub-ranges of one table
 // would otherwise flip the arithmetic - and with it the format of the extent's copy - from task to task).  BLAZE_MSM_PLAN
-// pc_repr=0|1 forces one (tests).  Switched only while nothing of the handle is in flight.
+// pc_repr=0|1 forces one (tests).
+//
+// The arithmetic is chosen PER TASK (task_repr_bn254pc below, from the path the task takes), and changed only while nothing of the
+// handle is in flight: the engine's shared workspace and the extent's Montgomery copy are in ONE format at a time, and a change
+// costs a device drain and a reconversion of the copy.  A task launched beside one in flight therefore keeps the arithmetic of
+// the one in flight - every path is correct on either arithmetic (same bytes: tests/test_gpu_msm_precompute.py), only the speed
+// differs - and the choice is made again by the first task that finds the handle idle.
 int plan_repr_bn254(uint64_t nelem) {
     const int forced = plan_override("pc_repr", -1);
     if (forced == 0 || forced == 1) return forced;
     return nelem > (1ull << 25) ? 1 : 0;
+}
+
+void task_repr_bn254pc(blz_msm* h, bool on_plan, uint64_t checked_elems) {
+    if (h->curve != BLZ_BN254 || h->pf != BLZ_PRECOMPUTE_FACTOR || !h->in_flight.empty()) return;
+    h->eng.repr = exp_knob("BLAZE_BN254_REPR", on_plan ? plan_repr_bn254(checked_elems) : 1) ? 1 : 0;
 }
 
 // Which task serves `n` elements whose bases sit in the arena at `pos`: a precompute handle on the checked-table plan whose
@@ -484,8 +510,9 @@ int resolve_arena_task(blz_msm* h, uint64_t pos, uint32_t n, bool allow_table, b
         bool ok = false;
         uint64_t checked = n;
         BLZ_TRY(arena_precompute_check(h, pos, n, &ok, &checked));
-        if (h->curve == BLZ_BN254 && h->in_flight.empty()) h->eng.repr = exp_knob("BLAZE_BN254_REPR", ok ? plan_repr_bn254(checked) : 1) ? 1 : 0;
-        if (ok && h->eng.plan_for(n * 4, 64).c != 0) {
+        const bool plan = ok && h->eng.plan_for(n * 4, 64).c != 0;
+        task_repr_bn254pc(h, plan, checked);
+        if (plan) {
             const void* even = nullptr;
             BLZ_TRY(arena_points_mont(h, pos, n * 8, &even, true));
             if (even) {
@@ -497,8 +524,10 @@ int resolve_arena_task(blz_msm* h, uint64_t pos, uint32_t n, bool allow_table, b
             }
             // (the extent was written between the check and now: this task takes the exact path, the next one checks again)
             h->pc_info[1] = 0;
-            if (h->curve == BLZ_BN254 && h->in_flight.empty()) h->eng.repr = exp_knob("BLAZE_BN254_REPR", 1) ? 1 : 0;
+            task_repr_bn254pc(h, false, 0);
         }
+    } else {
+        task_repr_bn254pc(h, false, 0);   // (a precompute handle off the plan: mode iii, the plan switched off)
     }
     if (allow_table && wants_table(h)) {
         const void* tab = nullptr;

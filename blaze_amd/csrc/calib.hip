@@ -45,7 +45,7 @@ extern "C" int blz_calib_mad_rate(int device_id, uint32_t target_ms, double out[
     hipError_t he = hipEventCreate(&e0);
     if (he == hipSuccess) he = hipEventCreate(&e1);
     int rc = BLZ_OK;
-    if (he != hipSuccess) rc = fail(BLZ_ERR_UNKNOWN, "event creation failed");
+    if (he != hipSuccess) rc = fail_hip(BLZ_ERR_UNKNOWN, "event creation failed");
     // 4 waves per SIMD (where the multiplier chains of the product kernels peak: profiles/r02_mul_variants.txt)
     const dim3 grid((unsigned)cus * 4), block(256);
     uint32_t reps = 1u << 14;
@@ -55,7 +55,7 @@ extern "C" int blz_calib_mad_rate(int device_id, uint32_t target_ms, double out[
         hipLaunchKernelGGL(k_calib_mad, grid, block, 0, 0, d, reps, 7u + pass);
         (void)hipEventRecord(e1, 0);
         if (sync_event_bounded(e1, "calibration kernel") != BLZ_OK || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || ms <= 0.f) {
-            rc = fail(BLZ_ERR_UNKNOWN, "calibration kernel failed");
+            rc = fail_hip(BLZ_ERR_UNKNOWN, "calibration kernel failed");
             break;
         }
         if (pass == 0) {   // the first launch only sizes the second

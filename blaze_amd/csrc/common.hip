@@ -18,10 +18,6 @@ void set_last_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
     BLZ_LOG(1, "error: %s", g_err);
-    // A failed runtime call (an allocation on a full device, say) also leaves its code behind as this thread's sticky "last error",
-    // where the next launch check - BLZ_HIP(hipGetLastError()) behind some kernel of some later, healthy call - would find it and
-    // fail for no reason.  Whatever went wrong is reported HERE: the slate is wiped with the report.
-    (void)hipGetLastError();
 }
 
 int log_level() {
@@ -90,7 +86,7 @@ static int bounded_wait(Q&& query, const char* what) {
         if (e == hipSuccess) return BLZ_OK;
         if (e != hipErrorNotReady) {
             (void)hipGetLastError();
-            return fail(BLZ_ERR_UNKNOWN, "%s failed: %s", what, hipGetErrorString(e));
+            return fail_hip(BLZ_ERR_UNKNOWN, "%s failed: %s", what, hipGetErrorString(e));
         }
         const auto dt = std::chrono::steady_clock::now() - t0;
         if (dt > std::chrono::milliseconds(limit_ms)) {
@@ -144,7 +140,7 @@ int sync_device_bounded(const char* what) {
     }
     if (job->err != hipSuccess) {
         (void)hipGetLastError();
-        return fail(BLZ_ERR_UNKNOWN, "%s failed: %s", what, hipGetErrorString(job->err));
+        return fail_hip(BLZ_ERR_UNKNOWN, "%s failed: %s", what, hipGetErrorString(job->err));
     }
     return BLZ_OK;
 }
@@ -171,7 +167,7 @@ int DevBuf::reserve(size_t bytes, bool exact) {
     }
     if (e != hipSuccess) {
         p = nullptr;
-        return fail(BLZ_ERR_UNKNOWN, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return fail_hip(BLZ_ERR_UNKNOWN, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
     }
     cap = want;
     return BLZ_OK;

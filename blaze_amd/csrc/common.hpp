@@ -26,13 +26,17 @@ int log_level();  // BLAZE_LOG=0..3 (env), the RUST_LOG analogue of README.md:15
         }                                                  \
     } while (0)
 
-// HIP call -> error code of the given class on failure
+// HIP call -> error code of the given class on failure.  A failed runtime call (an allocation on a full device, say) also leaves
+// its code behind as the thread's sticky "last error", where the next launch check - BLZ_HIP(hipGetLastError()) behind some kernel
+// of some later, healthy call - would find it and fail for no reason: it is wiped HERE, where the runtime call failed and is
+// reported (and in fail_hip below) - not in the generic reporter, which argument checks reach on threads that never touched the GPU.
 #define BLZ_HIP(call, errcode)                                                                     \
     do {                                                                                           \
         hipError_t e__ = (call);                                                                   \
         if (e__ != hipSuccess) {                                                                   \
             ::blz::set_last_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, \
                                   __LINE__);                                                       \
+            (void)hipGetLastError();                                                               \
             return (errcode);                                                                      \
         }                                                                                          \
     } while (0)
@@ -50,6 +54,17 @@ inline int fail(int code, const char* fmt, ...) {
     vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
     set_last_error("%s", buf);
+    return code;
+}
+// the report of a HIP runtime call that failed: fail() + the runtime's sticky error wiped (see BLZ_HIP)
+inline int fail_hip(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    set_last_error("%s", buf);
+    (void)hipGetLastError();
     return code;
 }
 
@@ -159,6 +174,7 @@ struct ArenaExtent {
         uint64_t first = 0, npts = 0;
         uint64_t redo_lo = 0, redo_hi = 0;
         float ms = 0;                      // device time of the (last) check
+        uint64_t gen = 0;                  // bumped by every commit of a check: one that ran unlocked commits only onto the record it read
     } pcheck;
     // Arena diet (blz_arena_set_policy, arena.hip): 0 raw bytes in place; 1 their canonical check is enqueued (diet_ev, diet_flag);
     // 2 raw DROPPED - the complete Montgomery copy is the only copy, and get_data_from_hbm / writes / exports / table builds
@@ -172,7 +188,7 @@ struct ArenaExtent {
     // last chunk adopts the table.
     struct TableBuild {
         void* tab = nullptr;
-        uint32_t* flag = nullptr;          // a slot of the arena's build_flags: set by the build when a multiple came out as infinity
+        uint32_t* flag = nullptr;          // a word of the arena's build_flags, owned by the build: set when a multiple came out as infinity
         size_t bytes = 0;
         hipEvent_t done = nullptr, t0 = nullptr;
         int format = -1, c = 0, W = 0, lo = 0, hi = 256;
@@ -189,8 +205,12 @@ struct Arena {
     size_t build_scratch_bytes = 0;
     hipEvent_t scratch_event = nullptr;    // recorded behind the last chunk that used the rows
     bool scratch_recorded = false;
-    uint32_t* build_flags = nullptr;       // 256 flag slots, one per build in turn
-    uint32_t build_flag_next = 0;
+    // 256 device flag words raised by kernels (a base of even order in a table build, a refuted table check, a non-canonical
+    // coordinate).  A word is OWNED from arena_flag_acquire to arena_flag_release - by an extent's diet check for as long as the
+    // extent lives, by a table build until it is adopted or dropped, by a check or a patch for the call - so a flag that is read
+    // long after it was armed (a diet check parked until the next task touches the extent) is still the reader's.
+    uint32_t* build_flags = nullptr;
+    std::vector<uint16_t> flag_free;       // the words nobody owns (filled when build_flags is allocated)
     int policy = 0;                        // blz_arena_set_policy: bit 0 = drop the raw bytes of an extent once its Montgomery copy is complete
 };
 Arena& arena_for(int device_id);
@@ -198,7 +218,9 @@ Arena& arena_for(int device_id);
 ArenaExtent* arena_find(Arena& a, uint64_t pos, size_t len);
 // write bytes (host or device source) at pos; extends / merges extents as needed; blocking
 int arena_write(int device_id, uint64_t pos, const void* src, size_t len, bool src_is_device, hipStream_t st);
-void arena_free_extent(ArenaExtent& x);
+void arena_free_extent(Arena& a, ArenaExtent& x);
+uint32_t* arena_flag_acquire(Arena& a);             // nullptr: no memory for the words, or all of them owned
+void arena_flag_release(Arena& a, uint32_t*& f);    // (null-safe; nulls f)
 uint64_t arena_next_epoch();
 // arena diet: give a dieted extent its raw bytes back (converted from the Montgomery copy, on st; blocking, bounded); no-op otherwise
 int arena_restore_raw(Arena& a, ArenaExtent& e, hipStream_t st);
@@ -206,7 +228,7 @@ int arena_restore_raw(Arena& a, ArenaExtent& e, hipStream_t st);
 int arena_diet_step(Arena& a, ArenaExtent& e, size_t point_bytes, hipStream_t st);
 // bytes [off, off + len) of an extent (relative to its start) into host memory, whichever copy holds them
 int arena_read_bytes(Arena& a, ArenaExtent& e, uint64_t off, size_t len, void* out, hipStream_t st);
-void arena_drop_table(ArenaExtent& x);   // the tables and a build in flight; the caller has drained the device
-void arena_drop_build(ArenaExtent& x);   // a build in flight only
+void arena_drop_table(Arena& a, ArenaExtent& x);   // the tables and a build in flight; the caller has drained the device
+void arena_drop_build(Arena& a, ArenaExtent& x);   // a build in flight only
 
 }  // namespace blz

@@ -23,10 +23,10 @@ int blz_msm_new(int device_id, int mem_type, int is_precompute, int curve, blz_m
     h->window_table = 0;   // opt-in: blz_msm_set_window_table
     int rc = h->eng.init(device_id, curve, (int)h->pf);
     if (rc == BLZ_OK && hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess)
-        rc = fail(BLZ_ERR_UNKNOWN, "copy stream creation failed");
+        rc = fail_hip(BLZ_ERR_UNKNOWN, "copy stream creation failed");
     for (int i = 0; i < 2 && rc == BLZ_OK; ++i)
         if (hipEventCreateWithFlags(&h->set_free[i], hipEventDisableTiming) != hipSuccess)
-            rc = fail(BLZ_ERR_UNKNOWN, "event creation failed");
+            rc = fail_hip(BLZ_ERR_UNKNOWN, "event creation failed");
     if (rc != BLZ_OK) {
         h->eng.destroy();
         delete h;
@@ -151,7 +151,7 @@ int blz_msm_prepare_precompute_plan(blz_msm* h, uint32_t nof_elements, uint64_t 
     BLZ_TRY(arena_precompute_check(h, hbm_addr + hbm_off, nof_elements, &ok, &checked));
     if (ok && h->in_flight.empty()) {
         // the even-base copy too, so that the first task finds it in place
-        if (h->curve == BLZ_BN254) h->eng.repr = exp_knob("BLAZE_BN254_REPR", plan_repr_bn254(checked)) ? 1 : 0;
+        task_repr_bn254pc(h, true, checked);
         const void* p = nullptr;
         BLZ_TRY(arena_points_mont(h, hbm_addr + hbm_off, nof_elements * 8, &p, true));
         if (!p) ok = false;   // (written in between)

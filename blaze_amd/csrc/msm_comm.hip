@@ -112,7 +112,7 @@ int blz_msm_comm_init_all(blz_msm* const* handles, int n) {
         BLZ_NCCL(api, api->GetUniqueId(&id));
         BLZ_NCCL(api, api->GroupStart());
         for (int i = 0; i < n; ++i) {
-            if (hipSetDevice(devs[i]) != hipSuccess) { (void)api->GroupEnd(); return fail(BLZ_ERR_FILE, "hipSetDevice(%d) failed", devs[i]); }
+            if (hipSetDevice(devs[i]) != hipSuccess) { (void)api->GroupEnd(); return fail_hip(BLZ_ERR_FILE, "hipSetDevice(%d) failed", devs[i]); }
             ncclResult_t r = api->CommInitRank(&j.comms[i], n, id, i);
             if (r != ncclSuccess) { (void)api->GroupEnd(); return fail(BLZ_ERR_UNKNOWN, "ncclCommInitRank(rank %d) failed: %s", i, api->GetErrorString(r)); }
         }

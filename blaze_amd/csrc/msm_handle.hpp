@@ -93,6 +93,7 @@ constexpr int TABLE_CHUNKS_PER_TASK = 4;           // ~22 ms on top of a 2^26 ta
 bool wants_table_mode(const blz_msm* h);
 bool wants_table(const blz_msm* h);
 int plan_repr_bn254(uint64_t nelem);
+void task_repr_bn254pc(blz_msm* h, bool on_plan, uint64_t checked_elems);   // the arithmetic of a BN254 precompute handle's next task
 int arena_points_mont(blz_msm* h, uint64_t pos, uint32_t npts, const void** out, bool even = false);
 int arena_precompute_check(blz_msm* h, uint64_t pos, uint32_t nelem, bool* ok, uint64_t* checked_elems = nullptr);
 int arena_points_table(blz_msm* h, uint64_t pos, uint32_t npts, const void** out, int* c_out, int chunk_budget);

@@ -89,6 +89,7 @@ int stage_common(blz_msm* h, bool have_points, const void* points, size_t points
         h->staged_arena_pos = hbm_addr + hbm_off;
     } else {
         h->staged_from_arena = false;
+        task_repr_bn254pc(h, false, 0);   // (DMA-mode task of a precompute handle: its arithmetic off the plan)
     }
     // Host buffers with a task already armed (DMA mode, the reference's primary flow: tests/integration_msm.rs:149-207):
     // the task is enqueued PIECE BY PIECE while its data crosses the link, the way the reference streams interleaved chunks
@@ -152,7 +153,7 @@ int stage_common(blz_msm* h, bool have_points, const void* points, size_t points
         pieces = h->eng.slots[slot].slices;
         int rc = BLZ_OK;
         auto copy_in = [&](void* dst, const void* src, size_t len, const char* what) -> int {
-            if (hipMemcpyAsync(dst, src, len, hipMemcpyHostToDevice, cst) != hipSuccess) return fail(BLZ_ERR_WRITE, "%s failed", what);
+            if (hipMemcpyAsync(dst, src, len, hipMemcpyHostToDevice, cst) != hipSuccess) return fail_hip(BLZ_ERR_WRITE, "%s failed", what);
             // the caller may drop its buffers as soon as we return (set_data is synchronous: utils.rs:71), and the piece's
             // device work is enqueued when its bytes are there.  The first copy waits for the staging set's previous user
             // (set_free, two tasks back): bounded like every wait

@@ -220,7 +220,7 @@ int blz_ntt_new_ex2(int device_id, int field, int log_size, int inverse, uint32_
     for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&h->xchg_ev[i], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreate(&h->ev0);
     if (e == hipSuccess) e = hipEventCreate(&h->ev1);
-    int rc = e == hipSuccess ? ntt_setup(h) : fail(BLZ_ERR_UNKNOWN, "stream/event creation failed: %s", hipGetErrorString(e));
+    int rc = e == hipSuccess ? ntt_setup(h) : fail_hip(BLZ_ERR_UNKNOWN, "stream/event creation failed: %s", hipGetErrorString(e));
     if (rc != BLZ_OK) {
         blz_ntt_free(h);
         return rc;
@@ -403,16 +403,40 @@ int blz_ntt_exchange(blz_ntt* h, size_t buf, const uint8_t* next_in, size_t in_l
     }
 #endif
     if (exp_knob("BLAZE_NTT_XCHG_PINNED", 1) != 0 && host_ptr_is_pinned(next_in) && host_ptr_is_pinned(prev_out)) {
-        for (size_t k = 0; k < npieces; ++k) {
+        // Whatever goes wrong while the pieces are being enqueued, BOTH copy streams are drained (bounded) before the call
+        // returns: the header lets the caller drop next_in / prev_out on return, and pieces already enqueued keep moving bytes
+        // between them and the device until they are through.
+        int rc = BLZ_OK;
+        std::string err;
+        auto step = [&](hipError_t e, int code, const char* what) {
+            if (e == hipSuccess) return true;
+            (void)hipGetLastError();
+            rc = code;
+            err = std::string("exchange: ") + what + " failed: " + hipGetErrorString(e);
+            return false;
+        };
+        for (size_t k = 0; k < npieces && rc == BLZ_OK; ++k) {
             const size_t o = cut[k], len = cut[k + 1] - cut[k];
             hipEvent_t ev = h->xchg_ev[k % 4];
-            BLZ_HIP(hipMemcpyAsync(prev_out + o, dbuf + o, len, hipMemcpyDeviceToHost, h->copy_stream), BLZ_ERR_READ);
-            BLZ_HIP(hipEventRecord(ev, h->copy_stream), BLZ_ERR_READ);
-            BLZ_HIP(hipStreamWaitEvent(h->copy_stream2, ev, 0), BLZ_ERR_WRITE);   // (captures this record: the event is free to be re-recorded)
-            BLZ_HIP(hipMemcpyAsync(dbuf + o, next_in + o, len, hipMemcpyHostToDevice, h->copy_stream2), BLZ_ERR_WRITE);
+            if (!step(hipMemcpyAsync(prev_out + o, dbuf + o, len, hipMemcpyDeviceToHost, h->copy_stream), BLZ_ERR_READ, "device -> host copy")) break;
+            if (!step(hipEventRecord(ev, h->copy_stream), BLZ_ERR_READ, "event record")) break;
+            if (!step(hipStreamWaitEvent(h->copy_stream2, ev, 0), BLZ_ERR_WRITE, "stream wait")) break;   // (captures this record: the event is free to be re-recorded)
+            if (!step(hipMemcpyAsync(dbuf + o, next_in + o, len, hipMemcpyHostToDevice, h->copy_stream2), BLZ_ERR_WRITE, "host -> device copy")) break;
         }
-        BLZ_NTT_WAIT(h, sync_stream_bounded(h->copy_stream, "exchange: copy out of the NTT buffer"));
-        BLZ_NTT_WAIT(h, sync_stream_bounded(h->copy_stream2, "exchange: copy into the NTT buffer"));
+        bool timed_out = false;
+        std::string werr;
+        int wrc = BLZ_OK;
+        for (hipStream_t st : {h->copy_stream, h->copy_stream2}) {
+            blz::wait_clear();
+            const int r = sync_stream_bounded(st, st == h->copy_stream ? "exchange: copy out of the NTT buffer" : "exchange: copy into the NTT buffer");
+            if (r != BLZ_OK) {
+                if (blz::wait_timed_out()) timed_out = true;
+                if (wrc == BLZ_OK) { wrc = r; werr = blz_last_error_message(); }
+            }
+        }
+        if (timed_out) h->wedged = true;   // (bytes may still be moving: reset / free only)
+        if (rc != BLZ_OK) return fail(rc, "%s", err.c_str());
+        if (wrc != BLZ_OK) return fail(wrc, "%s", werr.c_str());
         return BLZ_OK;
     }
     std::atomic<size_t> departed{0};     // pieces [0, departed) are in prev_out
@@ -422,7 +446,7 @@ int blz_ntt_exchange(blz_ntt* h, size_t buf, const uint8_t* next_in, size_t in_l
     std::string err_in;
     const int dev = h->device;
     hipStream_t st_in = h->copy_stream2;
-    std::thread writer([&, dev, st_in] {
+    auto writer_fn = [&, dev, st_in] {
         if (hipSetDevice(dev) != hipSuccess) { rc_in = BLZ_ERR_FILE; err_in = "hipSetDevice failed on the exchange's helper thread"; return; }
         for (size_t k = 0; k < npieces; ++k) {
             while (departed.load(std::memory_order_acquire) <= k) {
@@ -440,14 +464,24 @@ int blz_ntt_exchange(blz_ntt* h, size_t buf, const uint8_t* next_in, size_t in_l
         blz::wait_clear();
         rc_in = sync_stream_bounded(st_in, "exchange: copy into the NTT buffer");
         if (rc_in != BLZ_OK) { err_in = blz_last_error_message(); timed_out_in = blz::wait_timed_out(); }
-    });
+    };
+    std::thread writer;
+    try {
+        writer = std::thread(writer_fn);
+    } catch (...) {
+        // no helper thread to be had (the process is at its thread limit): the two-call sequence, one direction after the other -
+        // nothing may unwind across the C ABI
+        BLZ_LOG(1, "exchange: no helper thread: result and set_data one after the other");
+        BLZ_TRY(ntt_result_common(h, buf, prev_out, out_cap, false));
+        return ntt_set_data_common(h, buf, next_in, in_len, false);
+    }
     int rc_out = BLZ_OK;
     bool timed_out_out = false;
     for (size_t k = 0; k < npieces && rc_out == BLZ_OK; ++k) {
         const size_t o = cut[k], len = cut[k + 1] - cut[k];
         if (hipMemcpyAsync(prev_out + o, dbuf + o, len, hipMemcpyDeviceToHost, h->copy_stream) != hipSuccess) {
             (void)hipGetLastError();
-            rc_out = fail(BLZ_ERR_READ, "exchange: device -> host copy failed");
+            rc_out = fail_hip(BLZ_ERR_READ, "exchange: device -> host copy failed");
             break;
         }
         // the piece must have LEFT before its place is overwritten: a host-side wait (bounded), which pageable copies have paid already

@@ -121,7 +121,7 @@ int synth_points_t(void* d_out, uint64_t n, int pf, uint64_t start) {
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipDeviceSynchronize();
     (void)hipFree(table);
-    if (e != hipSuccess) return fail(BLZ_ERR_UNKNOWN, "synth_points failed: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return fail_hip(BLZ_ERR_UNKNOWN, "synth_points failed: %s", hipGetErrorString(e));
     return BLZ_OK;
 }
 
