@@ -61,6 +61,7 @@ _SIGS = {
     "blz_msm_task_label": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "blz_msm_nof_elements": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "blz_msm_is_engine_ready": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
+    "blz_msm_stream_progress": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "blz_msm_reset": (C.c_int, [C.c_void_p]),
     "blz_msm_last_timings": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "blz_comm_unique_id": (C.c_int, [_u8p]),

@@ -208,6 +208,8 @@ int blz_msm_start_process(blz_msm* h) {
     if (!h) return fail(BLZ_ERR_INVALID_PARAM, "null handle");
     BLZ_LIVE(h);
     if (!h->initialized) return fail(BLZ_ERR_INVALID_PARAM, "start_process before initialize");
+    if (h->armed && h->strm.open)
+        return fail(BLZ_ERR_INVALID_PARAM, "a task is already queued and has received %u of its %u elements", h->strm.received, h->strm.total);
     if (h->armed) return fail(BLZ_ERR_INVALID_PARAM, "a task is already queued and waits for data");
     h->armed = true;
     h->task_label += 1;
@@ -218,16 +220,18 @@ int blz_msm_start_process(blz_msm* h) {
 
 int blz_msm_set_data(blz_msm* h, const uint8_t* points, size_t points_len, const uint8_t* scalars, size_t scalars_len,
                      uint32_t nof_elements, int has_hbm, uint64_t hbm_addr, uint64_t hbm_off) {
-    if (h && h->armed && nof_elements != h->nof_elements)
-        return fail(BLZ_ERR_INVALID_PARAM, "set_data carries %u elements, queued task expects %u", nof_elements, h->nof_elements);
+    // with a task queued, fewer elements than the task still lacks = the next slice of it (msm_stage.hip stage_stream: the card
+    // counts what its FIFOs receive against NUMBER_OF_MSM_ELEMENTS, msm_api.rs:155-202); more is refused there
+    if (h && h->armed && (h->strm.open || nof_elements != h->nof_elements))
+        return stage_stream(h, points != nullptr, points, points_len, scalars, scalars_len, nof_elements, has_hbm, hbm_addr, hbm_off, false);
     return stage_common(h, points != nullptr, points, points_len, scalars, scalars_len, nof_elements, has_hbm, hbm_addr,
                         hbm_off, false);
 }
 
 int blz_msm_set_data_device(blz_msm* h, const void* d_points, size_t points_len, const void* d_scalars,
                             size_t scalars_len, uint32_t nof_elements, int has_hbm, uint64_t hbm_addr, uint64_t hbm_off) {
-    if (h && h->armed && nof_elements != h->nof_elements)
-        return fail(BLZ_ERR_INVALID_PARAM, "set_data carries %u elements, queued task expects %u", nof_elements, h->nof_elements);
+    if (h && h->armed && (h->strm.open || nof_elements != h->nof_elements))
+        return stage_stream(h, d_points != nullptr, d_points, points_len, d_scalars, scalars_len, nof_elements, has_hbm, hbm_addr, hbm_off, true);
     return stage_common(h, d_points != nullptr, d_points, points_len, d_scalars, scalars_len, nof_elements, has_hbm,
                         hbm_addr, hbm_off, true);
 }
@@ -237,6 +241,9 @@ int blz_msm_wait_result(blz_msm* h) {
     BLZ_LIVE(h);
     if (h->in_flight.empty()) {
         if (!h->results.empty()) return BLZ_OK;  // RESULT_VALID already set
+        if (h->strm.open)
+            return fail(BLZ_ERR_INVALID_PARAM, "wait_result: the queued task has received %u of its %u elements (the reference would spin forever)",
+                        h->strm.received, h->strm.total);
         return fail(BLZ_ERR_INVALID_PARAM, "wait_result with no task in flight (the reference would spin forever)");
     }
     // tasks complete in submission order: wait for the oldest, move its bytes to the result queue.  The wait is
@@ -311,6 +318,12 @@ int blz_msm_nof_elements(blz_msm* h, uint32_t* out) {
     *out = h->nof_elements;
     return BLZ_OK;
 }
+int blz_msm_stream_progress(blz_msm* h, uint32_t out[2]) {
+    if (!h || !out) return fail(BLZ_ERR_INVALID_PARAM, "null argument");
+    out[0] = h->strm.open ? h->strm.received : 0u;
+    out[1] = h->armed ? h->nof_elements : 0u;
+    return BLZ_OK;
+}
 int blz_msm_is_engine_ready(blz_msm* h, uint32_t* out) {
     if (!h || !out) return fail(BLZ_ERR_INVALID_PARAM, "null argument");
     *out = h->eng.can_accept() ? 1u : 0u;
@@ -324,6 +337,7 @@ int blz_msm_reset(blz_msm* h) {
     // complete stays wedged and reset fails with Unknown again
     BLZ_TRY(sync_stream_bounded(h->copy_stream, "reset: copy stream"));
     BLZ_TRY(h->eng.sync_all());
+    stream_abandon(h);   // (a half-fed task goes with the reset)
     h->wedged = false;
     h->armed = h->data_ready = false;
     h->in_flight.clear();

@@ -40,6 +40,25 @@ struct blz_msm {
     bool staged_from_arena = false;
     bool staged_loaded_now = false;   // this set_data also loaded the bases (mode iii: points + hbm address)
     uint64_t staged_arena_pos = 0;
+    // A task fed by SEVERAL set_data calls (msm_stage.hip stage_stream): the card takes a task's scalars and points through FIFOs and
+    // counts elements against NUMBER_OF_MSM_ELEMENTS (msm_api.rs:155-202, msm_hw_code.rs:18-19), so any split of an armed task's
+    // bytes over calls is the same task.  SURVEY.md 8(b): {armed_n, received}, launch when received == armed_n.
+    struct Stream {
+        bool open = false;
+        int mode = 0;              // 1 scalars only, bases in the arena; 2 points + scalars (DMA mode); 3 points into the arena + scalars
+        bool src_device = false;   // the slices are device pointers (set_data_device)
+        uint32_t total = 0;        // elements of the armed task (initialize's nof_elements)
+        uint32_t received = 0;     // elements delivered so far
+        int set = -1;              // staging set the slices land in
+        int slot = -1;             // engine slot of a task enqueued piece by piece; -1: launched whole when the last slice is in
+        uint32_t per = 0;          // points per piece
+        int pieces = 0, next_piece = 0;
+        uint32_t ppe = 1;          // points per element as the engine counts them (1; 8; 4 on the checked-table plan)
+        uint32_t npts = 0, done_pts = 0;   // points of the task / handed to the engine so far
+        int sbits = 0;
+        bool even = false;         // checked-table plan: pieces gather from the even-base copy
+        uint64_t arena_pos = 0;    // modes 1 and 3: where the task's bases start
+    } strm;
     blz::MsmEngine eng;
     // a wait ran into its deadline (BLAZE_WAIT_TIMEOUT_MS): device work of this handle may never complete, so nothing
     // new is queued behind it; reset (which waits, bounded, for the streams to drain) or free are the ways out
@@ -100,6 +119,9 @@ int arena_points_table(blz_msm* h, uint64_t pos, uint32_t npts, const void** out
 int resolve_arena_task(blz_msm* h, uint64_t pos, uint32_t n, bool allow_table, bool allow_plan, uint32_t* npts, int* sbits, int* table_c);
 // ---- msm_stage.hip
 int launch_if_ready(blz_msm* h);
+int stage_stream(blz_msm* h, bool have_points, const void* points, size_t points_len, const void* scalars, size_t scalars_len, uint32_t m,
+                 int has_hbm, uint64_t hbm_addr, uint64_t hbm_off, bool on_device);
+void stream_abandon(blz_msm* h);   // give up a half-fed task (reset, a failed slice)
 int stage_common(blz_msm* h, bool have_points, const void* points, size_t points_len, const void* scalars, size_t scalars_len, uint32_t n,
                  int has_hbm, uint64_t hbm_addr, uint64_t hbm_off, bool on_device);
 

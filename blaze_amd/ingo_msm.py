@@ -188,6 +188,14 @@ class MSMClient(DriverPrimitive[MSMInit, MSMParams, MSMInput, MSMResult]):
         check(lib().blz_msm_is_engine_ready(self._h, C.byref(v)))
         return int(v.value)
 
+    def stream_progress(self) -> Tuple[int, int]:
+        """A task fed by several set_data calls (blaze_hip.h "STREAMED TASKS": with a task queued, a set_data whose
+        params.nof_elements is smaller than what the task still lacks is its next slice, msm_api.rs:155-202 /
+        msm_hw_code.rs:18-19): (elements received so far, elements of the queued task)."""
+        v = (C.c_uint32 * 2)()
+        check(lib().blz_msm_stream_progress(self._h, v))
+        return int(v[0]), int(v[1])
+
     def load_data_to_hbm(self, points, addr: int, offset: int) -> None:
         if isinstance(points, DeviceBuffer):
             check(lib().blz_msm_load_data_to_hbm_device(self._h, points.ptr, points.nbytes, addr, offset))

@@ -111,6 +111,8 @@ class MSMClient : public DriverPrimitive<MSMInit, MSMParams, MSMInput, MSMResult
     uint32_t task_label() const { uint32_t v; check(blz_msm_task_label(h_, &v)); return v; }
     uint32_t nof_elements() const { uint32_t v; check(blz_msm_nof_elements(h_, &v)); return v; }
     uint32_t is_msm_engine_ready() const { uint32_t v; check(blz_msm_is_engine_ready(h_, &v)); return v; }
+    // a task fed by several set_data calls (blaze_hip.h "STREAMED TASKS"): {elements received, elements of the queued task}
+    std::pair<uint32_t, uint32_t> stream_progress() const { uint32_t v[2]; check(blz_msm_stream_progress(h_, v)); return {v[0], v[1]}; }
     void load_data_to_hbm(const std::vector<uint8_t>& points, uint64_t addr, uint64_t offset) {
         check(blz_msm_load_data_to_hbm(h_, points.data(), points.size(), addr, offset));
     }

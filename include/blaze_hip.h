@@ -87,13 +87,29 @@ int blz_msm_start_process(blz_msm* h);
  * Largest task: points x windows <= 2^32 - 2^26 - 352 321 536 points at precompute_factor 1 (5 x the reference's largest shape;
  * 134 GiB of device memory on BN254), 2^31 - 2^25 points at precompute_factor 8 (2^30 run: 172 GiB); beyond: InvalidPrimitiveParam
  * before anything is copied.  hbm_addr + hbm_off must not wrap around 2^64.
- * Blocking: host buffers may be dropped when it returns (pwrite with O_SYNC, utils.rs:71). */
+ * Blocking: host buffers may be dropped when it returns (pwrite with O_SYNC, utils.rs:71).
+ *
+ * STREAMED TASKS.  The reference writes the input to the card's FIFOs in 2048-element chunks (:175-202) and the card counts
+ * elements against NUMBER_OF_MSM_ELEMENTS, the register initialize() wrote (msm_hw_code.rs:18-19): a task's bytes may be split
+ * over any number of set_data calls.  Same here ({armed_n, received}, launch when received == armed_n): with a
+ * task queued (start_process), a set_data whose nof_elements is SMALLER than what the task still lacks is its next slice -
+ * lengths are checked against the slice's own nof_elements; any slice sizes (2048-element cadence, ragged tails, zero);
+ * every slice in the mode of the first (scalars only: the same hbm_point_addr, the address of the task's FIRST base, in every
+ * slice; points + scalars; points + hbm_point_addr: slice k's table is loaded right behind slice k - 1's, its address must say
+ * so).  The task is handed to the device piece by piece while later slices are still with the host (the pieces of a one-call
+ * DMA-mode task) and is complete with the slice that brings received to nof_elements; more than that is refused and changes
+ * nothing, start_process / wait_result with a half-fed task are refused (a task already in flight can still be waited for),
+ * blz_msm_reset drops it.  A slice that fails in transfer loses the stream: the task stays queued and may be sent again from
+ * its first element.  Results are byte-identical to the one-call task's (tests/test_gpu_msm_stream.py).  The reference's
+ * largest DMA-mode shape - tests/integration_msm.rs:386-467, 2^26 elements x 8 bases = a 48 GiB host vector - runs from host
+ * slices of any size this way.  blz_msm_stream_progress: {elements received, elements of the queued task}. */
 int blz_msm_set_data(blz_msm* h, const uint8_t* points, size_t points_len, const uint8_t* scalars,
                      size_t scalars_len, uint32_t nof_elements, int has_hbm, uint64_t hbm_addr,
                      uint64_t hbm_off);
 
 /* Same semantics with inputs already resident in this device's HBM (device pointers, borrowed until
- * wait_result returns).  No reference counterpart: the FPGA path has no device-pointer notion; this
+ * wait_result returns; the slices of a streamed task are COPIED into the handle's staging set and may be dropped on
+ * return).  No reference counterpart: the FPGA path has no device-pointer notion; this
  * is what a multi-GPU host or a pipeline that produced scalars on the GPU calls. */
 int blz_msm_set_data_device(blz_msm* h, const void* d_points, size_t points_len, const void* d_scalars,
                             size_t scalars_len, uint32_t nof_elements, int has_hbm, uint64_t hbm_addr,
@@ -156,6 +172,9 @@ int blz_msm_stream(blz_msm* h, void** hip_stream, int* device_id);
 int blz_msm_task_label(blz_msm* h, uint32_t* out);
 int blz_msm_nof_elements(blz_msm* h, uint32_t* out);
 int blz_msm_is_engine_ready(blz_msm* h, uint32_t* out);
+/* streamed tasks (blz_msm_set_data): out = {elements the queued task has received so far, elements it was queued with}; {0, 0}
+ * with nothing queued.  Diagnostic (the card's FIFO fill is not readable at all). */
+int blz_msm_stream_progress(blz_msm* h, uint32_t out[2]);
 /* DriverClient::reset (dclient.rs:88-93): drop armed task, queued results and staged data. */
 int blz_msm_reset(blz_msm* h);
 

@@ -46,6 +46,7 @@ extern "C" {
     pub fn blz_msm_task_label(h: *mut BlzMsm, out: *mut u32) -> c_int;
     pub fn blz_msm_nof_elements(h: *mut BlzMsm, out: *mut u32) -> c_int;
     pub fn blz_msm_is_engine_ready(h: *mut BlzMsm, out: *mut u32) -> c_int;
+    pub fn blz_msm_stream_progress(h: *mut BlzMsm, out: *mut u32) -> c_int;
     pub fn blz_msm_reset(h: *mut BlzMsm) -> c_int;
     pub fn blz_msm_memory_info(h: *mut BlzMsm, out: *mut u64) -> c_int;
     pub fn blz_msm_set_window_table(h: *mut BlzMsm, enable: c_int) -> c_int;

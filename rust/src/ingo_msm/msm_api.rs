@@ -143,6 +143,15 @@ impl MSMClient {
         Ok(v)
     }
 
+    /// A task fed by several `set_data` calls (the card counts what its FIFOs receive against NUMBER_OF_MSM_ELEMENTS,
+    /// msm_api.rs:155-202 / msm_hw_code.rs:18-19; blaze_hip.h "STREAMED TASKS"): with a task queued, a `set_data` whose
+    /// `params.nof_elements` is smaller than what the task still lacks is its next slice.  `(received, queued)`.
+    pub fn stream_progress(&self) -> Result<(u32, u32)> {
+        let mut v = [0u32; 2];
+        check(unsafe { blz_msm_stream_progress(self.h, v.as_mut_ptr()) })?;
+        Ok((v[0], v[1]))
+    }
+
     /// msm_api.rs:299-313: raw bytes at arena offset `addr + offset`; bases then come from there.
     pub fn load_data_to_hbm(&self, points: &[u8], addr: u64, offset: u64) -> Result<()> {
         log::debug!("HBM adress: {:#X?}", &addr);

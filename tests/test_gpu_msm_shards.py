@@ -139,3 +139,80 @@ def test_layouts_with_window_tables(gpu, orc, curve, logn):
         assert tab.combine_partials(parts, world) == exp, f"{curve} world={world}"
     tab.close(); plain.close(); dp.free(); ds.free()
     blaze_amd._lib.check(blaze_amd.lib().blz_arena_release(0))
+
+
+@pytest.mark.parametrize("curve", ["BLS381", "BLS377"])
+def test_auto_layouts_full_size_all_ranks(gpu, orc, curve):
+    """What `bench.py --gpus N` executes, at its real size, on this one GPU: for 2, 4 and 8 ranks EVERY rank's task of a 2^26 job
+    as blz_msm_shard_layout_ex(flags = 0) cuts it (2 and 4 ranks split the scalars' bits of all elements, 8 ranks take 64-bit
+    ranges of half of the elements: the top range with the carry window, 22-bit windows, the three-level sort on 64 / 128-bit
+    widths) and as BLAZE_SHARD=elements cuts it - bases in the arena, two tasks in flight.  Each partial is checked against
+    the oracle on its own (linearity over P_i = (i + 1) G with the scalars masked to the rank's bit range, as bench.py's config 4
+    leg does for rank 0), and the rank-ordered combine_partials against the full result."""
+    import os
+
+    import numpy as np
+
+    from blaze_amd.ingo_msm import MSMInput, MSMParams, PointMemoryType
+    from blaze_amd.multi_gpu import shard_layout_ex
+
+    n = 1 << 26
+    dp, ds = synth(curve, n, seed=0x26)
+    blaze_amd._lib.check(blaze_amd.lib().blz_arena_release(0))
+    cl = msm_client(curve, 1, PointMemoryType.HBM)
+    cl.load_data_to_hbm(dp, 0, 0)
+    dp.free()
+    sc = np.frombuffer(ds.download(), dtype=np.uint8).reshape(n, 32)
+
+    def expect(first, count, lo, hi):
+        m = np.zeros((count, 32), dtype=np.uint8)
+        m[:, lo // 8: hi // 8] = sc[first: first + count, lo // 8: hi // 8]
+        k = orc.index_weighted_sum(curve, m, count, first, threads=16)
+        return orc.result_from_affine(curve, orc.generator_mul(curve, k))
+
+    full = expect(0, n, 0, 256)
+    seen = {}   # (first, count, lo, hi) -> checked partial: the element split's halves and quarters recur across worlds
+    saved = os.environ.get("BLAZE_SHARD")
+    try:
+        for mode in ("auto", "elements"):
+            if mode == "elements":
+                os.environ["BLAZE_SHARD"] = "elements"
+            else:
+                os.environ.pop("BLAZE_SHARD", None)
+            for world in (2, 4, 8):
+                lays = [shard_layout_ex(Curve[curve], n, r, world, 0) for r in range(world)]
+                assert sum(l["count"] * (l["bit_hi"] - l["bit_lo"]) for l in lays) == n * 256, lays
+                if mode == "elements":
+                    assert all((l["bit_lo"], l["bit_hi"]) == (0, 256) for l in lays), lays
+                elif world == 8:
+                    assert {l["bit_hi"] - l["bit_lo"] for l in lays} == {64} and {l["count"] for l in lays} == {n // 2}, lays
+                parts, pending = [], 0
+
+                def collect():
+                    cl.wait_result()
+                    parts.append(cl.result().result)
+
+                for l in lays:
+                    cl.set_scalar_range(l["bit_lo"], l["bit_hi"])
+                    vs = DeviceBuffer.__new__(DeviceBuffer); vs.device_id = 0; vs.ptr = ds.ptr + l["first"] * 32; vs.nbytes = l["count"] * 32
+                    params = MSMParams(l["count"], (0, l["first"] * 96))
+                    cl.initialize(params); cl.start_process(); cl.set_data(MSMInput(None, vs, params))
+                    vs.ptr = None
+                    pending += 1
+                    if pending == 2:
+                        collect(); pending -= 1
+                while pending:
+                    collect(); pending -= 1
+                for r, (l, got) in enumerate(zip(lays, parts)):
+                    key = (l["first"], l["count"], l["bit_lo"], l["bit_hi"])
+                    if key not in seen:
+                        seen[key] = expect(*key)
+                    assert got == seen[key], f"{curve} {mode} world={world} rank={r} {l}"
+                assert cl.combine_partials(b"".join(parts), world) == full, f"{curve} {mode} world={world}"
+    finally:
+        if saved is None:
+            os.environ.pop("BLAZE_SHARD", None)
+        else:
+            os.environ["BLAZE_SHARD"] = saved
+    cl.close(); ds.free()
+    blaze_amd._lib.check(blaze_amd.lib().blz_arena_release(0))
