@@ -89,6 +89,7 @@ _SIGS = {
     "blz_ntt_new_ex": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "blz_ntt_new_field": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "blz_ntt_new_ex2": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "blz_ntt_new_ex3": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_void_p, C.POINTER(C.c_void_p)]),
     "blz_ntt_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "blz_ntt_exchange": (C.c_int, [C.c_void_p, C.c_size_t, _u8p, C.c_size_t, _u8p, C.c_size_t]),
     "blz_ntt_free": (None, [C.c_void_p]),

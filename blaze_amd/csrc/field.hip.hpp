@@ -595,6 +595,26 @@ BLZ_DEV void fp_load(Fp<P>& r, const void* p) {
         r.v[4 * i] = x.x; r.v[4 * i + 1] = x.y; r.v[4 * i + 2] = x.z; r.v[4 * i + 3] = x.w;
     }
 }
+// the same with the non-temporal hint (streamed once: do not keep the lines in the caches)
+typedef uint32_t blz_u32x4 __attribute__((ext_vector_type(4)));
+template <class P>
+BLZ_DEV void fp_load_nt(Fp<P>& r, const void* p) {
+    const blz_u32x4* q = reinterpret_cast<const blz_u32x4*>(p);
+#pragma unroll
+    for (int i = 0; i < P::N / 4; ++i) {
+        blz_u32x4 x = __builtin_nontemporal_load(q + i);
+        r.v[4 * i] = x.x; r.v[4 * i + 1] = x.y; r.v[4 * i + 2] = x.z; r.v[4 * i + 3] = x.w;
+    }
+}
+template <class P>
+BLZ_DEV void fp_store_nt(void* p, const Fp<P>& a) {
+    blz_u32x4* q = reinterpret_cast<blz_u32x4*>(p);
+#pragma unroll
+    for (int i = 0; i < P::N / 4; ++i) {
+        blz_u32x4 x = {a.v[4 * i], a.v[4 * i + 1], a.v[4 * i + 2], a.v[4 * i + 3]};
+        __builtin_nontemporal_store(x, q + i);
+    }
+}
 template <class P>
 BLZ_DEV void fp_store(void* p, const Fp<P>& a) {
     uint4* q = reinterpret_cast<uint4*>(p);

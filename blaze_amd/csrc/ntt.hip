@@ -70,7 +70,9 @@ struct blz_ntt {
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;  // host<->buffer traffic, concurrent with the compute stream
     hipStream_t copy_stream2 = nullptr; // blz_ntt_exchange: the host -> device direction, while copy_stream carries device -> host
-    uint32_t flags = 0;                 // blz_ntt_new_ex2
+    uint32_t flags = 0;                 // blz_ntt_new_ex2 / _ex3
+    bool has_root = false;              // blz_ntt_new_ex3: the caller's primitive 2^logn-th root (canonical little-endian words)
+    uint8_t root[32] = {};
     hipEvent_t xchg_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // blz_ntt_exchange with pinned host buffers: piece k has left
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     DevBuf buf[2], scratch, tables, tables_rr, table_b;
@@ -118,7 +120,7 @@ int ntt_setup(blz_ntt* h) {
     int lb = (l - la) > 9 ? 9 : (l - la);
     int lc = l - la - lb;
     if (lc > 9) return fail(BLZ_ERR_INVALID_PARAM, "log_size %d not supported (max 27)", l);
-    h->geom = NttGeom{la, lb, lc, l, lc ? 1 : lb ? 2 : 3};
+    h->geom = NttGeom{la, lb, lc, l, lc ? 1 : lb ? 2 : 3, (h->flags & BLZ_NTT_BITREV_INPUT) ? 1 : 0, (h->flags & BLZ_NTT_BITREV_OUTPUT) ? 1 : 0};
     // columns per tile: LDS = radix * (COLS + 1) * 32 B <= 160 KiB, and COLS <= extent of the column index
     auto pick = [](int lr, int lcols_avail) {
         int c = 17 - 5 - lr;  // log2(128 KiB / 32 B / radix)
@@ -130,14 +132,19 @@ int ntt_setup(blz_ntt* h) {
     h->cols_log[0] = pick(lc, la);  // pass 1: cols i0 (< A)
     h->cols_log[1] = pick(lb, la);  // pass 2: cols i0 (< A)
     h->cols_log[2] = pick(la, lc);  // pass 3: cols k2 (< C)
-    size_t tb = (size_t)(3 * 512 + 3 * 512 + 1) * 32;
+    size_t tb = (size_t)(3 * 512 + 3 * 512 + 1 + 1 + 2) * 32;   // wpass x 3, t0..t2, ninv, wbase, (the caller's root | the root check's flag)
     BLZ_TRY(h->tables.reserve(tb));
     uint32_t* p = h->tables.as<uint32_t>();
     for (int i = 0; i < 3; ++i) { h->T.wpass[i] = p; p += 512 * 8; }
     h->T.t0 = p; p += 512 * 8;
     h->T.t1 = p; p += 512 * 8;
     h->T.t2 = p; p += 512 * 8;
-    h->T.ninv = h->inverse ? p : nullptr;
+    h->T.ninv = h->inverse ? p : nullptr; p += 8;
+    h->T.wbase = p; p += 8;
+    uint32_t* const d_user_root = p; p += 8;
+    uint32_t* const d_root_flag = p; p += 8;
+    BLZ_HIP(hipMemsetAsync(d_root_flag, 0, 4, h->stream), BLZ_ERR_UNKNOWN);
+    if (h->has_root) BLZ_HIP(hipMemcpyAsync(d_user_root, h->root, 32, hipMemcpyHostToDevice, h->stream), BLZ_ERR_WRITE);
     // the boundary table exists only where all three passes run the 512-point kernel (2^27), so that the factor it
     // splits off is re-joined by the same kernel in pass 2
     const bool want_ta = lc == 9 && !h->force_generic && exp_knob("BLAZE_NTT_TABLE", 1) != 0;
@@ -165,7 +172,16 @@ int ntt_setup(blz_ntt* h) {
         h->TR.swz = (la == 9 && lb == 9) ? (uint32_t)exp_knob("BLAZE_NTT_SWZ", 4) : 0u;
         if ((h->TR.swz & 15u) > 6u) h->TR.swz = 6u;
     }
-    BLZ_TRY(h->ops->setup(h->stream, h->T, h->TR, h->geom, h->inverse));
+    BLZ_TRY(h->ops->setup(h->stream, h->T, h->TR, h->geom, h->inverse, h->has_root ? d_user_root : nullptr, d_root_flag));
+    if (h->has_root) {
+        // the caller's root was checked on the device ahead of the tables built from it (k_ntt_root)
+        uint32_t bad = 0;
+        BLZ_TRY(sync_stream_bounded(h->stream, "NTT set-up: root check"));
+        BLZ_HIP(hipMemcpy(&bad, d_root_flag, 4, hipMemcpyDeviceToHost), BLZ_ERR_READ);
+        if (bad)
+            return fail(BLZ_ERR_INVALID_PARAM, bad == 1 ? "the root is not a canonical element of the field (>= r)"
+                                                        : "the root is not a primitive 2^%d-th root of unity (root^(2^%d) != -1)", h->logn, h->logn - 1);
+    }
     // both transform buffers exist from the start, zero-filled, like the card's two HBM buffers: the reference's
     // double-buffer loop opens with start_process on a buffer nobody wrote and result on the other
     // (tests/integration_ntt.rs:102-136, cycle 0)
@@ -197,9 +213,16 @@ int blz_ntt_new_field(int device_id, int field, int log_size, int inverse, blz_n
 }
 
 int blz_ntt_new_ex2(int device_id, int field, int log_size, int inverse, uint32_t flags, blz_ntt** out) {
+    if (flags & ~(uint32_t)BLZ_NTT_NO_FACTOR_TABLE) return fail(BLZ_ERR_INVALID_PARAM, "unknown NTT flags 0x%x", flags);
+    return blz_ntt_new_ex3(device_id, field, log_size, flags | (inverse ? BLZ_NTT_INVERSE : 0u), nullptr, out);
+}
+
+int blz_ntt_new_ex3(int device_id, int field, int log_size, uint32_t flags, const uint8_t* root, blz_ntt** out) {
     if (!out) return fail(BLZ_ERR_INVALID_PARAM, "null out");
     *out = nullptr;
-    if (flags & ~(uint32_t)BLZ_NTT_NO_FACTOR_TABLE) return fail(BLZ_ERR_INVALID_PARAM, "unknown NTT flags 0x%x", flags);
+    if (flags & ~(uint32_t)(BLZ_NTT_NO_FACTOR_TABLE | BLZ_NTT_INVERSE | BLZ_NTT_BITREV_INPUT | BLZ_NTT_BITREV_OUTPUT))
+        return fail(BLZ_ERR_INVALID_PARAM, "unknown NTT flags 0x%x", flags);
+    const int inverse = (flags & BLZ_NTT_INVERSE) ? 1 : 0;
     const NttFieldOps* ops = ntt_ops_for(field);
     if (!ops) return fail(BLZ_ERR_INVALID_PARAM, "unknown field %d", field);
     if (log_size < 1 || log_size > 27) return fail(BLZ_ERR_INVALID_PARAM, "log_size %d out of range [1,27]", log_size);
@@ -213,6 +236,10 @@ int blz_ntt_new_ex2(int device_id, int field, int log_size, int inverse, uint32_
     h->logn = log_size;
     h->inverse = inverse ? 1 : 0;
     h->flags = flags;
+    if (root) {
+        h->has_root = true;
+        memcpy(h->root, root, 32);
+    }
     h->force_generic = exp_knob("BLAZE_NTT_GENERIC", 0) != 0;
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking);

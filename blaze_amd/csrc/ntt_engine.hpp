@@ -10,6 +10,8 @@ struct NttTables {  // all Montgomery form, device memory
     uint32_t* t1;        // w^(512 j)      j < 512
     uint32_t* t2;        // w^(2^18 j)     j < 512
     uint32_t* ninv;      // n^-1 (Montgomery) for the inverse transform, else nullptr
+    uint32_t* wbase;     // w (Montgomery): the transform's primitive 2^logn-th root - the field generator's (ROOT^(2^(s - logn)))
+                         // or the caller's (blz_ntt_new_ex3), inverted for the inverse transform; every table is powers of it
 };
 
 // reduced-radix twiddle tables of the 512-point kernel (ntt_rr.hip.hpp): entries of 10 dwords (27-bit limbs), Montgomery
@@ -38,13 +40,17 @@ constexpr size_t NTT_RR_BOUNDARY_BYTES = NTT_RR_BOUNDARY_ENTRIES * 2 * NTT_RR_EN
 struct NttGeom {
     int logA, logB, logC, logn;
     int wire_pass;   // the pass that reads the caller's words (1, 2 or 3): the first one that runs
+    int brin, brout; // blz_ntt_new_ex3: the caller's input / output buffers are in bit-reversed order (position p holds the element of
+                     // index bitrev(p)): folded into the wire pass's loads / the last pass's stores
 };
 
 // per-field entry points.  Field ids follow enum blz_curve: the scalar field Fr of that curve.
 struct NttFieldOps {
     int two_adicity;
     // fill the twiddle tables (device memory already carved into T) for a 2^logn transform
-    int (*setup)(hipStream_t st, NttTables& T, NttTablesRR& TR, const NttGeom& g, int inverse);
+    // user_root: device pointer to the caller's root (8 canonical words) or nullptr; *flag (device u32): 1 the root is not a
+    // canonical field element, 2 it is not a primitive 2^logn-th root of unity
+    int (*setup)(hipStream_t st, NttTables& T, NttTablesRR& TR, const NttGeom& g, int inverse, const uint32_t* user_root, uint32_t* flag);
     // one of the three passes; cols_log is the tile width of the radix-2-in-LDS kernel
     int (*pass)(int pass, hipStream_t st, const void* in, void* out, const NttGeom& g, const NttTables& T, const NttTablesRR& TR,
                 int cols_log, bool force_generic);

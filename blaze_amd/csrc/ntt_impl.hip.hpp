@@ -7,16 +7,46 @@
 
 namespace blz {
 
-// out[j] = base^(j * mult) where base = ROOT^(2^(TWO_ADICITY - logn))
+// The transform's root of unity w, Montgomery form, into wbase: the field generator's ROOT^(2^(TWO_ADICITY - logn)) - or the
+// CALLER's (blz_ntt_new_ex3: `user` = 8 canonical words): any primitive 2^logn-th root, checked here (w^(n/2) == -1 is exactly
+// "order 2^logn"); the inverse transform runs on w^-1.  *flag: 0 fine, 1 not a canonical field element, 2 not primitive.
 template <class Fr>
-__global__ void k_ntt_table(uint32_t* out, int count, int logn, uint64_t mult, int inverse) {
+__global__ void k_ntt_root(uint32_t* wbase, uint32_t* flag, const uint32_t* user, int logn, int inverse) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    using E = Fp<Fr>;
+    E w;
+    if (user) {
+        E x;
+        fp_load(x, user);
+        bool lt = false;   // x < m ?
+        for (int i = Fr::N - 1; i >= 0; --i) {
+            if (x.v[i] != Fr::MOD[i]) { lt = x.v[i] < Fr::MOD[i]; break; }
+        }
+        if (!lt) { *flag = 1u; return; }
+        fp_to_mont(w, x);
+        E t = w, m1, one;
+        for (int i = 0; i + 1 < logn; ++i) fp_sqr(t, t);
+        fp_one(one);
+        fp_neg(m1, one);
+        if (!fp_eq(t, m1)) { *flag = 2u; return; }
+        if (inverse) { E wi; fp_inv(wi, w); w = wi; }
+        fp_reduce(w);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w.v[i] = inverse ? Fr::ROOT_INV[i] : Fr::ROOT[i];
+        for (int i = 0; i < Fr::TWO_ADICITY - logn; ++i) fp_sqr(w, w);
+    }
+    fp_store(wbase, w);
+}
+
+// out[j] = w^(j * mult), w = *wbase
+template <class Fr>
+__global__ void k_ntt_table(uint32_t* out, int count, const uint32_t* __restrict__ wbase, uint64_t mult) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= count) return;
     using E = Fp<Fr>;
     E w;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) w.v[i] = inverse ? Fr::ROOT_INV[i] : Fr::ROOT[i];
-    for (int i = 0; i < Fr::TWO_ADICITY - logn; ++i) fp_sqr(w, w);
+    fp_load(w, wbase);
     uint64_t e = (uint64_t)j * mult;
     E acc;
     fp_one(acc);
@@ -151,7 +181,9 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const uint32_t* __rest
         if (PASS == 3) { row = e & (radix - 1); col = e >> lr; }   // contiguous along rows
         else { col = e & (COLS - 1); row = e >> cols_log; }         // contiguous along cols
         E x;
-        fp_load(x, in + (in_base + row * in_rstride + col * in_cstride) * 8);
+        uint64_t iaddr = in_base + row * in_rstride + col * in_cstride;
+        if (PASS == g.wire_pass && g.brin) iaddr = __brevll(iaddr) >> (64 - g.logn);   // the caller's buffer is in bit-reversed order
+        fp_load(x, in + iaddr * 8);
         if (PASS == g.wire_pass) NttOps<E>::wire_in(x);
         uint32_t rrow = lr ? (__brev(row) >> (32 - lr)) : 0;
         lds_store(lds, rrow * RS + col * 8, x);
@@ -213,6 +245,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const uint32_t* __rest
                 if (T.ninv) { E s; fp_load(s, T.ninv); NttOps<E>::mul(x, x, s); }  // inverse transform: * n^-1
                 NttOps<E>::canon(x);                                               // the wire format is canonical
                 oaddr = (col_base + col0 + j) + (uint64_t)C * fixed + (uint64_t)C * B * row;
+                if (g.brout) oaddr = __brevll(oaddr) >> (64 - g.logn);
             } else {
                 if (tw) {
                     NttOps<E>::mul(x, x, w);
@@ -233,19 +266,20 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const uint32_t* __rest
 // host launchers
 // ------------------------------------------------------------------------------------------------
 template <class Fr>
-int ntt_setup_t(hipStream_t st, NttTables& T, NttTablesRR& TR, const NttGeom& g, int inverse) {
+int ntt_setup_t(hipStream_t st, NttTables& T, NttTablesRR& TR, const NttGeom& g, int inverse, const uint32_t* user_root, uint32_t* flag) {
     const int l = g.logn;
     if (l > Fr::TWO_ADICITY) return fail(BLZ_ERR_INVALID_PARAM, "log_size %d exceeds the field's two-adicity %d", l, Fr::TWO_ADICITY);
+    hipLaunchKernelGGL(k_ntt_root<Fr>, dim3(1), dim3(64), 0, st, T.wbase, flag, user_root, l, inverse);
     if (inverse) hipLaunchKernelGGL(k_ntt_ninv<Fr>, dim3(1), dim3(64), 0, st, T.ninv, l);
     const uint64_t n = 1ull << l;
     int lrs[3] = {g.logC, g.logB, g.logA};
     for (int i = 0; i < 3; ++i) {
         int cnt = lrs[i] ? (1 << lrs[i]) : 1;  // the whole circle: the radix-8 kernel indexes exponents up to radix-1
-        hipLaunchKernelGGL(k_ntt_table<Fr>, dim3(2), dim3(256), 0, st, T.wpass[i], cnt, l, n >> lrs[i], inverse);
+        hipLaunchKernelGGL(k_ntt_table<Fr>, dim3(2), dim3(256), 0, st, T.wpass[i], cnt, (const uint32_t*)T.wbase, n >> lrs[i]);
     }
-    hipLaunchKernelGGL(k_ntt_table<Fr>, dim3(2), dim3(256), 0, st, T.t0, 512, l, (uint64_t)1, inverse);
-    hipLaunchKernelGGL(k_ntt_table<Fr>, dim3(2), dim3(256), 0, st, T.t1, 512, l, (uint64_t)512, inverse);
-    hipLaunchKernelGGL(k_ntt_table<Fr>, dim3(2), dim3(256), 0, st, T.t2, 512, l, (uint64_t)1 << 18, inverse);
+    hipLaunchKernelGGL(k_ntt_table<Fr>, dim3(2), dim3(256), 0, st, T.t0, 512, (const uint32_t*)T.wbase, (uint64_t)1);
+    hipLaunchKernelGGL(k_ntt_table<Fr>, dim3(2), dim3(256), 0, st, T.t1, 512, (const uint32_t*)T.wbase, (uint64_t)512);
+    hipLaunchKernelGGL(k_ntt_table<Fr>, dim3(2), dim3(256), 0, st, T.t2, 512, (const uint32_t*)T.wbase, (uint64_t)1 << 18);
     // the same tables in the reduced radix for the 512-point kernel (ntt_rr.hip.hpp)
     static_assert(rr_stride<typename Fr::RR>() == NTT_RR_ENTRY_DWORDS, "table entry size");
     for (int i = 0; i < 3; ++i)
@@ -254,10 +288,10 @@ int ntt_setup_t(hipStream_t st, NttTables& T, NttTablesRR& TR, const NttGeom& g,
     hipLaunchKernelGGL(k_ntt_table_to_rr<Fr>, dim3(2), dim3(256), 0, st, T.t1, TR.t1, 512);
     hipLaunchKernelGGL(k_ntt_table_to_rr<Fr>, dim3(2), dim3(256), 0, st, T.t2, TR.t2, 512);
     if (TR.fin) hipLaunchKernelGGL(k_ntt_fin_rr<Fr>, dim3(1), dim3(64), 0, st, (const uint32_t*)T.ninv, TR.fin);
-    hipLaunchKernelGGL((k_ntt_table_rr_pow<Fr, true>), dim3(2), dim3(256), 0, st, TR.ts2, 512u, l, (uint64_t)64 << g.logC, inverse);   // Shoup entries
+    hipLaunchKernelGGL((k_ntt_table_rr_pow<Fr, true>), dim3(2), dim3(256), 0, st, TR.ts2, 512u, (const uint32_t*)T.wbase, (uint64_t)64 << g.logC);   // Shoup entries
     if (TR.tA)
         hipLaunchKernelGGL((k_ntt_table_rr_pow<Fr, NTT_TA_SHOUP>), dim3((unsigned)(NTT_RR_BOUNDARY_ENTRIES / 256)), dim3(256), 0, st, TR.tA,
-                           (uint32_t)NTT_RR_BOUNDARY_ENTRIES, l, (uint64_t)1 << g.logA, inverse);
+                           (uint32_t)NTT_RR_BOUNDARY_ENTRIES, (const uint32_t*)T.wbase, (uint64_t)1 << g.logA);
     if (TR.tB)
         hipLaunchKernelGGL(k_ntt_table_b<Fr>, dim3((unsigned)(n / 256)), dim3(256), 0, st, TR.tB, g, TR);   // (after t0 / t1 / t2: same stream)
     BLZ_HIP(hipGetLastError(), BLZ_ERR_UNKNOWN);

@@ -269,14 +269,12 @@ __global__ void k_ntt_fin_rr(const uint32_t* __restrict__ ninv32, uint32_t* __re
 
 // out[j] = w^(j * mult) in the reduced radix, straight from the exponent (the boundary table tA)
 template <class Fr, bool SHOUP = false>
-__global__ void k_ntt_table_rr_pow(uint32_t* __restrict__ out, uint32_t count, int logn, uint64_t mult, int inverse) {
+__global__ void k_ntt_table_rr_pow(uint32_t* __restrict__ out, uint32_t count, const uint32_t* __restrict__ wbase, uint64_t mult) {
     using Q = typename Fr::RR;
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= count) return;
     Fp<Fr> w, acc;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) w.v[i] = inverse ? Fr::ROOT_INV[i] : Fr::ROOT[i];
-    for (int i = 0; i < Fr::TWO_ADICITY - logn; ++i) fp_sqr(w, w);
+    fp_load(w, wbase);   // the transform's root (ntt_impl.hip.hpp k_ntt_root)
     const uint64_t e = (uint64_t)j * mult;
     fp_one(acc);
     for (int b = 63; b >= 0; --b) {
@@ -336,6 +334,11 @@ __global__ void k_ntt_table_b(uint32_t* __restrict__ out, NttGeom g, NttTablesRR
 #endif
 constexpr bool NTT_TA_SHOUP = BLZ_NTT_TA_SHOUP != 0;
 
+// Experiment of round 6 (profiles/r06_ntt_sq.txt): non-temporal loads / stores of the passes' data, a bit per (pass, direction):
+// bit 2 (p - 1) = pass p's loads, bit 2 (p - 1) + 1 = its stores.  Shipped: 0.
+#ifndef BLZ_NTT_NT
+#define BLZ_NTT_NT 0
+#endif
 constexpr int NR_COLS_LOG = NTT_RR_COLS_LOG;
 constexpr int NR_COLS = 1 << NR_COLS_LOG;
 constexpr int NR_THREADS = 64 * NR_COLS;
@@ -419,7 +422,10 @@ __global__ __launch_bounds__(NR_THREADS, 3) void k_ntt512_rr(const uint32_t* __r
     for (int j = 0; j < 8; ++j) {
         const uint32_t row = 64u * BR[j] + n2;
         Fp<Fr> x;
-        fp_load(x, in + (in_base + row * in_rstride + col * in_cstride) * 8);
+        uint64_t iaddr = in_base + row * in_rstride + col * in_cstride;
+        if (PASS == g.wire_pass && g.brin) iaddr = __brevll(iaddr) >> (64 - g.logn);   // the caller's buffer is in bit-reversed order
+        if constexpr (((BLZ_NTT_NT >> (2 * (PASS - 1))) & 1) != 0) fp_load_nt(x, in + iaddr * 8);
+        else fp_load(x, in + iaddr * 8);
         rr_from_words<Q>(a1[j], x.v);
     }
     auto o1 = dft8_rr<Q>(a1, w1, w2, w3);
@@ -559,6 +565,7 @@ __global__ __launch_bounds__(NR_THREADS, 3) void k_ntt512_rr(const uint32_t* __r
         if (PASS == 3) {
             fp_csub_const<Fr, Fr::MOD>(y);   // < 2m -> canonical: the wire format
             oaddr = (col_base + col) + (uint64_t)C * fixed + (uint64_t)C * B * row;
+            if (g.brout) oaddr = __brevll(oaddr) >> (64 - g.logn);
         } else {
             if (K != 7 && !(PASS == 1 && split) && !(PASS == 2 && tabB)) {   // twiddle x twiddle
                 if (PASS == 2) rr_mul_shoup(w, w, step_s);
@@ -566,7 +573,8 @@ __global__ __launch_bounds__(NR_THREADS, 3) void k_ntt512_rr(const uint32_t* __r
             }
             oaddr = in_base + row * in_rstride + col;
         }
-        fp_store(out + oaddr * 8, y);
+        if constexpr (((BLZ_NTT_NT >> (2 * (PASS - 1) + 1)) & 1) != 0) fp_store_nt(out + oaddr * 8, y);
+        else fp_store(out + oaddr * 8, y);
     })
 }
 

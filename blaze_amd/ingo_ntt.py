@@ -36,16 +36,23 @@ class NTTClient(DriverPrimitive[NTT, NttInit, NTTInput, bytes]):
     _FIELDS = {"BLS377": 0, "BLS381": 1, "BN254": 2}  # enum blz_curve
 
     NO_FACTOR_TABLE = 1  # include/blaze_hip.h BLZ_NTT_NO_FACTOR_TABLE
+    INVERSE = 2          # BLZ_NTT_INVERSE
+    BITREV_INPUT = 4     # BLZ_NTT_BITREV_INPUT
+    BITREV_OUTPUT = 8    # BLZ_NTT_BITREV_OUTPUT
 
     def __init__(self, _ptype: NTT, dclient: DriverClient, log_size: int = NTT_LOG_SIZE, inverse: bool = False,
-                 field: str = "BLS381", flags: int = 0):
+                 field: str = "BLS381", flags: int = 0, root: Optional[int] = None):
+        """root / BITREV_* flags: the transform's convention, which the reference leaves unstated (NttInit {} is empty,
+        ntt_api.rs:8-23) - any primitive 2^log_size-th root of unity (an int, checked on the device) instead of this
+        build's g^((r - 1) / 2^log_size), input and / or output in bit-reversed order (include/blaze_hip.h blz_ntt_new_ex3)."""
         self.driver_client = dclient
         self.log_size = log_size
-        self.inverse = inverse
+        self.inverse = inverse or bool(flags & self.INVERSE)
         self.field = field
         self.nbytes = NTT_WORD_SIZE << log_size
         h = C.c_void_p()
-        check(lib().blz_ntt_new_ex2(dclient.id, self._FIELDS[field], log_size, int(inverse), int(flags), C.byref(h)))
+        rb = None if root is None else int(root).to_bytes(32, "little")
+        check(lib().blz_ntt_new_ex3(dclient.id, self._FIELDS[field], log_size, int(flags) | (self.INVERSE if inverse else 0), rb, C.byref(h)))
         self._h = h
 
     def close(self):

@@ -211,10 +211,13 @@ class NTTClient : public DriverPrimitive<NTT, NttInit, NTTInput, std::vector<uin
     DriverClient driver_client;
     // ntt_api.rs:26-31; 2^27 over BLS12-381 Fr, forward, is the reference shape.  `field` (a Curve: the
     // scalar field of that curve) and `inverse` have no reference counterpart.
-    // flags: BLZ_NTT_NO_FACTOR_TABLE (blaze_hip.h)
-    NTTClient(NTT, DriverClient dclient, int log_size = 27, Curve field = Curve::BLS381, bool inverse = false, uint32_t flags = 0)
+    // flags: BLZ_NTT_NO_FACTOR_TABLE | BLZ_NTT_INVERSE | BLZ_NTT_BITREV_INPUT | BLZ_NTT_BITREV_OUTPUT; root: any primitive
+    // 2^log_size-th root of unity (32 canonical little-endian bytes, checked on the device) instead of g^((r - 1) / 2^log_size) -
+    // the transform's convention, which the reference leaves unstated (blaze_hip.h blz_ntt_new_ex3)
+    NTTClient(NTT, DriverClient dclient, int log_size = 27, Curve field = Curve::BLS381, bool inverse = false, uint32_t flags = 0,
+              const uint8_t* root = nullptr)
         : nbytes_(size_t(32) << log_size), driver_client(dclient) {
-        check(blz_ntt_new_ex2(dclient.id, int(field), log_size, inverse ? 1 : 0, flags, &h_));
+        check(blz_ntt_new_ex3(dclient.id, int(field), log_size, flags | (inverse ? BLZ_NTT_INVERSE : 0u), root, &h_));
     }
     ~NTTClient() override { blz_ntt_free(h_); }
     NTTClient(const NTTClient&) = delete;

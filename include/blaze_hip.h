@@ -339,6 +339,21 @@ int blz_ntt_new_field(int device_id, int field, int log_size, int inverse, blz_n
  * one every smaller transform runs.  blz_ntt_info says which one a handle got. */
 #define BLZ_NTT_NO_FACTOR_TABLE 1u
 int blz_ntt_new_ex2(int device_id, int field, int log_size, int inverse, uint32_t flags, blz_ntt** out);
+/* The transform's CONVENTION, chosen by the caller.  The reference states none of it (NttInit {} is empty, ntt_api.rs:8-23; its
+ * golden files are external, tests/integration_ntt.rs:15-18): this build's default is X[k] = sum_i x[i] w^(i k) with
+ * w = g^((r - 1) / 2^log_size), g the field's multiplicative generator (7 / 22 / 5 for BLS12-381 / BLS12-377 / BN254 Fr), natural
+ * order in and out.  A host that holds vectors made for the card says here what they assume:
+ *   root   (nullable) 32 bytes, canonical little-endian: ANY primitive 2^log_size-th root of unity replaces w; checked on the
+ *          device (root < r and root^(2^(log_size - 1)) == -1), else BLZ_ERR_INVALID_PARAM;
+ *   flags  BLZ_NTT_NO_FACTOR_TABLE as above; BLZ_NTT_INVERSE: x = n^-1 sum_k X[k] w^(-i k) (the same w: the inverse of the
+ *          handle without the flag); BLZ_NTT_BITREV_INPUT / BLZ_NTT_BITREV_OUTPUT: position p of the buffer passed to
+ *          set_data / returned by result holds the element of index bitrev(p) over log_size bits (the orders decimation-in-time
+ *          inputs / decimation-in-frequency outputs come in) - folded into the first pass's loads and the last pass's stores.
+ * Handles made without root and order flags are byte-identical to blz_ntt_new_ex2's. */
+#define BLZ_NTT_INVERSE 2u
+#define BLZ_NTT_BITREV_INPUT 4u
+#define BLZ_NTT_BITREV_OUTPUT 8u
+int blz_ntt_new_ex3(int device_id, int field, int log_size, uint32_t flags, const uint8_t* root, blz_ntt** out);
 /* out = {device bytes the handle holds (two transform buffers + scratch + twiddle / factor tables), 1 if pass 2 reads the
  * per-element factor table / 0 if it steps its factors, 1 if pass 1 reads the column-independent boundary table, log_size} */
 int blz_ntt_info(blz_ntt* h, uint64_t out[4]);

@@ -48,6 +48,8 @@ def lib():
         L.orc_msm_pippenger.argtypes = [C.c_int, C.c_void_p, C.c_void_p, u64, C.c_int, C.c_int, C.c_int, u8p]
         L.orc_omega.argtypes = [C.c_int, C.c_int, u8p]
         L.orc_ntt.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.orc_ntt_ex.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_int]
+        L.orc_bitrev_permute.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.orc_ntt_eval_at.argtypes = [C.c_int, C.c_void_p, C.c_int, u64, u8p]
         L.orc_ntt_eval_at_mt.argtypes = [C.c_int, C.c_void_p, C.c_int, u64, C.c_int, u8p]
         L.orc_dft_naive.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int]
@@ -179,9 +181,22 @@ def omega(curve, logn: int) -> int:
     return int.from_bytes(out.raw, "little")
 
 
-def ntt(curve, data, logn: int, inverse: bool = False, threads: int = 1) -> bytearray:
+def ntt(curve, data, logn: int, inverse: bool = False, threads: int = 1, root: int | None = None, bitrev_in: bool = False,
+        bitrev_out: bool = False) -> bytearray:
+    """root: any primitive 2^logn-th root of unity instead of the generator's; bitrev_*: the buffer is in bit-reversed order
+    (the conventions the device's blz_ntt_new_ex3 offers; the reference states none)."""
     out = bytearray(32 << logn)
-    rc = lib().orc_ntt(_cid(curve), _ptr(data), _ptr(out), logn, int(inverse), threads)
+    flags = int(inverse) | (2 if bitrev_in else 0) | (4 if bitrev_out else 0)
+    rb = None if root is None else C.c_char_p(int(root).to_bytes(32, "little"))
+    rc = lib().orc_ntt_ex(_cid(curve), _ptr(data), _ptr(out), logn, flags, rb, threads)
+    assert rc == 0, rc
+    return out
+
+
+def bitrev_permute(data, logn: int, threads: int = 1) -> bytearray:
+    """out[bitrev(i)] = in[i] over logn bits, 32-byte elements."""
+    out = bytearray(32 << logn)
+    rc = lib().orc_bitrev_permute(_ptr(data), _ptr(out), logn, threads)
     assert rc == 0
     return out
 

@@ -835,15 +835,20 @@ static void* ntt_stage_worker(void* arg) {
 }
 /* the three element-wise sweeps of orc_ntt (bit-reversed load, twiddle table, scaled store), split over threads */
 typedef struct { const curve_t* c; int phase, logn, tid, nth; u64 n; const uint8_t* in; uint8_t* out; u64* a; u64* tw;
-                 const u64* w; const u64* ninv; int inverse; } ntt_sweep;
+                 const u64* w; const u64* ninv; int inverse; int brin, brout; } ntt_sweep;
+static u64 bitrev_u64(u64 i, int logn) {
+    u64 rev = 0;
+    for (int b = 0; b < logn; ++b) rev |= ((i >> b) & 1) << (logn - 1 - b);
+    return rev;
+}
 static void* ntt_sweep_worker(void* arg) {
     ntt_sweep* S = (ntt_sweep*)arg;
     const fctx* f = &S->c->fr;
     if (S->phase == 0) {
         u64 lo = S->n * S->tid / S->nth, hi = S->n * (S->tid + 1) / S->nth;
         for (u64 i = lo; i < hi; ++i) {
-            u64 rev = 0;
-            for (int b = 0; b < S->logn; ++b) rev |= ((i >> b) & 1) << (S->logn - 1 - b);
+            /* the decimation-in-time stages want a[bitrev(i)] = x[i]; a buffer in bit-reversed order holds x[bitrev(p)] at p */
+            u64 rev = S->brin ? i : bitrev_u64(i, S->logn);
             u64 t[MAXL];
             f_from_bytes(f, t, S->in + 32 * i);
             memcpy(S->a + 4 * rev, t, 32);
@@ -867,15 +872,23 @@ static void* ntt_sweep_worker(void* arg) {
             u64 t[MAXL];
             memcpy(t, S->a + 4 * i, 32);
             if (S->inverse) f_mul(f, t, t, S->ninv);
-            f_to_bytes(f, S->out + 32 * i, t);
+            f_to_bytes(f, S->out + 32 * (S->brout ? bitrev_u64(i, S->logn) : i), t);
         }
     }
     return NULL;
 }
+/* The transform under a caller-chosen convention (the device's blz_ntt_new_ex3; the reference states none: ntt_api.rs:8-23):
+ * flags bit 0 inverse (w^-1, times n^-1), bit 1 input in bit-reversed order, bit 2 output in bit-reversed order; root32 (nullable):
+ * a primitive 2^logn-th root of unity, canonical LE, instead of the generator's.  -2: root^(n/2) != -1. */
+int orc_ntt_ex(int curve, const uint8_t* in, uint8_t* out, int logn, int flags, const uint8_t* root32, int threads);
 int orc_ntt(int curve, const uint8_t* in, uint8_t* out, int logn, int inverse, int threads) {
+    return orc_ntt_ex(curve, in, out, logn, inverse ? 1 : 0, NULL, threads);
+}
+int orc_ntt_ex(int curve, const uint8_t* in, uint8_t* out, int logn, int flags, const uint8_t* root32, int threads) {
     const curve_t* c = get_curve(curve);
-    if (!c || logn > c->two_adicity) return -1;
+    if (!c || logn > c->two_adicity || logn < 1) return -1;
     const fctx* f = &c->fr;
+    const int inverse = flags & 1, brin = (flags >> 1) & 1, brout = (flags >> 2) & 1;
     u64 n = (u64)1 << logn;
     if (threads < 1) threads = 1;
     u64* a = (u64*)malloc(32 * n);
@@ -884,8 +897,18 @@ int orc_ntt(int curve, const uint8_t* in, uint8_t* out, int logn, int inverse, i
     ntt_job* jobs = (ntt_job*)malloc(sizeof(ntt_job) * threads);
     ntt_sweep* sw = (ntt_sweep*)malloc(sizeof(ntt_sweep) * threads);
     u64 w[MAXL];
-    memcpy(w, c->root, sizeof(w));
-    for (int i = 0; i < c->two_adicity - logn; ++i) f_sqr(f, w, w);
+    if (root32) {
+        u64 t[MAXL], m1[MAXL], zero[MAXL];
+        f_from_bytes(f, w, root32);
+        memcpy(t, w, sizeof(t));
+        for (int i = 0; i + 1 < logn; ++i) f_sqr(f, t, t);
+        memset(zero, 0, sizeof(zero));
+        f_sub(f, m1, zero, f->one);
+        if (memcmp(t, m1, 8 * (size_t)f->n) != 0) { free(a); free(tw); free(th); free(jobs); free(sw); return -2; }
+    } else {
+        memcpy(w, c->root, sizeof(w));
+        for (int i = 0; i < c->two_adicity - logn; ++i) f_sqr(f, w, w);
+    }
     if (inverse) f_inv(f, w, w);
     u64 ninv[MAXL];
     memset(ninv, 0, sizeof(ninv));
@@ -896,7 +919,7 @@ int orc_ntt(int curve, const uint8_t* in, uint8_t* out, int logn, int inverse, i
     }
     for (int phase = 0; phase < 2; ++phase) {   /* x[bitrev(i)] into a; tw[i] = w^i */
         for (int t = 0; t < threads; ++t) {
-            sw[t] = (ntt_sweep){c, phase, logn, t, threads, n, in, out, a, tw, w, ninv, inverse};
+            sw[t] = (ntt_sweep){c, phase, logn, t, threads, n, in, out, a, tw, w, ninv, inverse, brin, brout};
             pthread_create(&th[t], NULL, ntt_sweep_worker, &sw[t]);
         }
         for (int t = 0; t < threads; ++t) pthread_join(th[t], NULL);
@@ -909,13 +932,35 @@ int orc_ntt(int curve, const uint8_t* in, uint8_t* out, int logn, int inverse, i
         for (int t = 0; t < threads; ++t) pthread_join(th[t], NULL);
     }
     for (int t = 0; t < threads; ++t) {
-        sw[t] = (ntt_sweep){c, 2, logn, t, threads, n, in, out, a, tw, w, ninv, inverse};
+        sw[t] = (ntt_sweep){c, 2, logn, t, threads, n, in, out, a, tw, w, ninv, inverse, brin, brout};
         pthread_create(&th[t], NULL, ntt_sweep_worker, &sw[t]);
     }
     for (int t = 0; t < threads; ++t) pthread_join(th[t], NULL);
     free(a); free(tw); free(th); free(jobs); free(sw);
     return 0;
 }
+/* out[bitrev(i)] = in[i] over logn bits (32-byte elements): the order blz_ntt_new_ex3's BITREV flags speak of */
+typedef struct { const uint8_t* in; uint8_t* out; int logn, tid, nth; } brp_job;
+static void* brp_worker(void* arg) {
+    brp_job* J = (brp_job*)arg;
+    u64 n = (u64)1 << J->logn, lo = n * J->tid / J->nth, hi = n * (J->tid + 1) / J->nth;
+    for (u64 i = lo; i < hi; ++i) memcpy(J->out + 32 * bitrev_u64(i, J->logn), J->in + 32 * i, 32);
+    return NULL;
+}
+int orc_bitrev_permute(const uint8_t* in, uint8_t* out, int logn, int threads) {
+    if (logn < 0 || logn > 40 || in == out) return -1;
+    if (threads < 1) threads = 1;
+    pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * threads);
+    brp_job* jobs = (brp_job*)malloc(sizeof(brp_job) * threads);
+    for (int t = 0; t < threads; ++t) {
+        jobs[t] = (brp_job){in, out, logn, t, threads};
+        pthread_create(&th[t], NULL, brp_worker, &jobs[t]);
+    }
+    for (int t = 0; t < threads; ++t) pthread_join(th[t], NULL);
+    free(th); free(jobs);
+    return 0;
+}
+
 /* X[k] = sum_i x[i] (w^k)^i by Horner: one output coefficient of a transform of any size, O(n).
  * Used to spot-check full-size (2^27) device transforms. */
 int orc_ntt_eval_at(int curve, const uint8_t* in, int logn, u64 k, uint8_t* out32) {

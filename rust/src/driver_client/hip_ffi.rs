@@ -83,6 +83,7 @@ extern "C" {
     pub fn blz_host_malloc(device_id: c_int, bytes: usize, out: *mut *mut std::os::raw::c_void) -> c_int;
     pub fn blz_host_free(p: *mut std::os::raw::c_void) -> c_int;
     pub fn blz_ntt_new_ex2(device_id: c_int, field: c_int, log_size: c_int, inverse: c_int, flags: u32, out: *mut *mut BlzNtt) -> c_int;
+    pub fn blz_ntt_new_ex3(device_id: c_int, field: c_int, log_size: c_int, flags: u32, root: *const u8, out: *mut *mut BlzNtt) -> c_int;
     pub fn blz_ntt_info(h: *mut BlzNtt, out: *mut u64) -> c_int;
     pub fn blz_ntt_exchange(h: *mut BlzNtt, buf: usize, next_in: *const u8, in_len: usize, prev_out: *mut u8, out_cap: usize) -> c_int;
     pub fn blz_ntt_free(h: *mut BlzNtt);

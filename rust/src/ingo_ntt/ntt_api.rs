@@ -81,6 +81,18 @@ impl NTTClient {
         NTTClient { nbytes: NTT_WORD_SIZE << log_size, driver_client: dclient, h }
     }
 
+    /// The transform's convention, which the reference leaves unstated (`NttInit {}` is empty, ntt_api.rs:8-23; its golden
+    /// files are external, tests/integration_ntt.rs:15-18): `field` = a `Curve` as i32 (its scalar field), `flags` =
+    /// BLZ_NTT_INVERSE (2) | BLZ_NTT_BITREV_INPUT (4) | BLZ_NTT_BITREV_OUTPUT (8) | BLZ_NTT_NO_FACTOR_TABLE (1), `root` = any
+    /// primitive 2^log_size-th root of unity as 32 canonical little-endian bytes (checked on the device) or `None` for
+    /// g^((r - 1) / 2^log_size).  A host that holds vectors made for the card says here what they assume.
+    pub fn with_convention(dclient: DriverClient, field: i32, log_size: i32, flags: u32, root: Option<&[u8; 32]>) -> Result<Self> {
+        let mut h: *mut BlzNtt = std::ptr::null_mut();
+        let rp = root.map_or(std::ptr::null(), |r| r.as_ptr());
+        check(unsafe { blz_ntt_new_ex3(dclient.id, field, log_size, flags, rp, &mut h) })?;
+        Ok(NTTClient { nbytes: NTT_WORD_SIZE << log_size, driver_client: dclient, h })
+    }
+
     /// Device time of the last transform in ms (HIP events around its three passes).
     pub fn last_kernel_ms(&self) -> Result<f32> {
         let mut v = 0f32;

@@ -578,3 +578,104 @@ def test_every_size_against_the_oracle(gpu):
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "probes", "ntt_sizes_probe.py"), "24"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "mismatches: 0" in r.stdout and "MISMATCH" not in r.stdout and r.stdout.count(": ok") >= 2 * 24 + 2 * 7
+
+
+def _nonres_root(orc, field, logn, t):
+    """A primitive 2^logn-th root that is NOT this build's default: the default's t-th power, t odd."""
+    r = pyref.CURVES[field]["r"]
+    return pow(orc.omega(field, logn), t, r)
+
+
+@pytest.mark.parametrize("field", ["BLS381", "BLS377", "BN254"])
+@pytest.mark.parametrize("logn", [1, 4, 9, 12, 18, 20])
+def test_convention_knobs_against_the_oracle(gpu, orc, field, logn):
+    """blz_ntt_new_ex3: a caller-supplied primitive root and bit-reversed input / output order (the reference states neither root,
+    direction nor order: NttInit {} is empty, ntt_api.rs:8-23; its goldens are external files, tests/integration_ntt.rs:15-18).
+    Two non-default roots x {natural, bit-reversed} input x {natural, bit-reversed} output x {forward, inverse} against the
+    oracle's transform under the same convention, every pass structure (1, 2, 3 passes; radix-2-in-LDS and 512-point kernels);
+    default handles stay byte-identical to blz_ntt_new_ex2's; a root that is not primitive, or not canonical, is refused."""
+    import numpy as np
+    r = pyref.CURVES[field]["r"]
+    n = 1 << logn
+    x = np.random.default_rng(logn).integers(0, 256, size=32 * n, dtype=np.uint8).reshape(n, 32)
+    x[:, 31] &= 0x0F
+    data = x.tobytes()
+    dflt = NTTClient(NTT.Ntt, DriverClient(0), log_size=logn, field=field)
+    base = _ntt(dflt, data)
+    assert base == bytes(orc.ntt(field, data, logn, threads=16))
+    dflt.close()
+    assert _ntt(NTTClient(NTT.Ntt, DriverClient(0), log_size=logn, field=field, flags=0, root=None), data) == base
+    assert _ntt(NTTClient(NTT.Ntt, DriverClient(0), log_size=logn, field=field, root=orc.omega(field, logn)), data) == base
+    roots = [_nonres_root(orc, field, logn, t) for t in ((3, 2 * n - 1 if n > 2 else 3) if n > 2 else (1,))]
+    for root in roots:
+        for fl in range(8):
+            inv, brin, brout = bool(fl & 1), bool(fl & 2), bool(fl & 4)
+            flags = (NTTClient.INVERSE if inv else 0) | (NTTClient.BITREV_INPUT if brin else 0) | (NTTClient.BITREV_OUTPUT if brout else 0)
+            cl = NTTClient(NTT.Ntt, DriverClient(0), log_size=logn, field=field, flags=flags, root=root)
+            got = _ntt(cl, data, buf=fl & 1)
+            exp = bytes(orc.ntt(field, data, logn, inverse=inv, threads=16, root=root, bitrev_in=brin, bitrev_out=brout))
+            assert got == exp, f"{field} 2^{logn} root={root:#x} inverse={inv} bitrev_in={brin} bitrev_out={brout}"
+            cl.close()
+    # refused roots: 1 (order 1), the default's square (order n / 2), a value >= r
+    bad = [1, r + 1] + ([pow(orc.omega(field, logn), 2, r)] if n > 1 else [])
+    for b in bad:
+        with pytest.raises(DriverClientError) as ei:
+            NTTClient(NTT.Ntt, DriverClient(0), log_size=logn, field=field, root=b)
+        assert ei.value.variant == "InvalidPrimitiveParam", b
+    with pytest.raises(DriverClientError):
+        NTTClient(NTT.Ntt, DriverClient(0), log_size=logn, field=field, flags=64)
+
+
+def test_convention_knobs_full_size_2e27(gpu, orc):
+    """The same knobs at the reference's size, where only the 512^3 kernels run: a non-default root with bit-reversed input and
+    output, every one of the 2^27 outputs against the oracle's transform under that convention; the other root and the mixed
+    orders through the identities that tie them to it (w -> w^t permutes the outputs: X_t[k] = X[t k mod n]; the orders are
+    permutations of the buffers), on the device results; and the inverse handle of the same convention brings the input back."""
+    import numpy as np
+    field, logn = "BLS381", 27
+    n = 1 << logn
+    r = pyref.CURVES[field]["r"]
+    threads = max(1, min(64, (os.cpu_count() or 8)))
+    d_in = DeviceBuffer(0, 32 * n)
+    blaze_amd._lib.check(blaze_amd.aux().blz_synth_field_elements(0, d_in.ptr, n, 2727))
+    x = np.frombuffer(d_in.download(), dtype=np.uint8)
+    root = _nonres_root(orc, field, logn, 5)
+    both = NTTClient.BITREV_INPUT | NTTClient.BITREV_OUTPUT
+
+    def run(flags, rt, src):
+        cl = NTTClient(NTT.Ntt, DriverClient(0), log_size=logn, flags=flags | NTTClient.NO_FACTOR_TABLE, root=rt)
+        cl.set_data(NTTInput(0, src)); cl.initialize(NttInit()); cl.start_process(0); cl.wait_result()
+        out = np.frombuffer(cl.result(0), dtype=np.uint8)
+        ms = cl.last_kernel_ms()
+        cl.close()
+        return out, ms
+
+    y_bb, ms_bb = run(both, root, d_in)
+    exp = np.frombuffer(orc.ntt(field, x, logn, threads=threads, root=root, bitrev_in=True, bitrev_out=True), dtype=np.uint8)
+    assert np.array_equal(y_bb, exp), "2^27, caller's root, bit-reversed in and out: differs from the oracle"
+    del exp
+    # natural in / out under the same root: the same transform of the permuted buffer, permuted back
+    d_xp = DeviceBuffer(0, 32 * n)
+    d_xp.upload(orc.bitrev_permute(x, logn, threads))                                   # xp[p] = x[bitrev(p)]: read as a bit-reversed buffer, x IS the sequence xp
+    y_nn, ms_nn = run(0, root, d_xp)                                                    # natural-order transform of xp ...
+    y_bn, ms_bn = run(NTTClient.BITREV_INPUT, root, d_in)                               # ... = bit-reversed-input transform of x
+    assert np.array_equal(y_nn, y_bn)
+    del y_bn
+    y_nb, ms_nb = run(NTTClient.BITREV_OUTPUT, root, d_xp)
+    d_xp.free()
+    assert np.array_equal(y_nb, y_bb)                                                   # (both flags on x = the transform of xp, written bit-reversed)
+    del y_nb
+    assert np.array_equal(np.frombuffer(orc.bitrev_permute(y_nn, logn, threads), dtype=np.uint8), y_bb)
+    # the second root: w' = w^3: X'[k] = X[3 k mod n], checked on a strided sample of 2^20 outputs and on the default root's handle
+    root2 = pow(root, 3, r)
+    y2, _ = run(NTTClient.BITREV_INPUT, root2, d_in)
+    ks = (np.arange(1 << 20, dtype=np.uint64) * 127 + 5) % n
+    assert np.array_equal(y2.reshape(n, 32)[ks], y_nn.reshape(n, 32)[(3 * ks) % n])
+    del y2
+    # inverse of the same convention
+    d_y = DeviceBuffer(0, 32 * n)
+    d_y.upload(y_bb)
+    z, _ = run(both | NTTClient.INVERSE, root, d_y)
+    assert np.array_equal(z, x), "inverse(forward(x)) != x under the caller's convention"
+    d_y.free(); d_in.free()
+    print(f"[2^27 kernel ms] natural/natural {ms_nn:.2f}  bitrev-in {ms_bn:.2f}  bitrev-out {ms_nb:.2f}  both {ms_bb:.2f}")

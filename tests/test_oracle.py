@@ -140,3 +140,28 @@ def test_oracle_under_sanitizers():
     p = subprocess.run([os.path.join(odir, "selftest_asan")], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "oracle selftest ok" in p.stdout
+
+
+def test_ntt_conventions_against_naive_sums(orc):
+    """orc_ntt_ex (a caller's root, bit-reversed buffers, inverse) against the definition evaluated with Python integers."""
+    import random
+
+    rng = random.Random(1)
+    for curve in ("BLS381", "BLS377", "BN254"):
+        r = pyref.CURVES[curve]["r"]
+        for logn in (1, 3, 6):
+            n = 1 << logn
+            xs = [rng.randrange(r) for _ in range(n)]
+            data = b"".join(x.to_bytes(32, "little") for x in xs)
+            w = orc.omega(curve, logn)
+            br = lambda i: int(format(i, f"0{logn}b")[::-1], 2)   # noqa: E731
+            for t in (1, 3, 5):
+                wt = pow(w, t, r)
+                exp = [sum(xs[i] * pow(wt, i * k, r) for i in range(n)) % r for k in range(n)]
+                got = orc.ntt(curve, data, logn, root=wt)
+                assert bytes(got) == b"".join(e.to_bytes(32, "little") for e in exp), (curve, logn, t)
+                din = b"".join(xs[br(p)].to_bytes(32, "little") for p in range(n))
+                got2 = orc.ntt(curve, din, logn, root=wt, bitrev_in=True, bitrev_out=True)
+                assert bytes(got2) == b"".join(exp[br(p)].to_bytes(32, "little") for p in range(n))
+                assert bytes(orc.bitrev_permute(data, logn, 2)) == din
+                assert bytes(orc.ntt(curve, bytes(got), logn, inverse=True, root=wt)) == data
