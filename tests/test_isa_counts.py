@@ -61,8 +61,8 @@ def test_ntt_pass_multiply_adds(disasm):
     assert want[2] <= got[2] <= want[2] + 8 * 153, (got, want)                # + the inverse transform's n^-1 products
     stepped = function_instructions(disasm, "_ZN3blz11k_ntt512_rrINS_9Fr_BLS381ELi2ELb0EEEvPKjPjNS_7NttGeomENS_11NttTablesRRE")
     assert abs(count(stepped, "v_mad_u64_u32") - (36 * 143 + 10 * 153 + 2 * 9)) <= 8
-    src = open(os.path.join(ROOT, "bench.py")).read()
-    # bench.py prices the transform with these very counts, picking pass 2's by what blz_ntt_info reports for the handle it times
+    src = open(os.path.join(ROOT, "bench_extras.py")).read()
+    # bench.py's NTT leg (bench_extras.py) prices the transform with these very counts, picking pass 2's by what blz_ntt_info reports for the handle it times
     assert "pass2_table, pass2_stepped = 29 * 143 + 8 * 153 + 2 * 9, 36 * 143 + 10 * 153 + 2 * 9" in src
     assert '(37 * 143 + 2 * 9) + (pass2_table if ninfo["pass2_factor_table"] else pass2_stepped) + (29 * 143 + 10 * 9)' in src
 

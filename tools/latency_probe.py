@@ -26,6 +26,10 @@ L.blz_arena_release(0)
 cl = MSMClient(MSMInit(PointMemoryType.HBM, False, Curve[curve]), DriverClient(0))
 cl.load_data_to_hbm(dp, 0, 0)
 params = MSMParams(n, (0, 0))
+table = os.environ.get("TABLE", "0") != "0"     # TABLE=1: the resident-base window table (opt-in), paid up front
+if table:
+    cl.set_window_table(2)
+    print("window table ready:", cl.prepare_window_table(n, (0, 0)), cl.window_table_info() if hasattr(cl, "window_table_info") else "")
 ts, dev, calls = [], [], []
 inp = MSMInput(None, ds, params)
 for k in range(reps + 2):
@@ -40,6 +44,6 @@ for k in range(reps + 2):
         calls.append([(b - a) * 1e3 for a, b in ((t0, t1), (t1, t2), (t2, t3), (t3, t4), (t4, t5))])
         dev.append(cl.get_api()["total_ms"])
 a = cl.get_api()
-print(f"{curve} 2^{logn} one at a time: wall {statistics.median(ts):.3f} ms, device pipeline {statistics.median(dev):.3f} ms "
+print(f"{curve} 2^{logn}{' (window table)' if table else ''} one at a time: wall {statistics.median(ts):.3f} ms, device pipeline {statistics.median(dev):.3f} ms "
       f"[calls: " + " ".join(f"{n} {statistics.median(c[i] for c in calls):.3f}" for i, n in enumerate(("initialize", "start", "set_data", "wait", "result"))) + "] "
       f"(sort {a['sort_ms']:.2f}, accumulate {a['accumulate_kernel_ms']:.2f}, reduce {a['phase2_reduce_ms']:.2f}, finish {a['phase3_final_ms']:.2f})")
