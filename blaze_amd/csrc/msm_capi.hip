@@ -27,6 +27,9 @@ int blz_msm_new(int device_id, int mem_type, int is_precompute, int curve, blz_m
     for (int i = 0; i < 2 && rc == BLZ_OK; ++i)
         if (hipEventCreateWithFlags(&h->set_free[i], hipEventDisableTiming) != hipSuccess)
             rc = fail_hip(BLZ_ERR_UNKNOWN, "event creation failed");
+    for (int i = 0; i < blz_msm::PieceRing::SLOTS && rc == BLZ_OK; ++i)
+        if (hipEventCreateWithFlags(&h->ring.raw_read[i], hipEventDisableTiming) != hipSuccess)
+            rc = fail_hip(BLZ_ERR_UNKNOWN, "event creation failed");
     if (rc != BLZ_OK) {
         h->eng.destroy();
         delete h;
@@ -51,6 +54,10 @@ void blz_msm_free(blz_msm* h) {
         if (h->set_free[i]) (void)hipEventDestroy(h->set_free[i]);
     }
     h->points_mont.release();
+    h->ring.raw.release();
+    h->ring.mont.release();
+    for (hipEvent_t& e : h->ring.raw_read)
+        if (e) (void)hipEventDestroy(e);
     delete h;
 }
 
@@ -367,7 +374,7 @@ int blz_msm_memory_info(blz_msm* h, uint64_t out[6]) {
         for (const DevBuf* b : {&B.count, &B.off, &B.unit_off, &B.unit_bucket, &B.unit_order, &B.lenhist, &B.entries, &B.stats, &B.range_scalars}) ws += b->cap;
     for (const auto& S : E.slots)
         for (const DevBuf* b : {&S.lvlA[0], &S.lvlA[1], &S.lvlC[0], &S.lvlC[1]}) ws += b->cap;
-    uint64_t staging = h->points_mont.cap + h->comm_buf.cap;
+    uint64_t staging = h->points_mont.cap + h->comm_buf.cap + h->ring.raw.cap + h->ring.mont.cap;
     for (int i = 0; i < 2; ++i) staging += h->scalars_buf[i].cap + h->points_raw[i].cap;
     uint64_t raw = 0, mont = 0, tables = 0;
     {

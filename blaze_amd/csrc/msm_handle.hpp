@@ -40,6 +40,20 @@ struct blz_msm {
     bool staged_from_arena = false;
     bool staged_loaded_now = false;   // this set_data also loaded the bases (mode iii: points + hbm address)
     uint64_t staged_arena_pos = 0;
+    // Tasks whose points arrive over the link and are consumed piece by piece (DMA mode: one-call and streamed tasks): a piece's raw
+    // points and their Montgomery copy live in a slot of a small ring, not in buffers of the whole task's size - 4 x (96 + 128) bytes
+    // x the piece instead of 48 + 64 GiB for the reference's largest shape (whose allocation alone took the first task 4 s).  A
+    // slot's raw bytes may be overwritten once the to-Montgomery pass that read them is through (raw_read, recorded on the main
+    // stream; the copy stream waits for it); its Montgomery copy is rewritten by a later piece's pass on the same main stream,
+    // behind the accumulation that gathered from it.
+    struct PieceRing {
+        static constexpr int SLOTS = 4;
+        blz::DevBuf raw, mont;
+        uint64_t slot_pts = 0;                // points a slot holds (grows to the largest piece seen)
+        hipEvent_t raw_read[SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+        bool recorded[SLOTS] = {false, false, false, false};
+        uint64_t next = 0;                    // pieces handed out so far: piece -> slot next % SLOTS
+    } ring;
     // A task fed by SEVERAL set_data calls (msm_stage.hip stage_stream): the card takes a task's scalars and points through FIFOs and
     // counts elements against NUMBER_OF_MSM_ELEMENTS (msm_api.rs:155-202, msm_hw_code.rs:18-19), so any split of an armed task's
     // bytes over calls is the same task.  SURVEY.md 8(b): {armed_n, received}, launch when received == armed_n.
@@ -55,6 +69,7 @@ struct blz_msm {
         int pieces = 0, next_piece = 0;
         uint32_t ppe = 1;          // points per element as the engine counts them (1; 8; 4 on the checked-table plan)
         uint32_t npts = 0, done_pts = 0;   // points of the task / handed to the engine so far
+        uint64_t ring_first = 0;   // mode 2 in pieces: ring piece number of the task's piece 0
         int sbits = 0;
         bool even = false;         // checked-table plan: pieces gather from the even-base copy
         uint64_t arena_pos = 0;    // modes 1 and 3: where the task's bases start
@@ -121,6 +136,7 @@ int resolve_arena_task(blz_msm* h, uint64_t pos, uint32_t n, bool allow_table, b
 int launch_if_ready(blz_msm* h);
 int stage_stream(blz_msm* h, bool have_points, const void* points, size_t points_len, const void* scalars, size_t scalars_len, uint32_t m,
                  int has_hbm, uint64_t hbm_addr, uint64_t hbm_off, bool on_device);
+int ring_reserve(blz_msm* h, uint32_t piece_pts);   // the ring's slots hold pieces of piece_pts points
 void stream_abandon(blz_msm* h);   // give up a half-fed task (reset, a failed slice)
 int stage_common(blz_msm* h, bool have_points, const void* points, size_t points_len, const void* scalars, size_t scalars_len, uint32_t n,
                  int has_hbm, uint64_t hbm_addr, uint64_t hbm_off, bool on_device);

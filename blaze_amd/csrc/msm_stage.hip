@@ -53,6 +53,44 @@ static int pick_pieces(const blz_msm* h, uint32_t npts, bool with_points) {
     return pieces < 1 ? 1 : pieces;
 }
 
+int ring_reserve(blz_msm* h, uint32_t piece_pts) {
+    blz_msm::PieceRing& R = h->ring;
+    if (piece_pts <= R.slot_pts) return BLZ_OK;
+    // (a growing ring is reallocated behind a bounded drain of the device - DevBuf::reserve - so no piece in flight reads the old one)
+    const size_t ps = point_size(h), mp = mont_point_bytes(h->curve);
+    BLZ_TRY(R.raw.reserve((size_t)piece_pts * blz_msm::PieceRing::SLOTS * ps + 16, true));
+    BLZ_TRY(R.mont.reserve((size_t)piece_pts * blz_msm::PieceRing::SLOTS * mp + 16, true));
+    R.slot_pts = piece_pts;
+    for (bool& r : R.recorded) r = false;
+    return BLZ_OK;
+}
+
+// piece `k` of the ring (a running number): where its raw points and their Montgomery copy go; the copy stream is ordered behind
+// the to-Montgomery pass that last read the slot
+static int ring_slot(blz_msm* h, uint64_t k, char** raw, char** mont) {
+    blz_msm::PieceRing& R = h->ring;
+    const int slot = (int)(k % blz_msm::PieceRing::SLOTS);
+    *raw = (char*)R.raw.p + (size_t)slot * R.slot_pts * point_size(h);
+    *mont = (char*)R.mont.p + (size_t)slot * R.slot_pts * mont_point_bytes(h->curve);
+    return slot;
+}
+static int ring_wait_free(blz_msm* h, uint64_t k) {
+    blz_msm::PieceRing& R = h->ring;
+    const int slot = (int)(k % blz_msm::PieceRing::SLOTS);
+    if (R.recorded[slot]) BLZ_HIP(hipStreamWaitEvent(h->copy_stream, R.raw_read[slot], 0), BLZ_ERR_UNKNOWN);
+    return BLZ_OK;
+}
+// the piece's raw points -> Montgomery copy on the main stream; the slot's raw bytes are free behind it
+static int ring_to_mont(blz_msm* h, uint64_t k, uint32_t np) {
+    blz_msm::PieceRing& R = h->ring;
+    char *raw = nullptr, *mont = nullptr;
+    const int slot = ring_slot(h, k, &raw, &mont);
+    BLZ_TRY(h->eng.points_to_mont(raw, mont, np));
+    BLZ_HIP(hipEventRecord(R.raw_read[slot], h->eng.stream), BLZ_ERR_UNKNOWN);
+    R.recorded[slot] = true;
+    return BLZ_OK;
+}
+
 int stage_common(blz_msm* h, bool have_points, const void* points, size_t points_len, const void* scalars,
                  size_t scalars_len, uint32_t n, int has_hbm, uint64_t hbm_addr, uint64_t hbm_off, bool on_device) {
     if (!h) return fail(BLZ_ERR_INVALID_PARAM, "null handle");
@@ -140,10 +178,7 @@ int stage_common(blz_msm* h, bool have_points, const void* points, size_t points
         const void* arena_mont = nullptr;
         memset(h->table_info, 0, sizeof(h->table_info));
         memset(h->pc_info, 0, sizeof(h->pc_info));
-        if (dma_pieces) {
-            BLZ_TRY(h->points_raw[set].reserve(want_pts));
-            BLZ_TRY(h->points_mont.reserve((size_t)npts * mp));
-        } else {
+        if (!dma_pieces) {
             // (stale spans are converted on the main stream; a precompute handle on the checked-table plan: 4n even bases, 64-bit chunks)
             int tc = 0;
             BLZ_TRY(resolve_arena_task(h, h->staged_arena_pos, n, false, !h->staged_loaded_now, &npts, &sbits, &tc));
@@ -156,7 +191,7 @@ int stage_common(blz_msm* h, bool have_points, const void* points, size_t points
         BLZ_TRY(h->eng.begin(npts, sbits, &slot, 0, h->range_lo, h->range_hi, pieces, true));
         const uint32_t per = h->eng.slots[slot].pts_per_slice;
         pieces = h->eng.slots[slot].slices;
-        int rc = BLZ_OK;
+        int rc = dma_pieces ? ring_reserve(h, per) : BLZ_OK;
         auto copy_in = [&](void* dst, const void* src, size_t len, const char* what) -> int {
             if (hipMemcpyAsync(dst, src, len, hipMemcpyHostToDevice, cst) != hipSuccess) return fail_hip(BLZ_ERR_WRITE, "%s failed", what);
             // the caller may drop its buffers as soon as we return (set_data is synchronous: utils.rs:71), and the piece's
@@ -174,11 +209,16 @@ int stage_common(blz_msm* h, bool have_points, const void* points, size_t points
             rc = copy_in(d_sc, (const char*)scalars + (size_t)p0 * sb, (size_t)np * sb, "set_data: host -> device copy of the scalars");
             if (rc == BLZ_OK) rc = h->eng.sort_slice(slot, k, d_sc, np);
             if (dma_pieces) {
-                char* d_raw = (char*)h->points_raw[set].p + (size_t)p0 * ps;
-                char* d_mont = (char*)h->points_mont.p + (size_t)p0 * mp;
+                const uint64_t rk = h->ring.next;
+                char *d_raw = nullptr, *d_mont = nullptr;
+                if (rc == BLZ_OK) {
+                    (void)ring_slot(h, rk, &d_raw, &d_mont);
+                    rc = ring_wait_free(h, rk);
+                }
                 if (rc == BLZ_OK) rc = copy_in(d_raw, (const char*)points + (size_t)p0 * ps, (size_t)np * ps, "set_data: host -> device copy of the points");
-                if (rc == BLZ_OK) rc = h->eng.points_to_mont(d_raw, d_mont, np);
+                if (rc == BLZ_OK) rc = ring_to_mont(h, rk, np);
                 if (rc == BLZ_OK) rc = h->eng.accumulate_slice(slot, k, d_mont);
+                if (rc == BLZ_OK) h->ring.next = rk + 1;
             } else if (rc == BLZ_OK) {
                 rc = h->eng.accumulate_slice(slot, k, (const char*)arena_mont + (size_t)p0 * mp);
             }
@@ -189,7 +229,7 @@ int stage_common(blz_msm* h, bool have_points, const void* points, size_t points
             return rc;
         }
         h->d_scalars = h->scalars_buf[set].p;
-        h->d_points_mont = dma_pieces ? h->points_mont.p : arena_mont;
+        h->d_points_mont = dma_pieces ? nullptr : arena_mont;   // (a DMA task's points lived in the ring, piece by piece)
         h->staged_n = n;
         h->set_used[set] = true;
         h->staged_set = -1;
@@ -254,7 +294,7 @@ void stream_abandon(blz_msm* h) {
 static int stream_pump(blz_msm* h) {
     blz_msm::Stream& S = h->strm;
     if (S.slot < 0) return BLZ_OK;
-    const size_t mp = mont_point_bytes(h->curve), ps = point_size(h), sb = (size_t)S.sbits / 8;
+    const size_t mp = mont_point_bytes(h->curve), sb = (size_t)S.sbits / 8;
     const uint32_t avail = S.received * S.ppe;
     while (S.done_pts < avail && (avail - S.done_pts >= S.per || S.received == S.total)) {
         const uint32_t np = avail - S.done_pts < S.per ? avail - S.done_pts : S.per;
@@ -262,9 +302,9 @@ static int stream_pump(blz_msm* h) {
         const char* d_sc = (const char*)h->scalars_buf[S.set].p + (size_t)S.done_pts * sb;
         BLZ_TRY(h->eng.sort_slice(S.slot, k, d_sc, np));
         if (S.mode == 2) {
-            const char* d_raw = (const char*)h->points_raw[S.set].p + (size_t)S.done_pts * ps;
-            char* d_mont = (char*)h->points_mont.p + (size_t)S.done_pts * mp;
-            BLZ_TRY(h->eng.points_to_mont(d_raw, d_mont, np));
+            char *d_raw = nullptr, *d_mont = nullptr;
+            (void)ring_slot(h, S.ring_first + (uint64_t)k, &d_raw, &d_mont);
+            BLZ_TRY(ring_to_mont(h, S.ring_first + (uint64_t)k, np));
             BLZ_TRY(h->eng.accumulate_slice(S.slot, k, d_mont));
         } else {
             // the extent's copy as it stands NOW: a load between two slices may have moved the extent or rewritten bases (their
@@ -329,10 +369,6 @@ int stage_stream(blz_msm* h, bool have_points, const void* points, size_t points
         N.set = h->stage_idx;
         if (h->set_used[N.set]) BLZ_HIP(hipStreamWaitEvent(cst, h->set_free[N.set], 0), BLZ_ERR_UNKNOWN);
         BLZ_TRY(h->scalars_buf[N.set].reserve((size_t)total * BLZ_SCALAR_SIZE));
-        if (mode == 2) {
-            BLZ_TRY(h->points_raw[N.set].reserve((size_t)N.npts * ps));
-            BLZ_TRY(h->points_mont.reserve((size_t)N.npts * mp));
-        }
         // in pieces?  The rules of a one-call task (stage_common): DMA mode always, scalars over resident bases when the handle is
         // idle and the task large; a task that brings its table (mode 3) is launched whole behind its last slice
         const bool overlap = exp_knob("BLAZE_DMA_OVERLAP", 1) != 0;
@@ -359,10 +395,25 @@ int stage_stream(blz_msm* h, bool have_points, const void* points, size_t points
                 if (N.pieces <= 1) {   // (the engine made one piece of it: the whole-task launch serves that)
                     h->eng.abandon(N.slot);
                     N.slot = -1;
+                } else if (mode == 2) {
+                    // the task's pieces take consecutive numbers of the handle's piece ring (stage_common's one-call tasks too)
+                    const int rrc = ring_reserve(h, N.per);
+                    if (rrc != BLZ_OK) {
+                        h->eng.abandon(N.slot);
+                        return rrc;
+                    }
+                    N.ring_first = h->ring.next;
+                    h->ring.next += (uint64_t)N.pieces;
                 }
             }
         }
-        if (N.slot < 0) { N.npts = total * h->pf; N.sbits = h->pf == 1 ? 256 : 32; N.ppe = h->pf; N.even = false; }
+        if (N.slot < 0) {
+            N.npts = total * h->pf; N.sbits = h->pf == 1 ? 256 : 32; N.ppe = h->pf; N.even = false;
+            if (mode == 2) {   // launched whole behind its last slice: buffers of the task's size (small tasks, BLAZE_MSM_PIECES=1)
+                BLZ_TRY(h->points_raw[N.set].reserve((size_t)N.npts * ps));
+                BLZ_TRY(h->points_mont.reserve((size_t)N.npts * mp));
+            }
+        }
         h->stage_idx ^= 1;
         N.open = true;
         S = N;
@@ -383,17 +434,44 @@ int stage_stream(blz_msm* h, bool have_points, const void* points, size_t points
     // waits; a failure from here on loses the task (bytes of it may be missing): the stream is given up, the task stays armed
     // and may be sent again from its first element
     int rc = BLZ_OK;
-    if (m) {
+    auto land = [&](const char* what) {   // what was enqueued must land before the caller's buffers go - also when an enqueue failed
+        wait_clear();
+        const int wrc = sync_stream_bounded(cst, what);
+        if (wrc != BLZ_OK && wait_timed_out()) h->wedged = true;
+        if (rc == BLZ_OK) rc = wrc;
+    };
+    if (m && mode == 2 && S.slot >= 0) {
+        // points + scalars of a task enqueued in pieces: the scalars to their place in the task's buffer, the points PART BY PART into
+        // the ring slots of the pieces they belong to (a slice may end in the middle of a piece, or span several), each part's pieces
+        // handed to the engine before the next part is copied - a ring slot is only free once its previous piece has been consumed
+        char* d_sc = (char*)h->scalars_buf[S.set].p + (size_t)S.received * BLZ_SCALAR_SIZE;
+        if (hipMemcpyAsync(d_sc, scalars, scalars_len, hipMemcpyDefault, cst) != hipSuccess) rc = fail_hip(BLZ_ERR_WRITE, "set_data: copy of the scalars failed");
+        uint32_t off = 0;   // elements of this slice already copied
+        while (rc == BLZ_OK && off < m) {
+            const uint64_t at_pts = (uint64_t)S.received * S.ppe;          // (S.received moves with every part)
+            const uint32_t k = (uint32_t)(at_pts / S.per), fill = (uint32_t)(at_pts % S.per);
+            uint32_t take = (S.per - fill) / S.ppe;                        // elements that still fit into piece k (per is a multiple of 16 points: whole elements)
+            if (take > m - off) take = m - off;
+            char *d_raw = nullptr, *d_mont = nullptr;
+            (void)ring_slot(h, S.ring_first + k, &d_raw, &d_mont);
+            if (fill == 0) rc = ring_wait_free(h, S.ring_first + k);
+            if (rc == BLZ_OK && hipMemcpyAsync(d_raw + (size_t)fill * ps, (const char*)points + (size_t)off * h->pf * ps, (size_t)take * h->pf * ps, hipMemcpyDefault, cst) != hipSuccess)
+                rc = fail_hip(BLZ_ERR_WRITE, "set_data: copy of the points failed");
+            land("set_data: copy of a slice of the task");
+            if (rc != BLZ_OK) break;
+            S.received += take;
+            off += take;
+            rc = stream_pump(h);
+        }
+        if (rc != BLZ_OK && off == 0) land("set_data: copy of a slice of the task");
+    } else if (m) {
         char* d_sc = (char*)h->scalars_buf[S.set].p + (size_t)S.received * BLZ_SCALAR_SIZE;
         if (hipMemcpyAsync(d_sc, scalars, scalars_len, hipMemcpyDefault, cst) != hipSuccess) rc = fail_hip(BLZ_ERR_WRITE, "set_data: copy of the scalars failed");
         if (rc == BLZ_OK && mode == 2) {
             char* d_raw = (char*)h->points_raw[S.set].p + (size_t)S.received * h->pf * ps;
             if (hipMemcpyAsync(d_raw, points, points_len, hipMemcpyDefault, cst) != hipSuccess) rc = fail_hip(BLZ_ERR_WRITE, "set_data: copy of the points failed");
         }
-        wait_clear();
-        const int wrc = sync_stream_bounded(cst, "set_data: copy of a slice of the task");   // (also when an enqueue failed: what was enqueued must land before the caller's buffers go)
-        if (wrc != BLZ_OK && wait_timed_out()) h->wedged = true;
-        if (rc == BLZ_OK) rc = wrc;
+        land("set_data: copy of a slice of the task");
         if (rc == BLZ_OK && mode == 3) {
             wait_clear();
             rc = arena_write(h->device, hbm_addr + hbm_off, points, points_len, on_device, h->eng.stream);
@@ -401,7 +479,7 @@ int stage_stream(blz_msm* h, bool have_points, const void* points, size_t points
             if (rc == BLZ_OK) { h->bases_from_hbm = true; h->hbm_addr = hbm_addr; }
         }
     }
-    if (rc == BLZ_OK) {
+    if (rc == BLZ_OK && !(mode == 2 && S.slot >= 0)) {
         S.received += m;
         rc = stream_pump(h);
     }
@@ -419,7 +497,7 @@ int stage_stream(blz_msm* h, bool have_points, const void* points, size_t points
             stream_abandon(h);
             return rc;
         }
-        h->d_points_mont = S.mode == 2 ? h->points_mont.p : nullptr;
+        h->d_points_mont = nullptr;
         h->set_used[S.set] = true;
         h->staged_set = -1;
         h->armed = false;
