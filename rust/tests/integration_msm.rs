@@ -73,3 +73,40 @@ fn msm_task_queue_two_in_flight() {
     // nothing armed: the reference would spin forever, this build reports it
     assert!(driver.wait_result().is_err());
 }
+
+#[test]
+fn msm_task_fed_by_several_set_data_calls() {
+    // The reference's set_data walks its input in 2048-element chunks into the card's FIFOs and the card counts elements against
+    // NUMBER_OF_MSM_ELEMENTS (/root/reference/src/ingo_msm/msm_api.rs:155-202, msm_hw_code.rs:18-19): a queued task may be fed by
+    // any number of set_data calls; it is complete when the counts add up.
+    let id = env::var("ID").unwrap_or_else(|_| 0.to_string());
+    for v in common::msm_vectors().into_iter().filter(|v| v.n >= 3) {
+        let driver = MSMClient::new(
+            MSMInit { mem_type: PointMemoryType::DMA, is_precompute: v.pf == PRECOMPUTE_FACTOR, curve: v.curve },
+            DriverClient::new(&id, DriverConfig::driver_client_cfg(CardType::C1100)),
+        );
+        let per_elem = v.points.len() / v.n as usize;
+        driver.initialize(MSMParams { nof_elements: v.n, hbm_point_addr: None }).unwrap();
+        driver.start_process(None).unwrap();
+        let cuts = [0u32, 1, v.n / 2, v.n];
+        for w in cuts.windows(2) {
+            let (a, b) = (w[0] as usize, w[1] as usize);
+            assert_eq!(driver.stream_progress().unwrap(), (if a == 0 { 0 } else { a as u32 }, v.n));
+            driver
+                .set_data(MSMInput {
+                    points: Some(v.points[a * per_elem..b * per_elem].to_vec()),
+                    scalars: v.scalars[a * 32..b * 32].to_vec(),
+                    params: MSMParams { nof_elements: (b - a) as u32, hbm_point_addr: None },
+                })
+                .unwrap();
+            if b < v.n as usize {
+                // a half-fed task: start_process and wait_result are refused, over-feeding too
+                assert!(driver.start_process(None).is_err());
+                assert!(driver.wait_result().is_err());
+            }
+        }
+        assert_eq!(driver.stream_progress().unwrap(), (0, 0));
+        driver.wait_result().unwrap();
+        assert_eq!(driver.result(None).unwrap().unwrap().result, v.result, "{:?} pf={} {}", v.curve, v.pf, v.name);
+    }
+}

@@ -48,14 +48,41 @@ static int run_ntt(const std::vector<uint8_t>& input, int logn, const char* out_
     std::printf("ntt log_size %llu device_bytes %llu\n", (unsigned long long)info[3], (unsigned long long)info[0]);
     return 0;
 }
+// mode "stream": the same task fed by several set_data calls (blaze_hip.h "STREAMED TASKS": the reference's chunk loop,
+// msm_api.rs:155-202, in the caller's hands): slices of 1, n / 3 and the rest; a half-fed task refuses wait_result
+static int run_stream(const std::vector<uint8_t>& points, const std::vector<uint8_t>& scalars, uint32_t n, const char* out_path) {
+    DriverClient dclient(0, DriverConfig::driver_client_cfg(CardType::MI355X));
+    MSMClient driver(MSMInit{PointMemoryType::DMA, false, Curve::BLS381}, dclient);
+    driver.initialize(MSMParams{n, std::nullopt});
+    driver.start_process();
+    const size_t ps = points.size() / n;
+    const uint32_t cuts[4] = {0, 1, n / 3 > 1 ? n / 3 : 2, n};
+    int refused = 0;
+    for (int i = 0; i < 3; ++i) {
+        const uint32_t a = cuts[i], b = cuts[i + 1];
+        MSMInput in{std::vector<uint8_t>(points.begin() + a * ps, points.begin() + b * ps),
+                    std::vector<uint8_t>(scalars.begin() + a * 32, scalars.begin() + b * 32), MSMParams{b - a, std::nullopt}};
+        driver.set_data(in);
+        if (b < n) {
+            try { driver.wait_result(); } catch (const DriverClientError&) { ++refused; }
+            if (driver.stream_progress() != std::make_pair(b, n)) return 3;
+        }
+    }
+    driver.wait_result();
+    MSMResult r = *driver.result();
+    std::ofstream(out_path, std::ios::binary).write((const char*)r.result.data(), r.result.size());
+    std::printf("streamed label %u bytes %zu refused %d\n", r.result_label, r.result.size(), refused);
+    return 0;
+}
 int main(int argc, char** argv) {
-    if (argc < 5) { std::fprintf(stderr, "usage: %s points.bin scalars.bin n out.bin [plan|ntt]\n", argv[0]); return 2; }
+    if (argc < 5) { std::fprintf(stderr, "usage: %s points.bin scalars.bin n out.bin [plan|ntt|stream]\n", argv[0]); return 2; }
     try {
         auto points = slurp(argv[1]);
         auto scalars = slurp(argv[2]);
         uint32_t msm_size = (uint32_t)std::stoul(argv[3]);
         if (argc > 5 && std::string(argv[5]) == "plan") return run_plan(points, scalars, msm_size, argv[4]);
         if (argc > 5 && std::string(argv[5]) == "ntt") return run_ntt(points, (int)msm_size, argv[4]);
+        if (argc > 5 && std::string(argv[5]) == "stream") return run_stream(points, scalars, msm_size, argv[4]);
         DriverClient dclient(0, DriverConfig::driver_client_cfg(CardType::MI355X));
         MSMClient driver(MSMInit{PointMemoryType::DMA, false, Curve::BLS381}, dclient);
         MSMParams params{msm_size, std::nullopt};

@@ -71,7 +71,7 @@ for b in range(bursts):
         off = rng.choice([0, 0, 0, ps[c] * 8 * rng.randrange(0, 64), 1 << 40, 7])
         hbm = None if kind == "dma" and rng.random() < 0.8 else (addr, off)
         op = rng.choice(("initialize", "start", "set_data", "set_data", "set_data_dev", "wait", "result", "load", "get", "range", "table", "plan",
-                         "prepare_table", "prepare_plan", "info", "reset"))
+                         "prepare_table", "prepare_plan", "info", "reset", "stream_task"))
         m = n if rng.random() < 0.8 else rng.choice([0, 1, 77, NMAX])   # (a set_data that does not match the initialize before it)
         pts_len = m * pf * ps[c]
         if op == "initialize":
@@ -108,6 +108,33 @@ for b in range(bursts):
             attempt(lambda: cl.prepare_precompute_plan(n, (addr, off)))
         elif op == "info":
             attempt(lambda: (cl.get_api(), cl.memory_info(), cl.window_table_info(), cl.precompute_plan_info(), cl.is_msm_engine_ready()))
+        elif op == "stream_task":
+            # a whole task fed by several set_data calls (blaze_hip.h "STREAMED TASKS") in the middle of whatever state the client is
+            # in - behind a reset, so that its result can be checked; DMA-mode clients only (the bursts rewrite the arenas' bases)
+            if kind != "dma":
+                continue
+            cl.reset()
+            cl.set_scalar_range(0, 0)
+            ns = rng.choice([1, 2, 255, 1000, 4096, NMAX])
+            cl.initialize(MSMParams(ns, None)); cl.start_process()
+            at = 0
+            while at < ns:
+                mm = min(ns - at, rng.choice([0, 1, 7, 100, 2048, 4097, ns]))
+                cl.set_data(MSMInput(host[c][0][at * ps[c]: (at + mm) * ps[c]], host[c][1][at: at + mm].tobytes(), MSMParams(mm, None)))
+                at += mm
+                if at < ns and rng.random() < 0.1:     # calls a half-fed task refuses, or ignores
+                    for f in (cl.start_process, cl.wait_result, lambda: cl.set_data(MSMInput(None, b"", MSMParams(0, None))),
+                              lambda: cl.set_data(MSMInput(host[c][0][: ps[c] * (ns - at + 1)], host[c][1][: ns - at + 1].tobytes(), MSMParams(ns - at + 1, None)))):
+                        attempt(f)
+                    assert cl.stream_progress() == (at, ns), (cl.stream_progress(), at, ns)
+            cl.wait_result()
+            got = cl.result().result
+            counts["streamed"] = counts.get("streamed", 0) + 1
+            if (c, ns) not in known:
+                known[(c, ns)] = expected(c, ns)
+            if got != known[(c, ns)]:
+                bad += 1
+                print("MISMATCH streamed task", b, c, ns, flush=True)
         else:
             attempt(cl.reset)
     # every client back to a known state, then a known task

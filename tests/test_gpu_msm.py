@@ -556,6 +556,10 @@ def test_cpp_host_mirror(gpu, orc, tmp_path):
     out = tmp_path / "r.bin"
     subprocess.check_call([exe, str(tmp_path / "p.bin"), str(tmp_path / "s.bin"), str(n), str(out)])
     assert out.read_bytes() == exp
+    # the same task fed by three set_data calls (round 6: streamed tasks), a half-fed task refusing wait_result twice
+    out.write_bytes(b"")
+    said = subprocess.check_output([exe, str(tmp_path / "p.bin"), str(tmp_path / "s.bin"), str(n), str(out), "stream"], text=True)
+    assert out.read_bytes() == exp and said.startswith("streamed label 1 bytes 144 refused 2"), said
     # the round-5 additions through the same mirror: a precompute client on the checked-table plan with its memory figures ...
     n8 = 900
     pts8, sc8, exp8 = orc.input_generator("BN254", n8, 8, 33)
