@@ -82,8 +82,18 @@ def worker(t):
                     prm = MSMParams(n, hbm)
                     pts = host[c][0][: n * ps[c]] if kind == "dma" else None
                     two = rng.random() < 0.5
+                    sliced = rng.random() < 0.35       # the task fed by several set_data calls (streamed tasks), any client kind
                     for _k in range(2 if two else 1):
-                        cl.initialize(prm); cl.start_process(); cl.set_data(MSMInput(pts, host[c][1][:n].tobytes(), prm))
+                        cl.initialize(prm); cl.start_process()
+                        if not sliced:
+                            cl.set_data(MSMInput(pts, host[c][1][:n].tobytes(), prm))
+                            continue
+                        at = 0
+                        while at < n:
+                            m = min(n - at, rng.choice((1, 2048, n // 3 + 1, n)))
+                            sp = None if pts is None else pts[at * ps[c]: (at + m) * ps[c]]
+                            cl.set_data(MSMInput(sp, host[c][1][at: at + m].tobytes(), MSMParams(m, hbm)))
+                            at += m
                     for _k in range(2 if two else 1):
                         cl.wait_result()
                         if cl.result().result != known[(c, n)]:
