@@ -339,6 +339,11 @@ constexpr bool NTT_TA_SHOUP = BLZ_NTT_TA_SHOUP != 0;
 #ifndef BLZ_NTT_NT
 #define BLZ_NTT_NT 0
 #endif
+// Second experiment of round 6: four blocks per CU (4 waves per SIMD: 128 registers per lane, the LDS's 4 x 40 KiB) for the passes
+// whose bit is set (bit p - 1 = pass p).  Shipped: 0 (three blocks; the kernels hold 143 - 166 VGPRs).
+#ifndef BLZ_NTT_OCC4
+#define BLZ_NTT_OCC4 0
+#endif
 constexpr int NR_COLS_LOG = NTT_RR_COLS_LOG;
 constexpr int NR_COLS = 1 << NR_COLS_LOG;
 constexpr int NR_THREADS = 64 * NR_COLS;
@@ -350,7 +355,7 @@ constexpr int NR_THREADS = 64 * NR_COLS;
 // k1 = K - waves 0 and 1 for the first half, waves 2 and 3 for the second - and of the second exchange the lanes with
 // k1' = K of the same wave.  Costs: three more block barriers and four outputs kept in registers across a half.
 template <class Fr, int PASS, bool TABB = false>   // TABB: pass 2 reads its boundary factors from the per-element table tB
-__global__ __launch_bounds__(NR_THREADS, 3) void k_ntt512_rr(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, NttGeom g,
+__global__ __launch_bounds__(NR_THREADS, ((BLZ_NTT_OCC4 >> (PASS - 1)) & 1) ? 4 : 3) void k_ntt512_rr(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, NttGeom g,
                                                             NttTablesRR T) {
     using Q = typename Fr::RR;
     constexpr uint32_t ES = rr_stride<Q>();  // element stride in LDS and in the tables (dwords)

@@ -15,7 +15,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" 
 done
 python3 tools/pmc_dump.py ntt512 gpurun_out/nttpmc*/*/*_results.db < /dev/null >> $out
 echo "# A/B on the same box: kernel ms of 12 transforms per build (HIP events), shipped first and last" >> $out
-for v in "" _nt1 _nt3 _nt5 _nt21 _nt63 ""; do
+for v in "" _nt1 _nt3 _nt5 _nt21 _nt63 _occ4 _occ6 _occ7 ""; do
   lib=blaze_amd/lib/libblaze_hip$v.so
   [ -f $lib ] || continue
   BLAZE_HIP_LIB=$PWD/$lib timeout 200 python3 tools/ntt_only.py 27 14 2>&1 < /dev/null | grep "kernel ms" | tail -12 | python3 -c "
