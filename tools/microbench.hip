@@ -54,6 +54,36 @@ __global__ __launch_bounds__(256) void k_rate(uint32_t* out, uint32_t seed) {
                 uint32_t lo = (uint32_t)acc[c], hi;
                 asm volatile("v_mul_hi_u32_u24 %1, %0, %2\n\tv_mul_u32_u24 %0, %0, %2" : "+v"(lo), "=&v"(hi) : "v"(b));
                 acc[c] = lo ^ hi;
+            } else if constexpr (OP == 10) {  // v_lshrrev_b64 (the column close of the reduced-radix products: acc >>= 29)
+                asm volatile("v_lshrrev_b64 %0, 1, %0" : "+v"(acc[c]));
+            } else if constexpr (OP == 11) {  // v_and_b32
+                uint32_t lo = (uint32_t)acc[c];
+                asm volatile("v_and_b32 %0, %1, %0" : "+v"(lo) : "v"(b));
+                acc[c] = lo;
+            } else if constexpr (OP == 12) {  // v_alignbit_b32
+                uint32_t lo = (uint32_t)acc[c];
+                asm volatile("v_alignbit_b32 %0, %1, %0, 29" : "+v"(lo) : "v"(b));
+                acc[c] = lo;
+            } else if constexpr (OP == 13) {  // v_lshrrev_b32
+                uint32_t lo = (uint32_t)acc[c];
+                asm volatile("v_lshrrev_b32 %0, 1, %0" : "+v"(lo));
+                acc[c] = lo;
+            } else if constexpr (OP == 14) {  // v_add3_u32
+                uint32_t lo = (uint32_t)acc[c];
+                asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(lo) : "v"(b), "v"(a));
+                acc[c] = lo;
+            } else if constexpr (OP == 15) {  // v_lshl_add_u64
+                asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(acc[c]) : "v"(acc[(c + 1) % CHAINS]));
+            } else if constexpr (OP == 16) {  // the column close as shipped: v_and_b32 + v_lshrrev_b64
+                uint32_t limb = (uint32_t)acc[c] & 0x1fffffffu;
+                acc[c] = (acc[c] >> 29) + 0x123456789abcull;     // (keeps the value alive across iterations: one v_lshl_add_u64 / add pair extra)
+                asm volatile("" : "+v"(acc[c]), "+v"(limb));
+                d[c] += (double)0 * limb;
+            } else if constexpr (OP == 17) {  // the column close on 32-bit shifts: v_and_b32 + v_alignbit_b32 + v_lshrrev_b32
+                uint32_t lo = (uint32_t)acc[c], hi = (uint32_t)(acc[c] >> 32), limb;
+                asm volatile("v_and_b32 %2, 0x1fffffff, %0\n\tv_alignbit_b32 %0, %1, %0, 29\n\tv_lshrrev_b32 %1, 29, %1" : "+v"(lo), "+v"(hi), "=&v"(limb));
+                acc[c] = ((uint64_t)hi << 32) | lo;
+                d[c] = limb;
             } else if constexpr (OP == 9) {  // v_mad_i32_i24 pure
                 uint32_t lo = (uint32_t)acc[c];
                 asm volatile("v_mad_i32_i24 %0, %0, %1, %2" : "+v"(lo) : "v"(b), "v"(a));
@@ -108,5 +138,13 @@ int main() {
     run<8>("v_mul_u32_u24+v_mul_hi_u32_u24 (pair)", 1, d_out);
     run<4>("v_fma_f64", 1, d_out);
     run<5>("v_add_co+v_addc (per pair)", 1, d_out);
+    run<10>("v_lshrrev_b64", 1, d_out);
+    run<11>("v_and_b32", 1, d_out);
+    run<12>("v_alignbit_b32", 1, d_out);
+    run<13>("v_lshrrev_b32", 1, d_out);
+    run<14>("v_add3_u32", 1, d_out);
+    run<15>("v_lshl_add_u64", 1, d_out);
+    run<16>("and + lshr_b64 (column close)", 1, d_out);
+    run<17>("and + alignbit + lshr_b32 (close)", 1, d_out);
     return 0;
 }
