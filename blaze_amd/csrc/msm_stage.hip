@@ -417,6 +417,9 @@ int stage_stream(blz_msm* h, bool have_points, const void* points, size_t points
         h->stage_idx ^= 1;
         N.open = true;
         S = N;
+        BLZ_LOG(2, "streamed task: %u elements, mode %d (%s), %s", total, mode, mode == 1 ? "scalars over arena bases" : mode == 2 ? "points + scalars" : "points into the arena + scalars",
+                S.slot >= 0 ? "enqueued in pieces as the slices arrive" : "launched whole behind its last slice");
+        if (S.slot >= 0) BLZ_LOG(2, "streamed task: %d pieces of %u points%s", S.pieces, S.per, mode == 2 ? " through the piece ring" : "");
     } else {
         if (mode != S.mode || on_device != S.src_device)
             return fail(BLZ_ERR_INVALID_PARAM, "the queued task is being fed in another mode (points / hbm_point_addr / host or device pointers differ from its first slice)");
