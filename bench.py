@@ -415,6 +415,7 @@ def main():
             nii = ntt["roofline"].get("integer_issue")
             roofline["ntt_integer_issue_frac"] = nii["frac"] if nii else None
             roofline["ntt_host_loop_ms"] = ntt.get("host_loop_ms")
+            roofline["ntt_host_loop_pinned_ms"] = ntt.get("host_loop_pinned_ms")
         line = {
             "metric": f"BLS12-381 MSM/s at 2^{LOG_N}", "value": round(value, 4), "unit": "MSM/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,

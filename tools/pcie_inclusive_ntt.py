@@ -10,6 +10,11 @@ import numpy as np
 from blaze_amd.driver_client import DriverClient
 from blaze_amd.ingo_ntt import NTT, NTTClient, NTTInput, NttInit
 
+if os.environ.get("IMPORT_TORCH") == "1":   # (does the host loop care whether torch owns the process's HIP context first?  bench.py imports it)
+    import torch
+    torch.cuda.synchronize(0)
+    if os.environ.get("TORCH_BIG") == "1":
+        _t = torch.empty(1 << 30, dtype=torch.uint8, device="cuda"); _h = _t.cpu(); del _t, _h
 logn = int(sys.argv[1]) if len(sys.argv) > 1 else 27
 n = 1 << logn
 x = np.random.default_rng(1).integers(0, 256, size=32 * n, dtype=np.uint8)
