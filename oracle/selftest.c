@@ -22,6 +22,8 @@ int orc_index_weighted_sum(int, const uint8_t*, uint64_t, uint64_t, uint8_t*);
 int orc_msm_pippenger(int, const uint8_t*, const uint8_t*, uint64_t, int, int, int, uint8_t*);
 int orc_omega(int, int, uint8_t*);
 int orc_ntt(int, const uint8_t*, uint8_t*, int, int, int);
+int orc_ntt_ex(int, const uint8_t*, uint8_t*, int, int, const uint8_t*, int);
+int orc_bitrev_permute(const uint8_t*, uint8_t*, int, int);
 int orc_ntt_eval_at(int, const uint8_t*, int, uint64_t, uint8_t*);
 int orc_ntt_eval_at_mt(int, const uint8_t*, int, uint64_t, int, uint8_t*);
 int orc_dft_naive(int, const uint8_t*, uint8_t*, int);
@@ -76,6 +78,19 @@ int main(void) {
         { uint8_t e2[32]; CHECK(orc_ntt_eval_at_mt(1, in, LOGN, 5, 3, e2) == 0); CHECK(memcmp(e, e2, 32) == 0); }
         CHECK(memcmp(e, out + 32 * 5, 32) == 0);
         CHECK(orc_omega(1, 27, w) == 0);
+        /* the conventions of orc_ntt_ex: the default root given explicitly = the default transform; bit-reversed buffers are the
+         * permuted buffers; a root of the wrong order is refused; the inverse of a convention undoes it */
+        uint8_t w6[32], perm[32 * N], o3[32 * N], o4[32 * N], one[32] = {1};
+        CHECK(orc_omega(1, LOGN, w6) == 0);
+        CHECK(orc_ntt_ex(1, in, o3, LOGN, 0, w6, 2) == 0);
+        CHECK(memcmp(o3, out, sizeof(out)) == 0);
+        CHECK(orc_bitrev_permute(in, perm, LOGN, 2) == 0);
+        CHECK(orc_ntt_ex(1, perm, o3, LOGN, 2 | 4, NULL, 1) == 0);       /* bit-reversed in and out */
+        CHECK(orc_bitrev_permute(o3, o4, LOGN, 1) == 0);
+        CHECK(memcmp(o4, out, sizeof(out)) == 0);
+        CHECK(orc_ntt_ex(1, o3, o4, LOGN, 1 | 2 | 4, w6, 3) == 0);        /* its inverse */
+        CHECK(memcmp(o4, perm, sizeof(perm)) == 0);
+        CHECK(orc_ntt_ex(1, in, o3, LOGN, 0, one, 1) == -2);              /* 1 is not a primitive 2^6-th root */
     }
     {
         uint64_t n = 4096;
